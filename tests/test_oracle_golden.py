@@ -1,0 +1,112 @@
+"""CPU: pin oracle/alpro_oracle.py against golden vectors captured from the reference itself
+(tests/golden/make_golden.py).  fp32 vs fp32 on the same closed-form weights/inputs; the only
+differences are summation order, so the tolerances are tight (rtol 2e-4 / atol 2e-5)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import alpro_oracle as ao
+from oracle.det_init import det_batch, det_param, unit_uniform
+from tests.conftest import GOLDEN
+
+RT, AT = 2e-4, 2e-5
+
+
+def close(a, b, rtol=RT, atol=AT, what=""):
+    a = a.detach().cpu().numpy() if torch.is_tensor(a) else np.asarray(a)
+    np.testing.assert_allclose(a.astype(np.float64), np.asarray(b, dtype=np.float64), rtol=rtol, atol=atol, err_msg=what)
+
+
+def test_state_spec_matches_reference_keys(bert_cfg):
+    keys = json.load(open(os.path.join(GOLDEN, "state_keys.json")))
+    spec = ao.alpro_state_spec("retrieval", bert_cfg, num_frm=2)
+    assert {k: list(v) for k, v in spec.items()} == keys["retrieval_T2"]
+    spec = ao.alpro_state_spec("pretrain", bert_cfg, num_frm=8)
+    assert {k: list(v) for k, v in spec.items()} == keys["pretrain_T8"]
+
+
+def test_block_droppath_train_mode():
+    g = np.load(os.path.join(GOLDEN, "block11_droppath_T2_B4.npz"))
+    B, T = 4, 2
+    name = "visual_encoder.model.blocks.11"
+    p = {k: det_param(k, s) for k, s in ao.alpro_state_spec("retrieval", {"hidden_size": 768, "max_position_embeddings": 8, "vocab_size": 8, "type_vocab_size": 2, "num_hidden_layers": 0, "intermediate_size": 8}, T).items() if k.startswith(name)}
+    x = torch.from_numpy(unit_uniform("block_in", B * (1 + 196 * T) * 768).astype(np.float32)).view(B, 1 + 196 * T, 768)
+    keep = 0.9  # drop_path 0.1 at layer 11 (vit.py:272); vit_utils.py:146-151
+    drop = {k: torch.floor(keep + torch.from_numpy(g["rand_%d" % i])) / keep for i, k in enumerate("tsm")}
+    y = ao.vit_block(x, p, name, B, T, 14, drop)
+    close(y[:, [0, 1, 2, 200, 392]], g["y_rows"], what="block rows")
+    close(y.norm(dim=-1), g["y_rownorm"], what="block row norms")
+    assert (drop["t"] == 0).any() and (drop["t"] > 1).any()
+
+
+@pytest.fixture(scope="module")
+def retrieval_case(bert_cfg):
+    T, B = 2, 3
+    p = ao.det_state("retrieval", bert_cfg, T)
+    orc = ao.AlproOracle(p, bert_cfg, T)
+    batch = det_batch(B, T, seed_name="retrieval_T2", with_mlm=False, with_mpm=False)
+    return orc, batch, np.load(os.path.join(GOLDEN, "retrieval_T2_B3.npz"))
+
+
+def test_retrieval_forward(retrieval_case):
+    orc, batch, g = retrieval_case
+    with torch.no_grad():
+        out = orc.forward_retrieval(batch)
+        ve = orc.visual_embeds(batch["visual_inputs"])
+    close(out["itc_loss"], g["itc_loss"]); close(out["itm_loss"], g["itm_loss"])
+    close(out["itm_scores"], g["itm_scores"]); close(out["itm_labels"], g["itm_labels"])
+    close(ve[:, [0, 1, 100, 196]], g["video_embeds_rows"]); close(ve.norm(dim=-1), g["video_embeds_rownorm"])
+    close(ve.sum(dim=-1), g["video_embeds_rowsum"], atol=2e-4)
+
+
+def test_retrieval_world2_vtc(retrieval_case):
+    """VTC targets use local_rank*B offsets into the gathered features (alpro_models.py:121-123)."""
+    orc, batch, g = retrieval_case
+    B = 3
+    ov = torch.nn.functional.normalize(torch.from_numpy(unit_uniform("w2/video", B * 256).astype(np.float32)).view(B, 256), dim=-1)
+    ot = torch.nn.functional.normalize(torch.from_numpy(unit_uniform("w2/text", B * 256).astype(np.float32)).view(B, 256), dim=-1)
+    with torch.no_grad():
+        out = orc.forward_retrieval(batch, world=(1, [ov, None], [ot, None]))
+    close(out["itc_loss"], g["w2_itc_loss"]); close(out["itm_loss"], g["w2_itm_loss"]); close(out["itm_scores"], g["w2_itm_scores"])
+
+
+def test_retrieval_inference(retrieval_case):
+    orc, batch, g = retrieval_case
+    with torch.no_grad():
+        inf = orc.forward_inference(dict(visual_inputs=batch["visual_inputs"][:1], text_input_ids=batch["text_input_ids"],
+                                         text_input_mask=batch["text_input_mask"]))
+    close(inf["logits"], g["inf_logits"]); close(inf["itc_scores"], g["inf_itc_scores"])
+
+
+@pytest.mark.slow
+def test_pretrain_forward_backward(bert_cfg):
+    """All 10 outputs of AlproForPretrain.forward + gradients of loss = mlm+itm+itc+mpm (run_pretrain_sparse.py:557)."""
+    T, B = 8, 2
+    g = np.load(os.path.join(GOLDEN, "pretrain_T8_B2.npz"))
+    skip = ("prompter.text_encoder.", "prompter.itm_head", "prompter.text_proj", "visual_encoder.model.head", "prompter.visual_encoder.model.head")
+    spec = ao.alpro_state_spec("pretrain", bert_cfg, T)
+    only = [k for k in spec if not k.startswith(skip)]
+    p = ao.det_state("pretrain", bert_cfg, T, only=only)
+    names = [str(n) for n in g["grad_norm_names"]]
+    for n in names:
+        p[n].requires_grad_(True)
+    orc = ao.AlproOracle(p, bert_cfg, T)
+    out = orc.forward_pretrain(det_batch(B, T, seed_name="pretrain_T8"))
+    for k in ("itc_loss", "itm_loss", "mlm_loss", "mpm_loss", "itm_scores", "mpm_logits", "mpm_labels", "video_feat", "text_feat",
+              "text_embeds", "sim_v2t"):
+        close(out[k], g[k], what=k)
+    close(out["mlm_scores"][:, :, ::61], g["mlm_scores_cols"], what="mlm cols")
+    close(torch.logsumexp(out["mlm_scores"], -1), g["mlm_scores_lse"], what="mlm lse")
+    ve = out["video_embeds"]
+    close(ve[:, [0, 1, 57, 196]], g["video_embeds_rows"]); close(ve.norm(dim=-1), g["video_embeds_rownorm"])
+    loss = out["mlm_loss"] + out["itm_loss"] + out["itc_loss"] + out["mpm_loss"]
+    loss.backward()
+    # tied tensors: the reference reports the word-embedding grad once (decoder grad accumulates into it)
+    got = np.array([float(p[n].grad.norm()) for n in names])
+    np.testing.assert_allclose(got, g["grad_norms"], rtol=2e-3, atol=1e-7)
+    for k in g.files:
+        if k.startswith("grad/"):
+            close(p[k[5:]].grad, g[k], rtol=2e-3, atol=2e-6, what=k)
