@@ -1,0 +1,345 @@
+// Attention forward kernels for gfx950 (head_dim 64, wave64, MFMA 32x32).
+//
+// Both kernels compute, per 32-query tile and per wave,
+//     S^T = K Q^T          (MFMA; lane l then owns query (l & 31) and 16 keys per 32-key tile, so the
+//                            row softmax is lane-local plus ONE exchange with lane l ^ 32)
+//     P   = softmax(S^T * scale + bias)      fp32 registers
+//     O^T = V^T P^T        (MFMA; P is consumed straight from the accumulator registers as the
+//                            B operand -- the MFMA k index is free to follow the C-layout key order)
+// alpro_attn_fwd      : one workgroup per (sequence, head); K and V of that head resident in LDS
+//                       (K XOR-swizzled for conflict-free ds_read_b128), 4 waves x 32-query tiles.
+// alpro_attn_temporal : groups of T frames; 32 consecutive tokens (= 32/T groups) form one MFMA
+//                       tile with a block-diagonal mask, one wave per (32 tokens, head).
+// Storage dtype T: bf16/f16 (K=16 MFMA) or f32 (K=2 MFMA, exact mode); a 16-byte chunk is the unit.
+#include "common.hpp"
+
+namespace alpro {
+namespace {
+
+constexpr int HD = 64;
+
+template <typename T> struct AttnCfg {
+  static constexpr int E = sizeof(T);
+  static constexpr int CN = 16 / E;        // elements per 16-byte chunk
+  static constexpr int RB = HD * E;        // bytes per head row
+  static constexpr int CPR = RB / 16;      // chunks per head row (8 or 16)
+  static constexpr int KS = CPR / 2;       // MFMA chunk-steps over head_dim (two lane halves per step)
+  static constexpr int CPT = 16 / CN;      // P chunks per 32-key tile (2 or 4)
+};
+
+template <typename T> __device__ __forceinline__ int k_swz(int row, int chunk) {
+  if (AttnCfg<T>::CPR == 8) return chunk ^ ((row >> 1) & 7);  // 128-B rows: two rows per 256-B bank row
+  return chunk ^ (row & 15);                                   // 256-B rows
+}
+
+// 4 consecutive keys of column d from a row-major (key, 64) LDS tile -> packed storage elements
+template <typename T> struct Col4;
+template <> struct Col4<float> {
+  typedef u32x4 type;
+  static __device__ __forceinline__ u32x4 load(const char* v, int key0, int d) {
+    const float* p = (const float*)(v + key0 * AttnCfg<float>::RB) + d;
+    return mk4(f2u(p[0]), f2u(p[64]), f2u(p[128]), f2u(p[192]));
+  }
+};
+template <typename T16> struct Col4_16 {
+  typedef u32x2 type;
+  static __device__ __forceinline__ u32x2 load(const char* v, int key0, int d) {
+    const uint16_t* p = (const uint16_t*)(v + key0 * (HD * 2)) + d;
+    u32x2 r;
+    r.x = (uint32_t)p[0] | ((uint32_t)p[64] << 16);
+    r.y = (uint32_t)p[128] | ((uint32_t)p[192] << 16);
+    return r;
+  }
+};
+template <> struct Col4<bf16_t> : Col4_16<bf16_t> {};
+template <> struct Col4<f16_t> : Col4_16<f16_t> {};
+
+// V image in LDS: row-major (key, 64).  16-bit dtypes XOR the 16-byte chunk index with 4*bit1(key) so
+// that the four key rows gathered by one ds_read_b64_tr_b16 land in distinct 64-B bank windows.
+template <typename T> __device__ __forceinline__ int v_swz(int row, int chunk) {
+  return sizeof(T) == 2 ? chunk ^ (((row >> 1) & 1) << 2) : chunk;
+}
+
+// A-operand chunk cc of the key tile at LDS `vt`: V[keys(cc, g)][d] with d = dt*32 + (lane & 31).
+template <typename T> __device__ __forceinline__ u32x4 load_vt_chunk(const char* vt, int cc, int lane, int dt);
+template <> __device__ __forceinline__ u32x4 load_vt_chunk<float>(const char* vt, int cc, int lane, int dt) {
+  return Col4<float>::load(vt, 8 * cc + 4 * (lane >> 5), dt * 32 + (lane & 31));  // one quad per chunk: regs 4cc..4cc+3
+}
+// 16-bit: hardware transpose read.  ds_read_b64_tr_b16 semantics (probed on gfx950, tools/probe_tr.hip):
+// within each 16-lane group, lane l receives element (l & 3) of the 8-byte piece addressed by lane
+// (l >> 2) + 4j, j = 0..3.  Lane p therefore points at key row key0 + (p >> 2), d-quad (p & 3) of its
+// group's 16-wide d block, and every lane gets 4 consecutive keys of its own d column.
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ u32x2 tr_quad(const char* vt, int key0, int lane, int dt) {
+  const int p = lane & 15, seg = dt * 2 + ((lane >> 4) & 1);
+  const int row = key0 + (p >> 2);
+  const char* a = vt + row * 128 + ((seg ^ (((row >> 1) & 1) << 1)) << 5) + ((p & 3) << 3);
+  const s16x4 r = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)a);
+  return __builtin_bit_cast(u32x2, r);
+}
+template <typename T> __device__ __forceinline__ u32x4 load_vt_chunk16(const char* vt, int cc, int lane, int dt) {
+  const int g = lane >> 5;
+  const u32x2 a = tr_quad(vt, 16 * cc + 4 * g, lane, dt);      // regs 8cc..8cc+3
+  const u32x2 b = tr_quad(vt, 16 * cc + 8 + 4 * g, lane, dt);  // regs 8cc+4..8cc+7
+  const uint32_t ax = a.x, ay = a.y, bx = b.x, by = b.y;
+  return mk4(ax, ay, bx, by);
+}
+template <> __device__ __forceinline__ u32x4 load_vt_chunk<bf16_t>(const char* vt, int cc, int lane, int dt) { return load_vt_chunk16<bf16_t>(vt, cc, lane, dt); }
+template <> __device__ __forceinline__ u32x4 load_vt_chunk<f16_t>(const char* vt, int cc, int lane, int dt) { return load_vt_chunk16<f16_t>(vt, cc, lane, dt); }
+
+// store 4 consecutive outputs d0..d0+3 of one query row
+template <typename T> __device__ __forceinline__ void store_quad(T* dst, const float* v) {
+  if constexpr (sizeof(T) == 4) {
+    *(float4*)dst = make_float4(v[0], v[1], v[2], v[3]);
+  } else {
+    u32x2 u;
+    u.x = pack2(v[0], v[1], (T*)0);
+    u.y = pack2(v[2], v[3], (T*)0);
+    *(u32x2*)dst = u;
+  }
+}
+
+// softmax over NKT key tiles held in C layout.  `bias4(kt, rq)` returns the additive fp32 bias of the
+// four keys of accumulator registers 4rq..4rq+3 (-inf masks a key).  p is normalised in place;
+// returns the row's log-sum-exp.
+template <int NKT, typename BiasF>
+__device__ __forceinline__ float softmax_tiles(f32x16 (&s)[NKT], float scale, BiasF bias4) {
+  float m = -INFINITY;
+#pragma unroll
+  for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+    for (int rq = 0; rq < 4; ++rq) {
+      const float4 bq = bias4(kt, rq);
+      const float bb[4] = {bq.x, bq.y, bq.z, bq.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float v = s[kt][4 * rq + e] * scale + bb[e];
+        s[kt][4 * rq + e] = v;
+        m = fmaxf(m, v);
+      }
+    }
+  m = fmaxf(m, __shfl_xor(m, 32, 64));
+  float sum = 0.f;
+#pragma unroll
+  for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float p = expf(s[kt][r] - m);  // exp(-inf) == 0 for masked keys
+      s[kt][r] = p;
+      sum += p;
+    }
+  sum += __shfl_xor(sum, 32, 64);
+  const float inv = 1.0f / sum;
+#pragma unroll
+  for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s[kt][r] *= inv;
+  return m + logf(sum);
+}
+
+// O^T (2 d-tiles) += V^T P^T over NKT key tiles; vt points at key 0 of the LDS V image
+template <typename T, int NKT>
+__device__ __forceinline__ void pv_tiles(f32x16 (&o)[2], const f32x16 (&p)[NKT], const char* vt, int lane) {
+  typedef AttnCfg<T> C;
+#pragma unroll
+  for (int kt = 0; kt < NKT; ++kt) {
+#pragma unroll
+    for (int cc = 0; cc < C::CPT; ++cc) {
+      float pv[C::CN];
+#pragma unroll
+      for (int e = 0; e < C::CN; ++e) pv[e] = p[kt][cc * C::CN + e];
+      const u32x4 b = pack_chunk<T>(pv);
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) {
+        const u32x4 a = load_vt_chunk<T>(vt + kt * 32 * C::RB, cc, lane, dt);
+        mma_chunk<T>(o[dt], a, b);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);  // keep the column reads of later key tiles from piling up in VGPRs
+  }
+}
+
+template <typename T>
+__device__ __forceinline__ void store_o(T* out_row, const f32x16 (&o)[2], int lane) {
+  const int g = lane >> 5;
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int rq = 0; rq < 4; ++rq) {
+      const float v[4] = {o[dt][4 * rq], o[dt][4 * rq + 1], o[dt][4 * rq + 2], o[dt][4 * rq + 3]};
+      store_quad<T>(out_row + dt * 32 + 8 * rq + 4 * g, v);
+    }
+}
+
+// ================================================================================================
+// full attention: grid = batch * H workgroups of 256 threads
+template <typename T, int NKT>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qkv, T* __restrict__ out, int L, int H, float scale,
+                                                       const float* __restrict__ key_bias, float* __restrict__ lse) {
+  typedef AttnCfg<T> C;
+  constexpr int LP = NKT * 32;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* Ks = smem;
+  char* Vs = smem + LP * C::RB;
+  float* Bs = (float*)(smem + 2 * LP * C::RB);  // additive key bias; -inf on the padded keys
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.x / H, h = blockIdx.x - b * H;
+  for (int c = tid; c < LP; c += 256) Bs[c] = c < L ? (key_bias ? key_bias[(int64_t)b * L + c] : 0.f) : -INFINITY;
+  const int64_t ldq = 3 * (int64_t)H * HD;  // elements per token row of qkv
+  const T* base = qkv + (int64_t)b * L * ldq + h * HD;
+
+  // stage K (swizzled) and V (row-major), zero-filling the padded keys
+  for (int c = tid; c < LP * C::CPR; c += 256) {
+    const int row = c / C::CPR, ch = c - row * C::CPR;
+    u32x4 kv = mk4(0, 0, 0, 0), vv = mk4(0, 0, 0, 0);
+    if (row < L) {
+      const T* src = base + (int64_t)row * ldq + ch * C::CN;
+      kv = *(const u32x4*)(src + H * HD);
+      vv = *(const u32x4*)(src + 2 * H * HD);
+    }
+    *(u32x4*)(Ks + row * C::RB + (k_swz<T>(row, ch) << 4)) = kv;
+    *(u32x4*)(Vs + row * C::RB + (v_swz<T>(row, ch) << 4)) = vv;
+  }
+  __syncthreads();
+
+  const int nqt = (L + 31) >> 5;
+  const int g = lane >> 5, ql = lane & 31;
+  for (int qt = wave; qt < nqt; qt += 4) {
+    const int q = qt * 32 + ql;
+    const int qc = min(q, L - 1);
+    u32x4 qf[C::KS];
+#pragma unroll
+    for (int ks = 0; ks < C::KS; ++ks) qf[ks] = *(const u32x4*)(base + (int64_t)qc * ldq + (2 * ks + g) * C::CN);
+
+    f32x16 s[NKT];
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[kt][r] = 0.f;
+      const int krow = kt * 32 + ql;
+#pragma unroll
+      for (int ks = 0; ks < C::KS; ++ks) {
+        const u32x4 a = *(const u32x4*)(Ks + krow * C::RB + (k_swz<T>(krow, 2 * ks + g) << 4));
+        mma_chunk<T>(s[kt], a, qf[ks]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    const float l_se = softmax_tiles<NKT>(s, scale, [&](int kt, int rq) { return *(const float4*)(Bs + kt * 32 + 8 * rq + 4 * g); });
+    if (lse && g == 0 && q < L) lse[((int64_t)b * H + h) * L + q] = l_se;
+
+    f32x16 o[2];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
+    pv_tiles<T, NKT>(o, s, Vs, lane);
+    if (q < L) store_o<T>(out + ((int64_t)b * L + q) * H * HD + h * HD, o, lane);
+  }
+}
+
+// ================================================================================================
+// temporal attention: one wave per (32 consecutive tokens, head); groups of Tn tokens
+template <typename T>
+__global__ __launch_bounds__(256) void attn_temporal_fwd_kernel(const T* __restrict__ qkv, T* __restrict__ out, int64_t rows, int Tn,
+                                                                int H, float scale, int64_t units) {
+  typedef AttnCfg<T> C;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  char* Vs = smem + wave * 32 * C::RB;
+  const int64_t ldq = 3 * (int64_t)H * HD;
+  const int g = lane >> 5, ql = lane & 31;
+  const int64_t iters = (units + (int64_t)gridDim.x * 4 - 1) / ((int64_t)gridDim.x * 4);
+  for (int64_t it = 0; it < iters; ++it) {
+    const int64_t unit = (it * gridDim.x + blockIdx.x) * 4 + wave;
+    const bool active = unit < units;
+    const int64_t chunk = active ? unit / H : 0;
+    const int h = active ? (int)(unit - chunk * H) : 0;
+    const int64_t r0 = chunk * 32;
+    const T* base = qkv + h * HD;
+    // V tile -> wave-private LDS (coalesced: CPR lanes cover one 64-wide row)
+    __syncthreads();  // previous iteration's column reads are done
+#pragma unroll
+    for (int i = 0; i < C::CPR / 2; ++i) {
+      const int c = lane + i * 64, row = c / C::CPR, ch = c - row * C::CPR;
+      u32x4 vv = mk4(0, 0, 0, 0);
+      if (active && r0 + row < rows) vv = *(const u32x4*)(base + (r0 + row) * ldq + 2 * H * HD + ch * C::CN);
+      *(u32x4*)(Vs + row * C::RB + (v_swz<T>(row, ch) << 4)) = vv;
+    }
+    const int64_t qrow = min(r0 + ql, rows - 1);
+    u32x4 qf[C::KS], kf[C::KS];
+#pragma unroll
+    for (int ks = 0; ks < C::KS; ++ks) {
+      const T* src = base + qrow * ldq + (2 * ks + g) * C::CN;
+      qf[ks] = *(const u32x4*)src;
+      kf[ks] = *(const u32x4*)(src + H * HD);
+    }
+    f32x16 s[1];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s[0][r] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < C::KS; ++ks) mma_chunk<T>(s[0], kf[ks], qf[ks]);
+    const int qgrp = ql / Tn;
+    softmax_tiles<1>(s, scale, [&](int, int rq) {
+      const int k0 = 8 * rq + 4 * g;  // block-diagonal mask: a query attends to the T frames of its own patch
+      return make_float4((k0 + 0) / Tn == qgrp ? 0.f : -INFINITY, (k0 + 1) / Tn == qgrp ? 0.f : -INFINITY,
+                         (k0 + 2) / Tn == qgrp ? 0.f : -INFINITY, (k0 + 3) / Tn == qgrp ? 0.f : -INFINITY);
+    });
+    __syncthreads();  // V tile visible
+    f32x16 o[2];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
+    pv_tiles<T, 1>(o, s, Vs, lane);
+    if (active && r0 + ql < rows) store_o<T>(out + (r0 + ql) * H * HD + h * HD, o, lane);
+  }
+}
+
+template <typename T, int NKT>
+int launch_attn(const void* qkv, void* out, int batch, int L, int H, float scale, const float* key_bias, float* lse, hipStream_t st) {
+  const size_t lds = 2 * (size_t)NKT * 32 * AttnCfg<T>::RB + (size_t)NKT * 32 * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<T, NKT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((attn_fwd_kernel<T, NKT>), dim3(batch * H), dim3(256), lds, st, (const T*)qkv, (T*)out, L, H, scale, key_bias, lse);
+  return check_launch("alpro_attn_fwd");
+}
+
+template <typename T>
+int dispatch_attn(const void* qkv, void* out, int batch, int L, int H, float scale, const float* key_bias, float* lse, hipStream_t st) {
+  const int nkt = (L + 31) / 32;
+  if (nkt <= 2) return launch_attn<T, 2>(qkv, out, batch, L, H, scale, key_bias, lse, st);
+  if (nkt <= 4) return launch_attn<T, 4>(qkv, out, batch, L, H, scale, key_bias, lse, st);
+  if (nkt <= 7) return launch_attn<T, 7>(qkv, out, batch, L, H, scale, key_bias, lse, st);
+  return launch_attn<T, 8>(qkv, out, batch, L, H, scale, key_bias, lse, st);
+}
+
+}  // namespace
+}  // namespace alpro
+
+using namespace alpro;
+
+extern "C" int alpro_attn_fwd(const void* qkv, void* out, int dtype, int batch, int L, int H, float scale,
+                              const float* key_bias, float* lse, void* stream) {
+  ALPRO_CHECK(qkv && out && batch > 0 && H > 0, "alpro_attn_fwd: bad args");
+  ALPRO_CHECK(L > 0 && L <= 256, "alpro_attn_fwd: L=%d unsupported (1..256; the path needs 40, 197, 237)", L);
+  ALPRO_CHECK(((uintptr_t)qkv % 16) == 0 && ((uintptr_t)out % 16) == 0, "alpro_attn_fwd: pointers must be 16-byte aligned");
+  ALPRO_DISPATCH_DTYPE(dtype, T, return dispatch_attn<T>(qkv, out, batch, L, H, scale, key_bias, lse, (hipStream_t)stream));
+  return ALPRO_OK;
+}
+
+extern "C" int alpro_attn_temporal_fwd(const void* qkv, void* out, int dtype, int64_t rows, int T, int H, float scale, void* stream) {
+  ALPRO_CHECK(qkv && out && rows > 0 && H > 0, "alpro_attn_temporal_fwd: bad args");
+  ALPRO_CHECK(T > 0 && 32 % T == 0, "alpro_attn_temporal_fwd: num_frm=%d must divide 32", T);
+  ALPRO_CHECK(rows % T == 0, "alpro_attn_temporal_fwd: rows=%lld not a multiple of T=%d", (long long)rows, T);
+  ALPRO_CHECK(((uintptr_t)qkv % 16) == 0 && ((uintptr_t)out % 16) == 0, "alpro_attn_temporal_fwd: pointers must be 16-byte aligned");
+  const int64_t units = ((rows + 31) / 32) * H;
+  int64_t grid = (units + 3) / 4;
+  if (grid > 256 * 8) grid = 256 * 8;
+  const int esz = dtype == ALPRO_F32 ? 4 : 2;
+  const size_t lds = 4 * 32 * 64 * (size_t)esz;
+  ALPRO_DISPATCH_DTYPE(dtype, T_, hipLaunchKernelGGL(attn_temporal_fwd_kernel<T_>, dim3((unsigned)grid), dim3(256), lds, (hipStream_t)stream, (const T_*)qkv, (T_*)out, rows, T, H, scale, units));
+  return check_launch("alpro_attn_temporal_fwd");
+}

@@ -1,0 +1,147 @@
+// Shared device/host helpers for the ALPRO gfx950 kernels.  CDNA4 only: wave64, MFMA 32x32.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/alpro_hip.h"
+
+namespace alpro {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+// native vector types for register-resident 16-/8-byte chunks (HIP's uint4 struct defeats SROA in
+// staged pipelines and lands in scratch)
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ u32x4 mk4(uint32_t a, uint32_t b, uint32_t c, uint32_t d) { return u32x4{a, b, c, d}; }
+__device__ __forceinline__ u32x2 mk2(uint32_t a, uint32_t b) { return u32x2{a, b}; }
+// by-value bit casts: __builtin_bit_cast applied directly to an ext-vector element lvalue (v.y)
+// reads element 0 on this toolchain, so always go through a scalar rvalue.
+__device__ __forceinline__ float u2f(uint32_t u) { return __builtin_bit_cast(float, u); }
+__device__ __forceinline__ uint32_t f2u(float f) { return __builtin_bit_cast(uint32_t, f); }
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+
+struct bf16_t { uint16_t v; };  // storage-only 16-bit types (arithmetic is always fp32)
+struct f16_t { uint16_t v; };
+
+// ---- scalar conversions (round-to-nearest-even, NaN preserved) -------------------------------
+__device__ __forceinline__ float to_f32(float x) { return x; }
+__device__ __forceinline__ float to_f32(bf16_t x) { return __builtin_bit_cast(float, (uint32_t)x.v << 16); }
+__device__ __forceinline__ float to_f32(f16_t x) { return (float)__builtin_bit_cast(_Float16, x.v); }
+
+__device__ __forceinline__ uint16_t f32_to_bf16_bits(float f) {
+  uint32_t u = __builtin_bit_cast(uint32_t, f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);  // quiet NaN
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+template <typename T> __device__ __forceinline__ T from_f32(float x);
+template <> __device__ __forceinline__ float from_f32<float>(float x) { return x; }
+template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float x) { return bf16_t{f32_to_bf16_bits(x)}; }
+template <> __device__ __forceinline__ f16_t from_f32<f16_t>(float x) {
+  return f16_t{__builtin_bit_cast(uint16_t, (_Float16)x)};
+}
+
+// Values as the MFMA will see them: round-trip through the storage type.
+template <typename T> __device__ __forceinline__ float quantize(float x) { return to_f32(from_f32<T>(x)); }
+
+// ---- 16-byte "k-chunk": the unit every tile/fragment path moves -------------------------------
+// bf16/f16: 8 elements = one K=16 MFMA operand per lane; f32: 4 elements = four K=2 MFMA operands.
+template <typename T> struct Chunk { static constexpr int N = 16 / sizeof(T); };
+
+template <typename T> __device__ __forceinline__ void unpack_chunk(const u32x4& c, float (&o)[Chunk<T>::N]);
+template <> __device__ __forceinline__ void unpack_chunk<float>(const u32x4& c, float (&o)[4]) {
+  o[0] = u2f(c.x); o[1] = u2f(c.y);
+  o[2] = u2f(c.z); o[3] = u2f(c.w);
+}
+template <> __device__ __forceinline__ void unpack_chunk<bf16_t>(const u32x4& c, float (&o)[8]) {
+  const uint32_t w[4] = {c.x, c.y, c.z, c.w};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    o[2 * i] = u2f(w[i] << 16);
+    o[2 * i + 1] = u2f(w[i] & 0xffff0000u);
+  }
+}
+template <> __device__ __forceinline__ void unpack_chunk<f16_t>(const u32x4& c, float (&o)[8]) {
+  const uint32_t w[4] = {c.x, c.y, c.z, c.w};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    o[2 * i] = (float)__builtin_bit_cast(_Float16, (uint16_t)(w[i] & 0xffffu));
+    o[2 * i + 1] = (float)__builtin_bit_cast(_Float16, (uint16_t)(w[i] >> 16));
+  }
+}
+
+__device__ __forceinline__ uint32_t pack2(float lo, float hi, bf16_t*) {
+  return (uint32_t)f32_to_bf16_bits(lo) | ((uint32_t)f32_to_bf16_bits(hi) << 16);
+}
+__device__ __forceinline__ uint32_t pack2(float lo, float hi, f16_t*) {
+  return (uint32_t)__builtin_bit_cast(uint16_t, (_Float16)lo) | ((uint32_t)__builtin_bit_cast(uint16_t, (_Float16)hi) << 16);
+}
+template <typename T> __device__ __forceinline__ u32x4 pack_chunk(const float* v);
+template <> __device__ __forceinline__ u32x4 pack_chunk<float>(const float* v) {
+  return mk4(f2u(v[0]), f2u(v[1]), f2u(v[2]), f2u(v[3]));
+}
+template <> __device__ __forceinline__ u32x4 pack_chunk<bf16_t>(const float* v) {
+  return mk4(pack2(v[0], v[1], (bf16_t*)0), pack2(v[2], v[3], (bf16_t*)0), pack2(v[4], v[5], (bf16_t*)0),
+                    pack2(v[6], v[7], (bf16_t*)0));
+}
+template <> __device__ __forceinline__ u32x4 pack_chunk<f16_t>(const float* v) {
+  return mk4(pack2(v[0], v[1], (f16_t*)0), pack2(v[2], v[3], (f16_t*)0), pack2(v[4], v[5], (f16_t*)0),
+                    pack2(v[6], v[7], (f16_t*)0));
+}
+
+// ---- MFMA on one pair of 16-byte chunks: acc(32x32) += A(32 x kc) * B(kc x 32) ----------------
+// Lane l supplies row (l & 31) of its operand and the k-slice selected by (l >> 5); both operands
+// use the same slice order, so any consistent k assignment is correct.
+template <typename T> __device__ __forceinline__ void mma_chunk(f32x16& acc, const u32x4& a, const u32x4& b);
+template <> __device__ __forceinline__ void mma_chunk<bf16_t>(f32x16& acc, const u32x4& a, const u32x4& b) {
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), acc, 0, 0, 0);
+}
+template <> __device__ __forceinline__ void mma_chunk<f16_t>(f32x16& acc, const u32x4& a, const u32x4& b) {
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), acc, 0, 0, 0);
+}
+template <> __device__ __forceinline__ void mma_chunk<float>(f32x16& acc, const u32x4& a, const u32x4& b) {
+  acc = __builtin_amdgcn_mfma_f32_32x32x2f32(u2f(a.x), u2f(b.x), acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x2f32(u2f(a.y), u2f(b.y), acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x2f32(u2f(a.z), u2f(b.z), acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x2f32(u2f(a.w), u2f(b.w), acc, 0, 0, 0);
+}
+// Row of a 32x32 accumulator register r held by lane l (column is l & 31): CDNA C/D layout.
+__device__ __forceinline__ int acc_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
+
+// ---- wave64 reductions ---------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+// ---- host side -----------------------------------------------------------------------------
+void set_error(const char* fmt, ...);
+#define ALPRO_CHECK(cond, ...)            \
+  do {                                    \
+    if (!(cond)) {                        \
+      alpro::set_error(__VA_ARGS__);      \
+      return ALPRO_ERR_INVALID;           \
+    }                                     \
+  } while (0)
+int check_launch(const char* what);
+
+// dispatch a templated launcher on the storage dtype
+#define ALPRO_DISPATCH_DTYPE(dt, T, ...)                                         \
+  switch (dt) {                                                                  \
+    case ALPRO_F32: { typedef float T; __VA_ARGS__; break; }                     \
+    case ALPRO_BF16: { typedef alpro::bf16_t T; __VA_ARGS__; break; }            \
+    case ALPRO_F16: { typedef alpro::f16_t T; __VA_ARGS__; break; }              \
+    default: alpro::set_error("bad dtype %d", (int)(dt)); return ALPRO_ERR_INVALID; \
+  }
+
+}  // namespace alpro

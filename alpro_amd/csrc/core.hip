@@ -1,0 +1,296 @@
+// Error plumbing + small memory-bound kernels (casts, patchify, CLS mean, BERT embeddings,
+// final-norm temporal pooling).  All are HBM-bound: one wave per 768-wide row, 16-byte accesses.
+#include <stdarg.h>
+#include <stdio.h>
+
+#include "common.hpp"
+
+namespace alpro {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+int check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    set_error("%s: launch failed: %s", what, hipGetErrorString(e));
+    return ALPRO_ERR_LAUNCH;
+  }
+  return ALPRO_OK;
+}
+
+namespace {
+
+// ---- cast ------------------------------------------------------------------------------------
+template <typename T>
+__global__ void cast_kernel(const float* __restrict__ src, T* __restrict__ dst, int64_t n) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x * 8;
+  for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 8; i < n; i += stride) {
+    if (i + 8 <= n) {
+      const float4 a = *(const float4*)(src + i), b = *(const float4*)(src + i + 4);
+      const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+      if constexpr (sizeof(T) == 4) {
+        *(float4*)(dst + i) = a;
+        *(float4*)(dst + i + 4) = b;
+      } else {
+        *(u32x4*)(dst + i) = pack_chunk<T>(v);
+      }
+    } else {
+      for (int64_t k = i; k < n; ++k) dst[k] = from_f32<T>(src[k]);
+    }
+  }
+}
+
+// ---- patchify: im2col rows of the 16x16/stride-16 conv -----------------------------------------
+// one thread per 16-byte output chunk... (8 or 4 consecutive j of one (c, i) patch row = contiguous pixels)
+template <typename T>
+__global__ void patchify_kernel(const float* __restrict__ img, T* __restrict__ out, int BT, int C, int H, int W) {
+  constexpr int E = Chunk<T>::N;  // elements per 16-byte chunk
+  const int gw = W / 16, gh = H / 16, N = gh * gw, K = C * 256;
+  const int chunks_per_row = K / E;
+  const int64_t total = (int64_t)BT * N * chunks_per_row;
+  for (int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; id < total; id += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t row = id / chunks_per_row;
+    const int kc = (int)(id - row * chunks_per_row) * E;  // k = c*256 + i*16 + j
+    const int bt = (int)(row / N), n = (int)(row - (int64_t)bt * N);
+    const int ph = n / gw, pw = n - ph * gw;
+    const int c = kc >> 8, i = (kc >> 4) & 15, j = kc & 15;
+    const float* src = img + (((int64_t)bt * C + c) * H + (ph * 16 + i)) * W + pw * 16 + j;
+    float v[E];
+#pragma unroll
+    for (int e = 0; e < E; e += 4) {
+      const float4 f = *(const float4*)(src + e);
+      v[e] = f.x; v[e + 1] = f.y; v[e + 2] = f.z; v[e + 3] = f.w;
+    }
+    *(u32x4*)(out + row * K + kc) = pack_chunk<T>(v);
+  }
+}
+
+// ---- CLS: x_out[b,0] = x_in[b,0] + mean_t side[b*T+t] --------------------------------------------
+__global__ void cls_mean_residual_kernel(const float* __restrict__ x_in, int64_t ldb_in, const float* __restrict__ side,
+                                         float* __restrict__ x_out, int64_t ldb_out, int B, int T, int D) {
+  const int b = blockIdx.x;
+  for (int d = threadIdx.x; d < D; d += blockDim.x) {
+    float s = 0.f;
+    for (int t = 0; t < T; ++t) s += side[((int64_t)b * T + t) * D + d];
+    x_out[b * ldb_out + d] = x_in[b * ldb_in + d] + s / (float)T;
+  }
+}
+
+// ---- row LayerNorm helpers (D = 768: 12 fp32 per lane, one wave per row) -------------------------
+constexpr int LN_D = 768, LN_V = 3;
+
+__device__ __forceinline__ void ln_load(const float* row, int lane, float (&v)[12]) {
+#pragma unroll
+  for (int i = 0; i < LN_V; ++i) {
+    const float4 f = *(const float4*)(row + i * 256 + lane * 4);
+    v[4 * i] = f.x; v[4 * i + 1] = f.y; v[4 * i + 2] = f.z; v[4 * i + 3] = f.w;
+  }
+}
+__device__ __forceinline__ void ln_stats(const float (&v)[12], float eps, float& mean, float& rstd) {
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 12; ++i) s += v[i];
+  mean = wave_sum(s) * (1.0f / LN_D);
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < 12; ++i) {
+    const float d = v[i] - mean;
+    q += d * d;
+  }
+  rstd = rsqrtf(wave_sum(q) * (1.0f / LN_D) + eps);
+}
+__device__ __forceinline__ void ln_affine(float (&v)[12], float mean, float rstd, const float* gamma, const float* beta, int lane) {
+#pragma unroll
+  for (int i = 0; i < LN_V; ++i) {
+    const float4 g = *(const float4*)(gamma + i * 256 + lane * 4), b = *(const float4*)(beta + i * 256 + lane * 4);
+    v[4 * i] = (v[4 * i] - mean) * rstd * g.x + b.x;
+    v[4 * i + 1] = (v[4 * i + 1] - mean) * rstd * g.y + b.y;
+    v[4 * i + 2] = (v[4 * i + 2] - mean) * rstd * g.z + b.z;
+    v[4 * i + 3] = (v[4 * i + 3] - mean) * rstd * g.w + b.w;
+  }
+}
+template <typename T>
+__device__ __forceinline__ void ln_store(T* row, int lane, const float (&v)[12]) {
+#pragma unroll
+  for (int i = 0; i < LN_V; ++i) {
+    if constexpr (sizeof(T) == 4) {
+      *(float4*)(row + i * 256 + lane * 4) = make_float4(v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]);
+    } else {
+      T* p = row + i * 256 + lane * 4;
+      u32x2 u;
+      u.x = pack2(v[4 * i], v[4 * i + 1], (T*)0);
+      u.y = pack2(v[4 * i + 2], v[4 * i + 3], (T*)0);
+      *(u32x2*)p = u;
+    }
+  }
+}
+
+__device__ __forceinline__ int64_t ln_src_row(int mode, int p0, int p1, int64_t m) {
+  if (mode == ALPRO_MAP_IDENTITY) return m;
+  if (mode == ALPRO_MAP_SKIP_CLS) return m + m / p0 + 1;
+  const int T = p0, N = p1;  // FRAME_TOKENS gather
+  const int64_t bt = m / (N + 1);
+  const int j = (int)(m - bt * (N + 1));
+  const int64_t b = bt / T;
+  const int t = (int)(bt - b * T);
+  const int64_t base = b * (1 + (int64_t)N * T);
+  return j == 0 ? base : base + 1 + (int64_t)(j - 1) * T + t;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, float eps, T* __restrict__ y, int64_t ldy,
+                                                            float* __restrict__ y32, float* __restrict__ mean_o,
+                                                            float* __restrict__ rstd_o, int64_t rows, int mode, int p0, int p1) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t nwaves = (int64_t)gridDim.x * 4;
+  for (int64_t m = wave; m < rows; m += nwaves) {
+    float v[12], mean, rstd;
+    ln_load(x + ln_src_row(mode, p0, p1, m) * ldx, lane, v);
+    ln_stats(v, eps, mean, rstd);
+    ln_affine(v, mean, rstd, gamma, beta, lane);
+    ln_store<T>(y + m * ldy, lane, v);
+    if (y32) ln_store<float>(y32 + m * LN_D, lane, v);
+    if (mean_o && lane == 0) {
+      mean_o[m] = mean;
+      rstd_o[m] = rstd;
+    }
+  }
+}
+
+// final norm + temporal mean pool: out row (b, 0) = LN(x[b,0]); (b, 1+n) = mean_t LN(x[b, 1+n*T+t])
+template <typename T>
+__global__ __launch_bounds__(256) void vit_final_pool_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, float eps, float* __restrict__ out32,
+                                                             T* __restrict__ out_t, int B, int Tn, int N) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t total = (int64_t)B * (N + 1);
+  if (wave >= total) return;
+  const int64_t b = wave / (N + 1);
+  const int j = (int)(wave - b * (N + 1));
+  const float* base = x + b * (1 + (int64_t)N * Tn) * LN_D;
+  float acc[12];
+#pragma unroll
+  for (int i = 0; i < 12; ++i) acc[i] = 0.f;
+  const int cnt = j == 0 ? 1 : Tn;
+  for (int t = 0; t < cnt; ++t) {
+    const float* row = j == 0 ? base : base + (1 + (int64_t)(j - 1) * Tn + t) * LN_D;
+    float v[12], mean, rstd;
+    ln_load(row, lane, v);
+    ln_stats(v, eps, mean, rstd);
+    ln_affine(v, mean, rstd, gamma, beta, lane);
+#pragma unroll
+    for (int i = 0; i < 12; ++i) acc[i] += v[i];
+  }
+  const float inv = 1.0f / (float)cnt;
+#pragma unroll
+  for (int i = 0; i < 12; ++i) acc[i] *= inv;
+  ln_store<float>(out32 + wave * LN_D, lane, acc);
+  if (out_t) ln_store<T>(out_t + wave * LN_D, lane, acc);
+}
+
+// BERT embeddings: word[id] + type0 + pos[l] -> LN
+template <typename T>
+__global__ __launch_bounds__(256) void bert_embed_kernel(const int64_t* __restrict__ ids, const float* __restrict__ word,
+                                                         const float* __restrict__ pos, const float* __restrict__ type0,
+                                                         const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                                         float* __restrict__ y32, T* __restrict__ y_t, float* __restrict__ mean_o,
+                                                         float* __restrict__ rstd_o, int rows, int L) {
+  const int lane = threadIdx.x & 63;
+  const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (m >= rows) return;
+  const int l = m % L;
+  float v[12], w[12], mean, rstd;
+  ln_load(word + ids[m] * LN_D, lane, v);
+  ln_load(type0, lane, w);
+#pragma unroll
+  for (int i = 0; i < 12; ++i) v[i] += w[i];
+  ln_load(pos + (int64_t)l * LN_D, lane, w);
+#pragma unroll
+  for (int i = 0; i < 12; ++i) v[i] += w[i];
+  ln_stats(v, eps, mean, rstd);
+  ln_affine(v, mean, rstd, gamma, beta, lane);
+  ln_store<float>(y32 + (int64_t)m * LN_D, lane, v);
+  if (y_t) ln_store<T>(y_t + (int64_t)m * LN_D, lane, v);
+  if (mean_o && lane == 0) {
+    mean_o[m] = mean;
+    rstd_o[m] = rstd;
+  }
+}
+
+inline int grid_for(int64_t work_items, int per_block, int cap = 256 * 16) {
+  int64_t g = (work_items + per_block - 1) / per_block;
+  if (g < 1) g = 1;
+  if (g > cap) g = cap;
+  return (int)g;
+}
+
+}  // namespace
+}  // namespace alpro
+
+using namespace alpro;
+
+extern "C" const char* alpro_hip_last_error(void) { return g_err; }
+extern "C" int alpro_hip_abi_version(void) { return ALPRO_HIP_ABI_VERSION; }
+
+extern "C" int alpro_cast_from_f32(const float* src, void* dst, int dtype, int64_t n, void* stream) {
+  ALPRO_CHECK(src && dst && n >= 0, "alpro_cast_from_f32: bad args");
+  if (n == 0) return ALPRO_OK;
+  ALPRO_CHECK(((uintptr_t)src % 16) == 0 && ((uintptr_t)dst % 16) == 0, "alpro_cast_from_f32: pointers must be 16-byte aligned");
+  ALPRO_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL(cast_kernel<T>, dim3(grid_for(n, 256 * 8)), dim3(256), 0, (hipStream_t)stream, src, (T*)dst, n));
+  return check_launch("alpro_cast_from_f32");
+}
+
+extern "C" int alpro_patchify(const float* img, void* out, int dtype, int BT, int C, int Himg, int Wimg, void* stream) {
+  ALPRO_CHECK(img && out && BT > 0 && C > 0, "alpro_patchify: bad args");
+  ALPRO_CHECK(Himg % 16 == 0 && Wimg % 16 == 0, "alpro_patchify: image %dx%d not a multiple of the 16x16 patch", Himg, Wimg);
+  const int64_t total = (int64_t)BT * (Himg / 16) * (Wimg / 16) * C * 256 / (dtype == ALPRO_F32 ? 4 : 8);
+  ALPRO_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL(patchify_kernel<T>, dim3(grid_for(total, 256, 256 * 32)), dim3(256), 0, (hipStream_t)stream, img, (T*)out, BT, C, Himg, Wimg));
+  return check_launch("alpro_patchify");
+}
+
+extern "C" int alpro_cls_mean_residual(const float* x_in, int64_t ld_batch_in, const float* side, float* x_out,
+                                       int64_t ld_batch_out, int B, int T, int D, void* stream) {
+  ALPRO_CHECK(x_in && side && x_out && B > 0 && T > 0 && D > 0, "alpro_cls_mean_residual: bad args");
+  hipLaunchKernelGGL(cls_mean_residual_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, x_in, ld_batch_in, side, x_out, ld_batch_out, B, T, D);
+  return check_launch("alpro_cls_mean_residual");
+}
+
+extern "C" int alpro_layernorm_fwd(const float* x, int64_t ldx, const float* gamma, const float* beta, float eps, void* y,
+                                   int y_dtype, int64_t ldy, float* y32, float* mean, float* rstd, int rows, int D,
+                                   int map_mode, int map_p0, int map_p1, void* stream) {
+  ALPRO_CHECK(x && gamma && beta && y && rows > 0, "alpro_layernorm_fwd: bad args");
+  ALPRO_CHECK(D == LN_D, "alpro_layernorm_fwd: D=%d unsupported (hidden size is 768 on this path)", D);
+  ALPRO_CHECK(map_mode >= 0 && map_mode <= ALPRO_MAP_FRAME_TOKENS, "alpro_layernorm_fwd: bad map_mode %d", map_mode);
+  ALPRO_CHECK((mean == nullptr) == (rstd == nullptr), "alpro_layernorm_fwd: mean and rstd go together");
+  ALPRO_CHECK(ldx % 4 == 0 && ldy % 4 == 0, "alpro_layernorm_fwd: row strides must be multiples of 4");
+  ALPRO_DISPATCH_DTYPE(y_dtype, T, hipLaunchKernelGGL(layernorm_fwd_kernel<T>, dim3(grid_for(rows, 4, 256 * 32)), dim3(256), 0, (hipStream_t)stream, x, ldx, gamma, beta, eps, (T*)y, ldy, y32, mean, rstd, (int64_t)rows, map_mode, map_p0, map_p1));
+  return check_launch("alpro_layernorm_fwd");
+}
+
+extern "C" int alpro_vit_final_pool(const float* x, const float* gamma, const float* beta, float eps, float* out32, void* out_t,
+                                    int dtype, int B, int T, int N, int D, void* stream) {
+  ALPRO_CHECK(x && gamma && beta && out32 && B > 0 && T > 0 && N > 0, "alpro_vit_final_pool: bad args");
+  ALPRO_CHECK(D == LN_D, "alpro_vit_final_pool: D=%d unsupported", D);
+  const int64_t total = (int64_t)B * (N + 1);
+  ALPRO_DISPATCH_DTYPE(dtype, T_, hipLaunchKernelGGL(vit_final_pool_kernel<T_>, dim3((unsigned)((total + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, eps, out32, (T_*)out_t, B, T, N));
+  return check_launch("alpro_vit_final_pool");
+}
+
+extern "C" int alpro_bert_embed_fwd(const int64_t* ids, const float* word, const float* pos, const float* type0,
+                                    const float* gamma, const float* beta, float eps, float* y32, void* y_t, int dtype,
+                                    float* mean, float* rstd, int rows, int L, int D, void* stream) {
+  ALPRO_CHECK(ids && word && pos && type0 && gamma && beta && y32 && rows > 0 && L > 0, "alpro_bert_embed_fwd: bad args");
+  ALPRO_CHECK(D == LN_D, "alpro_bert_embed_fwd: D=%d unsupported", D);
+  ALPRO_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL(bert_embed_kernel<T>, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, ids, word, pos, type0, gamma, beta, eps, y32, (T*)y_t, mean, rstd, rows, L));
+  return check_launch("alpro_bert_embed_fwd");
+}

@@ -1,0 +1,225 @@
+"""ctypes binding of libalpro_hip.so (include/alpro_hip.h) + thin tensor-level wrappers.
+
+There is NO CPU / eager fallback: if the library is missing or a kernel reports an error the
+call raises.  torch is used for device memory and streams only.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libalpro_hip.so")
+
+F32, BF16, F16 = 0, 1, 2
+ACT_NONE, ACT_GELU, ACT_RELU = 0, 1, 2
+MAP_IDENTITY, MAP_SKIP_CLS, MAP_FRAME_TOKENS, MAP_PATCH_EMBED = 0, 1, 2, 3
+
+_TORCH_DTYPE = {F32: torch.float32, BF16: torch.bfloat16, F16: torch.float16}
+_CODE = {v: k for k, v in _TORCH_DTYPE.items()}
+
+EXPORTS = ["alpro_hip_last_error", "alpro_hip_abi_version", "alpro_gemm", "alpro_layernorm_fwd",
+           "alpro_attn_temporal_fwd", "alpro_attn_fwd", "alpro_patchify", "alpro_cls_mean_residual",
+           "alpro_vit_final_pool", "alpro_bert_embed_fwd", "alpro_cast_from_f32"]
+
+
+class GemmDesc(ctypes.Structure):
+    _fields_ = [("A", ctypes.c_void_p), ("W", ctypes.c_void_p), ("C", ctypes.c_void_p),
+                ("lda", ctypes.c_int64), ("ldw", ctypes.c_int64), ("ldc", ctypes.c_int64),
+                ("M", ctypes.c_int), ("N", ctypes.c_int), ("K", ctypes.c_int),
+                ("dtype", ctypes.c_int), ("c_dtype", ctypes.c_int), ("alpha", ctypes.c_float),
+                ("bias", ctypes.c_void_p), ("act", ctypes.c_int),
+                ("row_scale", ctypes.c_void_p), ("row_scale_group", ctypes.c_int),
+                ("residual", ctypes.c_void_p), ("ldr", ctypes.c_int64),
+                ("map_mode", ctypes.c_int), ("map_p0", ctypes.c_int), ("map_p1", ctypes.c_int),
+                ("side", ctypes.c_void_p), ("ld_side", ctypes.c_int64)]
+
+
+_lib = None
+
+
+def load():
+    """Load libalpro_hip.so (built by `python -m alpro_amd.build`); raises if absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError("libalpro_hip.so not found at %s -- run `python -m alpro_amd.build` "
+                           "(there is no CPU fallback for the ALPRO hot path)" % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    lib.alpro_hip_last_error.restype = ctypes.c_char_p
+    for name in EXPORTS:
+        getattr(lib, name)  # AttributeError if the ABI is incomplete
+    vp, i32, i64, f32 = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float
+    lib.alpro_gemm.argtypes = [ctypes.POINTER(GemmDesc), vp]
+    lib.alpro_layernorm_fwd.argtypes = [vp, i64, vp, vp, f32, vp, i32, i64, vp, vp, vp, i32, i32, i32, i32, i32, vp]
+    lib.alpro_attn_temporal_fwd.argtypes = [vp, vp, i32, i64, i32, i32, f32, vp]
+    lib.alpro_attn_fwd.argtypes = [vp, vp, i32, i32, i32, i32, f32, vp, vp, vp]
+    lib.alpro_patchify.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp]
+    lib.alpro_cls_mean_residual.argtypes = [vp, i64, vp, vp, i64, i32, i32, i32, vp]
+    lib.alpro_vit_final_pool.argtypes = [vp, vp, vp, f32, vp, vp, i32, i32, i32, i32, i32, vp]
+    lib.alpro_bert_embed_fwd.argtypes = [vp, vp, vp, vp, vp, vp, f32, vp, vp, i32, vp, vp, i32, i32, i32, vp]
+    lib.alpro_cast_from_f32.argtypes = [vp, vp, i32, i64, vp]
+    if lib.alpro_hip_abi_version() != 1:
+        raise RuntimeError("libalpro_hip.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise RuntimeError("%s failed (%d): %s" % (what, rc, load().alpro_hip_last_error().decode()))
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _dev(t, dtype=None):
+    if not t.is_cuda:
+        raise RuntimeError("alpro_amd ops need device tensors (got %s): the hot path has no CPU fallback" % t.device)
+    if dtype is not None and t.dtype != dtype:
+        raise RuntimeError("expected %s, got %s" % (dtype, t.dtype))
+    if not t.is_contiguous():
+        raise RuntimeError("expected a contiguous tensor")
+    return t
+
+
+def dtype_code(torch_dtype):
+    return _CODE[torch_dtype]
+
+
+def torch_dtype(code):
+    return _TORCH_DTYPE[code]
+
+
+# ------------------------------------------------------------------------------------------------
+def gemm(a, w, out=None, bias=None, act=ACT_NONE, out_dtype=None, alpha=1.0, row_scale=None, row_scale_group=1,
+         residual=None, map_mode=MAP_IDENTITY, map_p0=0, map_p1=0, side=None, out_rows=None):
+    """out[map(m)] = residual[map(m)] + row_scale * act(alpha * a @ w.T + bias)   (see alpro_gemm)."""
+    lib = load()
+    _dev(a); _dev(w, a.dtype)
+    M, K = a.shape
+    N = w.shape[0]
+    assert w.shape[1] == K
+    out_dtype = out_dtype or a.dtype
+    if out is None:
+        out = torch.empty((out_rows if out_rows is not None else M, N), dtype=out_dtype, device=a.device)
+    _dev(out, out_dtype)
+    d = GemmDesc()
+    d.A, d.W, d.C = a.data_ptr(), w.data_ptr(), out.data_ptr()
+    d.lda, d.ldw, d.ldc = a.stride(0), w.stride(0), out.shape[-1]
+    d.M, d.N, d.K = M, N, K
+    d.dtype, d.c_dtype, d.alpha = _CODE[a.dtype], _CODE[out_dtype], alpha
+    d.bias = _dev(bias, torch.float32).data_ptr() if bias is not None else None
+    d.act = act
+    d.row_scale = _dev(row_scale, torch.float32).data_ptr() if row_scale is not None else None
+    d.row_scale_group = row_scale_group
+    d.residual = _dev(residual, torch.float32).data_ptr() if residual is not None else None
+    d.ldr = residual.shape[-1] if residual is not None else 0
+    d.map_mode, d.map_p0, d.map_p1 = map_mode, map_p0, map_p1
+    d.side = _dev(side, torch.float32).data_ptr() if side is not None else None
+    d.ld_side = side.shape[-1] if side is not None else 0
+    _check(lib.alpro_gemm(ctypes.byref(d), _stream()), "alpro_gemm")
+    return out
+
+
+def layernorm(x, gamma, beta, eps, out_dtype, rows=None, out32=False, stats=False, map_mode=MAP_IDENTITY, map_p0=0, map_p1=0):
+    """x: fp32 (..., 768) token tensor; returns y (rows, 768) [, y32] [, mean, rstd]."""
+    lib = load()
+    _dev(x, torch.float32)
+    D = x.shape[-1]
+    rows = rows if rows is not None else x.numel() // D
+    y = torch.empty((rows, D), dtype=out_dtype, device=x.device)
+    y32 = torch.empty((rows, D), dtype=torch.float32, device=x.device) if out32 else None
+    mean = torch.empty(rows, dtype=torch.float32, device=x.device) if stats else None
+    rstd = torch.empty(rows, dtype=torch.float32, device=x.device) if stats else None
+    _check(lib.alpro_layernorm_fwd(_ptr(x), D, _ptr(_dev(gamma, torch.float32)), _ptr(_dev(beta, torch.float32)), eps, _ptr(y),
+                                   _CODE[out_dtype], D, _ptr(y32), _ptr(mean), _ptr(rstd), rows, D, map_mode, map_p0, map_p1,
+                                   _stream()), "alpro_layernorm_fwd")
+    res = (y,)
+    if out32:
+        res += (y32,)
+    if stats:
+        res += (mean, rstd)
+    return res if len(res) > 1 else y
+
+
+def attn_temporal(qkv, T, H, scale):
+    lib = load()
+    _dev(qkv)
+    rows = qkv.shape[0]
+    out = torch.empty((rows, H * 64), dtype=qkv.dtype, device=qkv.device)
+    _check(lib.alpro_attn_temporal_fwd(_ptr(qkv), _ptr(out), _CODE[qkv.dtype], rows, T, H, scale, _stream()), "alpro_attn_temporal_fwd")
+    return out
+
+
+def attn(qkv, batch, L, H, scale, key_bias=None, want_lse=False):
+    lib = load()
+    _dev(qkv)
+    assert qkv.shape[0] == batch * L
+    out = torch.empty((batch * L, H * 64), dtype=qkv.dtype, device=qkv.device)
+    lse = torch.empty((batch, H, L), dtype=torch.float32, device=qkv.device) if want_lse else None
+    kb = _dev(key_bias, torch.float32) if key_bias is not None else None
+    _check(lib.alpro_attn_fwd(_ptr(qkv), _ptr(out), _CODE[qkv.dtype], batch, L, H, scale, _ptr(kb), _ptr(lse), _stream()), "alpro_attn_fwd")
+    return (out, lse) if want_lse else out
+
+
+def patchify(img, dtype):
+    """img (BT, C, H, W) fp32 -> (BT * (H/16) * (W/16), C*256) im2col rows."""
+    lib = load()
+    _dev(img, torch.float32)
+    BT, C, Hh, Ww = img.shape
+    out = torch.empty((BT * (Hh // 16) * (Ww // 16), C * 256), dtype=dtype, device=img.device)
+    _check(lib.alpro_patchify(_ptr(img), _ptr(out), _CODE[dtype], BT, C, Hh, Ww, _stream()), "alpro_patchify")
+    return out
+
+
+def cls_mean_residual(x_in, side, x_out, B, T):
+    lib = load()
+    D = x_in.shape[-1]
+    _check(lib.alpro_cls_mean_residual(_ptr(_dev(x_in, torch.float32)), x_in.stride(0), _ptr(_dev(side, torch.float32)), _ptr(x_out), x_out.stride(0),
+                                       B, T, D, _stream()), "alpro_cls_mean_residual")
+    return x_out
+
+
+def vit_final_pool(x, gamma, beta, eps, B, T, N, dtype):
+    lib = load()
+    _dev(x, torch.float32)
+    D = x.shape[-1]
+    out32 = torch.empty((B, N + 1, D), dtype=torch.float32, device=x.device)
+    out_t = torch.empty((B, N + 1, D), dtype=dtype, device=x.device) if dtype != torch.float32 else None
+    _check(lib.alpro_vit_final_pool(_ptr(x), _ptr(gamma), _ptr(beta), eps, _ptr(out32), _ptr(out_t), _CODE[dtype], B, T, N, D, _stream()),
+           "alpro_vit_final_pool")
+    return out32, (out_t if out_t is not None else out32)
+
+
+def bert_embed(ids, word, pos, type_emb, gamma, beta, eps, dtype, stats=False):
+    lib = load()
+    _dev(ids, torch.int64)
+    B, L = ids.shape
+    D = word.shape[1]
+    rows = B * L
+    y32 = torch.empty((rows, D), dtype=torch.float32, device=ids.device)
+    y_t = torch.empty((rows, D), dtype=dtype, device=ids.device) if dtype != torch.float32 else None
+    mean = torch.empty(rows, dtype=torch.float32, device=ids.device) if stats else None
+    rstd = torch.empty(rows, dtype=torch.float32, device=ids.device) if stats else None
+    _check(lib.alpro_bert_embed_fwd(_ptr(ids), _ptr(_dev(word, torch.float32)), _ptr(_dev(pos, torch.float32)), _ptr(_dev(type_emb, torch.float32)),
+                                    _ptr(gamma), _ptr(beta), eps, _ptr(y32), _ptr(y_t), _CODE[dtype], _ptr(mean), _ptr(rstd), rows, L, D,
+                                    _stream()), "alpro_bert_embed_fwd")
+    return y32, (y_t if y_t is not None else y32)
+
+
+def cast(src, dtype):
+    """fp32 -> dtype copy on device (parameters are kept fp32; 16-bit operand copies are refreshed per step)."""
+    lib = load()
+    _dev(src, torch.float32)
+    if dtype == torch.float32:
+        return src
+    dst = torch.empty(src.shape, dtype=dtype, device=src.device)
+    _check(lib.alpro_cast_from_f32(_ptr(src), _ptr(dst), _CODE[dtype], src.numel(), _stream()), "alpro_cast_from_f32")
+    return dst

@@ -1,0 +1,127 @@
+/*
+ * alpro_hip.h -- C ABI of libalpro_hip.so: the MI355X (gfx950) kernels behind ALPRO's
+ * video-text hot path.  Plain pointers and sizes only; every pointer is a DEVICE pointer owned
+ * by the caller (torch allocates), `stream` is a hipStream_t passed as void*, nothing is
+ * allocated internally, every entry point is asynchronous on `stream` and re-entrant.
+ * Return value: 0 = ok, nonzero = error (text via alpro_hip_last_error()).
+ *
+ * The reference (salesforce/ALPRO) is pure Python: the "FFI" these entry points replace is the
+ * set of torch/ATen calls its nn.Modules make on this path.  Each declaration cites the reference
+ * call sites it stands in for (paths relative to the reference root).  INTEGRATION.md shows
+ * the ctypes binding.
+ *
+ * Storage dtypes: GEMM/attention operands are ALPRO_BF16 (throughput), ALPRO_F16, or ALPRO_F32
+ * (exact mode: fp32 MFMA, used to prove parity at 1e-3 on VTC logits).  The residual stream,
+ * LayerNorm statistics, softmax, accumulators, losses and all gradients w.r.t. parameters are
+ * always fp32.
+ */
+#ifndef ALPRO_HIP_H
+#define ALPRO_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ALPRO_HIP_ABI_VERSION 1
+
+enum { ALPRO_OK = 0, ALPRO_ERR_INVALID = 1, ALPRO_ERR_LAUNCH = 2 };
+enum { ALPRO_F32 = 0, ALPRO_BF16 = 1, ALPRO_F16 = 2 };
+enum { ALPRO_ACT_NONE = 0, ALPRO_ACT_GELU = 1, ALPRO_ACT_RELU = 2 };
+
+/* Row maps: how GEMM/LayerNorm row m addresses the (B, 1 + N*T, D) token tensor whose patch token
+ * (n, t) lives at row 1 + n*T + t of its clip (vit.py:147 'b (h w t) m').
+ *   IDENTITY        row = m
+ *   SKIP_CLS        p0 = N*T.  m enumerates x[:, 1:]           -> row = m + m / p0 + 1     (vit.py:146,162)
+ *   FRAME_TOKENS    p0 = T, p1 = N.  m = (b*T + t)*(N+1) + j   -> j == 0: CLS of clip b (gather) /
+ *                   side-buffer row b*T+t (scatter); j > 0: row = b*(1+N*T) + 1 + (j-1)*T + t
+ *                                                                              (vit.py:165-172,184-196)
+ *   PATCH_EMBED     p0 = T, p1 = N.  m = (b*T + t)*N + n       -> out row = b*(1+N*T) + 1 + n*T + t,
+ *                   residual row = n*T + t (a (N*T, D) table)              (vit.py:233-239,342,349-361)
+ */
+enum { ALPRO_MAP_IDENTITY = 0, ALPRO_MAP_SKIP_CLS = 1, ALPRO_MAP_FRAME_TOKENS = 2, ALPRO_MAP_PATCH_EMBED = 3 };
+
+const char* alpro_hip_last_error(void);
+int alpro_hip_abi_version(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * C[map(m), n] = residual[map(m), n] + row_scale[m / row_scale_group] * act(alpha * sum_k A[m,k] W[n,k] + bias[n])
+ * A (M,K) and W (N,K) are K-contiguous in `dtype`; accumulation is fp32 on MFMA
+ * (v_mfma_f32_32x32x16_{bf16,f16} / v_mfma_f32_32x32x2_f32).  K % (128 / sizeof(dtype)) == 0.
+ * Replaces every nn.Linear on the path: vit.py:60-63 (Mlp), :84,:98 (Attention.qkv/proj), :161
+ * (temporal_fc), :230-239 (PatchEmbed conv as GEMM over alpro_patchify rows); xbert.py:273-294
+ * (query/key/value, fused as one N=3*H GEMM), :357, :422, :435, :659, :681; alpro_models.py:38-39,42,66-71.
+ * The residual add / drop_path scale / GELU that follow those Linears in the reference
+ * (vit.py:157-162,181-196,212; vit_utils.py:137-151) are fused here.
+ */
+typedef struct {
+  const void* A;
+  const void* W;
+  void* C;
+  int64_t lda, ldw, ldc;
+  int M, N, K;
+  int dtype;   /* storage dtype of A and W */
+  int c_dtype; /* dtype of C: `dtype` or ALPRO_F32 */
+  float alpha;
+  const float* bias;      /* (N) fp32 or NULL */
+  int act;                /* ALPRO_ACT_* */
+  const float* row_scale; /* fp32 or NULL; entry m / row_scale_group */
+  int row_scale_group;
+  const float* residual;  /* fp32 or NULL */
+  int64_t ldr;
+  int map_mode, map_p0, map_p1; /* ALPRO_MAP_* applied to C rows and residual rows */
+  float* side;            /* FRAME_TOKENS: (B*T, N) fp32 buffer receiving the j == 0 rows (no residual) */
+  int64_t ld_side;
+} alpro_gemm_desc_t;
+
+int alpro_gemm(const alpro_gemm_desc_t* d, void* stream);
+
+/* y[m] = LayerNorm(x[map(m)]) * gamma + beta over D == 768 fp32 inputs; writes `y` in y_dtype and,
+ * if non-NULL, an fp32 copy y32 plus mean/rstd (rows) for the backward pass.
+ * Replaces nn.LayerNorm at vit.py:154,180,200,372 (eps 1e-6) and xbert.py:211,359,437,661 (eps 1e-12);
+ * the rearrange/cat copies of vit.py:147,165-172 become the gather map. */
+int alpro_layernorm_fwd(const float* x, int64_t ldx, const float* gamma, const float* beta, float eps, void* y,
+                        int y_dtype, int64_t ldy, float* y32, float* mean, float* rstd, int rows, int D,
+                        int map_mode, int map_p0, int map_p1, void* stream);
+
+/* Divided space-time attention, temporal half (vit.py:146-157 -> Attention.forward :81-96):
+ * rows = B*N*T tokens in (b, n, t) order, each group of T consecutive rows attends within itself.
+ * qkv (rows, 3*H*64) as written by the qkv Linear, out (rows, H*64) == 'transpose(1,2).reshape'.
+ * T must divide 32.  softmax(q k^T * scale) v on MFMA with a block-diagonal group mask. */
+int alpro_attn_temporal_fwd(const void* qkv, void* out, int dtype, int64_t rows, int T, int H, float scale,
+                            void* stream);
+
+/* Full (bidirectional) attention over `batch` sequences of L <= 256 tokens, head_dim 64:
+ * spatial half of divided attention (vit.py:180 on (B*T, 1+N) tokens, :81-96) and the BERT
+ * text / fusion self-attention (xbert.py:299-341) where key_bias (batch, L) is the additive
+ * (1 - mask) * -10000 of xbert.py:936-937 (NULL = no mask).  K/V of one (sequence, head) stay
+ * resident in LDS; QK^T and PV run on MFMA; softmax in fp32 registers.  lse (batch, H, L) optional. */
+int alpro_attn_fwd(const void* qkv, void* out, int dtype, int batch, int L, int H, float scale,
+                   const float* key_bias, float* lse, void* stream);
+
+/* out[(b*T+t)*N + n, c*256 + i*16 + j] = img[b, t, c, ph*16 + i, pw*16 + j], n = ph*(W/16) + pw:
+ * the im2col rows of the stride-16 Conv2d (vit.py:230-238), cast to `dtype`. */
+int alpro_patchify(const float* img, void* out, int dtype, int BT, int C, int Himg, int Wimg, void* stream);
+
+/* x_out[b, 0, :] = x_in[b, 0, :] + mean_t side[b*T + t, :]   (vit.py:184-187,195-196) */
+int alpro_cls_mean_residual(const float* x_in, int64_t ld_batch_in, const float* side, float* x_out,
+                            int64_t ld_batch_out, int B, int T, int D, void* stream);
+
+/* Final LayerNorm + temporal mean pool (vit.py:372 + :484-492): x (B, 1+N*T, D) ->
+ * out32 (B, 1+N, D) fp32 [and out_t in `dtype` if non-NULL]. */
+int alpro_vit_final_pool(const float* x, const float* gamma, const float* beta, float eps, float* out32,
+                         void* out_t, int dtype, int B, int T, int N, int D, void* stream);
+
+/* BERT embeddings (xbert.py:186-213): word[ids] + type[0] + pos[l] -> LayerNorm -> y32 (+ y_t). */
+int alpro_bert_embed_fwd(const int64_t* ids, const float* word, const float* pos, const float* type0,
+                         const float* gamma, const float* beta, float eps, float* y32, void* y_t, int dtype,
+                         float* mean, float* rstd, int rows, int L, int D, void* stream);
+
+/* dst[i] = (dtype) src[i]: parameter / activation cast used when the storage dtype is 16-bit. */
+int alpro_cast_from_f32(const float* src, void* dst, int dtype, int64_t n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ALPRO_HIP_H */

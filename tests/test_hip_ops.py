@@ -1,0 +1,230 @@
+"""GPU: every C-ABI kernel against the oracle's arithmetic (torch fp64 on CPU) on seeded inputs.
+
+16-bit storage dtypes: inputs are pre-rounded to the dtype so both sides see identical operands;
+the remaining difference is fp32 accumulation order (+ one output rounding when the output is
+16-bit), hence the tolerances below.  f32 is the exact mode: fp32 MFMA == fmaf chain.
+"""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+torch.backends.cuda.matmul.allow_tf32 = False
+
+
+def _hip():
+    from alpro_amd import hip
+    hip.load()
+    return hip
+
+
+DTYPES = [torch.float32, torch.bfloat16, torch.float16]
+OUT_TOL = {torch.float32: (2e-5, 2e-5), torch.bfloat16: (1e-2, 1e-2), torch.float16: (2e-3, 2e-3)}
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+def q(x, dt):
+    return x.to(dt).to(torch.float64)
+
+
+def close(got, ref, rtol, atol, what=""):
+    got = got.detach().cpu().to(torch.float64)
+    ref = ref.to(torch.float64)
+    err = (got - ref).abs()
+    bad = err > atol + rtol * ref.abs()
+    assert not bad.any(), "%s: %d/%d mismatches, max err %.3e (ref max %.3e)" % (what, int(bad.sum()), bad.numel(), float(err.max()), float(ref.abs().max()))
+
+
+def gelu(x):
+    return 0.5 * x * (1 + torch.erf(x / math.sqrt(2.0)))
+
+
+# ------------------------------------------------------------------------------------------------ GEMM
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("M,N,K", [(300, 200, 768), (128, 256, 3072), (77, 1002, 768), (1, 2, 768)])
+def test_gemm_bias_act(dt, M, N, K):
+    hip = _hip()
+    a, w, b = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.05), rnd(N, seed=3)
+    ref = q(a, dt) @ q(w, dt).T + b.double()
+    for act, f in ((hip.ACT_NONE, lambda x: x), (hip.ACT_GELU, gelu), (hip.ACT_RELU, torch.relu)):
+        out = hip.gemm(a.to(dt).cuda(), w.to(dt).cuda(), bias=b.cuda(), act=act, out_dtype=torch.float32)
+        close(out, f(ref), 2e-5, 2e-4 if dt != torch.float32 else 2e-5, "gemm f32-out act=%d" % act)
+    out = hip.gemm(a.to(dt).cuda(), w.to(dt).cuda(), bias=b.cuda(), act=hip.ACT_GELU)
+    assert out.dtype == dt
+    close(out, gelu(ref), *OUT_TOL[dt], "gemm T-out")
+
+
+def test_gemm_transpose_detecting():
+    """A = I (padded) with an asymmetric W must reproduce W^T exactly: catches row/col swaps in the C layout."""
+    hip = _hip()
+    K = 768
+    a = torch.zeros(130, K)
+    a[torch.arange(130), torch.arange(130)] = 1.0
+    w = (torch.arange(200 * K, dtype=torch.float32).reshape(200, K) % 251) - 125.0
+    out = hip.gemm(a.cuda(), w.cuda(), out_dtype=torch.float32)
+    assert torch.equal(out.cpu(), w[:, :130].T.contiguous())
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_gemm_residual_rowscale_alpha(dt):
+    hip = _hip()
+    M, N, K = 260, 768, 768
+    a, w, b, r = rnd(M, K, seed=4), rnd(N, K, seed=5, scale=0.05), rnd(N, seed=6), rnd(M, N, seed=7)
+    rs = (torch.rand(M // 65 + 1) > 0.3).float() / 0.7
+    ref = r.double() + rs.double().repeat_interleave(65)[:M, None] * (0.5 * (q(a, dt) @ q(w, dt).T) + b.double())
+    out = hip.gemm(a.to(dt).cuda(), w.to(dt).cuda(), bias=b.cuda(), alpha=0.5, out_dtype=torch.float32, row_scale=rs.cuda(), row_scale_group=65,
+                   residual=r.cuda())
+    close(out, ref, 2e-5, 2e-4, "gemm residual")
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_gemm_row_maps(dt):
+    """SKIP_CLS / FRAME_TOKENS / PATCH_EMBED row maps against the reference's rearranges (vit.py:146-196,349-361)."""
+    hip = _hip()
+    B, T, N, D = 2, 4, 9, 768
+    S = 1 + N * T
+    w, bias = rnd(D, D, seed=8, scale=0.05), rnd(D, seed=9)
+    x = rnd(B, S, D, seed=10)
+    # SKIP_CLS: rows enumerate x[:, 1:]; out = x[:, 1:] + lin(a)
+    a = rnd(B * N * T, D, seed=11)
+    out = x.clone().cuda()
+    hip.gemm(a.to(dt).cuda(), w.to(dt).cuda(), out=out.view(B * S, D), bias=bias.cuda(), out_dtype=torch.float32, residual=x.cuda().view(B * S, D),
+             map_mode=hip.MAP_SKIP_CLS, map_p0=N * T)
+    lin = (q(a, dt) @ q(w, dt).T + bias.double()).view(B, N * T, D)
+    ref = x.double().clone()
+    ref[:, 1:] += lin
+    close(out, ref, 2e-5, 2e-4, "skip_cls")
+    # FRAME_TOKENS scatter: rows (b t)(1+n); CLS rows -> side, patches -> x[b, 1 + n*T + t] + lin
+    a = rnd(B * T * (N + 1), D, seed=12)
+    out = torch.zeros(B, S, D).cuda()
+    side = torch.zeros(B * T, D).cuda()
+    hip.gemm(a.to(dt).cuda(), w.to(dt).cuda(), out=out.view(B * S, D), bias=bias.cuda(), out_dtype=torch.float32, residual=x.cuda().view(B * S, D),
+             map_mode=hip.MAP_FRAME_TOKENS, map_p0=T, map_p1=N, side=side)
+    lin = (q(a, dt) @ q(w, dt).T + bias.double()).view(B, T, N + 1, D)
+    ref = torch.zeros(B, S, D, dtype=torch.float64)
+    ref[:, 1:] = x.double()[:, 1:] + lin[:, :, 1:].permute(0, 2, 1, 3).reshape(B, N * T, D)
+    close(out, ref, 2e-5, 2e-4, "frame_tokens patches")
+    close(side, lin[:, :, 0].reshape(B * T, D), 2e-5, 2e-4, "frame_tokens cls side")
+    # PATCH_EMBED: rows (b t) n -> x[b, 1 + n*T + t] = lin + table[n*T + t]
+    a = rnd(B * T * N, D, seed=13)
+    table = rnd(N * T, D, seed=14)
+    out = torch.zeros(B, S, D).cuda()
+    hip.gemm(a.to(dt).cuda(), w.to(dt).cuda(), out=out.view(B * S, D), out_dtype=torch.float32, residual=table.cuda(), map_mode=hip.MAP_PATCH_EMBED,
+             map_p0=T, map_p1=N)
+    lin = (q(a, dt) @ q(w, dt).T).view(B, T, N, D).permute(0, 2, 1, 3).reshape(B, N * T, D)
+    ref = torch.zeros(B, S, D, dtype=torch.float64)
+    ref[:, 1:] = lin + table.double()
+    close(out, ref, 2e-5, 2e-4, "patch_embed")
+
+
+def test_gemm_rejects_bad_k():
+    hip = _hip()
+    with pytest.raises(RuntimeError, match="K="):
+        hip.gemm(torch.zeros(4, 100).cuda(), torch.zeros(4, 100).cuda())
+
+
+# ------------------------------------------------------------------------------------------------ LayerNorm & friends
+@pytest.mark.parametrize("dt", DTYPES)
+def test_layernorm_maps(dt):
+    hip = _hip()
+    B, T, N, D = 2, 4, 9, 768
+    S = 1 + N * T
+    x = rnd(B, S, D, seed=20) * 3 + 0.5
+    g, b = 1 + 0.1 * rnd(D, seed=21), 0.1 * rnd(D, seed=22)
+    ln = torch.nn.functional.layer_norm(x.double(), (D,), g.double(), b.double(), 1e-6)
+    y, y32, mean, rstd = hip.layernorm(x.cuda(), g.cuda(), b.cuda(), 1e-6, dt, out32=True, stats=True)
+    close(y32, ln.view(-1, D), 1e-5, 1e-5, "ln identity f32")
+    close(y, ln.view(-1, D), *OUT_TOL[dt], "ln identity T")
+    close(mean, x.double().mean(-1).flatten(), 1e-5, 1e-5)
+    close(rstd, 1 / torch.sqrt(x.double().var(-1, unbiased=False) + 1e-6).flatten(), 1e-5, 1e-5)
+    y = hip.layernorm(x.cuda(), g.cuda(), b.cuda(), 1e-6, torch.float32, rows=B * N * T, map_mode=hip.MAP_SKIP_CLS, map_p0=N * T)
+    close(y, ln[:, 1:].reshape(-1, D), 1e-5, 1e-5, "ln skip_cls")
+    y = hip.layernorm(x.cuda(), g.cuda(), b.cuda(), 1e-6, torch.float32, rows=B * T * (N + 1), map_mode=hip.MAP_FRAME_TOKENS, map_p0=T, map_p1=N)
+    xs = ln[:, 1:].reshape(B, N, T, D).permute(0, 2, 1, 3)
+    ref = torch.cat([ln[:, :1].unsqueeze(1).expand(B, T, 1, D), xs], 2).reshape(-1, D)
+    close(y, ref, 1e-5, 1e-5, "ln frame_tokens gather")
+
+
+def test_small_kernels():
+    hip = _hip()
+    B, T, N, D = 3, 4, 6, 768
+    S = 1 + N * T
+    x = rnd(B, S, D, seed=30)
+    side = rnd(B * T, D, seed=31)
+    out = torch.zeros(B, S, D).cuda()
+    hip.cls_mean_residual(x.cuda(), side.cuda(), out, B, T)
+    close(out[:, 0], x[:, 0].double() + side.double().view(B, T, D).mean(1), 1e-6, 1e-6, "cls mean")
+    g, b = 1 + 0.1 * rnd(D, seed=32), 0.1 * rnd(D, seed=33)
+    o32, ot = hip.vit_final_pool(x.cuda(), g.cuda(), b.cuda(), 1e-6, B, T, N, torch.bfloat16)
+    ln = torch.nn.functional.layer_norm(x.double(), (D,), g.double(), b.double(), 1e-6)
+    ref = torch.cat([ln[:, :1], ln[:, 1:].reshape(B, N, T, D).mean(2)], 1)
+    close(o32, ref, 1e-5, 1e-5, "final pool")
+    close(ot, ref, 1e-2, 1e-2, "final pool bf16")
+    img = rnd(2, 3, 32, 48, seed=34)
+    p = hip.patchify(img.cuda(), torch.float32)
+    ref = torch.nn.functional.unfold(img, 16, stride=16).transpose(1, 2).reshape(-1, 768)  # (c, i, j) fastest = conv weight order
+    assert torch.equal(p.cpu(), ref)
+    pb = hip.patchify(img.cuda(), torch.bfloat16)
+    assert torch.equal(pb.cpu(), ref.to(torch.bfloat16))
+    v = rnd(1000003, seed=35)
+    assert torch.equal(hip.cast(v.cuda(), torch.bfloat16).cpu(), v.to(torch.bfloat16))
+    assert torch.equal(hip.cast(v.cuda(), torch.float16).cpu(), v.to(torch.float16))
+    ids = torch.randint(0, 500, (3, 40))
+    word, pos, typ = rnd(500, D, seed=36), rnd(64, D, seed=37), rnd(2, D, seed=38)
+    y32, yt = hip.bert_embed(ids.cuda(), word.cuda(), pos.cuda(), typ.cuda(), g.cuda(), b.cuda(), 1e-12, torch.bfloat16)
+    e = word[ids].double() + typ[0].double() + pos[:40].double()
+    ref = torch.nn.functional.layer_norm(e, (D,), g.double(), b.double(), 1e-12).view(-1, D)
+    close(y32, ref, 1e-5, 1e-5, "bert embed")
+    close(yt, ref, 1e-2, 1e-2, "bert embed bf16")
+
+
+# ------------------------------------------------------------------------------------------------ attention
+def ref_attention(qkv, batch, L, H, scale, bias=None, group=None):
+    """qkv (batch*L, 3*H*64) float64 -> (batch*L, H*64); same arithmetic as vit.py:84-96 / xbert.py:299-341."""
+    t = qkv.view(batch, L, 3, H, 64).permute(2, 0, 3, 1, 4)
+    s = (t[0] @ t[1].transpose(-1, -2)) * scale
+    if bias is not None:
+        s = s + bias[:, None, None, :].double()
+    if group is not None:
+        idx = torch.arange(L) // group
+        s = s.masked_fill(idx[:, None] != idx[None, :], float("-inf"))
+    p = s.softmax(-1)
+    return (p @ t[2]).transpose(1, 2).reshape(batch * L, H * 64), torch.logsumexp(s, -1)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("batch,L,masked", [(3, 40, True), (2, 197, False), (2, 237, True), (1, 100, False), (2, 256, False)])
+def test_attn_full(dt, batch, L, masked):
+    hip = _hip()
+    H = 12
+    qkv = rnd(batch * L, 3 * H * 64, seed=40 + L).to(dt)
+    bias = None
+    if masked:
+        m = torch.ones(batch, L)
+        for b in range(batch):
+            m[b, L - 3 - 5 * b:] = 0
+        bias = (1.0 - m) * -10000.0
+    out, lse = hip.attn(qkv.cuda(), batch, L, H, 0.125, None if bias is None else bias.cuda(), want_lse=True)
+    ref, ref_lse = ref_attention(qkv.double(), batch, L, H, 0.125, bias)
+    tol = {torch.float32: (2e-5, 2e-5), torch.bfloat16: (2e-2, 2e-2), torch.float16: (3e-3, 3e-3)}[dt]  # P and O are rounded to dt
+    close(out, ref, *tol, "attn out")
+    close(lse, ref_lse, 1e-5, 1e-4, "attn lse")
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("T,groups", [(8, 11), (4, 17), (2, 5), (16, 3), (8, 64)])
+def test_attn_temporal(dt, T, groups):
+    hip = _hip()
+    H = 12
+    rows = groups * T
+    qkv = rnd(rows, 3 * H * 64, seed=60 + T).to(dt)
+    out = hip.attn_temporal(qkv.cuda(), T, H, 0.125)
+    ref, _ = ref_attention(qkv.double(), groups, T, H, 0.125)
+    tol = {torch.float32: (2e-5, 2e-5), torch.bfloat16: (2e-2, 2e-2), torch.float16: (3e-3, 3e-3)}[dt]
+    close(out, ref, *tol, "temporal attn")
