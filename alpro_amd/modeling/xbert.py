@@ -1,0 +1,273 @@
+"""BERT text / fusion encoder on the MI355X kernels.
+
+Mirrors the part of the reference's src/modeling/xbert.py that ALPRO instantiates
+(BertEmbeddings :166, BertSelfAttention :216, BertSelfOutput :349, BertIntermediate :412,
+BertOutput :427, BertLayer :441, BertEncoder :522 with its `mode` layer ranges :549-559,
+BertModel :832 with the `encoder_embeds` bypass :1044-1053, BertLMPredictionHead :665,
+BertForMaskedLM :1343): same module tree and state_dict keys, no dependency on HuggingFace
+internals at run time (config is duck-typed: a transformers.BertConfig or any attribute bag).
+
+Per layer (post-LN):  fused QKV GEMM (one (3H, H) operand built from query/key/value) ->
+alpro_attn with the additive (1-mask)*-10000 key bias -> dense GEMM with the residual add fused ->
+LayerNorm (fp32 + operand-dtype outputs) -> GELU GEMM -> dense GEMM + residual -> LayerNorm.
+Dropout (hidden_dropout_prob / attention_probs_dropout_prob) is an identity in eval mode; training
+with p > 0 is rejected loudly until the fused dropout lands.
+"""
+import math
+from types import SimpleNamespace
+
+import torch
+import torch.nn as nn
+
+from alpro_amd import config as rt
+from alpro_amd import hip
+from alpro_amd.modeling.weights import OperandCache
+
+
+def _cfg_get(cfg, name, default=None):
+    if isinstance(cfg, dict):
+        return cfg.get(name, default)
+    return getattr(cfg, name, default)
+
+
+class BertEmbeddings(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.word_embeddings = nn.Embedding(config.vocab_size, config.hidden_size, padding_idx=config.pad_token_id)
+        self.position_embeddings = nn.Embedding(config.max_position_embeddings, config.hidden_size)
+        self.token_type_embeddings = nn.Embedding(config.type_vocab_size, config.hidden_size)
+        self.LayerNorm = nn.LayerNorm(config.hidden_size, eps=config.layer_norm_eps)
+        self.dropout = nn.Dropout(config.hidden_dropout_prob)
+        self.register_buffer("position_ids", torch.arange(config.max_position_embeddings).expand((1, -1)))
+        self.config = config
+
+
+class BertSelfAttention(nn.Module):
+    def __init__(self, config, is_cross_attention=False):
+        super().__init__()
+        assert not is_cross_attention, "has_cross_attention is hard-disabled in the reference (xbert.py:450)"
+        self.num_attention_heads = config.num_attention_heads
+        self.attention_head_size = config.hidden_size // config.num_attention_heads
+        assert self.attention_head_size == 64, "kernels are specialised for head_dim 64"
+        self.all_head_size = self.num_attention_heads * self.attention_head_size
+        self.query = nn.Linear(config.hidden_size, self.all_head_size)
+        self.key = nn.Linear(config.hidden_size, self.all_head_size)
+        self.value = nn.Linear(config.hidden_size, self.all_head_size)
+        self.dropout = nn.Dropout(config.attention_probs_dropout_prob)
+
+
+class BertSelfOutput(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.dense = nn.Linear(config.hidden_size, config.hidden_size)
+        self.LayerNorm = nn.LayerNorm(config.hidden_size, eps=config.layer_norm_eps)
+        self.dropout = nn.Dropout(config.hidden_dropout_prob)
+
+
+class BertAttention(nn.Module):
+    def __init__(self, config, is_cross_attention=False):
+        super().__init__()
+        self.self = BertSelfAttention(config, is_cross_attention)
+        self.output = BertSelfOutput(config)
+
+
+class BertIntermediate(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.dense = nn.Linear(config.hidden_size, config.intermediate_size)
+        assert config.hidden_act == "gelu", "only the erf GELU of config_release/base_model.json is fused"
+
+
+class BertOutput(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.dense = nn.Linear(config.intermediate_size, config.hidden_size)
+        self.LayerNorm = nn.LayerNorm(config.hidden_size, eps=config.layer_norm_eps)
+        self.dropout = nn.Dropout(config.hidden_dropout_prob)
+
+
+class BertLayer(nn.Module):
+    def __init__(self, config, layer_num):
+        super().__init__()
+        self.config = config
+        self.attention = BertAttention(config)
+        self.has_cross_attention = False
+        self.layer_num = layer_num
+        self.intermediate = BertIntermediate(config)
+        self.output = BertOutput(config)
+        self._ops = OperandCache()
+
+    def _check_dropout(self):
+        if self.training and (self.config.hidden_dropout_prob > 0 or self.config.attention_probs_dropout_prob > 0):
+            raise RuntimeError("BertLayer in train() mode with dropout > 0 is not implemented on the HIP path yet; "
+                               "call .eval() or set hidden_dropout_prob = attention_probs_dropout_prob = 0")
+
+    def forward(self, h32, h_t, key_bias, B, L):
+        """h32 (B*L, H) fp32 residual stream, h_t the same in the operand dtype; returns the next pair."""
+        self._check_dropout()
+        dt = rt.compute_dtype()
+        sa, so = self.attention.self, self.attention.output
+        eps = self.config.layer_norm_eps
+        wqkv = self._ops.get("qkv_w", (sa.query.weight, sa.key.weight, sa.value.weight), dt)
+        bqkv = self._ops.get("qkv_b", (sa.query.bias, sa.key.bias, sa.value.bias), torch.float32)
+        qkv = hip.gemm(h_t, wqkv, bias=bqkv)
+        ctx = hip.attn(qkv, B, L, sa.num_attention_heads, 1.0 / math.sqrt(sa.attention_head_size), key_bias)
+        s1 = hip.gemm(ctx, self._ops.get("ao_w", so.dense.weight, dt), bias=so.dense.bias, out_dtype=torch.float32, residual=h32)
+        a_t, a32 = hip.layernorm(s1, so.LayerNorm.weight, so.LayerNorm.bias, eps, dt, out32=True)
+        it = hip.gemm(a_t, self._ops.get("i_w", self.intermediate.dense.weight, dt), bias=self.intermediate.dense.bias, act=hip.ACT_GELU)
+        s2 = hip.gemm(it, self._ops.get("o_w", self.output.dense.weight, dt), bias=self.output.dense.bias, out_dtype=torch.float32, residual=a32)
+        o_t, o32 = hip.layernorm(s2, self.output.LayerNorm.weight, self.output.LayerNorm.bias, eps, dt, out32=True)
+        return o32, o_t
+
+
+class BertEncoder(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.config = config
+        self.layer = nn.ModuleList([BertLayer(config, i) for i in range(config.num_hidden_layers)])
+
+    def layer_range(self, mode):
+        if mode == 'text':
+            return 0, self.config.fusion_layer
+        if mode == 'fusion':
+            return self.config.fusion_layer, self.config.num_hidden_layers
+        return 0, self.config.num_hidden_layers  # 'multi_modal' (xbert.py:557-559)
+
+
+class BertPreTrainedModel(nn.Module):
+    """Weight init of xbert.py:728-738 (normal(0, initializer_range), LN ones/zeros, zero biases)."""
+
+    def __init__(self, config):
+        super().__init__()
+        self.config = config
+
+    def _init_weights(self, module):
+        if isinstance(module, (nn.Linear, nn.Embedding)):
+            module.weight.data.normal_(mean=0.0, std=self.config.initializer_range)
+        elif isinstance(module, nn.LayerNorm):
+            module.bias.data.zero_()
+            module.weight.data.fill_(1.0)
+        if isinstance(module, nn.Linear) and module.bias is not None:
+            module.bias.data.zero_()
+
+    def init_weights(self):
+        self.apply(self._init_weights)
+
+    @classmethod
+    def from_pretrained(cls, name_or_path, config=None, **kwargs):
+        """Reference call sites (alpro_models.py:30,637) pass 'bert-base-uncased'.  There is no network on the
+        GPU box: a local directory / file with a HF-format `pytorch_model.bin` (or .pt state_dict) is loaded if
+        given, otherwise the model is randomly initialised exactly like xbert.py:728-738."""
+        import os
+        model = cls(config, **kwargs)
+        path = name_or_path
+        if isinstance(path, str) and os.path.isdir(path):
+            path = os.path.join(path, "pytorch_model.bin")
+        if isinstance(path, str) and os.path.isfile(path):
+            sd = torch.load(path, map_location="cpu")
+            sd = {k.replace("gamma", "weight").replace("beta", "bias"): v for k, v in sd.items()}
+            model.load_state_dict(sd, strict=False)
+            model.tie_weights()
+        return model
+
+    def tie_weights(self):
+        pass
+
+
+class BertModel(BertPreTrainedModel):
+    def __init__(self, config, add_pooling_layer=True):
+        super().__init__(config)
+        self.embeddings = BertEmbeddings(config)
+        self.encoder = BertEncoder(config)
+        self.pooler = None  # ALPRO builds BertForMaskedLM(add_pooling_layer=False) (xbert.py:1352)
+        self.init_weights()
+
+    def get_input_embeddings(self):
+        return self.embeddings.word_embeddings
+
+    @staticmethod
+    def key_bias(attention_mask):
+        """(B, L) {0,1} -> additive fp32 bias (1 - m) * -10000 (xbert.py:936-937)."""
+        return ((1.0 - attention_mask.to(torch.float32)) * -10000.0).contiguous()
+
+    def forward(self, input_ids=None, attention_mask=None, encoder_embeds=None, return_dict=True, mode='multi_modal', **unused):
+        dt = rt.compute_dtype()
+        cfg = self.config
+        if encoder_embeds is None:
+            B, L = input_ids.shape
+            emb = self.embeddings
+            if emb.training and cfg.hidden_dropout_prob > 0:
+                raise RuntimeError("BertEmbeddings dropout in train() mode is not implemented on the HIP path yet")
+            h32, h_t = hip.bert_embed(input_ids.contiguous(), emb.word_embeddings.weight, emb.position_embeddings.weight,
+                                      emb.token_type_embeddings.weight, emb.LayerNorm.weight, emb.LayerNorm.bias, cfg.layer_norm_eps, dt)
+        else:
+            B, L, Hd = encoder_embeds.shape
+            h32 = encoder_embeds.reshape(B * L, Hd).contiguous().float()
+            h_t = hip.cast(h32, dt)
+        if attention_mask is None:
+            attention_mask = torch.ones((B, L), device=h32.device)
+        kb = self.key_bias(attention_mask)
+        lo, hi = self.encoder.layer_range(mode)
+        for i in range(lo, hi):
+            h32, h_t = self.encoder.layer[i](h32, h_t, kb, B, L)
+        out = h32.view(B, L, -1)
+        if not return_dict:
+            return (out,)
+        return SimpleNamespace(last_hidden_state=out, pooler_output=None, hidden_states=None, attentions=None,
+                               past_key_values=None, cross_attentions=None)
+
+
+class BertPredictionHeadTransform(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.dense = nn.Linear(config.hidden_size, config.hidden_size)
+        self.LayerNorm = nn.LayerNorm(config.hidden_size, eps=config.layer_norm_eps)
+
+
+class BertLMPredictionHead(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.config = config
+        self.transform = BertPredictionHeadTransform(config)
+        self.decoder = nn.Linear(config.hidden_size, config.vocab_size, bias=False)
+        self.bias = nn.Parameter(torch.zeros(config.vocab_size))
+        self.decoder.bias = self.bias  # xbert.py:677
+        self._ops = OperandCache()
+
+    def forward(self, hidden_states):
+        """(B, Lt, H) fp32 -> (B, Lt, vocab) fp32 logits (xbert.py:679-682)."""
+        dt = rt.compute_dtype()
+        shp = hidden_states.shape
+        h = hip.cast(hidden_states.reshape(-1, shp[-1]).contiguous().float(), dt)
+        t = self.transform
+        g = hip.gemm(h, self._ops.get("t_w", t.dense.weight, dt), bias=t.dense.bias, act=hip.ACT_GELU, out_dtype=torch.float32)
+        n = hip.layernorm(g, t.LayerNorm.weight, t.LayerNorm.bias, self.config.layer_norm_eps, dt)
+        logits = hip.gemm(n, self._ops.get("dec_w", self.decoder.weight, dt), bias=self.bias, out_dtype=torch.float32)
+        return logits.view(*shp[:-1], -1)
+
+
+class BertOnlyMLMHead(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.predictions = BertLMPredictionHead(config)
+
+    def forward(self, sequence_output):
+        return self.predictions(sequence_output)
+
+
+class BertForMaskedLM(BertPreTrainedModel):
+    def __init__(self, config):
+        super().__init__(config)
+        self.bert = BertModel(config, add_pooling_layer=False)
+        self.cls = BertOnlyMLMHead(config)
+        self.init_weights()
+        self.tie_weights()
+
+    def tie_weights(self):
+        self.cls.predictions.decoder.weight = self.bert.embeddings.word_embeddings.weight  # xbert.py:670-677 + HF tie
+
+    def get_input_embeddings(self):
+        return self.bert.embeddings.word_embeddings
+
+    def get_output_embeddings(self):
+        return self.cls.predictions.decoder
