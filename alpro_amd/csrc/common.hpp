@@ -123,6 +123,20 @@ __device__ __forceinline__ float wave_max(float v) {
 }
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// erf via Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7, far below bf16/f16 output resolution): one rcp,
+// one exp and five FMAs instead of libm's erff (~3x fewer VALU ops in the fc1 epilogue).
+__device__ __forceinline__ float erf_as(float x) {
+  const float ax = fabsf(x);
+  const float t = __frcp_rn(1.0f + 0.3275911f * ax);
+  const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+  const float r = 1.0f - poly * __expf(-ax * ax);
+  return copysignf(r, x);
+}
+// exact-mode (f32 storage) keeps libm erff; 16-bit storage uses the fast form
+template <typename T> __device__ __forceinline__ float gelu_fast(float x) {
+  if constexpr (sizeof(T) == 4) return gelu_erf(x);
+  else return 0.5f * x * (1.0f + erf_as(x * 0.70710678118654752440f));
+}
 
 // ---- host side -----------------------------------------------------------------------------
 void set_error(const char* fmt, ...);

@@ -1,0 +1,223 @@
+"""Benchmark of the ALPRO hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W [--workload visual_fwd|pretrain_fwd] [--batch B] [--dtype bf16]
+
+N > 1 is launched by the driver as `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`
+(one rank per GPU over RCCL).  Rank 0 prints ONE JSON line.  A "step" is one pass of the hot path over one
+synthetic batch already resident in HBM; weights are random-init of the real architecture.
+
+Workloads (BASELINE.json configs):
+  visual_fwd   configs[1]: TimeSformer-divST visual encoder only, B=32 clips x 8 frames x 224^2, bf16 forward
+  pretrain_fwd configs[2] forward half: AlproForPretrain VTC+VTM+MLM+MPM forward, B=64 pairs (eval-mode dropout)
+The data path shards by clip with no collective in these workloads (weak scaling: every rank runs B clips).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+BERT_CFG = {"attention_probs_dropout_prob": 0.1, "hidden_act": "gelu", "hidden_dropout_prob": 0.1, "hidden_size": 768,
+            "initializer_range": 0.02, "intermediate_size": 3072, "layer_norm_eps": 1e-12, "max_position_embeddings": 512,
+            "model_type": "bert", "num_attention_heads": 12, "num_hidden_layers": 12, "pad_token_id": 0,
+            "type_vocab_size": 2, "vocab_size": 30522, "fusion_layer": 6, "encoder_width": 768, "itc_token_type": "cls"}
+VENC = {"cls": "TimeSformer", "patch_size": 16, "attn_drop_rate": 0, "drop_rate": 0, "drop_path_rate": 0.1,
+        "maxpool_kernel_size": 2, "use_maxpooling": False, "gradient_checkpointing": False, "img_size": 224}
+MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp16": 2500.0, "fp32": 157.3}  # dense, MI355X_MICROARCH.md
+VISUAL_GFLOP_PER_CLIP_8F = 391.7  # 12 x 32.48 + 1.85 (2*M*N*K, forward)
+
+
+class Cfg:
+    def __init__(self, d):
+        self.__dict__.update(d)
+        self.num_entities = 1000
+        self.max_n_example_per_group = 1
+
+
+def synth_batch(B, T, device, seed, full):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    batch = {"visual_inputs": torch.randn(B, T, 3, 224, 224, generator=g).to(device)}
+    ids = torch.randint(1000, 30000, (B, 40), generator=g)
+    ids[:, 0] = 101
+    batch["text_input_ids"] = ids.to(device)
+    batch["text_input_mask"] = torch.ones(B, 40, dtype=torch.long, device=device)
+    if full:
+        sel = torch.rand(B, 40, generator=g) < 0.15
+        sel[:, 0] = False
+        sel[:, 1] = True
+        mlm = ids.clone()
+        mlm[sel] = 103
+        lab = torch.full((B, 40), -100, dtype=torch.long)
+        lab[sel] = ids[sel]
+        batch["mlm_text_input_ids"], batch["mlm_labels"] = mlm.to(device), lab.to(device)
+        mask = torch.ones(B, 14, 14)
+        mask[:, 4:10, 4:10] = 0
+        batch["mpm_mask"] = mask.to(device)
+        batch["crop_visual_inputs"] = torch.randn(B, T, 3, 224, 224, generator=g).to(device)
+        batch["context_visual_inputs"] = batch["visual_inputs"]
+        batch["type"] = "video"
+    return batch
+
+
+class KernelTimer:
+    """Per-kernel-family device time via HIP events on the launch stream (a separate, untimed pass)."""
+
+    def __init__(self, hip):
+        self.hip, self.rec, self.orig = hip, [], {}
+
+    def __enter__(self):
+        def wrap(name, flops_fn):
+            fn = getattr(self.hip, name)
+            self.orig[name] = fn
+
+            def timed(*a, **k):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                out = fn(*a, **k)
+                e1.record()
+                self.rec.append((name, flops_fn(*a, **k), e0, e1))
+                return out
+            setattr(self.hip, name, timed)
+        wrap("gemm", lambda a, w, *r, **k: 2.0 * a.shape[0] * a.shape[1] * w.shape[0])
+        wrap("attn", lambda qkv, batch, L, H, *r, **k: 4.0 * batch * H * L * L * 64)
+        wrap("attn_temporal", lambda qkv, T, H, *r, **k: 4.0 * qkv.shape[0] * T * H * 64)
+        wrap("layernorm", lambda *a, **k: 0.0)
+        return self
+
+    def __exit__(self, *a):
+        for n, f in self.orig.items():
+            setattr(self.hip, n, f)
+
+    def summary(self):
+        torch.cuda.synchronize()
+        agg = {}
+        for name, fl, e0, e1 in self.rec:
+            d = agg.setdefault(name, [0, 0.0, 0.0])
+            d[0] += 1
+            d[1] += fl
+            d[2] += e0.elapsed_time(e1)
+        return {n: {"launches": c, "flops": f, "ms": ms} for n, (c, f, ms) in agg.items()}
+
+
+def cpu_baseline(T, seconds_budget=25.0):
+    """The oracle (CPU restatement of the reference, fp32) timed on this box's host cores: visual encoder forward."""
+    from oracle import alpro_oracle as ao
+    spec = ao.alpro_state_spec("retrieval", BERT_CFG, T)
+    g = torch.Generator().manual_seed(0)
+    p = {k: torch.randn(*s, generator=g) * 0.02 for k, s in spec.items() if k.startswith("visual_encoder") and "head" not in k}
+    threads = torch.get_num_threads()
+    Bc = 2
+    x = torch.randn(Bc, 3, T, 224, 224, generator=g)
+    with torch.no_grad():
+        ao.timesformer_forward_features(x, p, "visual_encoder", T)  # warm-up
+        t0, n = time.time(), 0
+        while n < 1 or (time.time() - t0 < seconds_budget and n < 8):
+            ao.timesformer_forward_features(x, p, "visual_encoder", T)
+            n += 1
+        dt = (time.time() - t0) / n
+    return {"value": Bc / dt, "unit": "clips/s", "cores": threads, "kind": "port",
+            "sample": "oracle TimeSformer forward, %d clips x %df x 224^2 fp32, %d passes, torch %d threads" % (Bc, T, n, threads)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="visual_fwd", choices=["visual_fwd", "pretrain_fwd"])
+    ap.add_argument("--batch", type=int, default=None)
+    ap.add_argument("--frames", type=int, default=8)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "fp32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    from alpro_amd import config as rt
+    from alpro_amd import dist, hip
+    dist.init()
+    rank, world = dist.rank(), dist.size()
+    assert world == args.gpus or (args.gpus == 1 and world == 1), "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    hip.load()
+    rt.set_compute_dtype(args.dtype)
+    T = args.frames
+    torch.manual_seed(1234)
+
+    if args.workload == "visual_fwd":
+        from alpro_amd.modeling.timesformer.vit import TimeSformer
+        B = args.batch or 32
+        model = TimeSformer(dict(VENC, num_frm=T), input_format="RGB").eval().to(dev)
+        batch = synth_batch(B, T, dev, seed=rank, full=False)
+        x = batch["visual_inputs"].transpose(1, 2)
+
+        def step():
+            return model.forward_features(x)
+        flops_per_unit = VISUAL_GFLOP_PER_CLIP_8F * 1e9 * (T / 8.0)
+        unit = "clips/s"
+        wl = "TimeSformer-divST visual encoder forward (BASELINE configs[1]), B=%d x %df x 224^2" % (B, T)
+    else:
+        from alpro_amd.modeling.alpro_models import AlproForPretrain
+        B = args.batch or 64
+        model = AlproForPretrain(Cfg(BERT_CFG), dict(VENC, num_frm=T)).eval().to(dev)
+        batch = synth_batch(B, T, dev, seed=rank, full=True)
+
+        def step():
+            return model(batch)
+        flops_per_unit = 877e9 * (T / 8.0)  # forward of one pair (3 visual passes incl. prompter, text x2, 4 fusion, heads)
+        unit = "pairs/s"
+        wl = "AlproForPretrain forward VTC+VTM+MLM+MPM (BASELINE configs[2], forward only; eval-mode dropout), B=%d x %df x 224^2 + 40 tok" % (B, T)
+
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            step()
+        dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize()
+        dist.barrier()
+        elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    result = None
+    if rank == 0:
+        ms = elapsed / args.steps * 1e3
+        value = world * B * args.steps / elapsed
+        with torch.no_grad(), KernelTimer(hip) as kt:
+            step()
+        ks = kt.summary()
+        gemm = ks["gemm"]
+        ach = gemm["flops"] / (gemm["ms"] * 1e-3) / 1e12
+        peak = MFMA_PEAK_TFLOPS[args.dtype]
+        result = {
+            "metric": "video-text pairs/sec (8f x 224^2, 40-tok)", "value": round(value, 3), "unit": unit, "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic (randn clips, random token ids; random-init weights)",
+            "config": {"workload": wl, "per_gpu_batch": B, "frames": T, "parallelism": "dp%d (independent clips, no data-path collective)" % world},
+            "model_tflops_per_gpu": round(value / world * flops_per_unit / 1e12, 2),
+            "roofline": {"bound": "mfma", "kernel": "gemm_nt_kernel<%s> (all %d launches of one step)" % (args.dtype, gemm["launches"]),
+                         "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+                         "avg_launch_ms": round(gemm["ms"] / gemm["launches"], 4),
+                         "gflop_per_launch": round(gemm["flops"] / gemm["launches"] / 1e9, 2), "traffic": None},
+            "kernel_ms_per_step": {k: round(v["ms"], 3) for k, v in ks.items()},
+        }
+        if not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(T)
+        print(json.dumps(result))
+    dist.barrier()
+    return result
+
+
+if __name__ == "__main__":
+    main()
