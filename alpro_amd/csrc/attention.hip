@@ -241,7 +241,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qkv
 // temporal attention: one wave per (32 consecutive tokens, head); groups of Tn tokens
 template <typename T>
 __global__ __launch_bounds__(256) void attn_temporal_fwd_kernel(const T* __restrict__ qkv, T* __restrict__ out, int64_t rows, int Tn,
-                                                                int H, float scale, int64_t units) {
+                                                                int H, float scale, int64_t units, float* __restrict__ lse) {
   typedef AttnCfg<T> C;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -279,11 +279,12 @@ __global__ __launch_bounds__(256) void attn_temporal_fwd_kernel(const T* __restr
 #pragma unroll
     for (int ks = 0; ks < C::KS; ++ks) mma_chunk<T>(s[0], kf[ks], qf[ks]);
     const int qgrp = ql / Tn;
-    softmax_tiles<1>(s, scale, [&](int, int rq) {
+    const float l_se = softmax_tiles<1>(s, scale, [&](int, int rq) {
       const int k0 = 8 * rq + 4 * g;  // block-diagonal mask: a query attends to the T frames of its own patch
       return make_float4((k0 + 0) / Tn == qgrp ? 0.f : -INFINITY, (k0 + 1) / Tn == qgrp ? 0.f : -INFINITY,
                          (k0 + 2) / Tn == qgrp ? 0.f : -INFINITY, (k0 + 3) / Tn == qgrp ? 0.f : -INFINITY);
     });
+    if (lse && active && g == 0) lse[unit * 32 + ql] = l_se;  // (chunk*H + h)*32 + token
     __syncthreads();  // V tile visible
     f32x16 o[2];
 #pragma unroll
@@ -330,7 +331,7 @@ extern "C" int alpro_attn_fwd(const void* qkv, void* out, int dtype, int batch, 
   return ALPRO_OK;
 }
 
-extern "C" int alpro_attn_temporal_fwd(const void* qkv, void* out, int dtype, int64_t rows, int T, int H, float scale, void* stream) {
+extern "C" int alpro_attn_temporal_fwd(const void* qkv, void* out, int dtype, int64_t rows, int T, int H, float scale, float* lse, void* stream) {
   ALPRO_CHECK(qkv && out && rows > 0 && H > 0, "alpro_attn_temporal_fwd: bad args");
   ALPRO_CHECK(T > 0 && 32 % T == 0, "alpro_attn_temporal_fwd: num_frm=%d must divide 32", T);
   ALPRO_CHECK(rows % T == 0, "alpro_attn_temporal_fwd: rows=%lld not a multiple of T=%d", (long long)rows, T);
@@ -340,6 +341,6 @@ extern "C" int alpro_attn_temporal_fwd(const void* qkv, void* out, int dtype, in
   if (grid > 256 * 8) grid = 256 * 8;
   const int esz = dtype == ALPRO_F32 ? 4 : 2;
   const size_t lds = 4 * 32 * 64 * (size_t)esz;
-  ALPRO_DISPATCH_DTYPE(dtype, T_, hipLaunchKernelGGL(attn_temporal_fwd_kernel<T_>, dim3((unsigned)grid), dim3(256), lds, (hipStream_t)stream, (const T_*)qkv, (T_*)out, rows, T, H, scale, units));
+  ALPRO_DISPATCH_DTYPE(dtype, T_, hipLaunchKernelGGL(attn_temporal_fwd_kernel<T_>, dim3((unsigned)grid), dim3(256), lds, (hipStream_t)stream, (const T_*)qkv, (T_*)out, rows, T, H, scale, units, lse));
   return check_launch("alpro_attn_temporal_fwd");
 }

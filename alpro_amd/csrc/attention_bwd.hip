@@ -1,0 +1,316 @@
+// Attention backward for gfx950 (head_dim 64): dQ, dK, dV from dO with the softmax recomputed from the saved
+// row log-sum-exp.  Same MFMA formulation as the forward (attention.hip): every product keeps its contraction
+// index in registers by choosing the orientation per product, so no accumulator ever crosses lanes.
+//
+//   phase 1 (K, V tiles resident in LDS; one 32-query tile per wave; lane = query)
+//       S^T = K Q^T, dP^T = V dO^T                  A = rows of K / V (ds_read_b128), B = Q / dO rows (registers)
+//       P^T = exp(S^T*scale + bias - lse[q]),  dS^T = P^T o (dP^T - delta[q]) * scale,  delta = rowsum(dO o O)
+//       dQ^T = K^T dS^T                             A = K^T via ds_read_b64_tr_b16, B = dS^T straight from registers
+//   phase 2 (Q, dO tiles re-staged into the same LDS; one 32-key tile per wave; lane = key)
+//       S = Q K^T, dP = dO V^T                      A = rows of Q / dO, B = K / V rows of the key tile (registers)
+//       dV^T += dO^T P,  dK^T += Q^T dS             A = dO^T / Q^T via transpose reads, B = P / dS from registers
+// One LDS swizzle serves both access kinds for 16-bit tiles: chunk ^= (bit1(row) << 2 | (row >> 2) & 3) is a bijection
+// of (row >> 1) & 7 (conflict-free ds_read_b128 fragments) AND moves rows r, r+2 into different 64-byte windows
+// (conflict-free 4-row transpose gathers).  The temporal variant treats 32 consecutive tokens as one tile with a
+// block-diagonal group mask (one wave per workgroup).
+#include "common.hpp"
+
+namespace alpro {
+namespace {
+
+constexpr int HD = 64;
+
+template <typename T> struct BCfg {
+  static constexpr int E = sizeof(T);
+  static constexpr int CN = 16 / E;
+  static constexpr int RB = HD * E;
+  static constexpr int CPR = RB / 16;
+  static constexpr int KS = CPR / 2;
+  static constexpr int CPT = 16 / CN;
+};
+
+template <typename T> __device__ __forceinline__ int u_swz(int row, int chunk) {
+  if (BCfg<T>::CPR == 8) return chunk ^ ((((row >> 1) & 1) << 2) | ((row >> 2) & 3));
+  return chunk ^ (row & 15);
+}
+template <typename T> __device__ __forceinline__ int tile_off(int row, int chunk) { return row * BCfg<T>::RB + (u_swz<T>(row, chunk) << 4); }
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+// transposed A-operand chunk: element (k, i) = tile[row0 + krow(cc, g, k)][dt*32 + (lane & 31)], the k order being
+// the accumulator-register order of the matching B operand (regs cc*CN .. cc*CN+CN-1).
+template <typename T> __device__ __forceinline__ u32x4 load_t_chunk(const char* tile, int row0, int cc, int lane, int dt);
+template <> __device__ __forceinline__ u32x4 load_t_chunk<float>(const char* tile, int row0, int cc, int lane, int dt) {
+  const int d = dt * 32 + (lane & 31), r = row0 + 8 * cc + 4 * (lane >> 5);
+  uint32_t v[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) v[e] = *(const uint32_t*)(tile + tile_off<float>(r + e, d >> 2) + ((d & 3) << 2));
+  return mk4(v[0], v[1], v[2], v[3]);
+}
+__device__ __forceinline__ u32x2 tr_quad_u(const char* tile, int krow0, int lane, int dt) {
+  const int p = lane & 15, seg = dt * 2 + ((lane >> 4) & 1);
+  const int row = krow0 + (p >> 2);
+  const int ch = seg * 2 + ((p >> 1) & 1);
+  const char* a = tile + row * 128 + ((ch ^ ((((row >> 1) & 1) << 2) | ((row >> 2) & 3))) << 4) + ((p & 1) << 3);
+  const s16x4 r = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)a);
+  return __builtin_bit_cast(u32x2, r);
+}
+template <typename T> __device__ __forceinline__ u32x4 load_t_chunk16(const char* tile, int row0, int cc, int lane, int dt) {
+  const int g = lane >> 5;
+  const u32x2 a = tr_quad_u(tile, row0 + 16 * cc + 4 * g, lane, dt);
+  const u32x2 b = tr_quad_u(tile, row0 + 16 * cc + 8 + 4 * g, lane, dt);
+  const uint32_t ax = a.x, ay = a.y, bx = b.x, by = b.y;
+  return mk4(ax, ay, bx, by);
+}
+template <> __device__ __forceinline__ u32x4 load_t_chunk<bf16_t>(const char* tile, int row0, int cc, int lane, int dt) { return load_t_chunk16<bf16_t>(tile, row0, cc, lane, dt); }
+template <> __device__ __forceinline__ u32x4 load_t_chunk<f16_t>(const char* tile, int row0, int cc, int lane, int dt) { return load_t_chunk16<f16_t>(tile, row0, cc, lane, dt); }
+
+template <typename T> __device__ __forceinline__ void store_quad_b(T* dst, const float* v) {
+  if constexpr (sizeof(T) == 4) {
+    *(float4*)dst = make_float4(v[0], v[1], v[2], v[3]);
+  } else {
+    u32x2 u;
+    u.x = pack2(v[0], v[1], (T*)0);
+    u.y = pack2(v[2], v[3], (T*)0);
+    *(u32x2*)dst = u;
+  }
+}
+// accumulator pair (2 d-tiles, C layout: column = token of this lane, rows = d) -> one token row of 64 values
+template <typename T> __device__ __forceinline__ void store_row64(T* row, const f32x16 (&o)[2], int lane) {
+  const int g = lane >> 5;
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int rq = 0; rq < 4; ++rq) {
+      const float v[4] = {o[dt][4 * rq], o[dt][4 * rq + 1], o[dt][4 * rq + 2], o[dt][4 * rq + 3]};
+      store_quad_b<T>(row + dt * 32 + 8 * rq + 4 * g, v);
+    }
+}
+
+template <typename T>
+__device__ __forceinline__ void stage_tile(char* tile, const T* src, int64_t ld, int rows_valid, int LP, int tid, int nthreads) {
+  typedef BCfg<T> C;
+  for (int c = tid; c < LP * C::CPR; c += nthreads) {
+    const int row = c / C::CPR, ch = c - row * C::CPR;
+    u32x4 v = mk4(0, 0, 0, 0);
+    if (row < rows_valid) v = *(const u32x4*)(src + (int64_t)row * ld + ch * C::CN);
+    *(u32x4*)(tile + tile_off<T>(row, ch)) = v;
+  }
+}
+
+template <typename T, int NKT, int NW, bool GROUPED>
+__global__ __launch_bounds__(NW * 64) void attn_bwd_kernel(const T* __restrict__ qkv, const T* __restrict__ out, const T* __restrict__ dout,
+                                                           const float* __restrict__ lse, T* __restrict__ dqkv, int L, int H, float scale,
+                                                           const float* __restrict__ key_bias, int Tn, int64_t total_rows) {
+  typedef BCfg<T> C;
+  constexpr int LP = NKT * 32;
+  constexpr int NT = NW * 64;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* tA = smem;                 // K, then Q
+  char* tB = smem + LP * C::RB;    // V, then dO
+  float* Bs = (float*)(smem + 2 * LP * C::RB);
+  float* Ls = Bs + LP;
+  float* Ds = Ls + LP;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.x / H, h = blockIdx.x - b * H;
+  const int64_t row0 = (int64_t)b * L;
+  const int Le = GROUPED ? (int)((total_rows - row0) < 32 ? (total_rows - row0) : 32) : L;
+  const int64_t ldq = 3 * (int64_t)H * HD, ldo = (int64_t)H * HD;
+  const T* qb = qkv + row0 * ldq + h * HD;
+  const T* ob = out + row0 * ldo + h * HD;
+  const T* dob = dout + row0 * ldo + h * HD;
+  T* db = dqkv + row0 * ldq + h * HD;
+  const float* lse_b = lse + ((int64_t)b * H + h) * L;
+  for (int c = tid; c < LP; c += NT) {
+    Bs[c] = c < Le ? ((!GROUPED && key_bias) ? key_bias[(int64_t)b * L + c] : 0.f) : -INFINITY;
+    Ls[c] = c < Le ? lse_b[c] : INFINITY;
+  }
+  stage_tile<T>(tA, qb + H * HD, ldq, Le, LP, tid, NT);
+  stage_tile<T>(tB, qb + 2 * H * HD, ldq, Le, LP, tid, NT);
+  __syncthreads();
+
+  const int g = lane >> 5, ql = lane & 31;
+  const int ntile = (Le + 31) >> 5;
+  // ---------------------------------------------------------------- phase 1: dQ (lane = query)
+  for (int qt = wave; qt < ntile; qt += NW) {
+    const int q = qt * 32 + ql;
+    const int qc = q < Le ? q : Le - 1;
+    u32x4 qf[C::KS], dof[C::KS];
+    float delta = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < C::KS; ++ks) {
+      const int off = (2 * ks + g) * C::CN;
+      qf[ks] = *(const u32x4*)(qb + (int64_t)qc * ldq + off);
+      dof[ks] = *(const u32x4*)(dob + (int64_t)qc * ldo + off);
+      const u32x4 of = *(const u32x4*)(ob + (int64_t)qc * ldo + off);
+      float a[C::CN], c2[C::CN];
+      unpack_chunk<T>(dof[ks], a);
+      unpack_chunk<T>(of, c2);
+#pragma unroll
+      for (int e = 0; e < C::CN; ++e) delta += a[e] * c2[e];
+    }
+    delta += __shfl_xor(delta, 32, 64);
+    const float lse_q = Ls[q];
+    if (g == 0) Ds[q] = delta;
+    f32x16 dq[2];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dq[dt][r] = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+      if (kt < ntile) {
+        f32x16 s, dp;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = dp[r] = 0.f;
+        const int krow = kt * 32 + ql;
+#pragma unroll
+        for (int ks = 0; ks < C::KS; ++ks) {
+          const u32x4 ka = *(const u32x4*)(tA + tile_off<T>(krow, 2 * ks + g));
+          const u32x4 va = *(const u32x4*)(tB + tile_off<T>(krow, 2 * ks + g));
+          mma_chunk<T>(s, ka, qf[ks]);
+          mma_chunk<T>(dp, va, dof[ks]);
+        }
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq) {
+          const float4 bq = *(const float4*)(Bs + kt * 32 + 8 * rq + 4 * g);
+          const float bb[4] = {bq.x, bq.y, bq.z, bq.w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int r = 4 * rq + e;
+            float p = expf(s[r] * scale + bb[e] - lse_q);
+            if (GROUPED && ((8 * rq + 4 * g + e) / Tn != ql / Tn)) p = 0.f;
+            s[r] = p * (dp[r] - delta) * scale;  // dS^T
+          }
+        }
+#pragma unroll
+        for (int cc = 0; cc < C::CPT; ++cc) {
+          float v[C::CN];
+#pragma unroll
+          for (int e = 0; e < C::CN; ++e) v[e] = s[cc * C::CN + e];
+          const u32x4 bop = pack_chunk<T>(v);
+#pragma unroll
+          for (int dt = 0; dt < 2; ++dt) mma_chunk<T>(dq[dt], load_t_chunk<T>(tA, kt * 32, cc, lane, dt), bop);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    if (q < Le) store_row64<T>(db + (int64_t)q * ldq, dq, lane);
+  }
+  __syncthreads();
+  // ---------------------------------------------------------------- phase 2: dK, dV (lane = key)
+  stage_tile<T>(tA, qb, ldq, Le, LP, tid, NT);
+  stage_tile<T>(tB, dob, ldo, Le, LP, tid, NT);
+  __syncthreads();
+  for (int kt = wave; kt < ntile; kt += NW) {
+    const int key = kt * 32 + ql;
+    const int kc = key < Le ? key : Le - 1;
+    u32x4 kf[C::KS], vf[C::KS];
+#pragma unroll
+    for (int ks = 0; ks < C::KS; ++ks) {
+      const int off = (2 * ks + g) * C::CN;
+      kf[ks] = *(const u32x4*)(qb + (int64_t)kc * ldq + H * HD + off);
+      vf[ks] = *(const u32x4*)(qb + (int64_t)kc * ldq + 2 * H * HD + off);
+    }
+    const float kb = Bs[key];
+    f32x16 dk[2], dv[2];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dk[dt][r] = dv[dt][r] = 0.f;
+#pragma unroll 1
+    for (int qt = 0; qt < ntile; ++qt) {
+      f32x16 s, dp;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[r] = dp[r] = 0.f;
+      const int qrow = qt * 32 + ql;
+#pragma unroll
+      for (int ks = 0; ks < C::KS; ++ks) {
+        const u32x4 qa = *(const u32x4*)(tA + tile_off<T>(qrow, 2 * ks + g));
+        const u32x4 da = *(const u32x4*)(tB + tile_off<T>(qrow, 2 * ks + g));
+        mma_chunk<T>(s, qa, kf[ks]);
+        mma_chunk<T>(dp, da, vf[ks]);
+      }
+#pragma unroll
+      for (int rq = 0; rq < 4; ++rq) {
+        const float4 lq = *(const float4*)(Ls + qt * 32 + 8 * rq + 4 * g);
+        const float4 dq4 = *(const float4*)(Ds + qt * 32 + 8 * rq + 4 * g);
+        const float ll[4] = {lq.x, lq.y, lq.z, lq.w}, dd[4] = {dq4.x, dq4.y, dq4.z, dq4.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int r = 4 * rq + e;
+          float p = expf(s[r] * scale + kb - ll[e]);
+          if (GROUPED && ((8 * rq + 4 * g + e) / Tn != ql / Tn)) p = 0.f;
+          s[r] = p;                                // P
+          dp[r] = p * (dp[r] - dd[e]) * scale;     // dS
+        }
+      }
+#pragma unroll
+      for (int cc = 0; cc < C::CPT; ++cc) {
+        float pv[C::CN], sv[C::CN];
+#pragma unroll
+        for (int e = 0; e < C::CN; ++e) {
+          pv[e] = s[cc * C::CN + e];
+          sv[e] = dp[cc * C::CN + e];
+        }
+        const u32x4 pb = pack_chunk<T>(pv), sb = pack_chunk<T>(sv);
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          mma_chunk<T>(dv[dt], load_t_chunk<T>(tB, qt * 32, cc, lane, dt), pb);
+          mma_chunk<T>(dk[dt], load_t_chunk<T>(tA, qt * 32, cc, lane, dt), sb);
+        }
+      }
+    }
+    if (key < Le) {
+      store_row64<T>(db + (int64_t)key * ldq + H * HD, dk, lane);
+      store_row64<T>(db + (int64_t)key * ldq + 2 * H * HD, dv, lane);
+    }
+  }
+}
+
+template <typename T, int NKT, int NW, bool GROUPED>
+int launch_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, int64_t nblocks_b, int L, int H, float scale,
+               const float* key_bias, int Tn, int64_t total_rows, hipStream_t st) {
+  const size_t lds = 2 * (size_t)NKT * 32 * BCfg<T>::RB + 3 * (size_t)NKT * 32 * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)attn_bwd_kernel<T, NKT, NW, GROUPED>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((attn_bwd_kernel<T, NKT, NW, GROUPED>), dim3((unsigned)(nblocks_b * H)), dim3(NW * 64), lds, st, (const T*)qkv, (const T*)out,
+                     (const T*)dout, lse, (T*)dqkv, L, H, scale, key_bias, Tn, total_rows);
+  return check_launch("alpro_attn_bwd");
+}
+
+template <typename T>
+int dispatch_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, int batch, int L, int H, float scale,
+                 const float* key_bias, hipStream_t st) {
+  const int nkt = (L + 31) / 32;
+  const int64_t rows = (int64_t)batch * L;
+  if (nkt <= 2) return launch_bwd<T, 2, 4, false>(qkv, out, dout, lse, dqkv, batch, L, H, scale, key_bias, 0, rows, st);
+  if (nkt <= 4) return launch_bwd<T, 4, 4, false>(qkv, out, dout, lse, dqkv, batch, L, H, scale, key_bias, 0, rows, st);
+  if (nkt <= 7) return launch_bwd<T, 7, 4, false>(qkv, out, dout, lse, dqkv, batch, L, H, scale, key_bias, 0, rows, st);
+  return launch_bwd<T, 8, 4, false>(qkv, out, dout, lse, dqkv, batch, L, H, scale, key_bias, 0, rows, st);
+}
+
+}  // namespace
+}  // namespace alpro
+
+using namespace alpro;
+
+extern "C" int alpro_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, int dtype, int batch, int L,
+                              int H, float scale, const float* key_bias, void* stream) {
+  ALPRO_CHECK(qkv && out && dout && lse && dqkv && batch > 0 && H > 0, "alpro_attn_bwd: bad args");
+  ALPRO_CHECK(L > 0 && L <= 256, "alpro_attn_bwd: L=%d unsupported (1..256)", L);
+  ALPRO_DISPATCH_DTYPE(dtype, T, return dispatch_bwd<T>(qkv, out, dout, lse, dqkv, batch, L, H, scale, key_bias, (hipStream_t)stream));
+  return ALPRO_OK;
+}
+
+extern "C" int alpro_attn_temporal_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, int dtype,
+                                       int64_t rows, int T, int H, float scale, void* stream) {
+  ALPRO_CHECK(qkv && out && dout && lse && dqkv && rows > 0 && H > 0, "alpro_attn_temporal_bwd: bad args");
+  ALPRO_CHECK(T > 0 && 32 % T == 0 && rows % T == 0, "alpro_attn_temporal_bwd: num_frm=%d must divide 32 and rows", T);
+  const int64_t chunks = (rows + 31) / 32;
+  ALPRO_DISPATCH_DTYPE(dtype, T_, return (launch_bwd<T_, 1, 1, true>(qkv, out, dout, lse, dqkv, chunks, 32, H, scale, nullptr, T, rows, (hipStream_t)stream)));
+  return ALPRO_OK;
+}

@@ -1,0 +1,268 @@
+// Memory-bound backward kernels: transposes feeding the NT GEMM for dgrad / wgrad, LayerNorm backward
+// (with the row maps of the forward gather turned into scatters), CLS-mean / final-pool / BERT-embedding
+// backward, and the GELU-gradient multiply.  All HBM-bound; 16-byte accesses wherever rows are contiguous.
+#include "common.hpp"
+
+namespace alpro {
+namespace {
+
+// ---- out[c, r] = (Tout) in[r, c] for r < R, zero for R <= r < Rpad; optional fp32 column sums (bias gradient) --
+// 64x64 tile through LDS (fp32, +1 padding).  wgrad needs both operands with the token dimension contiguous.
+template <typename Tin, typename Tout>
+__global__ __launch_bounds__(256) void transpose_kernel(const Tin* __restrict__ in, int64_t ld_in, Tout* __restrict__ out, int64_t ld_out,
+                                                        int R, int C, int Rpad, float* __restrict__ colsum) {
+  __shared__ float tile[64][65];
+  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;  // 4 row-groups of 64 lanes
+#pragma unroll 4
+  for (int i = ty; i < 64; i += 4) {
+    const int r = r0 + i, c = c0 + tx;
+    tile[i][tx] = (r < R && c < C) ? to_f32(in[(int64_t)r * ld_in + c]) : 0.f;
+  }
+  __syncthreads();
+  if (colsum && ty == 0 && c0 + tx < C) {
+    float s = 0.f;
+#pragma unroll 8
+    for (int i = 0; i < 64; ++i) s += tile[i][tx];
+    atomicAdd(colsum + c0 + tx, s);
+  }
+#pragma unroll 4
+  for (int i = ty; i < 64; i += 4) {
+    const int c = c0 + i, r = r0 + tx;
+    if (c < C && r < Rpad) out[(int64_t)c * ld_out + r] = from_f32<Tout>(tile[tx][i]);
+  }
+}
+
+// ---- LayerNorm backward, D = 768, one wave per row ------------------------------------------------------
+constexpr int LN_D = 768;
+
+__device__ __forceinline__ void ld12(const float* row, int lane, float (&v)[12]) {
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const float4 f = *(const float4*)(row + i * 256 + lane * 4);
+    v[4 * i] = f.x; v[4 * i + 1] = f.y; v[4 * i + 2] = f.z; v[4 * i + 3] = f.w;
+  }
+}
+template <typename T> __device__ __forceinline__ void ld12_t(const T* row, int lane, float (&v)[12]) {
+  if constexpr (sizeof(T) == 4) {
+    ld12((const float*)row, lane, v);
+  } else {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const u32x2 u = *(const u32x2*)(row + i * 256 + lane * 4);
+      const uint32_t w0 = u.x, w1 = u.y;
+      v[4 * i] = to_f32(T{(uint16_t)(w0 & 0xffffu)}); v[4 * i + 1] = to_f32(T{(uint16_t)(w0 >> 16)});
+      v[4 * i + 2] = to_f32(T{(uint16_t)(w1 & 0xffffu)}); v[4 * i + 3] = to_f32(T{(uint16_t)(w1 >> 16)});
+    }
+  }
+}
+
+struct SrcRow {
+  int64_t row;
+  bool shared;  // the source row is gathered by several output rows (CLS under FRAME_TOKENS): scatter atomically
+};
+__device__ __forceinline__ SrcRow ln_src_row(int mode, int p0, int p1, int64_t m) {
+  SrcRow s;
+  s.shared = false;
+  if (mode == ALPRO_MAP_IDENTITY) { s.row = m; return s; }
+  if (mode == ALPRO_MAP_SKIP_CLS) { s.row = m + m / p0 + 1; return s; }
+  const int T = p0, N = p1;
+  const int64_t bt = m / (N + 1);
+  const int j = (int)(m - bt * (N + 1));
+  const int64_t b = bt / T;
+  const int t = (int)(bt - b * T);
+  const int64_t base = b * (1 + (int64_t)N * T);
+  s.shared = j == 0;
+  s.row = j == 0 ? base : base + 1 + (int64_t)(j - 1) * T + t;
+  return s;
+}
+
+// dx[src(m)] += rstd * (dy*g - mean(dy*g) - xhat * mean(dy*g*xhat));  dgamma += dy*xhat;  dbeta += dy
+template <typename T>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict__ dy, int64_t ld_dy, const float* __restrict__ dy2,
+                                                            const float* __restrict__ x, int64_t ldx, const float* __restrict__ gamma, float eps,
+                                                            float* __restrict__ dx, int64_t ld_dx, int accumulate, float* __restrict__ dgamma,
+                                                            float* __restrict__ dbeta, int64_t rows, int mode, int p0, int p1) {
+  __shared__ float red[2][4][LN_D];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int64_t wave = (int64_t)blockIdx.x * 4 + w;
+  const int64_t nwaves = (int64_t)gridDim.x * 4;
+  float g[12], ag[12], ab[12];
+  ld12(gamma, lane, g);
+#pragma unroll
+  for (int i = 0; i < 12; ++i) ag[i] = ab[i] = 0.f;
+  for (int64_t m = wave; m < rows; m += nwaves) {
+    const SrcRow src = ln_src_row(mode, p0, p1, m);
+    float xv[12], d[12];
+    ld12(x + src.row * ldx, lane, xv);
+    ld12_t<T>(dy + m * ld_dy, lane, d);
+    if (dy2) {  // second gradient stream on the same LN output (fp32 copy consumed as a residual)
+      float d2[12];
+      ld12(dy2 + m * LN_D, lane, d2);
+#pragma unroll
+      for (int i = 0; i < 12; ++i) d[i] += d2[i];
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) s += xv[i];
+    const float mean = wave_sum(s) * (1.0f / LN_D);
+    float qq = 0.f;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) { xv[i] -= mean; qq += xv[i] * xv[i]; }
+    const float rstd = rsqrtf(wave_sum(qq) * (1.0f / LN_D) + eps);
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) {
+      xv[i] *= rstd;            // xhat
+      ab[i] += d[i];
+      ag[i] += d[i] * xv[i];
+      d[i] *= g[i];             // dy * gamma
+      s1 += d[i];
+      s2 += d[i] * xv[i];
+    }
+    s1 = wave_sum(s1) * (1.0f / LN_D);
+    s2 = wave_sum(s2) * (1.0f / LN_D);
+    float* o = dx + src.row * ld_dx;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      float4 r;
+      r.x = rstd * (d[4 * i] - s1 - xv[4 * i] * s2);
+      r.y = rstd * (d[4 * i + 1] - s1 - xv[4 * i + 1] * s2);
+      r.z = rstd * (d[4 * i + 2] - s1 - xv[4 * i + 2] * s2);
+      r.w = rstd * (d[4 * i + 3] - s1 - xv[4 * i + 3] * s2);
+      float* p = o + i * 256 + lane * 4;
+      if (src.shared) {
+        atomicAdd(p, r.x); atomicAdd(p + 1, r.y); atomicAdd(p + 2, r.z); atomicAdd(p + 3, r.w);
+      } else if (accumulate) {
+        const float4 c = *(const float4*)p;
+        *(float4*)p = make_float4(c.x + r.x, c.y + r.y, c.z + r.z, c.w + r.w);
+      } else {
+        *(float4*)p = r;
+      }
+    }
+  }
+  // block reduction of dgamma / dbeta, then one atomic per column per block
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      red[0][w][i * 256 + lane * 4 + e] = ag[4 * i + e];
+      red[1][w][i * 256 + lane * 4 + e] = ab[4 * i + e];
+    }
+  __syncthreads();
+  for (int c = threadIdx.x; c < LN_D; c += 256) {
+    atomicAdd(dgamma + c, red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c]);
+    atomicAdd(dbeta + c, red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c]);
+  }
+}
+
+// ---- du = dh * gelu'(u) (erf GELU), elementwise over 16-byte chunks ---------------------------------------
+template <typename T>
+__global__ void gelu_bwd_kernel(const T* __restrict__ dh, const T* __restrict__ u, T* __restrict__ du, int64_t n) {
+  constexpr int E = Chunk<T>::N;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x * E;
+  for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * E; i + E <= n; i += stride) {
+    float a[E], b[E], o[E];
+    unpack_chunk<T>(*(const u32x4*)(dh + i), a);
+    unpack_chunk<T>(*(const u32x4*)(u + i), b);
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      const float x = b[e];
+      const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+      const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
+      o[e] = a[e] * (cdf + x * pdf);
+    }
+    *(u32x4*)(du + i) = pack_chunk<T>(o);
+  }
+}
+
+// ---- CLS mean backward: dside[b*T+t] = dx_out[b,0] / T  (rows of the spatial proj output), dx_in[b,0] += dx_out[b,0]
+__global__ void cls_mean_bwd_kernel(const float* __restrict__ dx_out, int64_t ldb, float* __restrict__ dside, int B, int T, int D) {
+  const int b = blockIdx.x;
+  const float inv = 1.0f / (float)T;
+  for (int d = threadIdx.x; d < D; d += blockDim.x) {
+    const float g = dx_out[b * ldb + d] * inv;
+    for (int t = 0; t < T; ++t) dside[((int64_t)b * T + t) * D + d] = g;
+  }
+}
+
+// ---- dst[idx[i], :] += src[i, :] (word / position embedding gradients), D = 768 ---------------------------
+__global__ __launch_bounds__(256) void scatter_add_rows_kernel(const float* __restrict__ src, const int64_t* __restrict__ idx, float* __restrict__ dst,
+                                                               int rows, int idx_mod) {
+  const int lane = threadIdx.x & 63;
+  const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (m >= rows) return;
+  const int64_t r = idx ? idx[m] : (m % idx_mod);
+  const float* s = src + (int64_t)m * LN_D;
+  float* d = dst + r * LN_D;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const float4 f = *(const float4*)(s + i * 256 + lane * 4);
+    float* p = d + i * 256 + lane * 4;
+    atomicAdd(p, f.x); atomicAdd(p + 1, f.y); atomicAdd(p + 2, f.z); atomicAdd(p + 3, f.w);
+  }
+}
+
+inline int grid_for(int64_t work_items, int per_block, int cap) {
+  int64_t g = (work_items + per_block - 1) / per_block;
+  if (g < 1) g = 1;
+  if (g > cap) g = cap;
+  return (int)g;
+}
+
+template <typename Tin, typename Tout>
+int launch_transpose(const void* in, int64_t ld_in, void* out, int64_t ld_out, int R, int C, int Rpad, float* colsum, hipStream_t st) {
+  dim3 grid((C + 63) / 64, (Rpad + 63) / 64);
+  hipLaunchKernelGGL((transpose_kernel<Tin, Tout>), grid, dim3(256), 0, st, (const Tin*)in, ld_in, (Tout*)out, ld_out, R, C, Rpad, colsum);
+  return check_launch("alpro_transpose");
+}
+
+}  // namespace
+}  // namespace alpro
+
+using namespace alpro;
+
+extern "C" int alpro_transpose(const void* in, int in_dtype, int64_t ld_in, void* out, int out_dtype, int64_t ld_out, int R, int C,
+                               int Rpad, float* colsum, void* stream) {
+  ALPRO_CHECK(in && out && R > 0 && C > 0 && Rpad >= R, "alpro_transpose: bad args");
+  ALPRO_CHECK(ld_out >= Rpad && ld_in >= C, "alpro_transpose: leading dimensions too small");
+  ALPRO_CHECK(in_dtype == out_dtype || in_dtype == ALPRO_F32, "alpro_transpose: input must be fp32 or the output dtype");
+  hipStream_t st = (hipStream_t)stream;
+  if (in_dtype == ALPRO_F32) {
+    ALPRO_DISPATCH_DTYPE(out_dtype, T, return (launch_transpose<float, T>(in, ld_in, out, ld_out, R, C, Rpad, colsum, st)));
+  } else {
+    ALPRO_DISPATCH_DTYPE(out_dtype, T, return (launch_transpose<T, T>(in, ld_in, out, ld_out, R, C, Rpad, colsum, st)));
+  }
+  return ALPRO_OK;
+}
+
+extern "C" int alpro_layernorm_bwd(const void* dy, int dy_dtype, int64_t ld_dy, const float* dy2, const float* x, int64_t ldx,
+                                   const float* gamma, float eps, float* dx, int64_t ld_dx, int accumulate, float* dgamma, float* dbeta,
+                                   int rows, int D, int map_mode, int map_p0, int map_p1, void* stream) {
+  ALPRO_CHECK(dy && x && gamma && dx && dgamma && dbeta && rows > 0, "alpro_layernorm_bwd: bad args");
+  ALPRO_CHECK(D == LN_D, "alpro_layernorm_bwd: D=%d unsupported", D);
+  ALPRO_CHECK(map_mode >= 0 && map_mode <= ALPRO_MAP_FRAME_TOKENS, "alpro_layernorm_bwd: bad map_mode %d", map_mode);
+  ALPRO_CHECK(map_mode != ALPRO_MAP_FRAME_TOKENS || accumulate, "alpro_layernorm_bwd: the FRAME_TOKENS scatter needs accumulate=1 (CLS rows are shared)");
+  ALPRO_DISPATCH_DTYPE(dy_dtype, T, hipLaunchKernelGGL(layernorm_bwd_kernel<T>, dim3(grid_for(rows, 4 * 8, 256 * 8)), dim3(256), 0, (hipStream_t)stream, (const T*)dy, ld_dy, dy2, x, ldx, gamma, eps, dx, ld_dx, accumulate, dgamma, dbeta, (int64_t)rows, map_mode, map_p0, map_p1));
+  return check_launch("alpro_layernorm_bwd");
+}
+
+extern "C" int alpro_gelu_bwd(const void* dh, const void* u, void* du, int dtype, int64_t n, void* stream) {
+  ALPRO_CHECK(dh && u && du && n > 0, "alpro_gelu_bwd: bad args");
+  ALPRO_CHECK(n % 8 == 0, "alpro_gelu_bwd: n must be a multiple of 8");
+  ALPRO_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL(gelu_bwd_kernel<T>, dim3(grid_for(n / Chunk<T>::N, 256, 256 * 16)), dim3(256), 0, (hipStream_t)stream, (const T*)dh, (const T*)u, (T*)du, n));
+  return check_launch("alpro_gelu_bwd");
+}
+
+extern "C" int alpro_cls_mean_bwd(const float* dx_out, int64_t ld_batch, float* dside, int B, int T, int D, void* stream) {
+  ALPRO_CHECK(dx_out && dside && B > 0 && T > 0 && D > 0, "alpro_cls_mean_bwd: bad args");
+  hipLaunchKernelGGL(cls_mean_bwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, dx_out, ld_batch, dside, B, T, D);
+  return check_launch("alpro_cls_mean_bwd");
+}
+
+extern "C" int alpro_scatter_add_rows(const float* src, const int64_t* idx, float* dst, int rows, int idx_mod, int D, void* stream) {
+  ALPRO_CHECK(src && dst && rows > 0 && (idx || idx_mod > 0), "alpro_scatter_add_rows: bad args");
+  ALPRO_CHECK(D == LN_D, "alpro_scatter_add_rows: D=%d unsupported", D);
+  hipLaunchKernelGGL(scatter_add_rows_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, src, idx, dst, rows, idx_mod);
+  return check_launch("alpro_scatter_add_rows");
+}

@@ -133,7 +133,19 @@ __device__ __forceinline__ void epilogue_rows(const alpro_gemm_desc_t& g, const 
         const float res[4] = {rr[p].x, rr[p].y, rr[p].z, rr[p].w};
         const float rs = g.row_scale ? g.row_scale[m / g.row_scale_group] : 1.0f;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = apply_act<T, ACT>(g.alpha * v[e] + bias[e]) * rs + res[e];
+        for (int e = 0; e < 4; ++e) v[e] = g.alpha * v[e] + bias[e];
+        if (ACT != ALPRO_ACT_NONE && g.C2 && vec_ok) {  // pre-activation copy for the activation's backward
+          if constexpr (sizeof(T) == 2) {
+            u32x2 u;
+            u.x = pack2(v[0], v[1], (T*)0);
+            u.y = pack2(v[2], v[3], (T*)0);
+            *(u32x2*)((T*)g.C2 + orow[p] * g.ldc2 + n) = u;
+          } else {
+            *(float4*)((float*)g.C2 + orow[p] * g.ldc2 + n) = make_float4(v[0], v[1], v[2], v[3]);
+          }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = apply_act<T, ACT>(v[e]) * rs + res[e];
         if (side[p]) {
           float* dst = g.side + orow[p] * g.ld_side + n;
           if (vec_ok) *(float4*)dst = make_float4(v[0], v[1], v[2], v[3]);
@@ -424,6 +436,7 @@ extern "C" int alpro_gemm(const alpro_gemm_desc_t* d, void* stream) {
   ALPRO_CHECK(d->c_dtype == d->dtype || d->c_dtype == ALPRO_F32, "alpro_gemm: c_dtype must be dtype or F32");
   ALPRO_CHECK(d->map_mode >= 0 && d->map_mode <= 3, "alpro_gemm: bad map_mode %d", d->map_mode);
   ALPRO_CHECK(d->act >= 0 && d->act <= 2, "alpro_gemm: bad act %d", d->act);
+  ALPRO_CHECK(!d->C2 || (d->N % 4 == 0 && d->ldc2 % 4 == 0 && d->ldc % 4 == 0), "alpro_gemm: C2 needs N, ldc, ldc2 multiples of 4");
   ALPRO_CHECK(d->map_mode != ALPRO_MAP_FRAME_TOKENS || d->side, "alpro_gemm: FRAME_TOKENS needs a side buffer");
   ALPRO_CHECK(!d->row_scale || d->row_scale_group > 0, "alpro_gemm: row_scale_group must be > 0");
   ALPRO_DISPATCH_DTYPE(d->dtype, T, return launch_gemm<T>(*d, (hipStream_t)stream));

@@ -20,7 +20,8 @@ _CODE = {v: k for k, v in _TORCH_DTYPE.items()}
 
 EXPORTS = ["alpro_hip_last_error", "alpro_hip_abi_version", "alpro_gemm", "alpro_layernorm_fwd",
            "alpro_attn_temporal_fwd", "alpro_attn_fwd", "alpro_patchify", "alpro_cls_mean_residual",
-           "alpro_vit_final_pool", "alpro_bert_embed_fwd", "alpro_cast_from_f32"]
+           "alpro_vit_final_pool", "alpro_bert_embed_fwd", "alpro_cast_from_f32", "alpro_attn_bwd", "alpro_attn_temporal_bwd",
+           "alpro_layernorm_bwd", "alpro_transpose", "alpro_gelu_bwd", "alpro_cls_mean_bwd", "alpro_scatter_add_rows"]
 
 
 class GemmDesc(ctypes.Structure):
@@ -32,7 +33,8 @@ class GemmDesc(ctypes.Structure):
                 ("row_scale", ctypes.c_void_p), ("row_scale_group", ctypes.c_int),
                 ("residual", ctypes.c_void_p), ("ldr", ctypes.c_int64),
                 ("map_mode", ctypes.c_int), ("map_p0", ctypes.c_int), ("map_p1", ctypes.c_int),
-                ("side", ctypes.c_void_p), ("ld_side", ctypes.c_int64)]
+                ("side", ctypes.c_void_p), ("ld_side", ctypes.c_int64),
+                ("C2", ctypes.c_void_p), ("ldc2", ctypes.c_int64)]
 
 
 _lib = None
@@ -53,14 +55,21 @@ def load():
     vp, i32, i64, f32 = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float
     lib.alpro_gemm.argtypes = [ctypes.POINTER(GemmDesc), vp]
     lib.alpro_layernorm_fwd.argtypes = [vp, i64, vp, vp, f32, vp, i32, i64, vp, vp, vp, i32, i32, i32, i32, i32, vp]
-    lib.alpro_attn_temporal_fwd.argtypes = [vp, vp, i32, i64, i32, i32, f32, vp]
+    lib.alpro_attn_temporal_fwd.argtypes = [vp, vp, i32, i64, i32, i32, f32, vp, vp]
+    lib.alpro_attn_bwd.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, vp, vp]
+    lib.alpro_attn_temporal_bwd.argtypes = [vp, vp, vp, vp, vp, i32, i64, i32, i32, f32, vp]
+    lib.alpro_layernorm_bwd.argtypes = [vp, i32, i64, vp, vp, i64, vp, f32, vp, i64, i32, vp, vp, i32, i32, i32, i32, i32, vp]
+    lib.alpro_transpose.argtypes = [vp, i32, i64, vp, i32, i64, i32, i32, i32, vp, vp]
+    lib.alpro_gelu_bwd.argtypes = [vp, vp, vp, i32, i64, vp]
+    lib.alpro_cls_mean_bwd.argtypes = [vp, i64, vp, i32, i32, i32, vp]
+    lib.alpro_scatter_add_rows.argtypes = [vp, vp, vp, i32, i32, i32, vp]
     lib.alpro_attn_fwd.argtypes = [vp, vp, i32, i32, i32, i32, f32, vp, vp, vp]
     lib.alpro_patchify.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp]
     lib.alpro_cls_mean_residual.argtypes = [vp, i64, vp, vp, i64, i32, i32, i32, vp]
     lib.alpro_vit_final_pool.argtypes = [vp, vp, vp, f32, vp, vp, i32, i32, i32, i32, i32, vp]
     lib.alpro_bert_embed_fwd.argtypes = [vp, vp, vp, vp, vp, vp, f32, vp, vp, i32, vp, vp, i32, i32, i32, vp]
     lib.alpro_cast_from_f32.argtypes = [vp, vp, i32, i64, vp]
-    if lib.alpro_hip_abi_version() != 1:
+    if lib.alpro_hip_abi_version() != 2:
         raise RuntimeError("libalpro_hip.so ABI version mismatch")
     _lib = lib
     return lib
@@ -99,7 +108,7 @@ def torch_dtype(code):
 
 # ------------------------------------------------------------------------------------------------
 def gemm(a, w, out=None, bias=None, act=ACT_NONE, out_dtype=None, alpha=1.0, row_scale=None, row_scale_group=1,
-         residual=None, map_mode=MAP_IDENTITY, map_p0=0, map_p1=0, side=None, out_rows=None):
+         residual=None, map_mode=MAP_IDENTITY, map_p0=0, map_p1=0, side=None, out_rows=None, pre_act=None):
     """out[map(m)] = residual[map(m)] + row_scale * act(alpha * a @ w.T + bias)   (see alpro_gemm)."""
     lib = load()
     _dev(a); _dev(w, a.dtype)
@@ -124,6 +133,8 @@ def gemm(a, w, out=None, bias=None, act=ACT_NONE, out_dtype=None, alpha=1.0, row
     d.map_mode, d.map_p0, d.map_p1 = map_mode, map_p0, map_p1
     d.side = _dev(side, torch.float32).data_ptr() if side is not None else None
     d.ld_side = side.shape[-1] if side is not None else 0
+    d.C2 = _dev(pre_act, a.dtype).data_ptr() if pre_act is not None else None
+    d.ldc2 = pre_act.shape[-1] if pre_act is not None else 0
     _check(lib.alpro_gemm(ctypes.byref(d), _stream()), "alpro_gemm")
     return out
 
@@ -149,13 +160,83 @@ def layernorm(x, gamma, beta, eps, out_dtype, rows=None, out32=False, stats=Fals
     return res if len(res) > 1 else y
 
 
-def attn_temporal(qkv, T, H, scale):
+def attn_temporal(qkv, T, H, scale, want_lse=False):
     lib = load()
     _dev(qkv)
     rows = qkv.shape[0]
     out = torch.empty((rows, H * 64), dtype=qkv.dtype, device=qkv.device)
-    _check(lib.alpro_attn_temporal_fwd(_ptr(qkv), _ptr(out), _CODE[qkv.dtype], rows, T, H, scale, _stream()), "alpro_attn_temporal_fwd")
+    lse = torch.empty(((rows + 31) // 32, H, 32), dtype=torch.float32, device=qkv.device) if want_lse else None
+    _check(lib.alpro_attn_temporal_fwd(_ptr(qkv), _ptr(out), _CODE[qkv.dtype], rows, T, H, scale, _ptr(lse), _stream()), "alpro_attn_temporal_fwd")
+    return (out, lse) if want_lse else out
+
+
+def attn_temporal_bwd(qkv, out, dout, lse, T, H, scale):
+    lib = load()
+    _dev(qkv); _dev(out, qkv.dtype); _dev(dout, qkv.dtype); _dev(lse, torch.float32)
+    dqkv = torch.empty_like(qkv)
+    _check(lib.alpro_attn_temporal_bwd(_ptr(qkv), _ptr(out), _ptr(dout), _ptr(lse), _ptr(dqkv), _CODE[qkv.dtype], qkv.shape[0], T, H, scale,
+                                       _stream()), "alpro_attn_temporal_bwd")
+    return dqkv
+
+
+def attn_bwd(qkv, out, dout, lse, batch, L, H, scale, key_bias=None):
+    lib = load()
+    _dev(qkv); _dev(out, qkv.dtype); _dev(dout, qkv.dtype); _dev(lse, torch.float32)
+    dqkv = torch.empty_like(qkv)
+    kb = _dev(key_bias, torch.float32) if key_bias is not None else None
+    _check(lib.alpro_attn_bwd(_ptr(qkv), _ptr(out), _ptr(dout), _ptr(lse), _ptr(dqkv), _CODE[qkv.dtype], batch, L, H, scale, _ptr(kb), _stream()),
+           "alpro_attn_bwd")
+    return dqkv
+
+
+def layernorm_bwd(dy, x, gamma, eps, dx, dgamma, dbeta, rows=None, dy2=None, accumulate=True, map_mode=MAP_IDENTITY, map_p0=0, map_p1=0):
+    """dx[map(m)] (+)= dLN; dgamma/dbeta (fp32, pre-initialised) are accumulated.  x, dx: fp32 (..., 768)."""
+    lib = load()
+    _dev(dy); _dev(x, torch.float32); _dev(dx, torch.float32); _dev(dgamma, torch.float32); _dev(dbeta, torch.float32)
+    D = x.shape[-1]
+    rows = rows if rows is not None else dy.numel() // D
+    _check(lib.alpro_layernorm_bwd(_ptr(dy), _CODE[dy.dtype], D, _ptr(_dev(dy2, torch.float32)) if dy2 is not None else None, _ptr(x), D,
+                                   _ptr(_dev(gamma, torch.float32)), eps, _ptr(dx), D, 1 if accumulate else 0, _ptr(dgamma), _ptr(dbeta), rows, D,
+                                   map_mode, map_p0, map_p1, _stream()), "alpro_layernorm_bwd")
+    return dx
+
+
+def transpose(x, out_dtype=None, pad_to=64, colsum=None):
+    """(R, C) -> (C, Rpad) with the R dimension zero-padded to a multiple of `pad_to`; optional fp32 column sums (+=)."""
+    lib = load()
+    _dev(x)
+    R, C = x.shape
+    out_dtype = out_dtype or x.dtype
+    Rpad = (R + pad_to - 1) // pad_to * pad_to
+    out = torch.empty((C, Rpad), dtype=out_dtype, device=x.device)
+    _check(lib.alpro_transpose(_ptr(x), _CODE[x.dtype], x.stride(0), _ptr(out), _CODE[out_dtype], Rpad, R, C, Rpad,
+                               _ptr(_dev(colsum, torch.float32)) if colsum is not None else None, _stream()), "alpro_transpose")
     return out
+
+
+def gelu_bwd(dh, u):
+    lib = load()
+    _dev(dh); _dev(u, dh.dtype)
+    du = torch.empty_like(dh)
+    _check(lib.alpro_gelu_bwd(_ptr(dh), _ptr(u), _ptr(du), _CODE[dh.dtype], dh.numel(), _stream()), "alpro_gelu_bwd")
+    return du
+
+
+def cls_mean_bwd(dx_out, B, T):
+    lib = load()
+    _dev(dx_out, torch.float32)
+    D = dx_out.shape[-1]
+    dside = torch.empty((B * T, D), dtype=torch.float32, device=dx_out.device)
+    _check(lib.alpro_cls_mean_bwd(_ptr(dx_out), dx_out.stride(0), _ptr(dside), B, T, D, _stream()), "alpro_cls_mean_bwd")
+    return dside
+
+
+def scatter_add_rows(src, idx, dst, idx_mod=0):
+    lib = load()
+    _dev(src, torch.float32); _dev(dst, torch.float32)
+    _check(lib.alpro_scatter_add_rows(_ptr(src), _ptr(_dev(idx, torch.int64)) if idx is not None else None, _ptr(dst), src.shape[0], idx_mod,
+                                      src.shape[1], _stream()), "alpro_scatter_add_rows")
+    return dst
 
 
 def attn(qkv, batch, L, H, scale, key_bias=None, want_lse=False):

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define ALPRO_HIP_ABI_VERSION 1
+#define ALPRO_HIP_ABI_VERSION 2
 
 enum { ALPRO_OK = 0, ALPRO_ERR_INVALID = 1, ALPRO_ERR_LAUNCH = 2 };
 enum { ALPRO_F32 = 0, ALPRO_BF16 = 1, ALPRO_F16 = 2 };
@@ -73,6 +73,8 @@ typedef struct {
   int map_mode, map_p0, map_p1; /* ALPRO_MAP_* applied to C rows and residual rows */
   float* side;            /* FRAME_TOKENS: (B*T, N) fp32 buffer receiving the j == 0 rows (no residual) */
   int64_t ld_side;
+  void* C2;               /* optional (M, N) `dtype` copy of the pre-activation alpha*acc+bias (kept for the GELU backward) */
+  int64_t ldc2;
 } alpro_gemm_desc_t;
 
 int alpro_gemm(const alpro_gemm_desc_t* d, void* stream);
@@ -90,7 +92,7 @@ int alpro_layernorm_fwd(const float* x, int64_t ldx, const float* gamma, const f
  * qkv (rows, 3*H*64) as written by the qkv Linear, out (rows, H*64) == 'transpose(1,2).reshape'.
  * T must divide 32.  softmax(q k^T * scale) v on MFMA with a block-diagonal group mask. */
 int alpro_attn_temporal_fwd(const void* qkv, void* out, int dtype, int64_t rows, int T, int H, float scale,
-                            void* stream);
+                            float* lse /* optional (ceil(rows/32), H, 32) row log-sum-exp for the backward */, void* stream);
 
 /* Full (bidirectional) attention over `batch` sequences of L <= 256 tokens, head_dim 64:
  * spatial half of divided attention (vit.py:180 on (B*T, 1+N) tokens, :81-96) and the BERT
@@ -120,6 +122,38 @@ int alpro_bert_embed_fwd(const int64_t* ids, const float* word, const float* pos
 
 /* dst[i] = (dtype) src[i]: parameter / activation cast used when the storage dtype is 16-bit. */
 int alpro_cast_from_f32(const float* src, void* dst, int dtype, int64_t n, void* stream);
+
+/* ---- backward of the same path (what autograd derives for the reference: loss.backward() at
+ * run_pretrain_sparse.py:599 through vit.py:136-213 and xbert.py:457-519) --------------------------------- */
+
+/* dQKV (rows, 3*H*64) from dO (rows, H*64), the saved qkv / out and the row log-sum-exp of the forward.
+ * P is recomputed on MFMA; delta = rowsum(dO o O); see attention_bwd.hip. */
+int alpro_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, int dtype,
+                   int batch, int L, int H, float scale, const float* key_bias, void* stream);
+int alpro_attn_temporal_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, int dtype,
+                            int64_t rows, int T, int H, float scale, void* stream);
+
+/* LayerNorm backward over D == 768: dx[map(m)] (+)= dLN(dy[m] (+ dy2[m]), x[map(m)]); dgamma/dbeta are ACCUMULATED
+ * (atomics) into fp32 buffers.  The forward gather map becomes a scatter; rows gathered more than once (the CLS
+ * row under FRAME_TOKENS) are accumulated atomically, so that map requires accumulate = 1. */
+int alpro_layernorm_bwd(const void* dy, int dy_dtype, int64_t ld_dy, const float* dy2, const float* x, int64_t ldx,
+                        const float* gamma, float eps, float* dx, int64_t ld_dx, int accumulate, float* dgamma,
+                        float* dbeta, int rows, int D, int map_mode, int map_p0, int map_p1, void* stream);
+
+/* out[c, r] = in[r, c] (r < R), 0 for R <= r < Rpad: puts the token dimension last so that dgrad / wgrad run on
+ * the NT GEMM (dX = dY (W^T)^T, dW = dY^T (X^T)^T).  `in` is fp32 or out_dtype.  colsum (C) fp32, optional:
+ * column sums are atomically accumulated into it (the bias gradient). */
+int alpro_transpose(const void* in, int in_dtype, int64_t ld_in, void* out, int out_dtype, int64_t ld_out, int R, int C,
+                    int Rpad, float* colsum, void* stream);
+
+/* du = dh * gelu'(u) with the erf GELU (vit.py:61 / xbert.py:423 backward). */
+int alpro_gelu_bwd(const void* dh, const void* u, void* du, int dtype, int64_t n, void* stream);
+
+/* dside[b*T+t, :] = dx_out[b, 0, :] / T  (backward of alpro_cls_mean_residual w.r.t. the parked CLS rows). */
+int alpro_cls_mean_bwd(const float* dx_out, int64_t ld_batch, float* dside, int B, int T, int D, void* stream);
+
+/* dst[idx[i], :] += src[i, :] (idx NULL: row i % idx_mod): embedding-table gradients (xbert.py:203-210 backward). */
+int alpro_scatter_add_rows(const float* src, const int64_t* idx, float* dst, int rows, int idx_mod, int D, void* stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,145 @@
+"""GPU: backward kernels (C ABI) against torch autograd in fp64 on identical (pre-rounded) operands."""
+import math
+
+import pytest
+import torch
+
+from tests.test_hip_ops import DTYPES, _hip, close, rnd
+
+pytestmark = pytest.mark.gpu
+
+GRAD_TOL = {torch.float32: (2e-4, 2e-5), torch.bfloat16: (3e-2, 3e-2), torch.float16: (5e-3, 5e-3)}
+
+
+def attn_ref(qkv, batch, L, H, scale, bias=None, group=None):
+    t = qkv.view(batch, L, 3, H, 64).permute(2, 0, 3, 1, 4)
+    s = (t[0] @ t[1].transpose(-1, -2)) * scale
+    if bias is not None:
+        s = s + bias[:, None, None, :].double()
+    if group is not None:
+        idx = torch.arange(L) // group
+        s = s.masked_fill(idx[:, None] != idx[None, :], float("-inf"))
+    return (s.softmax(-1) @ t[2]).transpose(1, 2).reshape(batch * L, H * 64)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("batch,L,masked", [(2, 40, True), (2, 197, False), (1, 237, True), (1, 70, False)])
+def test_attn_bwd(dt, batch, L, masked):
+    hip = _hip()
+    H = 12
+    qkv = (rnd(batch * L, 3 * H * 64, seed=70 + L) * 0.7).to(dt)
+    dout = rnd(batch * L, H * 64, seed=71 + L).to(dt)
+    bias = None
+    if masked:
+        m = torch.ones(batch, L)
+        for b in range(batch):
+            m[b, L - 4 - 3 * b:] = 0
+        bias = (1.0 - m) * -10000.0
+    q64 = qkv.double().requires_grad_(True)
+    ref = attn_ref(q64, batch, L, H, 0.125, bias)
+    ref.backward(dout.double())
+    out, lse = hip.attn(qkv.cuda(), batch, L, H, 0.125, None if bias is None else bias.cuda(), want_lse=True)
+    dqkv = hip.attn_bwd(qkv.cuda(), out, dout.cuda(), lse, batch, L, H, 0.125, None if bias is None else bias.cuda())
+    g = q64.grad.view(batch * L, 3, H * 64)
+    d = dqkv.view(batch * L, 3, H * 64)
+    for i, name in enumerate("QKV"):
+        close(d[:, i], g[:, i], *GRAD_TOL[dt], "d%s" % name)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("T,groups", [(8, 9), (4, 17), (2, 48), (16, 3)])
+def test_attn_temporal_bwd(dt, T, groups):
+    hip = _hip()
+    H = 12
+    rows = groups * T
+    qkv = (rnd(rows, 3 * H * 64, seed=80 + T) * 0.7).to(dt)
+    dout = rnd(rows, H * 64, seed=81 + T).to(dt)
+    q64 = qkv.double().requires_grad_(True)
+    attn_ref(q64, groups, T, H, 0.125).backward(dout.double())
+    out, lse = hip.attn_temporal(qkv.cuda(), T, H, 0.125, want_lse=True)
+    dqkv = hip.attn_temporal_bwd(qkv.cuda(), out, dout.cuda(), lse, T, H, 0.125)
+    close(dqkv, q64.grad, *GRAD_TOL[dt], "temporal dqkv")
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+def test_layernorm_bwd_maps(dt):
+    hip = _hip()
+    B, T, N, D = 2, 4, 9, 768
+    S = 1 + N * T
+    x = rnd(B, S, D, seed=90) * 2 + 0.3
+    g, b = 1 + 0.1 * rnd(D, seed=91), 0.1 * rnd(D, seed=92)
+    for mode, rows, kw in (("identity", B * S, {}), ("skip", B * N * T, dict(map_mode=hip.MAP_SKIP_CLS, map_p0=N * T)),
+                           ("frame", B * T * (N + 1), dict(map_mode=hip.MAP_FRAME_TOKENS, map_p0=T, map_p1=N))):
+        dy = rnd(rows, D, seed=93).to(dt)
+        x64 = x.double().requires_grad_(True)
+        g64, b64 = g.double().requires_grad_(True), b.double().requires_grad_(True)
+        ln = torch.nn.functional.layer_norm(x64, (D,), g64, b64, 1e-6)
+        if mode == "identity":
+            y = ln.view(-1, D)
+        elif mode == "skip":
+            y = ln[:, 1:].reshape(-1, D)
+        else:
+            xs = ln[:, 1:].reshape(B, N, T, D).permute(0, 2, 1, 3)
+            y = torch.cat([ln[:, :1].unsqueeze(1).expand(B, T, 1, D), xs], 2).reshape(-1, D)
+        dres = rnd(B, S, D, seed=94)
+        (y * dy.double()).sum().backward()
+        dx = dres.clone().cuda()
+        dg, db = torch.zeros(D).cuda(), torch.zeros(D).cuda()
+        hip.layernorm_bwd(dy.cuda(), x.cuda(), g.cuda(), 1e-6, dx, dg, db, rows=rows, **kw)
+        close(dx, dres.double() + x64.grad, 1e-4, 2e-4, "ln bwd dx " + mode)
+        close(dg, g64.grad, 1e-4, 2e-3, "ln bwd dgamma " + mode)
+        close(db, b64.grad, 1e-4, 2e-3, "ln bwd dbeta " + mode)
+
+
+def test_layernorm_bwd_two_streams():
+    hip = _hip()
+    rows, D = 37, 768
+    x, dy, dy2 = rnd(rows, D, seed=95), rnd(rows, D, seed=96).to(torch.bfloat16), rnd(rows, D, seed=97)
+    g = 1 + 0.1 * rnd(D, seed=98)
+    x64 = x.double().requires_grad_(True)
+    y = torch.nn.functional.layer_norm(x64, (D,), g.double(), torch.zeros(D, dtype=torch.float64), 1e-12)
+    (y * (dy.double() + dy2.double())).sum().backward()
+    dx = torch.empty(rows, D).cuda()
+    hip.layernorm_bwd(dy.cuda(), x.cuda(), g.cuda(), 1e-12, dx, torch.zeros(D).cuda(), torch.zeros(D).cuda(), dy2=dy2.cuda(), accumulate=False)
+    close(dx, x64.grad, 1e-4, 2e-4, "ln bwd two streams")
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+def test_transpose_gelu_misc(dt):
+    hip = _hip()
+    x = rnd(300, 200, seed=100).to(dt)
+    cs = torch.ones(200).cuda()
+    t = hip.transpose(x.cuda(), colsum=cs)
+    assert t.shape == (200, 320)
+    assert torch.equal(t[:, :300].cpu(), x.t().contiguous()) and float(t[:, 300:].abs().sum()) == 0
+    close(cs, 1 + x.double().sum(0), 1e-5, 1e-4, "colsum")
+    w = rnd(100, 768, seed=101)
+    t2 = hip.transpose(w.cuda(), out_dtype=dt, pad_to=64)
+    assert torch.equal(t2[:, :100].cpu(), w.to(dt).t().contiguous())
+    u, dh = rnd(64, 3072, seed=102).to(dt), rnd(64, 3072, seed=103).to(dt)
+    u64 = u.double().requires_grad_(True)
+    (torch.nn.functional.gelu(u64) * dh.double()).sum().backward()
+    close(hip.gelu_bwd(dh.cuda(), u.cuda()), u64.grad, *{torch.float32: (1e-5, 1e-5), torch.bfloat16: (1e-2, 1e-2), torch.float16: (2e-3, 2e-3)}[dt], "gelu bwd")
+    if dt == torch.float32:
+        dxo = rnd(3, 5, 768, seed=104)
+        ds = hip.cls_mean_bwd(dxo.cuda(), 3, 4)
+        close(ds, (dxo[:, 0] / 4).repeat_interleave(4, 0), 1e-6, 1e-6, "cls mean bwd")
+        src, idx = rnd(50, 768, seed=105), torch.randint(0, 7, (50,))
+        dst = torch.zeros(7, 768).cuda()
+        hip.scatter_add_rows(src.cuda(), idx.cuda(), dst)
+        close(dst, torch.zeros(7, 768, dtype=torch.float64).index_add_(0, idx, src.double()), 1e-5, 1e-5, "scatter add")
+        dst = torch.zeros(10, 768).cuda()
+        hip.scatter_add_rows(src.cuda(), None, dst, idx_mod=10)
+        close(dst, src.double().view(5, 10, 768).sum(0), 1e-5, 1e-5, "scatter add mod")
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_gemm_pre_activation_copy(dt):
+    hip = _hip()
+    a, w, b = rnd(300, 768, seed=110), rnd(256, 768, seed=111, scale=0.05), rnd(256, seed=112)
+    pre = torch.empty(300, 256, dtype=dt).cuda()
+    out = hip.gemm(a.to(dt).cuda(), w.to(dt).cuda(), bias=b.cuda(), act=hip.ACT_GELU, pre_act=pre)
+    ref = a.to(dt).double() @ w.to(dt).double().T + b.double()
+    tol = (2e-5, 2e-5) if dt == torch.float32 else (1e-2, 1e-2)
+    close(pre, ref, *tol, "pre-activation")
+    close(out, torch.nn.functional.gelu(ref), *tol, "gelu out")
