@@ -156,6 +156,46 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
   }
 }
 
+// ---- out[m, :] = (T)(scale(m) * src[row(m), :]): gathers fp32 token-gradient rows into a GEMM operand ---------------
+// row(m) follows the forward maps; under FRAME_TOKENS the j == 0 rows read the clip's CLS row times cls_scale (1/T).
+template <typename T>
+__global__ __launch_bounds__(256) void gather_cast_kernel(const float* __restrict__ src, int64_t ld, T* __restrict__ out, int64_t rows, int mode,
+                                                          int p0, int p1, const float* __restrict__ row_scale, int group, float cls_scale) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t nwaves = (int64_t)gridDim.x * 4;
+  for (int64_t m = wave; m < rows; m += nwaves) {
+    int64_t r;
+    float sc = row_scale ? row_scale[m / group] : 1.0f;
+    if (mode == ALPRO_MAP_PATCH_EMBED) {
+      const int T_ = p0, N = p1;
+      const int64_t bt = m / N;
+      const int n = (int)(m - bt * N);
+      const int64_t b = bt / T_;
+      const int t = (int)(bt - b * T_);
+      r = b * (1 + (int64_t)N * T_) + 1 + (int64_t)n * T_ + t;
+    } else {
+      const SrcRow s = ln_src_row(mode, p0, p1, m);
+      r = s.row;
+      if (s.shared) sc *= cls_scale;
+    }
+    float v[12];
+    ld12(src + r * ld, lane, v);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      T* p = out + m * LN_D + i * 256 + lane * 4;
+      if constexpr (sizeof(T) == 4) {
+        *(float4*)p = make_float4(v[4 * i] * sc, v[4 * i + 1] * sc, v[4 * i + 2] * sc, v[4 * i + 3] * sc);
+      } else {
+        u32x2 u;
+        u.x = pack2(v[4 * i] * sc, v[4 * i + 1] * sc, (T*)0);
+        u.y = pack2(v[4 * i + 2] * sc, v[4 * i + 3] * sc, (T*)0);
+        *(u32x2*)p = u;
+      }
+    }
+  }
+}
+
 // ---- du = dh * gelu'(u) (erf GELU), elementwise over 16-byte chunks ---------------------------------------
 template <typename T>
 __global__ void gelu_bwd_kernel(const T* __restrict__ dh, const T* __restrict__ u, T* __restrict__ du, int64_t n) {
@@ -245,6 +285,16 @@ extern "C" int alpro_layernorm_bwd(const void* dy, int dy_dtype, int64_t ld_dy, 
   ALPRO_CHECK(map_mode != ALPRO_MAP_FRAME_TOKENS || accumulate, "alpro_layernorm_bwd: the FRAME_TOKENS scatter needs accumulate=1 (CLS rows are shared)");
   ALPRO_DISPATCH_DTYPE(dy_dtype, T, hipLaunchKernelGGL(layernorm_bwd_kernel<T>, dim3(grid_for(rows, 4 * 8, 256 * 8)), dim3(256), 0, (hipStream_t)stream, (const T*)dy, ld_dy, dy2, x, ldx, gamma, eps, dx, ld_dx, accumulate, dgamma, dbeta, (int64_t)rows, map_mode, map_p0, map_p1));
   return check_launch("alpro_layernorm_bwd");
+}
+
+extern "C" int alpro_gather_cast(const float* src, int64_t ld, void* out, int dtype, int rows, int D, int map_mode, int map_p0, int map_p1,
+                                 const float* row_scale, int row_scale_group, float cls_scale, void* stream) {
+  ALPRO_CHECK(src && out && rows > 0, "alpro_gather_cast: bad args");
+  ALPRO_CHECK(D == LN_D, "alpro_gather_cast: D=%d unsupported", D);
+  ALPRO_CHECK(map_mode >= 0 && map_mode <= ALPRO_MAP_PATCH_EMBED, "alpro_gather_cast: bad map_mode %d", map_mode);
+  ALPRO_CHECK(!row_scale || row_scale_group > 0, "alpro_gather_cast: row_scale_group must be > 0");
+  ALPRO_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL(gather_cast_kernel<T>, dim3(grid_for(rows, 4, 256 * 32)), dim3(256), 0, (hipStream_t)stream, src, ld, (T*)out, (int64_t)rows, map_mode, map_p0, map_p1, row_scale, row_scale_group, cls_scale));
+  return check_launch("alpro_gather_cast");
 }
 
 extern "C" int alpro_gelu_bwd(const void* dh, const void* u, void* du, int dtype, int64_t n, void* stream) {

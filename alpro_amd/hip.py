@@ -21,7 +21,7 @@ _CODE = {v: k for k, v in _TORCH_DTYPE.items()}
 EXPORTS = ["alpro_hip_last_error", "alpro_hip_abi_version", "alpro_gemm", "alpro_layernorm_fwd",
            "alpro_attn_temporal_fwd", "alpro_attn_fwd", "alpro_patchify", "alpro_cls_mean_residual",
            "alpro_vit_final_pool", "alpro_bert_embed_fwd", "alpro_cast_from_f32", "alpro_attn_bwd", "alpro_attn_temporal_bwd",
-           "alpro_layernorm_bwd", "alpro_transpose", "alpro_gelu_bwd", "alpro_cls_mean_bwd", "alpro_scatter_add_rows"]
+           "alpro_layernorm_bwd", "alpro_transpose", "alpro_gelu_bwd", "alpro_cls_mean_bwd", "alpro_scatter_add_rows", "alpro_gather_cast"]
 
 
 class GemmDesc(ctypes.Structure):
@@ -61,6 +61,7 @@ def load():
     lib.alpro_layernorm_bwd.argtypes = [vp, i32, i64, vp, vp, i64, vp, f32, vp, i64, i32, vp, vp, i32, i32, i32, i32, i32, vp]
     lib.alpro_transpose.argtypes = [vp, i32, i64, vp, i32, i64, i32, i32, i32, vp, vp]
     lib.alpro_gelu_bwd.argtypes = [vp, vp, vp, i32, i64, vp]
+    lib.alpro_gather_cast.argtypes = [vp, i64, vp, i32, i32, i32, i32, i32, i32, vp, i32, f32, vp]
     lib.alpro_cls_mean_bwd.argtypes = [vp, i64, vp, i32, i32, i32, vp]
     lib.alpro_scatter_add_rows.argtypes = [vp, vp, vp, i32, i32, i32, vp]
     lib.alpro_attn_fwd.argtypes = [vp, vp, i32, i32, i32, i32, f32, vp, vp, vp]
@@ -211,6 +212,19 @@ def transpose(x, out_dtype=None, pad_to=64, colsum=None):
     out = torch.empty((C, Rpad), dtype=out_dtype, device=x.device)
     _check(lib.alpro_transpose(_ptr(x), _CODE[x.dtype], x.stride(0), _ptr(out), _CODE[out_dtype], Rpad, R, C, Rpad,
                                _ptr(_dev(colsum, torch.float32)) if colsum is not None else None, _stream()), "alpro_transpose")
+    return out
+
+
+def gather_cast(src, dtype, rows=None, map_mode=MAP_IDENTITY, map_p0=0, map_p1=0, row_scale=None, row_scale_group=1, cls_scale=1.0):
+    """fp32 (..., 768) token-gradient rows -> (rows, 768) GEMM operand in `dtype` (see alpro_gather_cast)."""
+    lib = load()
+    _dev(src, torch.float32)
+    D = src.shape[-1]
+    rows = rows if rows is not None else src.numel() // D
+    out = torch.empty((rows, D), dtype=dtype, device=src.device)
+    _check(lib.alpro_gather_cast(_ptr(src), D, _ptr(out), _CODE[dtype], rows, D, map_mode, map_p0, map_p1,
+                                 _ptr(_dev(row_scale, torch.float32)) if row_scale is not None else None, row_scale_group, cls_scale, _stream()),
+           "alpro_gather_cast")
     return out
 
 

@@ -27,6 +27,7 @@ import torch.nn as nn
 
 from alpro_amd import config as rt
 from alpro_amd import hip
+from alpro_amd.modeling import train as tr
 from alpro_amd.modeling.weights import OperandCache
 
 VIT_EPS = 1e-6
@@ -138,6 +139,86 @@ class Block(nn.Module):
                  row_scale=self._drop(B, x.device), row_scale_group=S)
         return x
 
+    # ---- training path: fresh buffers (the backward needs every LayerNorm input), explicit backward ----------
+    def forward_train(self, x, B, T, W):
+        """Same arithmetic as forward() but out of place; returns (out, saved)."""
+        dt = rt.compute_dtype()
+        S, D = x.shape[1], x.shape[2]
+        N = (S - 1) // T
+        H = self.attn.num_heads
+        ta, sa = self.temporal_attn, self.attn
+        dev = x.device
+        sv = {"x": x, "dims": (B, T, N, S, D, H), "dt": dt}
+        sv["drop_t"], sv["drop_s"], sv["drop_m"] = self._drop(B * N, dev), self._drop(B * T, dev), self._drop(B, dev)
+        h = hip.layernorm(x, self.temporal_norm1.weight, self.temporal_norm1.bias, VIT_EPS, dt, rows=B * N * T,
+                          map_mode=hip.MAP_SKIP_CLS, map_p0=N * T)
+        qkv_t = hip.gemm(h, self._w("t_qkv", ta.qkv, dt), bias=ta.qkv.bias)
+        a_t, lse_t = hip.attn_temporal(qkv_t, T, H, ta.scale, want_lse=True)
+        pr = hip.gemm(a_t, self._w("t_proj", ta.proj, dt), bias=ta.proj.bias, row_scale=sv["drop_t"], row_scale_group=T)
+        xt = torch.empty_like(x)
+        xt[:, 0] = x[:, 0]
+        hip.gemm(pr, self._w("t_fc", self.temporal_fc, dt), out=xt.view(B * S, D), bias=self.temporal_fc.bias, out_dtype=torch.float32,
+                 residual=x.view(B * S, D), map_mode=hip.MAP_SKIP_CLS, map_p0=N * T)
+        hs = hip.layernorm(xt, self.norm1.weight, self.norm1.bias, VIT_EPS, dt, rows=B * T * (N + 1),
+                           map_mode=hip.MAP_FRAME_TOKENS, map_p0=T, map_p1=N)
+        qkv_s = hip.gemm(hs, self._w("s_qkv", sa.qkv, dt), bias=sa.qkv.bias)
+        a_s, lse_s = hip.attn(qkv_s, B * T, N + 1, H, sa.scale, want_lse=True)
+        x2 = torch.empty_like(x)
+        side = torch.empty((B * T, D), dtype=torch.float32, device=dev)
+        hip.gemm(a_s, self._w("s_proj", sa.proj, dt), out=x2.view(B * S, D), bias=sa.proj.bias, out_dtype=torch.float32,
+                 residual=xt.view(B * S, D), row_scale=sv["drop_s"], row_scale_group=N + 1,
+                 map_mode=hip.MAP_FRAME_TOKENS, map_p0=T, map_p1=N, side=side)
+        hip.cls_mean_residual(xt, side, x2, B, T)
+        h2 = hip.layernorm(x2, self.norm2.weight, self.norm2.bias, VIT_EPS, dt)
+        u = torch.empty((B * S, self.mlp.fc1.out_features), dtype=dt, device=dev)
+        f1 = hip.gemm(h2, self._w("fc1", self.mlp.fc1, dt), bias=self.mlp.fc1.bias, act=hip.ACT_GELU, pre_act=u)
+        out = torch.empty_like(x)
+        hip.gemm(f1, self._w("fc2", self.mlp.fc2, dt), out=out.view(B * S, D), bias=self.mlp.fc2.bias, out_dtype=torch.float32,
+                 residual=x2.view(B * S, D), row_scale=sv["drop_m"], row_scale_group=S)
+        sv.update(h=h, qkv_t=qkv_t, a_t=a_t, lse_t=lse_t, pr=pr, xt=xt, hs=hs, qkv_s=qkv_s, a_s=a_s, lse_s=lse_s, x2=x2, h2=h2, u=u, f1=f1)
+        return out, sv
+
+    def _wt(self, name, lin, dt):
+        return tr.transposed_operand(self._ops, name + "^T", lin.weight, dt)
+
+    def backward(self, sv, dx):
+        """dx: gradient w.r.t. the block output, (B, S, D) fp32; overwritten with the gradient w.r.t. the block input."""
+        B, T, N, S, D, H = sv["dims"]
+        dt = sv["dt"]
+        ta, sa = self.temporal_attn, self.attn
+        # ---- MLP: out = x2 + drop_m * (fc2(gelu(fc1(LN2(x2)))))
+        dz = hip.gather_cast(dx, dt, row_scale=sv["drop_m"], row_scale_group=S)
+        tr.wgrad(dz, sv["f1"], self.mlp.fc2.weight, self.mlp.fc2.bias)
+        du = hip.gelu_bwd(tr.dgrad(dz, self._wt("fc2", self.mlp.fc2, dt)), sv["u"])
+        tr.wgrad(du, sv["h2"], self.mlp.fc1.weight, self.mlp.fc1.bias)
+        dh2 = tr.dgrad(du, self._wt("fc1", self.mlp.fc1, dt))
+        g, b_ = tr.grad_buffer(self.norm2.weight, zero=True)[0], tr.grad_buffer(self.norm2.bias, zero=True)[0]
+        hip.layernorm_bwd(dh2, sv["x2"], self.norm2.weight, VIT_EPS, dx, g, b_)
+        # ---- spatial: x2 = scatter(xt + drop_s * proj(attn(qkv(LN1(gather(xt)))))), CLS averaged over frames
+        dpo = hip.gather_cast(dx, dt, rows=B * T * (N + 1), map_mode=hip.MAP_FRAME_TOKENS, map_p0=T, map_p1=N,
+                              row_scale=sv["drop_s"], row_scale_group=N + 1, cls_scale=1.0 / T)
+        tr.wgrad(dpo, sv["a_s"], sa.proj.weight, sa.proj.bias)
+        da = tr.dgrad(dpo, self._wt("s_proj", sa.proj, dt))
+        dqkv = hip.attn_bwd(sv["qkv_s"], sv["a_s"], da, sv["lse_s"], B * T, N + 1, H, sa.scale)
+        tr.wgrad(dqkv, sv["hs"], sa.qkv.weight, sa.qkv.bias)
+        dhs = tr.dgrad(dqkv, self._wt("s_qkv", sa.qkv, dt))
+        g, b_ = tr.grad_buffer(self.norm1.weight, zero=True)[0], tr.grad_buffer(self.norm1.bias, zero=True)[0]
+        hip.layernorm_bwd(dhs, sv["xt"], self.norm1.weight, VIT_EPS, dx, g, b_, rows=B * T * (N + 1),
+                          map_mode=hip.MAP_FRAME_TOKENS, map_p0=T, map_p1=N)
+        # ---- temporal: xt[:, 1:] = x[:, 1:] + fc(drop_t * proj(attn(qkv(LN_t(x[:, 1:])))))
+        dfo = hip.gather_cast(dx, dt, rows=B * N * T, map_mode=hip.MAP_SKIP_CLS, map_p0=N * T)
+        tr.wgrad(dfo, sv["pr"], self.temporal_fc.weight, self.temporal_fc.bias)
+        dpp = tr.dgrad(dfo, self._wt("t_fc", self.temporal_fc, dt), row_scale=sv["drop_t"], row_scale_group=T)
+        tr.wgrad(dpp, sv["a_t"], ta.proj.weight, ta.proj.bias)
+        da = tr.dgrad(dpp, self._wt("t_proj", ta.proj, dt))
+        dqkv = hip.attn_temporal_bwd(sv["qkv_t"], sv["a_t"], da, sv["lse_t"], T, H, ta.scale)
+        tr.wgrad(dqkv, sv["h"], ta.qkv.weight, ta.qkv.bias)
+        dh = tr.dgrad(dqkv, self._wt("t_qkv", ta.qkv, dt))
+        g, b_ = tr.grad_buffer(self.temporal_norm1.weight, zero=True)[0], tr.grad_buffer(self.temporal_norm1.bias, zero=True)[0]
+        hip.layernorm_bwd(dh, sv["x"], self.temporal_norm1.weight, VIT_EPS, dx, g, b_, rows=B * N * T,
+                          map_mode=hip.MAP_SKIP_CLS, map_p0=N * T)
+        return dx
+
 
 class PatchEmbed(nn.Module):
     """Image to patch embedding: the stride-16 conv (vit.py:230) evaluated as im2col rows x weight GEMM."""
@@ -215,7 +296,24 @@ class VisionTransformer(nn.Module):
         tok = torch.empty((B, 1 + N * T, D), dtype=torch.float32, device=x.device)
         tok[:, 0] = (self.cls_token.detach() + self.pos_embed.detach()[:, :1]).view(1, D)
         hip.gemm(rows, w, out=tok.view(-1, D), out_dtype=torch.float32, residual=table, map_mode=hip.MAP_PATCH_EMBED, map_p0=T, map_p1=N)
+        self._last_rows = rows
         return tok, T, Ww // 16, N
+
+    def _embed_backward(self, rows, dtok, B, T, N):
+        """Gradients of patch_embed.proj / cls_token / pos_embed / time_embed from dtok (B, 1+N*T, D)."""
+        dt = rows.dtype
+        D = self.embed_dim
+        drows = hip.gather_cast(dtok, dt, rows=B * T * N, map_mode=hip.MAP_PATCH_EMBED, map_p0=T, map_p1=N)
+        pe = self.patch_embed.proj
+        gw, existed = tr.grad_buffer(pe.weight)
+        gw2 = gw.view(D, -1)
+        hip.gemm(hip.transpose(drows), hip.transpose(rows), out=gw2, out_dtype=torch.float32, residual=gw2 if existed else None)
+        dtable = dtok[:, 1:].sum(0).view(N, T, D)  # small (N*T, D) reductions: parameter-sized, stay in torch
+        tr.add_grad(pe.bias, dtable.sum((0, 1)))
+        dcls = dtok[:, 0].sum(0)
+        tr.add_grad(self.cls_token, dcls)
+        tr.add_grad(self.pos_embed, torch.cat([dcls[None], dtable.sum(1)], 0))
+        tr.add_grad(self.time_embed, dtable.sum(0))
 
     def forward_features(self, x, return_all_tokens=False):
         B = x.shape[0]
@@ -263,8 +361,11 @@ class TimeSformer(nn.Module):
         self.num_patches = (self.img_size // self.patch_size) * (self.img_size // self.patch_size)
 
     def forward_features(self, x, return_all_tokens=True, pooling='temporal'):
-        """x: (b, c, t, h, w) -> (b, 1 + h*w/256, 768): final LayerNorm fused with the temporal mean pool."""
+        """x: (b, c, t, h, w) -> (b, 1 + h*w/256, 768): final LayerNorm fused with the temporal mean pool.
+        With autograd enabled the whole encoder is one autograd node with a hand-written backward."""
         assert pooling == 'temporal' and return_all_tokens, "ALPRO only calls forward_features(return_all_tokens=True) with temporal pooling"
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            return tr.run_anchored(_VisualRun(self), [x], list(self.parameters()))
         m = self.model
         B = x.shape[0]
         tok, T, W, N = m._embed(x)
@@ -281,3 +382,42 @@ class TimeSformer(nn.Module):
             raise RuntimeError("checkpoint download/remap helpers (helpers.py:262-375) are outside the hot path; "
                                "load a converted state_dict instead of %r" % state_dict)
         return super().load_state_dict(state_dict, strict=strict, **kw)
+
+
+class _VisualRun:
+    """Forward/backward of the whole visual encoder for tr.Anchor (alpro_models.py:186-194 under autograd)."""
+
+    def __init__(self, enc):
+        self.enc = enc
+
+    def forward(self, x):
+        m = self.enc.model
+        B = x.shape[0]
+        tok, T, W, N = m._embed(x)
+        self.rows, self.dims = m._last_rows, (B, T, N)
+        self.saved = []
+        for blk in m.blocks:
+            tok, sv = blk.forward_train(tok, B, T, W)
+            self.saved.append(sv)
+        self.tok = tok
+        out32, _ = hip.vit_final_pool(tok, m.norm.weight, m.norm.bias, VIT_EPS, B, T, N, torch.float32)
+        return out32
+
+    def backward(self, dout):
+        m = self.enc.model
+        B, T, N = self.dims
+        D = m.embed_dim
+        # final norm + temporal mean pool (vit.py:372,484-492): every frame token receives dout / T, the CLS token dout
+        dy = torch.empty((B, 1 + N * T, D), dtype=torch.float32, device=dout.device)
+        dy[:, 0] = dout[:, 0]
+        dy[:, 1:] = (dout[:, 1:] * (1.0 / T)).repeat_interleave(T, dim=1)
+        dtok = torch.empty_like(dy)
+        g, b_ = tr.grad_buffer(m.norm.weight, zero=True)[0], tr.grad_buffer(m.norm.bias, zero=True)[0]
+        hip.layernorm_bwd(dy.view(-1, D), self.tok, m.norm.weight, VIT_EPS, dtok, g, b_, accumulate=False)
+        del dy
+        for blk, sv in zip(reversed(m.blocks), reversed(self.saved)):
+            dtok = blk.backward(sv, dtok)
+            sv.clear()
+        m._embed_backward(self.rows, dtok, B, T, N)
+        self.saved = self.rows = self.tok = None
+        return None  # pixels need no gradient

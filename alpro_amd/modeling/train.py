@@ -1,0 +1,113 @@
+"""Training-side plumbing shared by the ViT and BERT blocks: gradient accumulation into `.grad`,
+Linear backward on the NT GEMM (dgrad with a cached transposed operand, wgrad on transposed
+activations with the bias gradient fused into the transpose), and the autograd anchor.
+
+Why not torch.autograd per op: the fused epilogues write through row maps into shared token buffers,
+so each block gets ONE hand-written backward built from the C-ABI kernels (alpro_attn_bwd,
+alpro_layernorm_bwd, alpro_gemm, alpro_transpose, ...).  Parameter gradients are accumulated in place
+into `param.grad` (fp32) by the wgrad GEMM's residual input, which is what `loss.backward()` leaves
+behind in the reference (run_pretrain_sparse.py:599), ready for the all-reduce and the optimizer.
+"""
+import torch
+
+from alpro_amd import hip
+
+
+def grad_buffer(p, zero=False):
+    """Return (p.grad, existed).  Allocates an fp32 buffer on first use."""
+    if p.grad is not None:
+        return p.grad, True
+    p.grad = torch.zeros_like(p, memory_format=torch.contiguous_format) if zero else torch.empty_like(p, memory_format=torch.contiguous_format)
+    return p.grad, False
+
+
+def add_grad(p, g):
+    if p.grad is None:
+        p.grad = g.detach().clone().reshape(p.shape).contiguous()
+    else:
+        p.grad.add_(g.reshape(p.shape))
+
+
+def transposed_operand(cache, key, weight, dt):
+    """(N, K) fp32 parameter -> cached (K, N64) operand in `dt` for dgrad (dX = dY @ W), refreshed on version change."""
+    ver = (weight.data_ptr(), weight._version)
+    hit = cache._store.get(key)
+    if hit is not None and hit[0] == ver and hit[1].dtype == dt:
+        return hit[1]
+    with torch.no_grad():
+        w = weight.detach()
+        w = w.reshape(w.shape[0], -1).contiguous()
+        out = hip.transpose(w, out_dtype=dt, pad_to=64)
+    cache._store[key] = (ver, out)
+    return out
+
+
+def wgrad(dy_t, x_t, weight, bias, dyT=None):
+    """weight.grad += dy^T x ; bias.grad += colsum(dy).  dy_t (M, N), x_t (M, K) operand-dtype activations."""
+    gb = None
+    if bias is not None:
+        gb, _ = grad_buffer(bias, zero=True) if bias.grad is None else (bias.grad, True)
+    if dyT is None:
+        dyT = hip.transpose(dy_t, colsum=gb)
+    xT = hip.transpose(x_t)
+    gw, existed = grad_buffer(weight)
+    gw2 = gw.view(gw.shape[0], -1)
+    hip.gemm(dyT, xT, out=gw2, out_dtype=torch.float32, residual=gw2 if existed else None)
+    return dyT
+
+
+def wgrad_rows(dyT_rows, xT, weight):
+    """weight.grad += dyT_rows @ xT^T for a row block of an already transposed dy (fused q/k/v projections)."""
+    gw, existed = grad_buffer(weight)
+    hip.gemm(dyT_rows, xT, out=gw, out_dtype=torch.float32, residual=gw if existed else None)
+
+
+def dgrad(dy_t, wT, out_dtype=None, row_scale=None, row_scale_group=1):
+    """dX = dy @ W using the cached transposed operand wT (K, N64); dy_t (M, N)."""
+    n = dy_t.shape[1]
+    w = wT if wT.shape[1] == n else wT[:, :n]
+    if not w.is_contiguous() or n % (64 if dy_t.dtype != torch.float32 else 32) != 0:
+        # contraction dim not a K-granule multiple (heads only): pad both operands with zero columns
+        pad = wT.shape[1] - n
+        dy_t = torch.nn.functional.pad(dy_t, (0, pad))
+        w = wT
+    return hip.gemm(dy_t, w, out_dtype=out_dtype or dy_t.dtype, row_scale=row_scale, row_scale_group=row_scale_group)
+
+
+class Anchor(torch.autograd.Function):
+    """Ties a hand-written encoder backward into torch.autograd.
+
+    forward(run, n_act, *inputs): `run.forward(*activations)` computes the outputs with the HIP kernels (under
+    no_grad) and stores what its backward needs on `run`; the parameters ride along only so that autograd
+    schedules the node.  backward: `run.backward(*grad_outputs)` returns gradients for the activation inputs
+    and accumulates parameter gradients directly into `.grad`.
+    """
+
+    @staticmethod
+    def forward(ctx, run, n_act, *inputs):
+        ctx.run = run
+        ctx.n_act = n_act
+        ctx.n_in = len(inputs)
+        with torch.no_grad():
+            outs = run.forward(*inputs[:n_act])
+        ctx.single = torch.is_tensor(outs)
+        return outs
+
+    @staticmethod
+    def backward(ctx, *grads):
+        with torch.no_grad():
+            g = ctx.run.backward(*[None if x is None else x.contiguous() for x in grads])
+        g = (g,) if (torch.is_tensor(g) or g is None) else tuple(g)
+        g = g + (None,) * (ctx.n_act - len(g))
+        ctx.run = None
+        return (None, None) + tuple(g) + (None,) * (ctx.n_in - ctx.n_act)
+
+
+def run_anchored(run, activations, params):
+    """Call `run` through autograd.  activations: tensors that may need gradients; params: nn.Parameters."""
+    params = [p for p in params if p.requires_grad]
+    need = torch.is_grad_enabled() and (any(torch.is_tensor(a) and a.requires_grad for a in activations) or len(params) > 0)
+    if not need:
+        with torch.no_grad():
+            return run.forward(*activations)
+    return Anchor.apply(run, len(activations), *activations, *params)

@@ -21,6 +21,7 @@ import torch.nn as nn
 
 from alpro_amd import config as rt
 from alpro_amd import hip
+from alpro_amd.modeling import train as tr
 from alpro_amd.modeling.weights import OperandCache
 
 
@@ -120,6 +121,74 @@ class BertLayer(nn.Module):
         return o32, o_t
 
 
+    # ---- training path ---------------------------------------------------------------------------------
+    def forward_train(self, h32, h_t, key_bias, B, L):
+        self._check_dropout()
+        dt = rt.compute_dtype()
+        sa, so = self.attention.self, self.attention.output
+        eps = self.config.layer_norm_eps
+        H = sa.num_attention_heads
+        scale = 1.0 / math.sqrt(sa.attention_head_size)
+        wqkv = self._ops.get("qkv_w", (sa.query.weight, sa.key.weight, sa.value.weight), dt)
+        bqkv = self._ops.get("qkv_b", (sa.query.bias, sa.key.bias, sa.value.bias), torch.float32)
+        qkv = hip.gemm(h_t, wqkv, bias=bqkv)
+        ctx, lse = hip.attn(qkv, B, L, H, scale, key_bias, want_lse=True)
+        s1 = hip.gemm(ctx, self._ops.get("ao_w", so.dense.weight, dt), bias=so.dense.bias, out_dtype=torch.float32, residual=h32)
+        a_t, a32 = hip.layernorm(s1, so.LayerNorm.weight, so.LayerNorm.bias, eps, dt, out32=True)
+        u = torch.empty((h_t.shape[0], self.intermediate.dense.out_features), dtype=dt, device=h_t.device)
+        it = hip.gemm(a_t, self._ops.get("i_w", self.intermediate.dense.weight, dt), bias=self.intermediate.dense.bias, act=hip.ACT_GELU, pre_act=u)
+        s2 = hip.gemm(it, self._ops.get("o_w", self.output.dense.weight, dt), bias=self.output.dense.bias, out_dtype=torch.float32, residual=a32)
+        o_t, o32 = hip.layernorm(s2, self.output.LayerNorm.weight, self.output.LayerNorm.bias, eps, dt, out32=True)
+        sv = dict(h_t=h_t, qkv=qkv, ctx=ctx, lse=lse, s1=s1, a_t=a_t, u=u, it=it, s2=s2, kb=key_bias, dims=(B, L, H, scale), dt=dt)
+        return o32, o_t, sv
+
+    def backward(self, sv, do32, do_t):
+        """Gradients w.r.t. the layer's two output streams (fp32 residual copy, operand-dtype copy; either may be
+        None) -> (dh32, dh_t) for the layer input.  Parameter gradients accumulate into .grad."""
+        B, L, H, scale = sv["dims"]
+        dt = sv["dt"]
+        sa, so = self.attention.self, self.attention.output
+        eps = self.config.layer_norm_eps
+        dev = sv["s1"].device
+        M, D = sv["s1"].shape
+
+        def ln_bwd(ln, x, dy_t, dy32):
+            if dy_t is None:
+                dy_t, dy32 = dy32, None
+            dx = torch.empty((M, D), dtype=torch.float32, device=dev)
+            g, b_ = tr.grad_buffer(ln.weight, zero=True)[0], tr.grad_buffer(ln.bias, zero=True)[0]
+            hip.layernorm_bwd(dy_t, x, ln.weight, eps, dx, g, b_, dy2=dy32, accumulate=False)
+            return dx
+
+        ds2 = ln_bwd(self.output.LayerNorm, sv["s2"], do_t, do32)          # also d(a32): identity residual
+        ds2_t = hip.gather_cast(ds2, dt)
+        tr.wgrad(ds2_t, sv["it"], self.output.dense.weight, self.output.dense.bias)
+        du = hip.gelu_bwd(tr.dgrad(ds2_t, tr.transposed_operand(self._ops, "o_w^T", self.output.dense.weight, dt)), sv["u"])
+        tr.wgrad(du, sv["a_t"], self.intermediate.dense.weight, self.intermediate.dense.bias)
+        da_t = tr.dgrad(du, tr.transposed_operand(self._ops, "i_w^T", self.intermediate.dense.weight, dt))
+        ds1 = ln_bwd(so.LayerNorm, sv["s1"], da_t, ds2)                     # also d(h32): identity residual
+        ds1_t = hip.gather_cast(ds1, dt)
+        tr.wgrad(ds1_t, sv["ctx"], so.dense.weight, so.dense.bias)
+        dctx = tr.dgrad(ds1_t, tr.transposed_operand(self._ops, "ao_w^T", so.dense.weight, dt))
+        dqkv = hip.attn_bwd(sv["qkv"], sv["ctx"], dctx, sv["lse"], B, L, H, scale, sv["kb"])
+        # fused q/k/v projection: one transpose of dqkv, three row blocks -> the three weight gradients
+        Hd = sa.all_head_size
+        db = torch.zeros(3 * Hd, dtype=torch.float32, device=dev)
+        dT = hip.transpose(dqkv, colsum=db)
+        xT = hip.transpose(sv["h_t"])
+        for i, lin in enumerate((sa.query, sa.key, sa.value)):
+            tr.wgrad_rows(dT[i * Hd:(i + 1) * Hd], xT, lin.weight)
+            tr.add_grad(lin.bias, db[i * Hd:(i + 1) * Hd])
+        wT = self._ops._store.get("qkv_w^T")
+        ver = tuple((p.data_ptr(), p._version) for p in (sa.query.weight, sa.key.weight, sa.value.weight))
+        if wT is None or wT[0] != ver or wT[1].dtype != dt:
+            wcat = torch.cat([sa.query.weight.detach(), sa.key.weight.detach(), sa.value.weight.detach()], 0).contiguous()
+            wT = (ver, hip.transpose(wcat, out_dtype=dt, pad_to=64))
+            self._ops._store["qkv_w^T"] = wT
+        dh_t = tr.dgrad(dqkv, wT[1])
+        return ds1, dh_t
+
+
 class BertEncoder(nn.Module):
     def __init__(self, config):
         super().__init__()
@@ -191,6 +260,17 @@ class BertModel(BertPreTrainedModel):
         return ((1.0 - attention_mask.to(torch.float32)) * -10000.0).contiguous()
 
     def forward(self, input_ids=None, attention_mask=None, encoder_embeds=None, return_dict=True, mode='multi_modal', **unused):
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            lo, hi = self.encoder.layer_range(mode)
+            params = [p for i in range(lo, hi) for p in self.encoder.layer[i].parameters()]
+            if encoder_embeds is None:
+                params += list(self.embeddings.parameters())
+            run = _BertRun(self, input_ids, attention_mask, mode)
+            out = tr.run_anchored(run, [encoder_embeds] if encoder_embeds is not None else [], params)
+            if not return_dict:
+                return (out,)
+            return SimpleNamespace(last_hidden_state=out, pooler_output=None, hidden_states=None, attentions=None,
+                                   past_key_values=None, cross_attentions=None)
         dt = rt.compute_dtype()
         cfg = self.config
         if encoder_embeds is None:
@@ -217,6 +297,67 @@ class BertModel(BertPreTrainedModel):
                                past_key_values=None, cross_attentions=None)
 
 
+class _BertRun:
+    """Forward/backward of one text-mode or fusion-mode pass of BertModel for tr.Anchor."""
+
+    def __init__(self, model, input_ids, attention_mask, mode):
+        self.m, self.ids, self.mask, self.mode = model, input_ids, attention_mask, mode
+
+    def forward(self, encoder_embeds=None):
+        m, cfg = self.m, self.m.config
+        dt = rt.compute_dtype()
+        emb = m.embeddings
+        if encoder_embeds is None:
+            B, L = self.ids.shape
+            if emb.training and cfg.hidden_dropout_prob > 0:
+                raise RuntimeError("BertEmbeddings dropout in train() mode is not implemented on the HIP path yet")
+            self.ids = self.ids.contiguous()
+            word = emb.word_embeddings.weight
+            # pre-LayerNorm sum is needed by the LN backward: recompute it there from the tables (cheap gather)
+            h32, h_t = hip.bert_embed(self.ids, word, emb.position_embeddings.weight, emb.token_type_embeddings.weight,
+                                      emb.LayerNorm.weight, emb.LayerNorm.bias, cfg.layer_norm_eps, dt)
+        else:
+            B, L, Hd = encoder_embeds.shape
+            h32 = encoder_embeds.reshape(B * L, Hd).contiguous().float()
+            h_t = hip.cast(h32, dt)
+        mask = self.mask if self.mask is not None else torch.ones((B, L), device=h32.device)
+        kb = m.key_bias(mask)
+        self.dims = (B, L)
+        self.from_ids = encoder_embeds is None
+        self.saved = []
+        lo, hi = m.encoder.layer_range(self.mode)
+        self.range = (lo, hi)
+        for i in range(lo, hi):
+            h32, h_t, sv = m.encoder.layer[i].forward_train(h32, h_t, kb, B, L)
+            self.saved.append(sv)
+        return h32.view(B, L, -1)
+
+    def backward(self, dout):
+        m, cfg = self.m, self.m.config
+        B, L = self.dims
+        lo, hi = self.range
+        d32, d_t = dout.reshape(B * L, -1).contiguous(), None
+        for i in range(hi - 1, lo - 1, -1):
+            d32, d_t = m.encoder.layer[i].backward(self.saved.pop(), d32, d_t)
+        if not self.from_ids:
+            return (d32 + d_t.float()).view(B, L, -1)
+        # embeddings: LN backward on word + type0 + pos, then scatter the row gradients into the tables
+        emb = m.embeddings
+        D = d32.shape[1]
+        pre = (emb.word_embeddings.weight.detach()[self.ids.view(-1)] + emb.token_type_embeddings.weight.detach()[0]
+               + emb.position_embeddings.weight.detach()[:L].repeat(B, 1)).contiguous()
+        de = torch.empty_like(pre)
+        g, b_ = tr.grad_buffer(emb.LayerNorm.weight, zero=True)[0], tr.grad_buffer(emb.LayerNorm.bias, zero=True)[0]
+        hip.layernorm_bwd(d_t, pre, emb.LayerNorm.weight, cfg.layer_norm_eps, de, g, b_, dy2=d32, accumulate=False)
+        gw = tr.grad_buffer(emb.word_embeddings.weight, zero=True)[0] if emb.word_embeddings.weight.grad is None else emb.word_embeddings.weight.grad
+        hip.scatter_add_rows(de, self.ids.view(-1), gw)
+        gp = tr.grad_buffer(emb.position_embeddings.weight, zero=True)[0] if emb.position_embeddings.weight.grad is None else emb.position_embeddings.weight.grad
+        hip.scatter_add_rows(de, None, gp, idx_mod=L)
+        gt = tr.grad_buffer(emb.token_type_embeddings.weight, zero=True)[0] if emb.token_type_embeddings.weight.grad is None else emb.token_type_embeddings.weight.grad
+        gt[0].add_(de.sum(0))
+        return None
+
+
 class BertPredictionHeadTransform(nn.Module):
     def __init__(self, config):
         super().__init__()
@@ -236,6 +377,8 @@ class BertLMPredictionHead(nn.Module):
 
     def forward(self, hidden_states):
         """(B, Lt, H) fp32 -> (B, Lt, vocab) fp32 logits (xbert.py:679-682)."""
+        if torch.is_grad_enabled() and (hidden_states.requires_grad or any(p.requires_grad for p in self.parameters())):
+            return tr.run_anchored(_LMHeadRun(self), [hidden_states], list(self.parameters()))
         dt = rt.compute_dtype()
         shp = hidden_states.shape
         h = hip.cast(hidden_states.reshape(-1, shp[-1]).contiguous().float(), dt)
@@ -244,6 +387,46 @@ class BertLMPredictionHead(nn.Module):
         n = hip.layernorm(g, t.LayerNorm.weight, t.LayerNorm.bias, self.config.layer_norm_eps, dt)
         logits = hip.gemm(n, self._ops.get("dec_w", self.decoder.weight, dt), bias=self.bias, out_dtype=torch.float32)
         return logits.view(*shp[:-1], -1)
+
+
+class _LMHeadRun:
+    """Forward/backward of BertLMPredictionHead for tr.Anchor; the decoder weight is the word-embedding table."""
+
+    def __init__(self, head):
+        self.h = head
+
+    def forward(self, hidden):
+        hd, dt = self.h, rt.compute_dtype()
+        self.shape = hidden.shape
+        t = hd.transform
+        x = hip.cast(hidden.reshape(-1, self.shape[-1]).contiguous().float(), dt)
+        u = torch.empty((x.shape[0], t.dense.out_features), dtype=dt, device=x.device)
+        g = hip.gemm(x, hd._ops.get("t_w", t.dense.weight, dt), bias=t.dense.bias, act=hip.ACT_GELU, out_dtype=torch.float32, pre_act=u)
+        n = hip.layernorm(g, t.LayerNorm.weight, t.LayerNorm.bias, hd.config.layer_norm_eps, dt)
+        logits = hip.gemm(n, hd._ops.get("dec_w", hd.decoder.weight, dt), bias=hd.bias, out_dtype=torch.float32)
+        self.x, self.u, self.g, self.n, self.dt = x, u, g, n, dt
+        return logits.view(*self.shape[:-1], -1)
+
+    def backward(self, dlogits):
+        hd, dt = self.h, self.dt
+        t = hd.transform
+        M, V = self.x.shape[0], dlogits.shape[-1]
+        Vp = (V + 63) // 64 * 64
+        dl = torch.zeros((M, Vp), dtype=dt, device=dlogits.device)
+        dl[:, :V] = dlogits.reshape(M, V)
+        dn = tr.dgrad(dl, tr.transposed_operand(hd._ops, "dec_w^T", hd.decoder.weight, dt))
+        cs = torch.zeros(Vp, dtype=torch.float32, device=dl.device)
+        dlT = hip.transpose(dl, colsum=cs)
+        tr.wgrad_rows(dlT[:V], hip.transpose(self.n), hd.decoder.weight)  # tied: accumulates into the word-embedding gradient
+        tr.add_grad(hd.bias, cs[:V])
+        dg = torch.empty_like(self.g)
+        gw, gb = tr.grad_buffer(t.LayerNorm.weight, zero=True)[0], tr.grad_buffer(t.LayerNorm.bias, zero=True)[0]
+        hip.layernorm_bwd(dn, self.g, t.LayerNorm.weight, hd.config.layer_norm_eps, dg, gw, gb, accumulate=False)
+        du = hip.gelu_bwd(hip.gather_cast(dg, dt), self.u)
+        tr.wgrad(du, self.x, t.dense.weight, t.dense.bias)
+        dx = tr.dgrad(du, tr.transposed_operand(hd._ops, "t_w^T", t.dense.weight, dt), out_dtype=torch.float32)
+        self.x = self.u = self.g = self.n = None
+        return dx.view(self.shape)
 
 
 class BertOnlyMLMHead(nn.Module):

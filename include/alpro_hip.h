@@ -146,6 +146,12 @@ int alpro_layernorm_bwd(const void* dy, int dy_dtype, int64_t ld_dy, const float
 int alpro_transpose(const void* in, int in_dtype, int64_t ld_in, void* out, int out_dtype, int64_t ld_out, int R, int C,
                     int Rpad, float* colsum, void* stream);
 
+/* out[m, :] = (dtype)(row_scale[m / group] * src[map(m), :]) over D == 768: turns the fp32 token-gradient tensor into
+ * the operand rows of the backward GEMMs (inverse of the forward scatter maps, drop-path scale re-applied).  Under
+ * FRAME_TOKENS the j == 0 rows read the clip's CLS row times cls_scale (= 1/T, the frame mean of vit.py:187). */
+int alpro_gather_cast(const float* src, int64_t ld, void* out, int dtype, int rows, int D, int map_mode, int map_p0,
+                      int map_p1, const float* row_scale, int row_scale_group, float cls_scale, void* stream);
+
 /* du = dh * gelu'(u) with the erf GELU (vit.py:61 / xbert.py:423 backward). */
 int alpro_gelu_bwd(const void* dh, const void* u, void* du, int dtype, int64_t n, void* stream);
 
