@@ -1,0 +1,94 @@
+// Step epilogue of the data-parallel training loop on flat fp32 buffers: global gradient norm and the
+// reference's HF-style AdamW (src/optimization/adamw.py:40-103) with the clip_grad_norm_ coefficient
+// (run_pretrain_sparse.py:633) folded in.  One pass over (param, grad, m, v): 16 B/param read + 12 B/param written.
+#include "common.hpp"
+
+namespace alpro {
+namespace {
+
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x, int64_t n, float* __restrict__ out) {
+  float s = 0.f;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x * 4;
+  for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += stride) {
+    if (i + 4 <= n) {
+      const float4 v = *(const float4*)(x + i);
+      s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+    } else {
+      for (int64_t k = i; k < n; ++k) s += x[k] * x[k];
+    }
+  }
+  s = wave_sum(s);
+  __shared__ float part[4];
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(out, part[0] + part[1] + part[2] + part[3]);
+}
+
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                    float* __restrict__ v, int64_t n, float lr, float beta1, float beta2, float eps,
+                                                    float weight_decay, float step_size, const float* __restrict__ gnorm_sq,
+                                                    float max_norm, float grad_scale) {
+  float coef = grad_scale;
+  if (gnorm_sq && max_norm > 0.f) {
+    const float total = sqrtf(*gnorm_sq) * grad_scale;
+    coef *= fminf(max_norm / (total + 1e-6f), 1.0f);  // torch.nn.utils.clip_grad_norm_
+  }
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x * 4;
+  for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += stride) {
+    const int cnt = (i + 4 <= n) ? 4 : (int)(n - i);
+    float pv[4], gv[4], mv[4], vv[4];
+    if (cnt == 4) {
+      const float4 a = *(const float4*)(p + i), b = *(const float4*)(g + i), c = *(const float4*)(m + i), d = *(const float4*)(v + i);
+      pv[0] = a.x; pv[1] = a.y; pv[2] = a.z; pv[3] = a.w;
+      gv[0] = b.x; gv[1] = b.y; gv[2] = b.z; gv[3] = b.w;
+      mv[0] = c.x; mv[1] = c.y; mv[2] = c.z; mv[3] = c.w;
+      vv[0] = d.x; vv[1] = d.y; vv[2] = d.z; vv[3] = d.w;
+    } else {
+      for (int k = 0; k < cnt; ++k) { pv[k] = p[i + k]; gv[k] = g[i + k]; mv[k] = m[i + k]; vv[k] = v[i + k]; }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float gr = gv[k] * coef;
+      mv[k] = mv[k] * beta1 + (1.0f - beta1) * gr;
+      vv[k] = vv[k] * beta2 + (1.0f - beta2) * gr * gr;
+      const float denom = sqrtf(vv[k]) + eps;
+      pv[k] = pv[k] - step_size * (mv[k] / denom);
+      if (weight_decay > 0.f) pv[k] = pv[k] - lr * weight_decay * pv[k];
+    }
+    if (cnt == 4) {
+      *(float4*)(p + i) = make_float4(pv[0], pv[1], pv[2], pv[3]);
+      *(float4*)(m + i) = make_float4(mv[0], mv[1], mv[2], mv[3]);
+      *(float4*)(v + i) = make_float4(vv[0], vv[1], vv[2], vv[3]);
+    } else {
+      for (int k = 0; k < cnt; ++k) { p[i + k] = pv[k]; m[i + k] = mv[k]; v[i + k] = vv[k]; }
+    }
+  }
+}
+
+inline int grid_for(int64_t n) {
+  int64_t g = (n / 4 + 255) / 256;
+  if (g < 1) g = 1;
+  if (g > 256 * 16) g = 256 * 16;
+  return (int)g;
+}
+}  // namespace
+}  // namespace alpro
+
+using namespace alpro;
+
+extern "C" int alpro_sumsq(const float* x, int64_t n, float* out, void* stream) {
+  ALPRO_CHECK(x && out && n > 0, "alpro_sumsq: bad args");
+  ALPRO_CHECK(((uintptr_t)x % 16) == 0, "alpro_sumsq: x must be 16-byte aligned");
+  hipLaunchKernelGGL(sumsq_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, x, n, out);
+  return check_launch("alpro_sumsq");
+}
+
+extern "C" int alpro_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+                                float weight_decay, float step_size, const float* gnorm_sq, float max_norm, float grad_scale, void* stream) {
+  ALPRO_CHECK(p && g && m && v && n > 0, "alpro_adamw_step: bad args");
+  ALPRO_CHECK(((uintptr_t)p % 16) == 0 && ((uintptr_t)g % 16) == 0 && ((uintptr_t)m % 16) == 0 && ((uintptr_t)v % 16) == 0,
+              "alpro_adamw_step: buffers must be 16-byte aligned");
+  hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1, beta2, eps, weight_decay,
+                     step_size, gnorm_sq, max_norm, grad_scale);
+  return check_launch("alpro_adamw_step");
+}

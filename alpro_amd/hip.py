@@ -21,7 +21,7 @@ _CODE = {v: k for k, v in _TORCH_DTYPE.items()}
 EXPORTS = ["alpro_hip_last_error", "alpro_hip_abi_version", "alpro_gemm", "alpro_layernorm_fwd",
            "alpro_attn_temporal_fwd", "alpro_attn_fwd", "alpro_patchify", "alpro_cls_mean_residual",
            "alpro_vit_final_pool", "alpro_bert_embed_fwd", "alpro_cast_from_f32", "alpro_attn_bwd", "alpro_attn_temporal_bwd",
-           "alpro_layernorm_bwd", "alpro_transpose", "alpro_gelu_bwd", "alpro_cls_mean_bwd", "alpro_scatter_add_rows", "alpro_gather_cast"]
+           "alpro_layernorm_bwd", "alpro_transpose", "alpro_gelu_bwd", "alpro_cls_mean_bwd", "alpro_scatter_add_rows", "alpro_gather_cast", "alpro_sumsq", "alpro_adamw_step"]
 
 
 class GemmDesc(ctypes.Structure):
@@ -61,6 +61,8 @@ def load():
     lib.alpro_layernorm_bwd.argtypes = [vp, i32, i64, vp, vp, i64, vp, f32, vp, i64, i32, vp, vp, i32, i32, i32, i32, i32, vp]
     lib.alpro_transpose.argtypes = [vp, i32, i64, vp, i32, i64, i32, i32, i32, vp, vp]
     lib.alpro_gelu_bwd.argtypes = [vp, vp, vp, i32, i64, vp]
+    lib.alpro_sumsq.argtypes = [vp, i64, vp, vp]
+    lib.alpro_adamw_step.argtypes = [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, f32, vp, f32, f32, vp]
     lib.alpro_gather_cast.argtypes = [vp, i64, vp, i32, i32, i32, i32, i32, i32, vp, i32, f32, vp]
     lib.alpro_cls_mean_bwd.argtypes = [vp, i64, vp, i32, i32, i32, vp]
     lib.alpro_scatter_add_rows.argtypes = [vp, vp, vp, i32, i32, i32, vp]
@@ -318,3 +320,19 @@ def cast(src, dtype):
     dst = torch.empty(src.shape, dtype=dtype, device=src.device)
     _check(lib.alpro_cast_from_f32(_ptr(src), _ptr(dst), _CODE[dtype], src.numel(), _stream()), "alpro_cast_from_f32")
     return dst
+
+
+def sumsq(x, out):
+    """out (1,) fp32 += sum(x^2)."""
+    lib = load()
+    _dev(x, torch.float32); _dev(out, torch.float32)
+    _check(lib.alpro_sumsq(_ptr(x), x.numel(), _ptr(out), _stream()), "alpro_sumsq")
+    return out
+
+
+def adamw_step(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step_size, gnorm_sq=None, max_norm=0.0, grad_scale=1.0):
+    lib = load()
+    for t in (p, g, m, v):
+        _dev(t, torch.float32)
+    _check(lib.alpro_adamw_step(_ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), lr, beta1, beta2, eps, weight_decay, step_size,
+                                _ptr(gnorm_sq), max_norm, grad_scale, _stream()), "alpro_adamw_step")

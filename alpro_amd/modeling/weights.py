@@ -10,6 +10,19 @@ import torch
 from alpro_amd import hip
 
 
+# Bumped by optimizers that update parameters through raw pointers (alpro_amd.optim.FlatAdamW): such updates do
+# not touch torch's per-tensor version counters, so the operand copies are keyed on this epoch as well.
+_PARAM_EPOCH = [0]
+
+
+def bump_param_epoch():
+    _PARAM_EPOCH[0] += 1
+
+
+def param_epoch():
+    return _PARAM_EPOCH[0]
+
+
 class OperandCache:
     def __init__(self):
         self._store = {}
@@ -21,7 +34,7 @@ class OperandCache:
         if single and dtype == torch.float32:
             w = params.detach()
             return w if w.is_contiguous() else w.contiguous()
-        ver = tuple((p.data_ptr(), p._version) for p in plist)
+        ver = (param_epoch(),) + tuple((p.data_ptr(), p._version) for p in plist)
         hit = self._store.get(key)
         if hit is not None and hit[0] == ver and hit[1].dtype == dtype:
             return hit[1]

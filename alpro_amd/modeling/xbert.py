@@ -180,7 +180,7 @@ class BertLayer(nn.Module):
             tr.wgrad_rows(dT[i * Hd:(i + 1) * Hd], xT, lin.weight)
             tr.add_grad(lin.bias, db[i * Hd:(i + 1) * Hd])
         wT = self._ops._store.get("qkv_w^T")
-        ver = tuple((p.data_ptr(), p._version) for p in (sa.query.weight, sa.key.weight, sa.value.weight))
+        ver = (tr.param_epoch(),) + tuple((p.data_ptr(), p._version) for p in (sa.query.weight, sa.key.weight, sa.value.weight))
         if wT is None or wT[0] != ver or wT[1].dtype != dt:
             wcat = torch.cat([sa.query.weight.detach(), sa.key.weight.detach(), sa.value.weight.detach()], 0).contiguous()
             wT = (ver, hip.transpose(wcat, out_dtype=dt, pad_to=64))

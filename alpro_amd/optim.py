@@ -1,0 +1,109 @@
+"""Step epilogue of ALPRO's data-parallel training loop, MI355X-first.
+
+The reference does, per optimizer step (run_pretrain_sparse.py:595-648): zero_none_grad -> Horovod all-reduce of
+every parameter gradient -> LR set -> clip_grad_norm_ -> HF-style AdamW.step (src/optimization/adamw.py:40-103, ~930
+tensors x ~8 tiny launches) -> zero_grad.  Here all trainable parameters, their gradients and the Adam moments live in
+FOUR flat fp32 buffers (0.94 GB each for AlproForPretrain's 234 M trained parameters; HBM is 288 GB):
+
+  * the wgrad GEMMs accumulate straight into views of the flat gradient buffer,
+  * the gradient all-reduce is a handful of large RCCL calls over that buffer (no bucketing copies),
+  * grad-norm + clip + AdamW are two kernels (alpro_sumsq, alpro_adamw_step), zero_grad is one memset.
+
+Same constructor / param_groups surface as the reference's AdamW so a driver only swaps the class.  Parameters that never
+receive a gradient (the frozen prompter, the unused Kinetics head) are left out instead of being zero-filled and reduced.
+"""
+import math
+
+import torch
+
+from alpro_amd import dist, hip
+from alpro_amd.modeling.weights import bump_param_epoch
+
+
+class FlatAdamW:
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-6, weight_decay=0.0, correct_bias=True, max_grad_norm=None,
+                 allreduce=True, bucket_elems=64 << 20):
+        self.params = [p for p in params if p.requires_grad]
+        self.param_groups = [dict(params=self.params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, correct_bias=correct_bias)]
+        self.max_grad_norm = max_grad_norm
+        self.allreduce = allreduce
+        self.bucket_elems = bucket_elems
+        self.step_count = 0
+        self.flat = None  # built at the first step(), when we know which parameters actually receive gradients
+        self.last_grad_norm = None
+
+    # ---- flat buffers ---------------------------------------------------------------------------------
+    def _build(self):
+        seen, live = set(), []
+        for p in self.params:
+            if p.grad is not None and id(p) not in seen:
+                seen.add(id(p))
+                live.append(p)
+        if not live:
+            raise RuntimeError("FlatAdamW.step() called before any backward pass")
+        dev = live[0].device
+        offs, n = [], 0
+        for p in live:
+            offs.append(n)
+            n += (p.numel() + 3) // 4 * 4  # keep every view 16-byte aligned
+        fp = torch.zeros(n, dtype=torch.float32, device=dev)
+        fg = torch.zeros(n, dtype=torch.float32, device=dev)
+        with torch.no_grad():
+            for p, o in zip(live, offs):
+                k = p.numel()
+                fp[o:o + k].copy_(p.data.reshape(-1))
+                fg[o:o + k].copy_(p.grad.reshape(-1))
+                p.data = fp[o:o + k].view(p.shape)
+                p.grad = fg[o:o + k].view(p.shape)
+        self.flat = dict(p=fp, g=fg, m=torch.zeros_like(fp), v=torch.zeros_like(fp), n=n, live=live, offs=offs,
+                         norm=torch.zeros(1, dtype=torch.float32, device=dev))
+        bump_param_epoch()
+
+    @property
+    def n_params(self):
+        return 0 if self.flat is None else sum(p.numel() for p in self.flat["live"])
+
+    def zero_grad(self, set_to_none=False):
+        if self.flat is None:
+            for p in self.params:
+                p.grad = None
+        else:
+            self.flat["g"].zero_()
+
+    def synchronize(self):
+        """Sum gradients across ranks (averaging is folded into the AdamW kernel's grad_scale)."""
+        if self.flat is None or not self.allreduce or dist.size() == 1:
+            return 0
+        g, n = self.flat["g"], self.flat["n"]
+        for s in range(0, n, self.bucket_elems):
+            torch.distributed.all_reduce(g[s:min(n, s + self.bucket_elems)])
+        return n * 4
+
+    def step(self):
+        if self.flat is None:
+            self._build()
+        f, grp = self.flat, self.param_groups[0]
+        late = [p for p in self.params if p.grad is not None and p.grad.data_ptr() < f["g"].data_ptr()
+                or (p.grad is not None and p.grad.data_ptr() >= f["g"].data_ptr() + f["n"] * 4)]
+        if late:
+            raise RuntimeError("%d parameters started receiving gradients after the flat buffers were built" % len(late))
+        self.synchronize()
+        world = dist.size() if self.allreduce else 1
+        self.step_count += 1
+        lr, (b1, b2) = grp["lr"], grp["betas"]
+        step_size = lr
+        if grp["correct_bias"]:
+            step_size = lr * math.sqrt(1.0 - b2 ** self.step_count) / (1.0 - b1 ** self.step_count)
+        norm = None
+        if self.max_grad_norm is not None and self.max_grad_norm > 0:
+            norm = f["norm"]
+            norm.zero_()
+            hip.sumsq(f["g"], norm)
+            self.last_grad_norm = norm  # squared norm of the SUMMED gradient, device tensor (no host sync)
+        hip.adamw_step(f["p"], f["g"], f["m"], f["v"], lr, b1, b2, grp["eps"], grp["weight_decay"], step_size, norm,
+                       float(self.max_grad_norm or 0.0), 1.0 / world)
+        bump_param_epoch()
+
+    def state_dict(self):
+        return dict(step=self.step_count, param_groups=[{k: v for k, v in g.items() if k != "params"} for g in self.param_groups],
+                    m=None if self.flat is None else self.flat["m"], v=None if self.flat is None else self.flat["v"])

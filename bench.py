@@ -9,7 +9,11 @@ synthetic batch already resident in HBM; weights are random-init of the real arc
 Workloads (BASELINE.json configs):
   visual_fwd   configs[1]: TimeSformer-divST visual encoder only, B=32 clips x 8 frames x 224^2, bf16 forward
   pretrain_fwd configs[2] forward half: AlproForPretrain VTC+VTM+MLM+MPM forward, B=64 pairs (eval-mode dropout)
-The data path shards by clip with no collective in these workloads (weak scaling: every rank runs B clips).
+  pretrain_step configs[2]/[3]: full training step of AlproForPretrain (VTC+VTM+MLM+MPM forward, hand-written HIP
+               backward, gradient all-reduce over RCCL, grad-norm clip 20.0 + AdamW lr 1e-4 betas (0.9, 0.98) as
+               config_release/pretrain_alpro.json), B pairs per GPU, drop_path 0.1 active
+The forward-only workloads shard by clip with no collective; pretrain_step adds the in-forward feature all-gather and
+the gradient all-reduce (weak scaling: every rank runs B pairs).
 """
 import argparse
 import json
@@ -88,6 +92,12 @@ class KernelTimer:
         wrap("attn", lambda qkv, batch, L, H, *r, **k: 4.0 * batch * H * L * L * 64)
         wrap("attn_temporal", lambda qkv, T, H, *r, **k: 4.0 * qkv.shape[0] * T * H * 64)
         wrap("layernorm", lambda *a, **k: 0.0)
+        wrap("attn_bwd", lambda qkv, out, dout, lse, batch, L, H, *r, **k: 10.0 * batch * H * L * L * 64)
+        wrap("attn_temporal_bwd", lambda qkv, out, dout, lse, T, H, *r, **k: 10.0 * qkv.shape[0] * T * H * 64)
+        wrap("layernorm_bwd", lambda *a, **k: 0.0)
+        wrap("transpose", lambda *a, **k: 0.0)
+        wrap("gather_cast", lambda *a, **k: 0.0)
+        wrap("gelu_bwd", lambda *a, **k: 0.0)
         return self
 
     def __exit__(self, *a):
@@ -130,7 +140,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="visual_fwd", choices=["visual_fwd", "pretrain_fwd"])
+    ap.add_argument("--workload", default="visual_fwd", choices=["visual_fwd", "pretrain_fwd", "pretrain_step"])
+    ap.add_argument("--bert-dropout", type=float, default=0.0, help="hidden/attention dropout of the BERT half in pretrain_step")
     ap.add_argument("--batch", type=int, default=None)
     ap.add_argument("--frames", type=int, default=8)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "fp32"])
@@ -162,7 +173,7 @@ def main():
         flops_per_unit = VISUAL_GFLOP_PER_CLIP_8F * 1e9 * (T / 8.0)
         unit = "clips/s"
         wl = "TimeSformer-divST visual encoder forward (BASELINE configs[1]), B=%d x %df x 224^2" % (B, T)
-    else:
+    elif args.workload == "pretrain_fwd":
         from alpro_amd.modeling.alpro_models import AlproForPretrain
         B = args.batch or 64
         model = AlproForPretrain(Cfg(BERT_CFG), dict(VENC, num_frm=T)).eval().to(dev)
@@ -173,8 +184,31 @@ def main():
         flops_per_unit = 877e9 * (T / 8.0)  # forward of one pair (3 visual passes incl. prompter, text x2, 4 fusion, heads)
         unit = "pairs/s"
         wl = "AlproForPretrain forward VTC+VTM+MLM+MPM (BASELINE configs[2], forward only; eval-mode dropout), B=%d x %df x 224^2 + 40 tok" % (B, T)
+    else:
+        from alpro_amd.modeling.alpro_models import AlproForPretrain
+        from alpro_amd.optim import FlatAdamW
+        B = args.batch or 64
+        cfg = Cfg(dict(BERT_CFG, hidden_dropout_prob=args.bert_dropout, attention_probs_dropout_prob=args.bert_dropout))
+        model = AlproForPretrain(cfg, dict(VENC, num_frm=T)).to(dev)
+        dist.broadcast_parameters(model)
+        model.train()
+        opt = FlatAdamW(model.parameters(), lr=1e-4, betas=(0.9, 0.98), eps=1e-6, weight_decay=0.0, max_grad_norm=20.0)
+        batch = synth_batch(B, T, dev, seed=rank, full=True)
 
-    with torch.no_grad():
+        def step():
+            out = model(batch)
+            loss = out["mlm_loss"] + out["itm_loss"] + out["itc_loss"] + out["mpm_loss"]  # run_pretrain_sparse.py:557
+            loss.backward()
+            opt.step()        # gradient all-reduce (RCCL) + global-norm clip + AdamW
+            opt.zero_grad()
+            return loss
+        flops_per_unit = 1847e9 * (T / 8.0)  # 877 G forward + 970 G backward per pair
+        unit = "pairs/s"
+        wl = ("AlproForPretrain training step VTC+VTM+MLM+MPM fwd+bwd+allreduce+clip+AdamW (BASELINE configs[2]/[3]), "
+              "B=%d pairs x %df x 224^2 + 40 tok per GPU, drop_path 0.1, BERT dropout %.2f" % (B, T, args.bert_dropout))
+
+    train = args.workload == "pretrain_step"
+    with torch.enable_grad() if train else torch.no_grad():
         for _ in range(args.warmup):
             step()
         dist.barrier()
@@ -194,7 +228,7 @@ def main():
     if rank == 0:
         ms = elapsed / args.steps * 1e3
         value = world * B * args.steps / elapsed
-        with torch.no_grad(), KernelTimer(hip) as kt:
+        with (torch.enable_grad() if train else torch.no_grad()), KernelTimer(hip) as kt:
             step()
         ks = kt.summary()
         gemm = ks["gemm"]
@@ -204,7 +238,7 @@ def main():
             "metric": "video-text pairs/sec (8f x 224^2, 40-tok)", "value": round(value, 3), "unit": unit, "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic (randn clips, random token ids; random-init weights)",
-            "config": {"workload": wl, "per_gpu_batch": B, "frames": T, "parallelism": "dp%d (independent clips, no data-path collective)" % world},
+            "config": {"workload": wl, "per_gpu_batch": B, "frames": T, "parallelism": ("dp%d (RCCL: feature all-gather + flat gradient all-reduce)" % world) if train else ("dp%d (independent clips, no data-path collective)" % world)},
             "model_tflops_per_gpu": round(value / world * flops_per_unit / 1e12, 2),
             "roofline": {"bound": "mfma", "kernel": "gemm_nt_kernel<%s> (all %d launches of one step)" % (args.dtype, gemm["launches"]),
                          "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),

@@ -161,6 +161,18 @@ int alpro_cls_mean_bwd(const float* dx_out, int64_t ld_batch, float* dside, int 
 /* dst[idx[i], :] += src[i, :] (idx NULL: row i % idx_mod): embedding-table gradients (xbert.py:203-210 backward). */
 int alpro_scatter_add_rows(const float* src, const int64_t* idx, float* dst, int rows, int idx_mod, int D, void* stream);
 
+/* ---- step epilogue on flat fp32 buffers (run_pretrain_sparse.py:633-648, src/optimization/adamw.py:40-103) ---- */
+
+/* *out += sum(x[i]^2): global gradient norm for clip_grad_norm_. */
+int alpro_sumsq(const float* x, int64_t n, float* out, void* stream);
+
+/* HF-style AdamW over n contiguous parameters: g' = g * grad_scale * min(1, max_norm / (sqrt(*gnorm_sq)*grad_scale + 1e-6));
+ * m = b1 m + (1-b1) g'; v = b2 v + (1-b2) g'^2; p -= step_size * m / (sqrt(v) + eps); p -= lr * wd * p.
+ * step_size = lr * sqrt(1-b2^t) / (1-b1^t) is computed by the caller (correct_bias).  gnorm_sq NULL or max_norm <= 0: no clip. */
+int alpro_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                     float eps, float weight_decay, float step_size, const float* gnorm_sq, float max_norm,
+                     float grad_scale, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -143,3 +143,38 @@ def test_gemm_pre_activation_copy(dt):
     tol = (2e-5, 2e-5) if dt == torch.float32 else (1e-2, 1e-2)
     close(pre, ref, *tol, "pre-activation")
     close(out, torch.nn.functional.gelu(ref), *tol, "gelu out")
+
+
+def test_flat_adamw_matches_reference_update():
+    """FlatAdamW (alpro_sumsq + alpro_adamw_step) vs the reference's HF-style AdamW + clip_grad_norm_ restated in torch fp64
+    (src/optimization/adamw.py:77-101, run_pretrain_sparse.py:633), three steps, odd-sized tensors."""
+    _hip()
+    from alpro_amd.optim import FlatAdamW
+    torch.manual_seed(0)
+    shapes = [(7, 13), (768,), (5, 3, 2), (1,)]
+    params = [torch.nn.Parameter(torch.randn(*s).cuda()) for s in shapes]
+    ref_p = [p.detach().double().cpu().clone() for p in params]
+    ref_m = [torch.zeros_like(p) for p in ref_p]
+    ref_v = [torch.zeros_like(p) for p in ref_p]
+    opt = FlatAdamW(params, lr=1e-2, betas=(0.9, 0.98), eps=1e-6, weight_decay=0.01, max_grad_norm=2.0)
+    for step in range(1, 4):
+        grads = [torch.randn(*s) * 3 for s in shapes]
+        for p, g in zip(params, grads):
+            if p.grad is None:
+                p.grad = g.cuda().clone()
+            else:
+                p.grad.copy_(g)
+        opt.step()
+        total = torch.sqrt(sum((g.double() ** 2).sum() for g in grads))
+        coef = min(2.0 / (float(total) + 1e-6), 1.0)
+        for i, g in enumerate(grads):
+            gg = g.double() * coef
+            ref_m[i] = ref_m[i] * 0.9 + 0.1 * gg
+            ref_v[i] = ref_v[i] * 0.98 + 0.02 * gg * gg
+            ss = 1e-2 * math.sqrt(1 - 0.98 ** step) / (1 - 0.9 ** step)
+            ref_p[i] = ref_p[i] - ss * ref_m[i] / (ref_v[i].sqrt() + 1e-6)
+            ref_p[i] = ref_p[i] - 1e-2 * 0.01 * ref_p[i]
+        for p, r in zip(params, ref_p):
+            close(p, r, 1e-5, 1e-6, "adamw step %d" % step)
+        opt.zero_grad()
+        assert all(float(p.grad.abs().sum()) == 0 for p in params)
