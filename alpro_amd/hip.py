@@ -21,7 +21,7 @@ _CODE = {v: k for k, v in _TORCH_DTYPE.items()}
 EXPORTS = ["alpro_hip_last_error", "alpro_hip_abi_version", "alpro_gemm", "alpro_layernorm_fwd",
            "alpro_attn_temporal_fwd", "alpro_attn_fwd", "alpro_patchify", "alpro_cls_mean_residual",
            "alpro_vit_final_pool", "alpro_bert_embed_fwd", "alpro_cast_from_f32", "alpro_attn_bwd", "alpro_attn_temporal_bwd",
-           "alpro_layernorm_bwd", "alpro_transpose", "alpro_gelu_bwd", "alpro_cls_mean_bwd", "alpro_scatter_add_rows", "alpro_gather_cast", "alpro_sumsq", "alpro_adamw_step"]
+           "alpro_layernorm_bwd", "alpro_transpose", "alpro_gelu_bwd", "alpro_cls_mean_bwd", "alpro_scatter_add_rows", "alpro_gather_cast", "alpro_sumsq", "alpro_adamw_step", "alpro_gemm_tn_acc", "alpro_colsum_acc"]
 
 
 class GemmDesc(ctypes.Structure):
@@ -62,6 +62,8 @@ def load():
     lib.alpro_transpose.argtypes = [vp, i32, i64, vp, i32, i64, i32, i32, i32, vp, vp]
     lib.alpro_gelu_bwd.argtypes = [vp, vp, vp, i32, i64, vp]
     lib.alpro_sumsq.argtypes = [vp, i64, vp, vp]
+    lib.alpro_gemm_tn_acc.argtypes = [vp, i64, vp, i64, vp, i64, i32, i32, i32, i32, vp]
+    lib.alpro_colsum_acc.argtypes = [vp, i64, vp, i32, i32, i32, vp]
     lib.alpro_adamw_step.argtypes = [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, f32, vp, f32, f32, vp]
     lib.alpro_gather_cast.argtypes = [vp, i64, vp, i32, i32, i32, i32, i32, i32, vp, i32, f32, vp]
     lib.alpro_cls_mean_bwd.argtypes = [vp, i64, vp, i32, i32, i32, vp]
@@ -96,8 +98,8 @@ def _dev(t, dtype=None):
         raise RuntimeError("alpro_amd ops need device tensors (got %s): the hot path has no CPU fallback" % t.device)
     if dtype is not None and t.dtype != dtype:
         raise RuntimeError("expected %s, got %s" % (dtype, t.dtype))
-    if not t.is_contiguous():
-        raise RuntimeError("expected a contiguous tensor")
+    if not (t.is_contiguous() or (t.dim() == 2 and t.stride(1) == 1)):
+        raise RuntimeError("expected a contiguous (or row-strided 2-D) tensor")
     return t
 
 
@@ -336,3 +338,20 @@ def adamw_step(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step_size, gnorm
         _dev(t, torch.float32)
     _check(lib.alpro_adamw_step(_ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), lr, beta1, beta2, eps, weight_decay, step_size,
                                 _ptr(gnorm_sq), max_norm, grad_scale, _stream()), "alpro_adamw_step")
+
+
+def gemm_tn_acc(a, b, c):
+    """c (N, K) fp32 += a(M, N)^T @ b(M, K) with 16-bit a, b in their natural row-major layout (alpro_gemm_tn_acc)."""
+    lib = load()
+    _dev(a); _dev(b, a.dtype); _dev(c, torch.float32)
+    assert a.shape[0] == b.shape[0] and tuple(c.shape) == (a.shape[1], b.shape[1])
+    _check(lib.alpro_gemm_tn_acc(_ptr(a), a.stride(0), _ptr(b), b.stride(0), _ptr(c), c.stride(0), _CODE[a.dtype], a.shape[0], a.shape[1],
+                                 b.shape[1], _stream()), "alpro_gemm_tn_acc")
+    return c
+
+
+def colsum_acc(a, out):
+    lib = load()
+    _dev(a); _dev(out, torch.float32)
+    _check(lib.alpro_colsum_acc(_ptr(a), a.stride(0), _ptr(out), _CODE[a.dtype], a.shape[0], a.shape[1], _stream()), "alpro_colsum_acc")
+    return out

@@ -43,24 +43,21 @@ def transposed_operand(cache, key, weight, dt):
     return out
 
 
-def wgrad(dy_t, x_t, weight, bias, dyT=None):
-    """weight.grad += dy^T x ; bias.grad += colsum(dy).  dy_t (M, N), x_t (M, K) operand-dtype activations."""
-    gb = None
+def wgrad(dy_t, x_t, weight, bias):
+    """weight.grad += dy^T x ; bias.grad += colsum(dy).  dy_t (M, N), x_t (M, K) operand-dtype activations.
+    16-bit operands: alpro_gemm_tn_acc reads both in place (split over tokens, fp32 atomics); fp32 (exact mode):
+    transposed copies + the NT GEMM."""
     if bias is not None:
-        gb, _ = grad_buffer(bias, zero=True) if bias.grad is None else (bias.grad, True)
-    if dyT is None:
-        dyT = hip.transpose(dy_t, colsum=gb)
-    xT = hip.transpose(x_t)
-    gw, existed = grad_buffer(weight)
+        gb = grad_buffer(bias, zero=True)[0]
+    gw, existed = grad_buffer(weight, zero=True)
     gw2 = gw.view(gw.shape[0], -1)
-    hip.gemm(dyT, xT, out=gw2, out_dtype=torch.float32, residual=gw2 if existed else None)
-    return dyT
-
-
-def wgrad_rows(dyT_rows, xT, weight):
-    """weight.grad += dyT_rows @ xT^T for a row block of an already transposed dy (fused q/k/v projections)."""
-    gw, existed = grad_buffer(weight)
-    hip.gemm(dyT_rows, xT, out=gw, out_dtype=torch.float32, residual=gw if existed else None)
+    if dy_t.dtype != torch.float32:
+        if bias is not None:
+            hip.colsum_acc(dy_t, gb)
+        hip.gemm_tn_acc(dy_t, x_t, gw2)
+        return
+    dyT = hip.transpose(dy_t, colsum=gb if bias is not None else None)
+    hip.gemm(dyT, hip.transpose(x_t), out=gw2, out_dtype=torch.float32, residual=gw2)
 
 
 def dgrad(dy_t, wT, out_dtype=None, row_scale=None, row_scale_group=1):

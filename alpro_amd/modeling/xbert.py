@@ -171,14 +171,10 @@ class BertLayer(nn.Module):
         tr.wgrad(ds1_t, sv["ctx"], so.dense.weight, so.dense.bias)
         dctx = tr.dgrad(ds1_t, tr.transposed_operand(self._ops, "ao_w^T", so.dense.weight, dt))
         dqkv = hip.attn_bwd(sv["qkv"], sv["ctx"], dctx, sv["lse"], B, L, H, scale, sv["kb"])
-        # fused q/k/v projection: one transpose of dqkv, three row blocks -> the three weight gradients
+        # fused q/k/v projection: the three weight gradients come from the three column blocks of dqkv
         Hd = sa.all_head_size
-        db = torch.zeros(3 * Hd, dtype=torch.float32, device=dev)
-        dT = hip.transpose(dqkv, colsum=db)
-        xT = hip.transpose(sv["h_t"])
         for i, lin in enumerate((sa.query, sa.key, sa.value)):
-            tr.wgrad_rows(dT[i * Hd:(i + 1) * Hd], xT, lin.weight)
-            tr.add_grad(lin.bias, db[i * Hd:(i + 1) * Hd])
+            tr.wgrad(dqkv[:, i * Hd:(i + 1) * Hd], sv["h_t"], lin.weight, lin.bias)
         wT = self._ops._store.get("qkv_w^T")
         ver = (tr.param_epoch(),) + tuple((p.data_ptr(), p._version) for p in (sa.query.weight, sa.key.weight, sa.value.weight))
         if wT is None or wT[0] != ver or wT[1].dtype != dt:
@@ -415,9 +411,15 @@ class _LMHeadRun:
         dl = torch.zeros((M, Vp), dtype=dt, device=dlogits.device)
         dl[:, :V] = dlogits.reshape(M, V)
         dn = tr.dgrad(dl, tr.transposed_operand(hd._ops, "dec_w^T", hd.decoder.weight, dt))
+        # decoder weight is the (tied) word-embedding table: dW (V, H) += dl^T n ; bias += colsum(dl)
+        gw = tr.grad_buffer(hd.decoder.weight, zero=True)[0]
         cs = torch.zeros(Vp, dtype=torch.float32, device=dl.device)
-        dlT = hip.transpose(dl, colsum=cs)
-        tr.wgrad_rows(dlT[:V], hip.transpose(self.n), hd.decoder.weight)  # tied: accumulates into the word-embedding gradient
+        if dt != torch.float32:
+            hip.colsum_acc(dl, cs)
+            hip.gemm_tn_acc(dl[:, :V], self.n, gw)
+        else:
+            dlT = hip.transpose(dl, colsum=cs)
+            hip.gemm(dlT[:V], hip.transpose(self.n), out=gw, out_dtype=torch.float32, residual=gw)
         tr.add_grad(hd.bias, cs[:V])
         dg = torch.empty_like(self.g)
         gw, gb = tr.grad_buffer(t.LayerNorm.weight, zero=True)[0], tr.grad_buffer(t.LayerNorm.bias, zero=True)[0]

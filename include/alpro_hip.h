@@ -161,6 +161,15 @@ int alpro_cls_mean_bwd(const float* dx_out, int64_t ld_batch, float* dside, int 
 /* dst[idx[i], :] += src[i, :] (idx NULL: row i % idx_mod): embedding-table gradients (xbert.py:203-210 backward). */
 int alpro_scatter_add_rows(const float* src, const int64_t* idx, float* dst, int rows, int idx_mod, int D, void* stream);
 
+/* Weight gradient without transposed copies: C[N, K] (fp32, ATOMICALLY accumulated) += A[M, N]^T B[M, K], A = dY and
+ * B = X row-major in a 16-bit dtype, contraction over tokens split across the grid (gemm_tn.hip).  C must be
+ * initialised (zero or the running gradient).  fp32 operands: use alpro_transpose + alpro_gemm. */
+int alpro_gemm_tn_acc(const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc, int dtype, int M,
+                      int N, int K, void* stream);
+
+/* out[n] (fp32) += sum_m A[m, n]: bias gradients. */
+int alpro_colsum_acc(const void* A, int64_t lda, float* out, int dtype, int M, int N, void* stream);
+
 /* ---- step epilogue on flat fp32 buffers (run_pretrain_sparse.py:633-648, src/optimization/adamw.py:40-103) ---- */
 
 /* *out += sum(x[i]^2): global gradient norm for clip_grad_norm_. */

@@ -178,3 +178,22 @@ def test_flat_adamw_matches_reference_update():
             close(p, r, 1e-5, 1e-6, "adamw step %d" % step)
         opt.zero_grad()
         assert all(float(p.grad.abs().sum()) == 0 for p in params)
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("M,N,K", [(3138, 768, 768), (1000, 2304, 768), (6400, 768, 3072), (130, 30522, 768), (64, 8, 8)])
+def test_gemm_tn_acc(dt, M, N, K):
+    """Weight-gradient GEMM on natural layouts (tr-read operands, split over tokens, atomic accumulate)."""
+    hip = _hip()
+    ldn = (N + 7) // 8 * 8
+    a = torch.zeros(M, ldn)
+    a[:, :N] = rnd(M, N, seed=120) * 0.5
+    b = rnd(M, K, seed=121)
+    c0 = rnd(N, K, seed=122)
+    c = c0.clone().cuda()
+    hip.gemm_tn_acc(a.to(dt).cuda()[:, :N], b.to(dt).cuda(), c)
+    ref = c0.double() + a[:, :N].to(dt).double().T @ b.to(dt).double()
+    close(c, ref, 2e-5, 2e-3 * math.sqrt(M / 1000.0), "gemm_tn_acc")
+    cs = torch.ones(ldn).cuda()
+    hip.colsum_acc(a.to(dt).cuda(), cs)
+    close(cs[:N], 1 + a[:, :N].to(dt).double().sum(0), 1e-5, 1e-3, "colsum_acc")
