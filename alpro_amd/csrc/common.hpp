@@ -30,12 +30,8 @@ __device__ __forceinline__ float to_f32(float x) { return x; }
 __device__ __forceinline__ float to_f32(bf16_t x) { return __builtin_bit_cast(float, (uint32_t)x.v << 16); }
 __device__ __forceinline__ float to_f32(f16_t x) { return (float)__builtin_bit_cast(_Float16, x.v); }
 
-__device__ __forceinline__ uint16_t f32_to_bf16_bits(float f) {
-  uint32_t u = __builtin_bit_cast(uint32_t, f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);  // quiet NaN
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (uint16_t)(u >> 16);
-}
+// hardware conversion (v_cvt_pk_bf16_f32 on gfx950: round-to-nearest-even, NaN preserved), branch-free
+__device__ __forceinline__ uint16_t f32_to_bf16_bits(float f) { return __builtin_bit_cast(uint16_t, (__bf16)f); }
 template <typename T> __device__ __forceinline__ T from_f32(float x);
 template <> __device__ __forceinline__ float from_f32<float>(float x) { return x; }
 template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float x) { return bf16_t{f32_to_bf16_bits(x)}; }
@@ -72,11 +68,14 @@ template <> __device__ __forceinline__ void unpack_chunk<f16_t>(const u32x4& c, 
   }
 }
 
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t pack2(float lo, float hi, bf16_t*) {
-  return (uint32_t)f32_to_bf16_bits(lo) | ((uint32_t)f32_to_bf16_bits(hi) << 16);
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2_t){lo, hi}, bf16x2_t));
 }
 __device__ __forceinline__ uint32_t pack2(float lo, float hi, f16_t*) {
-  return (uint32_t)__builtin_bit_cast(uint16_t, (_Float16)lo) | ((uint32_t)__builtin_bit_cast(uint16_t, (_Float16)hi) << 16);
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2_t){lo, hi}, f16x2_t));
 }
 template <typename T> __device__ __forceinline__ u32x4 pack_chunk(const float* v);
 template <> __device__ __forceinline__ u32x4 pack_chunk<float>(const float* v) {

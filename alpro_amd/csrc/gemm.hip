@@ -13,6 +13,8 @@
 #include <stdio.h>
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "common.hpp"
 
 namespace alpro {
@@ -63,20 +65,11 @@ __device__ __forceinline__ void store_c(void* C, int c_dtype, int64_t idx, float
 }
 
 
-// Epilogue of one 64x64 wave sub-tile: accumulators -> wave-private LDS -> row-wise 16-byte I/O, so that
-// bias / activation / drop-path scale / residual / row-map work on 4 consecutive columns of ONE row per lane.
-__device__ __forceinline__ void stage_acc(float* stage, const f32x16& a00, const f32x16& a01, const f32x16& a10, const f32x16& a11, int lane) {
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int row = acc_row(r, lane), col = lane & 31;
-    stage[row * 64 + col] = a00[r];
-    stage[row * 64 + 32 + col] = a01[r];
-    stage[(32 + row) * 64 + col] = a10[r];
-    stage[(32 + row) * 64 + 32 + col] = a11[r];
-  }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+// Wave-private LDS hand-off: DS operations of one wave execute in issue order, so a ds_read after a ds_write of the
+// same wave needs no hardware wait -- only the compiler must not reorder them.
+__device__ __forceinline__ void wave_lds_sync() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
 template <typename T, int ACT> __device__ __forceinline__ float apply_act(float x) {
@@ -85,94 +78,113 @@ template <typename T, int ACT> __device__ __forceinline__ float apply_act(float 
   return x;
 }
 
-// Rows of the staged 64x64 tile.  Two sweeps (runtime loop: keeps the code small enough for the I-cache)
-// of 8 row-passes; phase A issues every residual load of the sweep (the accumulator registers are dead by
-// now), phase B does the math and the stores -- otherwise the epilogue is a chain of dependent HBM round trips.
-template <typename T, int ACT, int MAP>
-__device__ __forceinline__ void epilogue_rows(const alpro_gemm_desc_t& g, const float* stage, int m_base, int n_base, int lane) {
+// Epilogue of 16 staged rows x 64 columns of one wave: lane l handles columns 4*(l&15)..+3 of rows p*4 + (l>>4),
+// p = 0..3, so every global access is a 16-byte (fp32) / 8-byte (16-bit) piece of a 256-/128-byte row segment.
+// FAST (wave-uniform): the whole 16x64 block is in range and every stride is vector-aligned -> no per-element
+// predication at all (the predicated variant is ~4x the instructions and was costing ~11 us per 256x256 tile).
+template <typename T, int ACT, int MAP, bool FAST, int PASSES = 4>
+__device__ __forceinline__ void epi_rows16(const alpro_gemm_desc_t& g, const float* stage, int m_base, int n_base, int lane, const float (&bias)[4]) {
   const int c4 = (lane & 15) * 4;
   const int n = n_base + c4;
-  const bool vec_ok = (n + 3 < g.N) && ((g.ldc & 3) == 0) && (!g.residual || (g.ldr & 3) == 0) && ((g.ld_side & 3) == 0);
-  float bias[4] = {0.f, 0.f, 0.f, 0.f};
-  if (g.bias) {
+  float4 rr[PASSES];
+  int64_t orow[PASSES];
+  bool live[PASSES], side[PASSES];
 #pragma unroll
-    for (int e = 0; e < 4; ++e)
-      if (n + e < g.N) bias[e] = g.bias[n + e];
-  }
-#pragma unroll 1
-  for (int sweep = 0; sweep < 2; ++sweep) {
-    float4 rr[8];
-    int64_t orow[8];
-    bool live[8], side[8];
-#pragma unroll
-    for (int p = 0; p < 8; ++p) {
-      const int m = m_base + (sweep * 8 + p) * 4 + (lane >> 4);
-      live[p] = m < g.M && n < g.N;
-      const RowDst d = map_row<MAP>(g.map_p0, g.map_p1, live[p] ? m : 0);
-      orow[p] = d.out;
-      side[p] = d.side;
-      rr[p] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (live[p] && g.residual && !d.side) {
-        const float* rp = g.residual + d.res * g.ldr + n;
-        if (vec_ok) rr[p] = *(const float4*)rp;
-        else {
-          rr[p].x = rp[0];
-          if (n + 1 < g.N) rr[p].y = rp[1];
-          if (n + 2 < g.N) rr[p].z = rp[2];
-          if (n + 3 < g.N) rr[p].w = rp[3];
-        }
-      }
-    }
-#pragma unroll
-    for (int p = 0; p < 8; ++p) {
-      const int row = (sweep * 8 + p) * 4 + (lane >> 4);
-      const int m = m_base + row;
-      if (live[p]) {
-        const float4 a = *(const float4*)(stage + row * 64 + c4);
-        float v[4] = {a.x, a.y, a.z, a.w};
-        const float res[4] = {rr[p].x, rr[p].y, rr[p].z, rr[p].w};
-        const float rs = g.row_scale ? g.row_scale[m / g.row_scale_group] : 1.0f;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = g.alpha * v[e] + bias[e];
-        if (ACT != ALPRO_ACT_NONE && g.C2 && vec_ok) {  // pre-activation copy for the activation's backward
-          if constexpr (sizeof(T) == 2) {
-            u32x2 u;
-            u.x = pack2(v[0], v[1], (T*)0);
-            u.y = pack2(v[2], v[3], (T*)0);
-            *(u32x2*)((T*)g.C2 + orow[p] * g.ldc2 + n) = u;
-          } else {
-            *(float4*)((float*)g.C2 + orow[p] * g.ldc2 + n) = make_float4(v[0], v[1], v[2], v[3]);
-          }
-        }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = apply_act<T, ACT>(v[e]) * rs + res[e];
-        if (side[p]) {
-          float* dst = g.side + orow[p] * g.ld_side + n;
-          if (vec_ok) *(float4*)dst = make_float4(v[0], v[1], v[2], v[3]);
-          else {
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-              if (n + e < g.N) dst[e] = v[e];
-          }
-        } else if (vec_ok) {
-          if (g.c_dtype == ALPRO_F32) {
-            *(float4*)((float*)g.C + orow[p] * g.ldc + n) = make_float4(v[0], v[1], v[2], v[3]);
-          } else if constexpr (sizeof(T) == 2) {
-            u32x2 u;
-            u.x = pack2(v[0], v[1], (T*)0);
-            u.y = pack2(v[2], v[3], (T*)0);
-            *(u32x2*)((T*)g.C + orow[p] * g.ldc + n) = u;
-          }
-        } else {
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-            if (n + e < g.N) store_c<T>(g.C, g.c_dtype, orow[p] * g.ldc + n + e, v[e]);
-        }
+  for (int p = 0; p < PASSES; ++p) {
+    const int m = m_base + p * 4 + (lane >> 4);
+    live[p] = FAST || (m < g.M && n < g.N);
+    const RowDst d = map_row<MAP>(g.map_p0, g.map_p1, live[p] ? m : 0);
+    orow[p] = d.out;
+    side[p] = d.side;
+    rr[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (g.residual && live[p] && !d.side) {
+      const float* rp = g.residual + d.res * g.ldr + n;
+      if (FAST) rr[p] = *(const float4*)rp;
+      else {
+        rr[p].x = rp[0];
+        if (n + 1 < g.N) rr[p].y = rp[1];
+        if (n + 2 < g.N) rr[p].z = rp[2];
+        if (n + 3 < g.N) rr[p].w = rp[3];
       }
     }
   }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int p = 0; p < PASSES; ++p) {
+    const int row = p * 4 + (lane >> 4);
+    if (!live[p]) continue;
+    const float4 a = *(const float4*)(stage + row * 64 + c4);
+    float v[4] = {a.x, a.y, a.z, a.w};
+    const float res[4] = {rr[p].x, rr[p].y, rr[p].z, rr[p].w};
+    const float rs = g.row_scale ? g.row_scale[(m_base + row) / g.row_scale_group] : 1.0f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = g.alpha * v[e] + bias[e];
+    if (ACT != ALPRO_ACT_NONE && g.C2) {  // pre-activation copy (host guarantees vector alignment for C2)
+      if constexpr (sizeof(T) == 2) {
+        *(u32x2*)((T*)g.C2 + orow[p] * g.ldc2 + n) = mk2(pack2(v[0], v[1], (T*)0), pack2(v[2], v[3], (T*)0));
+      } else {
+        *(float4*)((float*)g.C2 + orow[p] * g.ldc2 + n) = make_float4(v[0], v[1], v[2], v[3]);
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = apply_act<T, ACT>(v[e]) * rs + res[e];
+    if (MAP == ALPRO_MAP_FRAME_TOKENS && side[p]) {
+      float* dst = g.side + orow[p] * g.ld_side + n;
+      if (FAST) *(float4*)dst = make_float4(v[0], v[1], v[2], v[3]);
+      else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (n + e < g.N) dst[e] = v[e];
+      }
+    } else if (FAST) {
+      if (g.c_dtype == ALPRO_F32) {
+        *(float4*)((float*)g.C + orow[p] * g.ldc + n) = make_float4(v[0], v[1], v[2], v[3]);
+      } else if constexpr (sizeof(T) == 2) {
+        *(u32x2*)((T*)g.C + orow[p] * g.ldc + n) = mk2(pack2(v[0], v[1], (T*)0), pack2(v[2], v[3], (T*)0));
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (n + e < g.N) store_c<T>(g.C, g.c_dtype, orow[p] * g.ldc + n + e, v[e]);
+    }
+  }
+}
+
+// 16-bit outputs under the identity map (qkv / proj / fc1 / every dgrad): 8 columns per lane -> one 16-byte store per
+// lane, 8 rows per wave instruction.  The store path is ISSUE-bound per CU (~one wave-store per ~100 cycles measured),
+// so halving the number of store instructions halves the epilogue tail.  Whole block in range (FAST) only.
+template <typename T, int ACT, int PASSES = 2>
+__device__ __forceinline__ void epi_rows16_c16(const alpro_gemm_desc_t& g, const float* stage, int m_base, int n_base, int lane, const float (&bias)[8]) {
+  const int c8 = (lane & 7) * 8;
+  const int n = n_base + c8;
+#pragma unroll
+  for (int p = 0; p < PASSES; ++p) {
+    const int row = p * 8 + (lane >> 3);
+    const int64_t m = m_base + row;
+    const float4 a0 = *(const float4*)(stage + row * 64 + c8), a1 = *(const float4*)(stage + row * 64 + c8 + 4);
+    float v[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+    const float rs = g.row_scale ? g.row_scale[m / g.row_scale_group] : 1.0f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = g.alpha * v[e] + bias[e];
+    if (ACT != ALPRO_ACT_NONE && g.C2) *(u32x4*)((T*)g.C2 + m * g.ldc2 + n) = pack_chunk<T>(v);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = apply_act<T, ACT>(v[e]) * rs;
+    if (g.residual) {
+      const float4 r0 = *(const float4*)(g.residual + m * g.ldr + n), r1 = *(const float4*)(g.residual + m * g.ldr + n + 4);
+      v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w; v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w;
+    }
+    *(u32x4*)((T*)g.C + m * g.ldc + n) = pack_chunk<T>(v);
+  }
+}
+
+// wave-uniform test for the FAST epilogue of a (rows x 64) wave sub-tile
+__device__ __forceinline__ bool epi_fast_ok(const alpro_gemm_desc_t& g, int m_base, int rows, int n_base) {
+  return (m_base + rows <= g.M) && (n_base + 64 <= g.N) && ((g.ldc & 3) == 0) && (!g.residual || (g.ldr & 3) == 0) &&
+         ((g.ld_side & 3) == 0);
+}
+
+__device__ __forceinline__ void load_bias4(const alpro_gemm_desc_t& g, int n, float (&bias)[4]) {
+#pragma unroll
+  for (int e = 0; e < 4; ++e) bias[e] = (g.bias && n + e < g.N) ? g.bias[n + e] : 0.f;
 }
 
 template <typename T, int ACT, int MAP>
@@ -285,8 +297,25 @@ __global__ __launch_bounds__(NT, 2) void gemm_nt_kernel(const alpro_gemm_desc_t 
 
   // ---- epilogue (the trailing __syncthreads of the K loop guarantees nobody still reads the staging tiles)
   float* stage = (float*)(smem + wave * (64 * 64 * 4));
-  stage_acc(stage, acc[0][0], acc[0][1], acc[1][0], acc[1][1], lane);
-  epilogue_rows<T, ACT, MAP>(g, stage, m0 + wr * 64, n0 + wc * 64, lane);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = acc_row(r, lane), col = lane & 31;
+    stage[row * 64 + col] = acc[0][0][r];
+    stage[row * 64 + 32 + col] = acc[0][1][r];
+    stage[(32 + row) * 64 + col] = acc[1][0][r];
+    stage[(32 + row) * 64 + 32 + col] = acc[1][1][r];
+  }
+  wave_lds_sync();
+  const int mb = m0 + wr * 64, nb = n0 + wc * 64;
+  float bias[4];
+  load_bias4(g, nb + (lane & 15) * 4, bias);
+  if (epi_fast_ok(g, mb, 64, nb)) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) epi_rows16<T, ACT, MAP, true>(g, stage + c * 16 * 64, mb + c * 16, nb, lane, bias);
+  } else {
+#pragma unroll 1
+    for (int c = 0; c < 4; ++c) epi_rows16<T, ACT, MAP, false>(g, stage + c * 16 * 64, mb + c * 16, nb, lane, bias);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -297,51 +326,45 @@ __global__ __launch_bounds__(NT, 2) void gemm_nt_kernel(const alpro_gemm_desc_t 
 constexpr int BM2 = 256, BN2 = 256, NT2 = 512;
 constexpr int TILE2_BYTES = BM2 * ROWB;  // 32 KiB per operand per stage
 
+// ------------------------------------------------------------------------------------------------
+// Persistent form of the 256x256 kernel: one workgroup per CU walks its tiles (XCD-contiguous order).  On the
+// K = 768 shapes of this model a tile is only 12 K-steps, so what the one-tile-per-workgroup kernel loses is the
+// ~16 us per tile of workgroup turn-around + first-tile DMA latency + epilogue; here the first K-tile of the
+// NEXT tile is DMA-prefetched before the epilogue runs, and the epilogue stages through its own 32 KiB of LDS
+// (16 rows x 64 columns per wave at a time) so the two 64 KiB stage buffers are free to receive it.
+// Fragment reads are register double-buffered (the reads of K-chunk s+1 are in flight under the MFMAs of s).
+constexpr int EPI_BYTES = 8 * 16 * 64 * 4;  // 32 KiB: 8 waves x (16 rows x 64 cols) fp32
+
 template <typename T, int ACT, int MAP>
-__global__ __launch_bounds__(NT2, 2) void gemm_nt256_kernel(const alpro_gemm_desc_t g) {
+__global__ __launch_bounds__(NT2, 2) void gemm_nt256p_kernel(const alpro_gemm_desc_t g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 2, wc = wave & 3;
   const int ntn = (g.N + BN2 - 1) / BN2, ntm = (g.M + BM2 - 1) / BM2;
   const int nblk = ntn * ntm;
-  int tile;
-  {
-    const int bid = blockIdx.x, xcd = bid & 7, idx = bid >> 3;
-    const int q = nblk >> 3, r = nblk & 7;
-    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-  }
-  const int tm = tile / ntn, tn = tile - tm * ntn;
-  const int m0 = tm * BM2, n0 = tn * BN2;
   const int64_t lda_b = g.lda * (int64_t)sizeof(T), ldw_b = g.ldw * (int64_t)sizeof(T);
-
-  // DMA pieces: piece p = 8 rows (1 KiB); wave w moves pieces w, w+8, w+16, w+24 of A and of W per K-tile
-  const char* a_src[4];
-  const char* w_src[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int row = (wave + 8 * i) * 8 + (lane >> 3);
-    const int ch = (lane & 7) ^ ((row >> 1) & 7);  // source chunk that belongs in LDS slot (row, lane & 7)
-    a_src[i] = (const char*)g.A + min(m0 + row, g.M - 1) * lda_b + ch * 16;
-    w_src[i] = (const char*)g.W + min(n0 + row, g.N - 1) * ldw_b + ch * 16;
-  }
-  int a_row[4], b_row[2];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) a_row[i] = wr * 128 + i * 32 + (lane & 31);
-#pragma unroll
-  for (int j = 0; j < 2; ++j) b_row[j] = wc * 64 + j * 32 + (lane & 31);
-  const int khalf = lane >> 5;
-
-  f32x16 acc[4][2];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
   const int nk = (g.K * (int)sizeof(T)) / ROWB;
+  // XCD-contiguous walk: within one round of gridDim.x tiles, XCD x (= blockIdx % 8) owns a contiguous run
+  const int per_xcd = (gridDim.x + 7) >> 3;
+  const int slot = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
   typedef __attribute__((address_space(3))) void* lds_ptr;
   typedef const __attribute__((address_space(1))) void* gbl_ptr;
+
+  const char* a_src[4];
+  const char* w_src[4];
+  int m0 = 0, n0 = 0;
+  auto setup = [&](int tile) {
+    const int tm = tile / ntn, tn = tile - tm * ntn;
+    m0 = tm * BM2;
+    n0 = tn * BN2;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = (wave + 8 * i) * 8 + (lane >> 3);
+      const int ch = (lane & 7) ^ ((row >> 1) & 7);
+      a_src[i] = (const char*)g.A + min(m0 + row, g.M - 1) * lda_b + ch * 16;
+      w_src[i] = (const char*)g.W + min(n0 + row, g.N - 1) * ldw_b + ch * 16;
+    }
+  };
   auto stage_tile = [&](int kt, int buf) {
     char* dA = smem + buf * 2 * TILE2_BYTES;
     char* dW = dA + TILE2_BYTES;
@@ -352,35 +375,135 @@ __global__ __launch_bounds__(NT2, 2) void gemm_nt256_kernel(const alpro_gemm_des
       __builtin_amdgcn_global_load_lds((gbl_ptr)(w_src[i] + ko), (lds_ptr)(dW + (wave + 8 * i) * 1024), 16, 0, 0);
     }
   };
+  int a_row[4], b_row[2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) a_row[i] = wr * 128 + i * 32 + (lane & 31);
+#pragma unroll
+  for (int j = 0; j < 2; ++j) b_row[j] = wc * 64 + j * 32 + (lane & 31);
+  const int khalf = lane >> 5;
+  float* stage = (float*)(smem + 4 * TILE2_BYTES + wave * (16 * 64 * 4));
+
+  int tile = slot;
+  if (tile >= nblk) return;
+  // Invariant at the top of every tile: K-tiles 0 and 1 are in buffers s0 and s0^1 and this wave has no DMA in flight,
+  // so the first two K-steps need no vmcnt wait -- the previous tile's output stores drain underneath them.
+  auto wait_vm0 = [] { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
+  auto block_sync = [] {  // barrier that does NOT drain vmcnt (a __syncthreads() would wait for the output stores)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  };
+  setup(tile);
+  int s0 = 0;
   stage_tile(0, 0);
-  __syncthreads();  // (drains vmcnt: the DMA of tile 0 has landed)
-
-  int cur = 0;
-  for (int kt = 0; kt < nk; ++kt) {
-    if (kt + 1 < nk) stage_tile(kt + 1, cur ^ 1);
-    const char* cA = smem + cur * 2 * TILE2_BYTES;
-    const char* cW = cA + TILE2_BYTES;
+  stage_tile(1, 1);
+  wait_vm0();
+  while (true) {
+    const int tm0 = m0, tn0 = n0;
+    const int next = tile + gridDim.x;
+    const bool more = next < nblk;
+    f32x16 acc[4][2];
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      u32x4 fa[4], fb[2];
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int j = 0; j < 2; ++j) fb[j] = *(const u32x4*)(cW + lds_off(b_row[j], 2 * s + khalf));
+      for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) fa[i] = *(const u32x4*)(cA + lds_off(a_row[i], 2 * s + khalf));
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    for (int kt = 0; kt < nk; ++kt) {
+      const int cur = s0 ^ (kt & 1);
+      if (kt >= 2) wait_vm0();  // own pieces of K-tile kt (issued one step ago); at kt == 2 also the previous tile's stores
+      block_sync();             // K-tile kt visible to everyone; everyone is done with K-tile kt-1
+      if (kt >= 1) {            // the buffer of K-tile kt-1 is free
+        if (kt + 1 < nk) {
+          stage_tile(kt + 1, cur ^ 1);
+        } else if (more) {      // last step: start the NEXT tile's first K-tile
+          setup(next);
+          stage_tile(0, cur ^ 1);
+        }
+      }
+      const char* cA = smem + cur * 2 * TILE2_BYTES;
+      const char* cW = cA + TILE2_BYTES;
+      u32x4 fa[2][4], fb[2][2];
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int j = 0; j < 2; ++j) fb[0][j] = *(const u32x4*)(cW + lds_off(b_row[j], khalf));
 #pragma unroll
-        for (int j = 0; j < 2; ++j) mma_chunk<T>(acc[i][j], fa[i], fb[j]);
+      for (int i = 0; i < 4; ++i) fa[0][i] = *(const u32x4*)(cA + lds_off(a_row[i], khalf));
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        if (s < 3) {
+#pragma unroll
+          for (int j = 0; j < 2; ++j) fb[(s + 1) & 1][j] = *(const u32x4*)(cW + lds_off(b_row[j], 2 * (s + 1) + khalf));
+#pragma unroll
+          for (int i = 0; i < 4; ++i) fa[(s + 1) & 1][i] = *(const u32x4*)(cA + lds_off(a_row[i], 2 * (s + 1) + khalf));
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) mma_chunk<T>(acc[i][j], fa[s & 1][i], fb[s & 1][j]);
+      }
     }
-    __syncthreads();  // next tile landed (vmcnt(0)) and everyone is done reading this one
-    cur ^= 1;
+    block_sync();  // everyone is done with the last K-tile: its buffer takes the next tile's K-tile 1
+    const int last = s0 ^ ((nk - 1) & 1);
+    if (more) stage_tile(1, last);
+    s0 = last ^ 1;
+    // epilogue; the two prefetched K-tiles must have landed before the first output store is issued (after that,
+    // vmcnt also counts the stores and nobody waits on it until K-step 2 of the next tile)
+    {
+      const int mb = tm0 + wr * 128, nb = tn0 + wc * 64;
+      float bias[4];
+      load_bias4(g, nb + (lane & 15) * 4, bias);
+      wait_vm0();
+      // 8-row chunks through two alternating 2 KiB staging buffers per wave: the ds_writes of chunk c+1 are independent
+      // of the ds_reads of chunk c, so LDS latency and the global stores of consecutive chunks overlap.  No explicit
+      // wave sync is needed: DS operations of one wave execute in order and the compiler keeps the may-alias order.
+      auto stage_chunk = [&](float* st, const f32x16& a0, const f32x16& a1, int q) {
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+          const int row = r4 + 4 * (lane >> 5);
+          st[row * 64 + (lane & 31)] = a0[4 * q + r4];
+          st[row * 64 + 32 + (lane & 31)] = a1[4 * q + r4];
+        }
+      };
+      auto run_epilogue = [&](auto fast_tag) {
+        constexpr bool FAST = decltype(fast_tag)::value;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            float* st = stage + ((i * 4 + q) & 1) * 512;
+            stage_chunk(st, acc[i][0], acc[i][1], q);
+            epi_rows16<T, ACT, MAP, FAST, 2>(g, st, mb + i * 32 + q * 8, nb, lane, bias);
+          }
+        }
+      };
+      const bool fast = epi_fast_ok(g, mb, 128, nb);
+      bool c16 = false;
+      if constexpr (sizeof(T) == 2 && MAP == ALPRO_MAP_IDENTITY)
+        c16 = fast && g.c_dtype != ALPRO_F32 && ((g.ldc & 7) == 0) && (!g.C2 || (g.ldc2 & 7) == 0);
+      if (c16) {
+        if constexpr (sizeof(T) == 2 && MAP == ALPRO_MAP_IDENTITY) {
+          float bias8[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) bias8[e] = g.bias ? g.bias[nb + (lane & 7) * 8 + e] : 0.f;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              float* st = stage + ((i * 4 + q) & 1) * 512;
+              stage_chunk(st, acc[i][0], acc[i][1], q);
+              epi_rows16_c16<T, ACT, 1>(g, st, mb + i * 32 + q * 8, nb, lane, bias8);
+            }
+          }
+        }
+      } else if (fast) {
+        run_epilogue(std::true_type{});
+      } else {
+        run_epilogue(std::false_type{});
+      }
+    }
+    if (!more) break;
+    tile = next;
   }
-
-  float* stage = (float*)(smem + wave * (64 * 64 * 4));
-  stage_acc(stage, acc[0][0], acc[0][1], acc[1][0], acc[1][1], lane);
-  epilogue_rows<T, ACT, MAP>(g, stage, m0 + wr * 128, n0 + wc * 64, lane);
-  stage_acc(stage, acc[2][0], acc[2][1], acc[3][0], acc[3][1], lane);
-  epilogue_rows<T, ACT, MAP>(g, stage, m0 + wr * 128 + 64, n0 + wc * 64, lane);
 }
 
 template <typename T, int ACT, int MAP>
@@ -388,14 +511,16 @@ int launch_gemm_inst(const alpro_gemm_desc_t& g, hipStream_t st) {
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<T, ACT, MAP>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE_BYTES);
-    (void)hipFuncSetAttribute((const void*)gemm_nt256_kernel<T, ACT, MAP>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE2_BYTES);
+    (void)hipFuncSetAttribute((const void*)gemm_nt256p_kernel<T, ACT, MAP>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE2_BYTES + EPI_BYTES);
     attr_set = true;
   }
   const int big_tiles = ((g.N + BN2 - 1) / BN2) * ((g.M + BM2 - 1) / BM2);
   const char* force = getenv("ALPRO_GEMM_TILE");
-  const bool use256 = force ? atoi(force) == 256 : big_tiles >= 256;  // at least one full wave of 256^2 tiles on 256 CUs
+  const int nk = (g.K * (int)sizeof(T)) / ROWB;
+  // at least one full wave of 256^2 tiles on the 256 CUs; the persistent kernel's pipeline needs >= 2 K-tiles
+  const bool use256 = nk >= 2 && (force ? atoi(force) == 256 : big_tiles >= 256);
   if (use256) {
-    hipLaunchKernelGGL((gemm_nt256_kernel<T, ACT, MAP>), dim3(big_tiles), dim3(NT2), 4 * TILE2_BYTES, st, g);
+    hipLaunchKernelGGL((gemm_nt256p_kernel<T, ACT, MAP>), dim3(big_tiles < 256 ? big_tiles : 256), dim3(NT2), 4 * TILE2_BYTES + EPI_BYTES, st, g);
   } else {
     const int ntn = (g.N + BN - 1) / BN, ntm = (g.M + BM - 1) / BM;
     hipLaunchKernelGGL((gemm_nt_kernel<T, ACT, MAP>), dim3(ntn * ntm), dim3(NT), 4 * TILE_BYTES, st, g);

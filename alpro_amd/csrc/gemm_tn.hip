@@ -132,24 +132,48 @@ __global__ __launch_bounds__(NT3, 2) void gemm_tn_kernel(const T* __restrict__ A
   }
 }
 
-// colsum[n] += sum_m A[m, n]: bias gradients (one pass over dY, 16-byte loads, fp32 atomics per 128-row strip)
+// colsum[n] += sum_m A[m, n]: bias gradients.  One pass over dY: a wave reads 64 consecutive 16-byte chunks of a row
+// (1 KiB), the 4 waves of a workgroup take rows r, r+4, ... of a 256-row strip with 8 independent loads in flight,
+// then a 4-way LDS reduction and one fp32 atomic per column per strip.
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ A, int64_t lda, float* __restrict__ out, int M, int N) {
   constexpr int E = Chunk<T>::N;
-  const int m0 = blockIdx.x * 128, m1 = min(m0 + 128, M);
-  for (int c = threadIdx.x; c * E < N; c += 256) {
-    float s[E];
+  __shared__ float red[4][64 * E];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lane;           // 16-byte chunk of the row
+  const bool cv = c * E < N;
+  const int m0 = blockIdx.y * 256, m1 = min(m0 + 256, M);
+  float s[E];
 #pragma unroll
-    for (int e = 0; e < E; ++e) s[e] = 0.f;
-    for (int m = m0; m < m1; ++m) {
-      float v[E];
-      unpack_chunk<T>(*(const u32x4*)(A + (int64_t)m * lda + c * E), v);
+  for (int e = 0; e < E; ++e) s[e] = 0.f;
+  if (cv) {
+    const T* base = A + c * E;
+    int m = m0 + w;
+    for (; m + 28 < m1; m += 32) {
+      u32x4 v[8];
 #pragma unroll
-      for (int e = 0; e < E; ++e) s[e] += v[e];
+      for (int u = 0; u < 8; ++u) v[u] = *(const u32x4*)(base + (int64_t)(m + 4 * u) * lda);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        float f[E];
+        unpack_chunk<T>(v[u], f);
+#pragma unroll
+        for (int e = 0; e < E; ++e) s[e] += f[e];
+      }
     }
+    for (; m < m1; m += 4) {
+      float f[E];
+      unpack_chunk<T>(*(const u32x4*)(base + (int64_t)m * lda), f);
 #pragma unroll
-    for (int e = 0; e < E; ++e)
-      if (c * E + e < N) unsafeAtomicAdd(out + c * E + e, s[e]);
+      for (int e = 0; e < E; ++e) s[e] += f[e];
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < E; ++e) red[w][lane * E + e] = s[e];
+  __syncthreads();
+  for (int i = threadIdx.x; i < 64 * E; i += 256) {
+    const int col = blockIdx.x * 64 * E + i;
+    if (col < N) unsafeAtomicAdd(out + col, red[0][i] + red[1][i] + red[2][i] + red[3][i]);
   }
 }
 
@@ -191,6 +215,6 @@ extern "C" int alpro_colsum_acc(const void* A, int64_t lda, float* out, int dtyp
   ALPRO_CHECK(A && out && M > 0 && N > 0, "alpro_colsum_acc: bad args");
   const int esz = dtype == ALPRO_F32 ? 4 : 2;
   ALPRO_CHECK((N * esz) % 16 == 0 && (lda * esz) % 16 == 0, "alpro_colsum_acc: rows must be 16-byte multiples");
-  ALPRO_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL(colsum_kernel<T>, dim3((M + 127) / 128), dim3(256), 0, (hipStream_t)stream, (const T*)A, lda, out, M, N));
+  ALPRO_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL(colsum_kernel<T>, dim3((N + 64 * Chunk<T>::N - 1) / (64 * Chunk<T>::N), (M + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const T*)A, lda, out, M, N));
   return check_launch("alpro_colsum_acc");
 }
