@@ -1,0 +1,87 @@
+"""CPU, world_size 2 over gloo: the data-parallel pieces of the path (alpro_amd/dist.py) -- differentiable
+all-gather (forward order = rank order, backward = sum-reduce + own slice, i.e. Horovod's allgather semantics used at
+alpro_models.py:110-111), bucketed gradient all-reduce, parameter broadcast, and the VTC loss identity
+"2 ranks x B pairs == 1 rank x 2B pairs" that makes data parallelism exact for the contrastive term."""
+import os
+import socket
+
+import torch
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _vtc(video_feat, text_feat, temp, rank, allgather):
+    b = video_feat.shape[0]
+    gv, gt = allgather(video_feat), allgather(text_feat)
+    sim_v2t = video_feat @ gt.t() / temp
+    sim_t2v = text_feat @ gv.t() / temp
+    tgt = torch.zeros_like(sim_v2t)
+    tgt[:, b * rank:b * (rank + 1)] = torch.eye(b)
+    lv = -torch.sum(torch.log_softmax(sim_v2t, 1) * tgt, 1).mean()
+    lt = -torch.sum(torch.log_softmax(sim_t2v, 1) * tgt, 1).mean()
+    return (lv + lt) / 2
+
+
+def _worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from alpro_amd import dist
+    dist.init(backend="gloo")
+    assert dist.size() == world and dist.rank() == rank and dist.local_rank() == rank
+    torch.manual_seed(0)
+    B, D = 3, 16
+    full_v = torch.nn.functional.normalize(torch.randn(world * B, D), dim=-1)
+    full_t = torch.nn.functional.normalize(torch.randn(world * B, D), dim=-1)
+    v = full_v[rank * B:(rank + 1) * B].clone().requires_grad_(True)
+    t = full_t[rank * B:(rank + 1) * B].clone().requires_grad_(True)
+    # forward: gathered rows in rank order
+    g = dist.allgather(v)
+    assert torch.allclose(g, full_v)
+    # loss averaged over ranks == single-process loss on the concatenated batch; same for the gradients
+    loss = _vtc(v, t, 0.07, rank, dist.allgather)
+    loss.backward()
+    fv, ft = full_v.clone().requires_grad_(True), full_t.clone().requires_grad_(True)
+    ref = _vtc(fv, ft, 0.07, 0, lambda x: x)
+    ref.backward()
+    lsum = loss.detach().clone()
+    torch.distributed.all_reduce(lsum)
+    assert torch.allclose(lsum / world, ref.detach(), atol=1e-6), (lsum / world, ref)
+    # d(mean over ranks of loss_r)/dv = fv.grad rows: each rank's backward already sums the other ranks' contributions
+    assert torch.allclose(v.grad / world, fv.grad[rank * B:(rank + 1) * B], atol=1e-6)
+    assert torch.allclose(t.grad / world, ft.grad[rank * B:(rank + 1) * B], atol=1e-6)
+    # bucketed gradient all-reduce (average), skipping parameters without gradients
+    ps = [torch.nn.Parameter(torch.zeros(5, 7)), torch.nn.Parameter(torch.zeros(11)), torch.nn.Parameter(torch.zeros(3))]
+    ps[0].grad = torch.full((5, 7), float(rank + 1))
+    ps[1].grad = torch.arange(11, dtype=torch.float32) * (rank + 1)
+    sent = dist.allreduce_grads_(ps, bucket_bytes=64)
+    assert sent == (35 + 11) * 4
+    assert torch.allclose(ps[0].grad, torch.full((5, 7), 1.5)) and torch.allclose(ps[1].grad, torch.arange(11, dtype=torch.float32) * 1.5)
+    assert ps[2].grad is None
+    # broadcast of parameters from rank 0
+    lin = torch.nn.Linear(4, 4)
+    with torch.no_grad():
+        lin.weight.fill_(float(rank + 7))
+    dist.broadcast_parameters(lin)
+    assert float(lin.weight[0, 0]) == 7.0
+    dist.barrier()
+    out.put((rank, "ok"))
+
+
+def test_world2_gloo():
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0, "rank process failed (exit %s)" % p.exitcode
+    got = sorted(q.get(timeout=5) for _ in range(2))
+    assert got == [(0, "ok"), (1, "ok")]
