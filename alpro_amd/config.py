@@ -33,3 +33,22 @@ class use_compute_dtype:
 
     def __exit__(self, *a):
         set_compute_dtype(self.prev)
+
+
+# ---- dropout seeds: the HIP kernels draw masks from hash(seed, element index); every dropout site of every forward
+# gets a fresh 31-bit seed from this counter-based stream (deterministic given seed_dropout()).
+_drop_state = [0x1234567, 0]
+
+
+def seed_dropout(seed):
+    _drop_state[0] = int(seed) & 0x7FFFFFFF
+    _drop_state[1] = 0
+
+
+def next_dropout_seed():
+    _drop_state[1] += 1
+    x = (_drop_state[0] * 0x9E3779B1 + _drop_state[1] * 0x85EBCA77) & 0xFFFFFFFF
+    x ^= x >> 15
+    x = (x * 0x2C1B3C6D) & 0xFFFFFFFF
+    x ^= x >> 12
+    return (x & 0x7FFFFFFF) | 1  # never 0 (0 means "dropout off" in the C ABI)

@@ -175,7 +175,8 @@ __device__ __forceinline__ void store_o(T* out_row, const f32x16 (&o)[2], int la
 // full attention: grid = batch * H workgroups of 256 threads
 template <typename T, int NKT>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qkv, T* __restrict__ out, int L, int H, float scale,
-                                                       const float* __restrict__ key_bias, float* __restrict__ lse) {
+                                                       const float* __restrict__ key_bias, float* __restrict__ lse, float drop_p,
+                                                       uint32_t drop_seed) {
   typedef AttnCfg<T> C;
   constexpr int LP = NKT * 32;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -226,6 +227,15 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qkv
     }
     const float l_se = softmax_tiles<NKT>(s, scale, [&](int kt, int rq) { return *(const float4*)(Bs + kt * 32 + 8 * rq + 4 * g); });
     if (lse && g == 0 && q < L) lse[((int64_t)b * H + h) * L + q] = l_se;
+    if (drop_seed) {  // attention-probability dropout (xbert.py:331): mask is a pure function of (b, h, q, key)
+      const uint32_t th = drop_thresh24(drop_p);
+      const float ks = 1.0f / (1.0f - drop_p);
+      const uint64_t base_i = (((uint64_t)b * H + h) * L + (uint64_t)qc) * L;
+#pragma unroll
+      for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[kt][r] = drop_keep(drop_seed, base_i + kt * 32 + acc_row(r, lane), th) ? s[kt][r] * ks : 0.f;
+    }
 
     f32x16 o[2];
 #pragma unroll
@@ -297,24 +307,26 @@ __global__ __launch_bounds__(256) void attn_temporal_fwd_kernel(const T* __restr
 }
 
 template <typename T, int NKT>
-int launch_attn(const void* qkv, void* out, int batch, int L, int H, float scale, const float* key_bias, float* lse, hipStream_t st) {
+int launch_attn(const void* qkv, void* out, int batch, int L, int H, float scale, const float* key_bias, float* lse, float drop_p,
+                uint32_t drop_seed, hipStream_t st) {
   const size_t lds = 2 * (size_t)NKT * 32 * AttnCfg<T>::RB + (size_t)NKT * 32 * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<T, NKT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  hipLaunchKernelGGL((attn_fwd_kernel<T, NKT>), dim3(batch * H), dim3(256), lds, st, (const T*)qkv, (T*)out, L, H, scale, key_bias, lse);
+  hipLaunchKernelGGL((attn_fwd_kernel<T, NKT>), dim3(batch * H), dim3(256), lds, st, (const T*)qkv, (T*)out, L, H, scale, key_bias, lse, drop_p, drop_seed);
   return check_launch("alpro_attn_fwd");
 }
 
 template <typename T>
-int dispatch_attn(const void* qkv, void* out, int batch, int L, int H, float scale, const float* key_bias, float* lse, hipStream_t st) {
+int dispatch_attn(const void* qkv, void* out, int batch, int L, int H, float scale, const float* key_bias, float* lse, float dp, uint32_t ds,
+                  hipStream_t st) {
   const int nkt = (L + 31) / 32;
-  if (nkt <= 2) return launch_attn<T, 2>(qkv, out, batch, L, H, scale, key_bias, lse, st);
-  if (nkt <= 4) return launch_attn<T, 4>(qkv, out, batch, L, H, scale, key_bias, lse, st);
-  if (nkt <= 7) return launch_attn<T, 7>(qkv, out, batch, L, H, scale, key_bias, lse, st);
-  return launch_attn<T, 8>(qkv, out, batch, L, H, scale, key_bias, lse, st);
+  if (nkt <= 2) return launch_attn<T, 2>(qkv, out, batch, L, H, scale, key_bias, lse, dp, ds, st);
+  if (nkt <= 4) return launch_attn<T, 4>(qkv, out, batch, L, H, scale, key_bias, lse, dp, ds, st);
+  if (nkt <= 7) return launch_attn<T, 7>(qkv, out, batch, L, H, scale, key_bias, lse, dp, ds, st);
+  return launch_attn<T, 8>(qkv, out, batch, L, H, scale, key_bias, lse, dp, ds, st);
 }
 
 }  // namespace
@@ -323,11 +335,12 @@ int dispatch_attn(const void* qkv, void* out, int batch, int L, int H, float sca
 using namespace alpro;
 
 extern "C" int alpro_attn_fwd(const void* qkv, void* out, int dtype, int batch, int L, int H, float scale,
-                              const float* key_bias, float* lse, void* stream) {
+                              const float* key_bias, float* lse, float drop_p, uint32_t drop_seed, void* stream) {
   ALPRO_CHECK(qkv && out && batch > 0 && H > 0, "alpro_attn_fwd: bad args");
   ALPRO_CHECK(L > 0 && L <= 256, "alpro_attn_fwd: L=%d unsupported (1..256; the path needs 40, 197, 237)", L);
   ALPRO_CHECK(((uintptr_t)qkv % 16) == 0 && ((uintptr_t)out % 16) == 0, "alpro_attn_fwd: pointers must be 16-byte aligned");
-  ALPRO_DISPATCH_DTYPE(dtype, T, return dispatch_attn<T>(qkv, out, batch, L, H, scale, key_bias, lse, (hipStream_t)stream));
+  ALPRO_CHECK(!drop_seed || (drop_p > 0.f && drop_p < 1.f), "alpro_attn_fwd: dropout needs 0 < p < 1");
+  ALPRO_DISPATCH_DTYPE(dtype, T, return dispatch_attn<T>(qkv, out, batch, L, H, scale, key_bias, lse, drop_p, drop_seed, (hipStream_t)stream));
   return ALPRO_OK;
 }
 

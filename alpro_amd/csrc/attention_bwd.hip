@@ -101,7 +101,8 @@ __device__ __forceinline__ void stage_tile(char* tile, const T* src, int64_t ld,
 template <typename T, int NKT, int NW, bool GROUPED>
 __global__ __launch_bounds__(NW * 64) void attn_bwd_kernel(const T* __restrict__ qkv, const T* __restrict__ out, const T* __restrict__ dout,
                                                            const float* __restrict__ lse, T* __restrict__ dqkv, int L, int H, float scale,
-                                                           const float* __restrict__ key_bias, int Tn, int64_t total_rows) {
+                                                           const float* __restrict__ key_bias, int Tn, int64_t total_rows, float drop_p,
+                                                           uint32_t drop_seed) {
   typedef BCfg<T> C;
   constexpr int LP = NKT * 32;
   constexpr int NT = NW * 64;
@@ -121,6 +122,9 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_kernel(const T* __restrict__
   const T* dob = dout + row0 * ldo + h * HD;
   T* db = dqkv + row0 * ldq + h * HD;
   const float* lse_b = lse + ((int64_t)b * H + h) * L;
+  const uint32_t dth = drop_thresh24(drop_p);
+  const float dks = drop_seed ? 1.0f / (1.0f - drop_p) : 1.0f;
+  const uint64_t dbase = ((uint64_t)b * H + h) * (uint64_t)L;  // + q, then * L + key
   for (int c = tid; c < LP; c += NT) {
     Bs[c] = c < Le ? ((!GROUPED && key_bias) ? key_bias[(int64_t)b * L + c] : 0.f) : -INFINITY;
     Ls[c] = c < Le ? lse_b[c] : INFINITY;
@@ -180,7 +184,9 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_kernel(const T* __restrict__
             const int r = 4 * rq + e;
             float p = expf(s[r] * scale + bb[e] - lse_q);
             if (GROUPED && ((8 * rq + 4 * g + e) / Tn != ql / Tn)) p = 0.f;
-            s[r] = p * (dp[r] - delta) * scale;  // dS^T
+            float gd = dp[r];
+            if (!GROUPED && drop_seed) gd = drop_keep(drop_seed, (dbase + qc) * L + kt * 32 + 8 * rq + 4 * g + e, dth) ? gd * dks : 0.f;
+            s[r] = p * (gd - delta) * scale;  // dS^T
           }
         }
 #pragma unroll
@@ -241,8 +247,13 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_kernel(const T* __restrict__
           const int r = 4 * rq + e;
           float p = expf(s[r] * scale + kb - ll[e]);
           if (GROUPED && ((8 * rq + 4 * g + e) / Tn != ql / Tn)) p = 0.f;
-          s[r] = p;                                // P
-          dp[r] = p * (dp[r] - dd[e]) * scale;     // dS
+          float dm = 1.0f;
+          if (!GROUPED && drop_seed) {
+            const int qq = qt * 32 + 8 * rq + 4 * g + e;
+            dm = drop_keep(drop_seed, (dbase + (qq < Le ? qq : Le - 1)) * L + key, dth) ? dks : 0.f;
+          }
+          s[r] = p * dm;                                // dropped P (feeds dV)
+          dp[r] = p * (dm * dp[r] - dd[e]) * scale;     // dS
         }
       }
 #pragma unroll
@@ -270,7 +281,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_kernel(const T* __restrict__
 
 template <typename T, int NKT, int NW, bool GROUPED>
 int launch_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, int64_t nblocks_b, int L, int H, float scale,
-               const float* key_bias, int Tn, int64_t total_rows, hipStream_t st) {
+               const float* key_bias, int Tn, int64_t total_rows, float dp, uint32_t ds, hipStream_t st) {
   const size_t lds = 2 * (size_t)NKT * 32 * BCfg<T>::RB + 3 * (size_t)NKT * 32 * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
@@ -278,19 +289,19 @@ int launch_bwd(const void* qkv, const void* out, const void* dout, const float* 
     attr_set = true;
   }
   hipLaunchKernelGGL((attn_bwd_kernel<T, NKT, NW, GROUPED>), dim3((unsigned)(nblocks_b * H)), dim3(NW * 64), lds, st, (const T*)qkv, (const T*)out,
-                     (const T*)dout, lse, (T*)dqkv, L, H, scale, key_bias, Tn, total_rows);
+                     (const T*)dout, lse, (T*)dqkv, L, H, scale, key_bias, Tn, total_rows, dp, ds);
   return check_launch("alpro_attn_bwd");
 }
 
 template <typename T>
 int dispatch_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, int batch, int L, int H, float scale,
-                 const float* key_bias, hipStream_t st) {
+                 const float* key_bias, float dp, uint32_t ds, hipStream_t st) {
   const int nkt = (L + 31) / 32;
   const int64_t rows = (int64_t)batch * L;
-  if (nkt <= 2) return launch_bwd<T, 2, 4, false>(qkv, out, dout, lse, dqkv, batch, L, H, scale, key_bias, 0, rows, st);
-  if (nkt <= 4) return launch_bwd<T, 4, 4, false>(qkv, out, dout, lse, dqkv, batch, L, H, scale, key_bias, 0, rows, st);
-  if (nkt <= 7) return launch_bwd<T, 7, 4, false>(qkv, out, dout, lse, dqkv, batch, L, H, scale, key_bias, 0, rows, st);
-  return launch_bwd<T, 8, 4, false>(qkv, out, dout, lse, dqkv, batch, L, H, scale, key_bias, 0, rows, st);
+  if (nkt <= 2) return launch_bwd<T, 2, 4, false>(qkv, out, dout, lse, dqkv, batch, L, H, scale, key_bias, 0, rows, dp, ds, st);
+  if (nkt <= 4) return launch_bwd<T, 4, 4, false>(qkv, out, dout, lse, dqkv, batch, L, H, scale, key_bias, 0, rows, dp, ds, st);
+  if (nkt <= 7) return launch_bwd<T, 7, 4, false>(qkv, out, dout, lse, dqkv, batch, L, H, scale, key_bias, 0, rows, dp, ds, st);
+  return launch_bwd<T, 8, 4, false>(qkv, out, dout, lse, dqkv, batch, L, H, scale, key_bias, 0, rows, dp, ds, st);
 }
 
 }  // namespace
@@ -299,10 +310,10 @@ int dispatch_bwd(const void* qkv, const void* out, const void* dout, const float
 using namespace alpro;
 
 extern "C" int alpro_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, int dtype, int batch, int L,
-                              int H, float scale, const float* key_bias, void* stream) {
+                              int H, float scale, const float* key_bias, float drop_p, uint32_t drop_seed, void* stream) {
   ALPRO_CHECK(qkv && out && dout && lse && dqkv && batch > 0 && H > 0, "alpro_attn_bwd: bad args");
   ALPRO_CHECK(L > 0 && L <= 256, "alpro_attn_bwd: L=%d unsupported (1..256)", L);
-  ALPRO_DISPATCH_DTYPE(dtype, T, return dispatch_bwd<T>(qkv, out, dout, lse, dqkv, batch, L, H, scale, key_bias, (hipStream_t)stream));
+  ALPRO_DISPATCH_DTYPE(dtype, T, return dispatch_bwd<T>(qkv, out, dout, lse, dqkv, batch, L, H, scale, key_bias, drop_p, drop_seed, (hipStream_t)stream));
   return ALPRO_OK;
 }
 
@@ -311,6 +322,6 @@ extern "C" int alpro_attn_temporal_bwd(const void* qkv, const void* out, const v
   ALPRO_CHECK(qkv && out && dout && lse && dqkv && rows > 0 && H > 0, "alpro_attn_temporal_bwd: bad args");
   ALPRO_CHECK(T > 0 && 32 % T == 0 && rows % T == 0, "alpro_attn_temporal_bwd: num_frm=%d must divide 32 and rows", T);
   const int64_t chunks = (rows + 31) / 32;
-  ALPRO_DISPATCH_DTYPE(dtype, T_, return (launch_bwd<T_, 1, 1, true>(qkv, out, dout, lse, dqkv, chunks, 32, H, scale, nullptr, T, rows, (hipStream_t)stream)));
+  ALPRO_DISPATCH_DTYPE(dtype, T_, return (launch_bwd<T_, 1, 1, true>(qkv, out, dout, lse, dqkv, chunks, 32, H, scale, nullptr, T, rows, 0.f, 0u, (hipStream_t)stream)));
   return ALPRO_OK;
 }

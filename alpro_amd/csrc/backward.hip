@@ -82,7 +82,8 @@ template <typename T>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict__ dy, int64_t ld_dy, const float* __restrict__ dy2,
                                                             const float* __restrict__ x, int64_t ldx, const float* __restrict__ gamma, float eps,
                                                             float* __restrict__ dx, int64_t ld_dx, int accumulate, float* __restrict__ dgamma,
-                                                            float* __restrict__ dbeta, int64_t rows, int mode, int p0, int p1) {
+                                                            float* __restrict__ dbeta, int64_t rows, int mode, int p0, int p1, float drop_p,
+                                                            uint32_t drop_seed) {
   __shared__ float red[2][4][LN_D];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int64_t wave = (int64_t)blockIdx.x * 4 + w;
@@ -101,6 +102,15 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
       ld12(dy2 + m * LN_D, lane, d2);
 #pragma unroll
       for (int i = 0; i < 12; ++i) d[i] += d2[i];
+    }
+    if (drop_seed) {  // gradient through the dropout applied to this LayerNorm's output
+      const uint32_t th = drop_thresh24(drop_p);
+      const float ks = 1.0f / (1.0f - drop_p);
+#pragma unroll
+      for (int i = 0; i < 12; ++i) {
+        const uint64_t idx = (uint64_t)m * LN_D + (uint64_t)((i >> 2) * 256 + lane * 4 + (i & 3));
+        d[i] = drop_keep(drop_seed, idx, th) ? d[i] * ks : 0.f;
+      }
     }
     float s = 0.f;
 #pragma unroll
@@ -160,7 +170,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
 // row(m) follows the forward maps; under FRAME_TOKENS the j == 0 rows read the clip's CLS row times cls_scale (1/T).
 template <typename T>
 __global__ __launch_bounds__(256) void gather_cast_kernel(const float* __restrict__ src, int64_t ld, T* __restrict__ out, int64_t rows, int mode,
-                                                          int p0, int p1, const float* __restrict__ row_scale, int group, float cls_scale) {
+                                                          int p0, int p1, const float* __restrict__ row_scale, int group, float cls_scale,
+                                                          float drop_p, uint32_t drop_seed) {
   const int lane = threadIdx.x & 63;
   const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int64_t nwaves = (int64_t)gridDim.x * 4;
@@ -181,6 +192,15 @@ __global__ __launch_bounds__(256) void gather_cast_kernel(const float* __restric
     }
     float v[12];
     ld12(src + r * ld, lane, v);
+    if (drop_seed) {
+      const uint32_t th = drop_thresh24(drop_p);
+      const float ks = 1.0f / (1.0f - drop_p);
+#pragma unroll
+      for (int i = 0; i < 12; ++i) {
+        const uint64_t idx = (uint64_t)m * LN_D + (uint64_t)((i >> 2) * 256 + lane * 4 + (i & 3));
+        v[i] = drop_keep(drop_seed, idx, th) ? v[i] * ks : 0.f;
+      }
+    }
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
       T* p = out + m * LN_D + i * 256 + lane * 4;
@@ -278,22 +298,22 @@ extern "C" int alpro_transpose(const void* in, int in_dtype, int64_t ld_in, void
 
 extern "C" int alpro_layernorm_bwd(const void* dy, int dy_dtype, int64_t ld_dy, const float* dy2, const float* x, int64_t ldx,
                                    const float* gamma, float eps, float* dx, int64_t ld_dx, int accumulate, float* dgamma, float* dbeta,
-                                   int rows, int D, int map_mode, int map_p0, int map_p1, void* stream) {
+                                   int rows, int D, int map_mode, int map_p0, int map_p1, float drop_p, uint32_t drop_seed, void* stream) {
   ALPRO_CHECK(dy && x && gamma && dx && dgamma && dbeta && rows > 0, "alpro_layernorm_bwd: bad args");
   ALPRO_CHECK(D == LN_D, "alpro_layernorm_bwd: D=%d unsupported", D);
   ALPRO_CHECK(map_mode >= 0 && map_mode <= ALPRO_MAP_FRAME_TOKENS, "alpro_layernorm_bwd: bad map_mode %d", map_mode);
   ALPRO_CHECK(map_mode != ALPRO_MAP_FRAME_TOKENS || accumulate, "alpro_layernorm_bwd: the FRAME_TOKENS scatter needs accumulate=1 (CLS rows are shared)");
-  ALPRO_DISPATCH_DTYPE(dy_dtype, T, hipLaunchKernelGGL(layernorm_bwd_kernel<T>, dim3(grid_for(rows, 4 * 8, 256 * 8)), dim3(256), 0, (hipStream_t)stream, (const T*)dy, ld_dy, dy2, x, ldx, gamma, eps, dx, ld_dx, accumulate, dgamma, dbeta, (int64_t)rows, map_mode, map_p0, map_p1));
+  ALPRO_DISPATCH_DTYPE(dy_dtype, T, hipLaunchKernelGGL(layernorm_bwd_kernel<T>, dim3(grid_for(rows, 4 * 8, 256 * 8)), dim3(256), 0, (hipStream_t)stream, (const T*)dy, ld_dy, dy2, x, ldx, gamma, eps, dx, ld_dx, accumulate, dgamma, dbeta, (int64_t)rows, map_mode, map_p0, map_p1, drop_p, drop_seed));
   return check_launch("alpro_layernorm_bwd");
 }
 
 extern "C" int alpro_gather_cast(const float* src, int64_t ld, void* out, int dtype, int rows, int D, int map_mode, int map_p0, int map_p1,
-                                 const float* row_scale, int row_scale_group, float cls_scale, void* stream) {
+                                 const float* row_scale, int row_scale_group, float cls_scale, float drop_p, uint32_t drop_seed, void* stream) {
   ALPRO_CHECK(src && out && rows > 0, "alpro_gather_cast: bad args");
   ALPRO_CHECK(D == LN_D, "alpro_gather_cast: D=%d unsupported", D);
   ALPRO_CHECK(map_mode >= 0 && map_mode <= ALPRO_MAP_PATCH_EMBED, "alpro_gather_cast: bad map_mode %d", map_mode);
   ALPRO_CHECK(!row_scale || row_scale_group > 0, "alpro_gather_cast: row_scale_group must be > 0");
-  ALPRO_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL(gather_cast_kernel<T>, dim3(grid_for(rows, 4, 256 * 32)), dim3(256), 0, (hipStream_t)stream, src, ld, (T*)out, (int64_t)rows, map_mode, map_p0, map_p1, row_scale, row_scale_group, cls_scale));
+  ALPRO_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL(gather_cast_kernel<T>, dim3(grid_for(rows, 4, 256 * 32)), dim3(256), 0, (hipStream_t)stream, src, ld, (T*)out, (int64_t)rows, map_mode, map_p0, map_p1, row_scale, row_scale_group, cls_scale, drop_p, drop_seed));
   return check_launch("alpro_gather_cast");
 }
 

@@ -137,6 +137,18 @@ template <typename T> __device__ __forceinline__ float gelu_fast(float x) {
   else return 0.5f * x * (1.0f + erf_as(x * 0.70710678118654752440f));
 }
 
+// ---- counter-based dropout mask: a pure function of (seed, element index), so the backward regenerates it ------
+__device__ __forceinline__ uint32_t mix32(uint32_t h) {  // "lowbias32" finalizer
+  h ^= h >> 16; h *= 0x7FEB352Du; h ^= h >> 15; h *= 0x846CA68Bu; h ^= h >> 16;
+  return h;
+}
+// keep probability 1 - p: keep iff the top 24 hash bits >= thresh24 = round(p * 2^24)
+__device__ __forceinline__ bool drop_keep(uint32_t seed, uint64_t idx, uint32_t thresh24) {
+  const uint32_t h = mix32(seed ^ ((uint32_t)idx * 0x9E3779B1u) ^ ((uint32_t)(idx >> 32) * 0x85EBCA77u));
+  return (h >> 8) >= thresh24;
+}
+__host__ __device__ inline uint32_t drop_thresh24(float p) { return (uint32_t)(p * 16777216.0f + 0.5f); }
+
 // ---- host side -----------------------------------------------------------------------------
 void set_error(const char* fmt, ...);
 #define ALPRO_CHECK(cond, ...)            \

@@ -204,7 +204,7 @@ __global__ __launch_bounds__(256) void bert_embed_kernel(const int64_t* __restri
                                                          const float* __restrict__ pos, const float* __restrict__ type0,
                                                          const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
                                                          float* __restrict__ y32, T* __restrict__ y_t, float* __restrict__ mean_o,
-                                                         float* __restrict__ rstd_o, int rows, int L) {
+                                                         float* __restrict__ rstd_o, int rows, int L, float drop_p, uint32_t drop_seed) {
   const int lane = threadIdx.x & 63;
   const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (m >= rows) return;
@@ -219,6 +219,15 @@ __global__ __launch_bounds__(256) void bert_embed_kernel(const int64_t* __restri
   for (int i = 0; i < 12; ++i) v[i] += w[i];
   ln_stats(v, eps, mean, rstd);
   ln_affine(v, mean, rstd, gamma, beta, lane);
+  if (drop_seed) {
+    const uint32_t th = drop_thresh24(drop_p);
+    const float ks = 1.0f / (1.0f - drop_p);
+#pragma unroll
+    for (int i = 0; i < 12; ++i) {
+      const uint64_t idx = (uint64_t)m * LN_D + (uint64_t)((i >> 2) * 256 + lane * 4 + (i & 3));
+      v[i] = drop_keep(drop_seed, idx, th) ? v[i] * ks : 0.f;
+    }
+  }
   ln_store<float>(y32 + (int64_t)m * LN_D, lane, v);
   if (y_t) ln_store<T>(y_t + (int64_t)m * LN_D, lane, v);
   if (mean_o && lane == 0) {
@@ -288,9 +297,9 @@ extern "C" int alpro_vit_final_pool(const float* x, const float* gamma, const fl
 
 extern "C" int alpro_bert_embed_fwd(const int64_t* ids, const float* word, const float* pos, const float* type0,
                                     const float* gamma, const float* beta, float eps, float* y32, void* y_t, int dtype,
-                                    float* mean, float* rstd, int rows, int L, int D, void* stream) {
+                                    float* mean, float* rstd, int rows, int L, int D, float drop_p, uint32_t drop_seed, void* stream) {
   ALPRO_CHECK(ids && word && pos && type0 && gamma && beta && y32 && rows > 0 && L > 0, "alpro_bert_embed_fwd: bad args");
   ALPRO_CHECK(D == LN_D, "alpro_bert_embed_fwd: D=%d unsupported", D);
-  ALPRO_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL(bert_embed_kernel<T>, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, ids, word, pos, type0, gamma, beta, eps, y32, (T*)y_t, mean, rstd, rows, L));
+  ALPRO_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL(bert_embed_kernel<T>, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, ids, word, pos, type0, gamma, beta, eps, y32, (T*)y_t, mean, rstd, rows, L, drop_p, drop_seed));
   return check_launch("alpro_bert_embed_fwd");
 }

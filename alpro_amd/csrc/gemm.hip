@@ -126,7 +126,16 @@ __device__ __forceinline__ void epi_rows16(const alpro_gemm_desc_t& g, const flo
       }
     }
 #pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] = apply_act<T, ACT>(v[e]) * rs + res[e];
+    for (int e = 0; e < 4; ++e) v[e] = apply_act<T, ACT>(v[e]) * rs;
+    if (MAP == ALPRO_MAP_IDENTITY && g.drop_seed) {
+      const uint32_t th = drop_thresh24(g.drop_p);
+      const float ks = 1.0f / (1.0f - g.drop_p);
+      const uint64_t i0 = (uint64_t)(m_base + row) * (uint64_t)g.N + (uint64_t)n;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = drop_keep(g.drop_seed, i0 + e, th) ? v[e] * ks : 0.f;
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] += res[e];
     if (MAP == ALPRO_MAP_FRAME_TOKENS && side[p]) {
       float* dst = g.side + orow[p] * g.ld_side + n;
       if (FAST) *(float4*)dst = make_float4(v[0], v[1], v[2], v[3]);
@@ -168,6 +177,13 @@ __device__ __forceinline__ void epi_rows16_c16(const alpro_gemm_desc_t& g, const
     if (ACT != ALPRO_ACT_NONE && g.C2) *(u32x4*)((T*)g.C2 + m * g.ldc2 + n) = pack_chunk<T>(v);
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] = apply_act<T, ACT>(v[e]) * rs;
+    if (g.drop_seed) {
+      const uint32_t th = drop_thresh24(g.drop_p);
+      const float ks = 1.0f / (1.0f - g.drop_p);
+      const uint64_t i0 = (uint64_t)m * (uint64_t)g.N + (uint64_t)n;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = drop_keep(g.drop_seed, i0 + e, th) ? v[e] * ks : 0.f;
+    }
     if (g.residual) {
       const float4 r0 = *(const float4*)(g.residual + m * g.ldr + n), r1 = *(const float4*)(g.residual + m * g.ldr + n + 4);
       v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w; v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w;
@@ -561,6 +577,7 @@ extern "C" int alpro_gemm(const alpro_gemm_desc_t* d, void* stream) {
   ALPRO_CHECK(d->c_dtype == d->dtype || d->c_dtype == ALPRO_F32, "alpro_gemm: c_dtype must be dtype or F32");
   ALPRO_CHECK(d->map_mode >= 0 && d->map_mode <= 3, "alpro_gemm: bad map_mode %d", d->map_mode);
   ALPRO_CHECK(d->act >= 0 && d->act <= 2, "alpro_gemm: bad act %d", d->act);
+  ALPRO_CHECK(!d->drop_seed || (d->map_mode == ALPRO_MAP_IDENTITY && d->drop_p > 0.f && d->drop_p < 1.f), "alpro_gemm: dropout needs the identity map and 0 < p < 1");
   ALPRO_CHECK(!d->C2 || (d->N % 4 == 0 && d->ldc2 % 4 == 0 && d->ldc % 4 == 0), "alpro_gemm: C2 needs N, ldc, ldc2 multiples of 4");
   ALPRO_CHECK(d->map_mode != ALPRO_MAP_FRAME_TOKENS || d->side, "alpro_gemm: FRAME_TOKENS needs a side buffer");
   ALPRO_CHECK(!d->row_scale || d->row_scale_group > 0, "alpro_gemm: row_scale_group must be > 0");

@@ -34,7 +34,8 @@ class GemmDesc(ctypes.Structure):
                 ("residual", ctypes.c_void_p), ("ldr", ctypes.c_int64),
                 ("map_mode", ctypes.c_int), ("map_p0", ctypes.c_int), ("map_p1", ctypes.c_int),
                 ("side", ctypes.c_void_p), ("ld_side", ctypes.c_int64),
-                ("C2", ctypes.c_void_p), ("ldc2", ctypes.c_int64)]
+                ("C2", ctypes.c_void_p), ("ldc2", ctypes.c_int64),
+                ("drop_p", ctypes.c_float), ("drop_seed", ctypes.c_uint32)]
 
 
 _lib = None
@@ -56,25 +57,26 @@ def load():
     lib.alpro_gemm.argtypes = [ctypes.POINTER(GemmDesc), vp]
     lib.alpro_layernorm_fwd.argtypes = [vp, i64, vp, vp, f32, vp, i32, i64, vp, vp, vp, i32, i32, i32, i32, i32, vp]
     lib.alpro_attn_temporal_fwd.argtypes = [vp, vp, i32, i64, i32, i32, f32, vp, vp]
-    lib.alpro_attn_bwd.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, vp, vp]
+    u32 = ctypes.c_uint32
+    lib.alpro_attn_bwd.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, vp, f32, u32, vp]
     lib.alpro_attn_temporal_bwd.argtypes = [vp, vp, vp, vp, vp, i32, i64, i32, i32, f32, vp]
-    lib.alpro_layernorm_bwd.argtypes = [vp, i32, i64, vp, vp, i64, vp, f32, vp, i64, i32, vp, vp, i32, i32, i32, i32, i32, vp]
+    lib.alpro_layernorm_bwd.argtypes = [vp, i32, i64, vp, vp, i64, vp, f32, vp, i64, i32, vp, vp, i32, i32, i32, i32, i32, f32, u32, vp]
     lib.alpro_transpose.argtypes = [vp, i32, i64, vp, i32, i64, i32, i32, i32, vp, vp]
     lib.alpro_gelu_bwd.argtypes = [vp, vp, vp, i32, i64, vp]
     lib.alpro_sumsq.argtypes = [vp, i64, vp, vp]
     lib.alpro_gemm_tn_acc.argtypes = [vp, i64, vp, i64, vp, i64, i32, i32, i32, i32, vp]
     lib.alpro_colsum_acc.argtypes = [vp, i64, vp, i32, i32, i32, vp]
     lib.alpro_adamw_step.argtypes = [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, f32, vp, f32, f32, vp]
-    lib.alpro_gather_cast.argtypes = [vp, i64, vp, i32, i32, i32, i32, i32, i32, vp, i32, f32, vp]
+    lib.alpro_gather_cast.argtypes = [vp, i64, vp, i32, i32, i32, i32, i32, i32, vp, i32, f32, f32, u32, vp]
     lib.alpro_cls_mean_bwd.argtypes = [vp, i64, vp, i32, i32, i32, vp]
     lib.alpro_scatter_add_rows.argtypes = [vp, vp, vp, i32, i32, i32, vp]
-    lib.alpro_attn_fwd.argtypes = [vp, vp, i32, i32, i32, i32, f32, vp, vp, vp]
+    lib.alpro_attn_fwd.argtypes = [vp, vp, i32, i32, i32, i32, f32, vp, vp, f32, u32, vp]
     lib.alpro_patchify.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp]
     lib.alpro_cls_mean_residual.argtypes = [vp, i64, vp, vp, i64, i32, i32, i32, vp]
     lib.alpro_vit_final_pool.argtypes = [vp, vp, vp, f32, vp, vp, i32, i32, i32, i32, i32, vp]
-    lib.alpro_bert_embed_fwd.argtypes = [vp, vp, vp, vp, vp, vp, f32, vp, vp, i32, vp, vp, i32, i32, i32, vp]
+    lib.alpro_bert_embed_fwd.argtypes = [vp, vp, vp, vp, vp, vp, f32, vp, vp, i32, vp, vp, i32, i32, i32, f32, u32, vp]
     lib.alpro_cast_from_f32.argtypes = [vp, vp, i32, i64, vp]
-    if lib.alpro_hip_abi_version() != 2:
+    if lib.alpro_hip_abi_version() != 3:
         raise RuntimeError("libalpro_hip.so ABI version mismatch")
     _lib = lib
     return lib
@@ -113,7 +115,7 @@ def torch_dtype(code):
 
 # ------------------------------------------------------------------------------------------------
 def gemm(a, w, out=None, bias=None, act=ACT_NONE, out_dtype=None, alpha=1.0, row_scale=None, row_scale_group=1,
-         residual=None, map_mode=MAP_IDENTITY, map_p0=0, map_p1=0, side=None, out_rows=None, pre_act=None):
+         residual=None, map_mode=MAP_IDENTITY, map_p0=0, map_p1=0, side=None, out_rows=None, pre_act=None, drop_p=0.0, drop_seed=0):
     """out[map(m)] = residual[map(m)] + row_scale * act(alpha * a @ w.T + bias)   (see alpro_gemm)."""
     lib = load()
     _dev(a); _dev(w, a.dtype)
@@ -140,6 +142,7 @@ def gemm(a, w, out=None, bias=None, act=ACT_NONE, out_dtype=None, alpha=1.0, row
     d.ld_side = side.shape[-1] if side is not None else 0
     d.C2 = _dev(pre_act, a.dtype).data_ptr() if pre_act is not None else None
     d.ldc2 = pre_act.shape[-1] if pre_act is not None else 0
+    d.drop_p, d.drop_seed = drop_p, drop_seed
     _check(lib.alpro_gemm(ctypes.byref(d), _stream()), "alpro_gemm")
     return out
 
@@ -184,17 +187,18 @@ def attn_temporal_bwd(qkv, out, dout, lse, T, H, scale):
     return dqkv
 
 
-def attn_bwd(qkv, out, dout, lse, batch, L, H, scale, key_bias=None):
+def attn_bwd(qkv, out, dout, lse, batch, L, H, scale, key_bias=None, drop_p=0.0, drop_seed=0):
     lib = load()
     _dev(qkv); _dev(out, qkv.dtype); _dev(dout, qkv.dtype); _dev(lse, torch.float32)
     dqkv = torch.empty_like(qkv)
     kb = _dev(key_bias, torch.float32) if key_bias is not None else None
-    _check(lib.alpro_attn_bwd(_ptr(qkv), _ptr(out), _ptr(dout), _ptr(lse), _ptr(dqkv), _CODE[qkv.dtype], batch, L, H, scale, _ptr(kb), _stream()),
+    _check(lib.alpro_attn_bwd(_ptr(qkv), _ptr(out), _ptr(dout), _ptr(lse), _ptr(dqkv), _CODE[qkv.dtype], batch, L, H, scale, _ptr(kb), drop_p, drop_seed, _stream()),
            "alpro_attn_bwd")
     return dqkv
 
 
-def layernorm_bwd(dy, x, gamma, eps, dx, dgamma, dbeta, rows=None, dy2=None, accumulate=True, map_mode=MAP_IDENTITY, map_p0=0, map_p1=0):
+def layernorm_bwd(dy, x, gamma, eps, dx, dgamma, dbeta, rows=None, dy2=None, accumulate=True, map_mode=MAP_IDENTITY, map_p0=0, map_p1=0,
+                  drop_p=0.0, drop_seed=0):
     """dx[map(m)] (+)= dLN; dgamma/dbeta (fp32, pre-initialised) are accumulated.  x, dx: fp32 (..., 768)."""
     lib = load()
     _dev(dy); _dev(x, torch.float32); _dev(dx, torch.float32); _dev(dgamma, torch.float32); _dev(dbeta, torch.float32)
@@ -202,7 +206,7 @@ def layernorm_bwd(dy, x, gamma, eps, dx, dgamma, dbeta, rows=None, dy2=None, acc
     rows = rows if rows is not None else dy.numel() // D
     _check(lib.alpro_layernorm_bwd(_ptr(dy), _CODE[dy.dtype], D, _ptr(_dev(dy2, torch.float32)) if dy2 is not None else None, _ptr(x), D,
                                    _ptr(_dev(gamma, torch.float32)), eps, _ptr(dx), D, 1 if accumulate else 0, _ptr(dgamma), _ptr(dbeta), rows, D,
-                                   map_mode, map_p0, map_p1, _stream()), "alpro_layernorm_bwd")
+                                   map_mode, map_p0, map_p1, drop_p, drop_seed, _stream()), "alpro_layernorm_bwd")
     return dx
 
 
@@ -219,7 +223,8 @@ def transpose(x, out_dtype=None, pad_to=64, colsum=None):
     return out
 
 
-def gather_cast(src, dtype, rows=None, map_mode=MAP_IDENTITY, map_p0=0, map_p1=0, row_scale=None, row_scale_group=1, cls_scale=1.0):
+def gather_cast(src, dtype, rows=None, map_mode=MAP_IDENTITY, map_p0=0, map_p1=0, row_scale=None, row_scale_group=1, cls_scale=1.0,
+                drop_p=0.0, drop_seed=0):
     """fp32 (..., 768) token-gradient rows -> (rows, 768) GEMM operand in `dtype` (see alpro_gather_cast)."""
     lib = load()
     _dev(src, torch.float32)
@@ -227,7 +232,7 @@ def gather_cast(src, dtype, rows=None, map_mode=MAP_IDENTITY, map_p0=0, map_p1=0
     rows = rows if rows is not None else src.numel() // D
     out = torch.empty((rows, D), dtype=dtype, device=src.device)
     _check(lib.alpro_gather_cast(_ptr(src), D, _ptr(out), _CODE[dtype], rows, D, map_mode, map_p0, map_p1,
-                                 _ptr(_dev(row_scale, torch.float32)) if row_scale is not None else None, row_scale_group, cls_scale, _stream()),
+                                 _ptr(_dev(row_scale, torch.float32)) if row_scale is not None else None, row_scale_group, cls_scale, drop_p, drop_seed, _stream()),
            "alpro_gather_cast")
     return out
 
@@ -257,14 +262,14 @@ def scatter_add_rows(src, idx, dst, idx_mod=0):
     return dst
 
 
-def attn(qkv, batch, L, H, scale, key_bias=None, want_lse=False):
+def attn(qkv, batch, L, H, scale, key_bias=None, want_lse=False, drop_p=0.0, drop_seed=0):
     lib = load()
     _dev(qkv)
     assert qkv.shape[0] == batch * L
     out = torch.empty((batch * L, H * 64), dtype=qkv.dtype, device=qkv.device)
     lse = torch.empty((batch, H, L), dtype=torch.float32, device=qkv.device) if want_lse else None
     kb = _dev(key_bias, torch.float32) if key_bias is not None else None
-    _check(lib.alpro_attn_fwd(_ptr(qkv), _ptr(out), _CODE[qkv.dtype], batch, L, H, scale, _ptr(kb), _ptr(lse), _stream()), "alpro_attn_fwd")
+    _check(lib.alpro_attn_fwd(_ptr(qkv), _ptr(out), _CODE[qkv.dtype], batch, L, H, scale, _ptr(kb), _ptr(lse), drop_p, drop_seed, _stream()), "alpro_attn_fwd")
     return (out, lse) if want_lse else out
 
 
@@ -297,7 +302,7 @@ def vit_final_pool(x, gamma, beta, eps, B, T, N, dtype):
     return out32, (out_t if out_t is not None else out32)
 
 
-def bert_embed(ids, word, pos, type_emb, gamma, beta, eps, dtype, stats=False):
+def bert_embed(ids, word, pos, type_emb, gamma, beta, eps, dtype, stats=False, drop_p=0.0, drop_seed=0):
     lib = load()
     _dev(ids, torch.int64)
     B, L = ids.shape
@@ -309,7 +314,7 @@ def bert_embed(ids, word, pos, type_emb, gamma, beta, eps, dtype, stats=False):
     rstd = torch.empty(rows, dtype=torch.float32, device=ids.device) if stats else None
     _check(lib.alpro_bert_embed_fwd(_ptr(ids), _ptr(_dev(word, torch.float32)), _ptr(_dev(pos, torch.float32)), _ptr(_dev(type_emb, torch.float32)),
                                     _ptr(gamma), _ptr(beta), eps, _ptr(y32), _ptr(y_t), _CODE[dtype], _ptr(mean), _ptr(rstd), rows, L, D,
-                                    _stream()), "alpro_bert_embed_fwd")
+                                    drop_p, drop_seed, _stream()), "alpro_bert_embed_fwd")
     return y32, (y_t if y_t is not None else y32)
 
 

@@ -10,8 +10,9 @@ internals at run time (config is duck-typed: a transformers.BertConfig or any at
 Per layer (post-LN):  fused QKV GEMM (one (3H, H) operand built from query/key/value) ->
 alpro_attn with the additive (1-mask)*-10000 key bias -> dense GEMM with the residual add fused ->
 LayerNorm (fp32 + operand-dtype outputs) -> GELU GEMM -> dense GEMM + residual -> LayerNorm.
-Dropout (hidden_dropout_prob / attention_probs_dropout_prob) is an identity in eval mode; training
-with p > 0 is rejected loudly until the fused dropout lands.
+Dropout (xbert.py:212,331,358,436) is fused: hidden dropout in the dense GEMM epilogues / the embedding kernel,
+attention-probability dropout inside alpro_attn; the masks are a pure hash of (seed, element index) so the backward
+regenerates them instead of storing them.  Identity in eval mode.
 """
 import math
 from types import SimpleNamespace
@@ -98,32 +99,22 @@ class BertLayer(nn.Module):
         self.output = BertOutput(config)
         self._ops = OperandCache()
 
-    def _check_dropout(self):
-        if self.training and (self.config.hidden_dropout_prob > 0 or self.config.attention_probs_dropout_prob > 0):
-            raise RuntimeError("BertLayer in train() mode with dropout > 0 is not implemented on the HIP path yet; "
-                               "call .eval() or set hidden_dropout_prob = attention_probs_dropout_prob = 0")
+    def _drop(self):
+        """(hidden_p, hidden_seed_attn_out, hidden_seed_ffn_out, attn_p, attn_seed): zeros in eval mode."""
+        if not self.training:
+            return 0.0, 0, 0, 0.0, 0
+        hp, ap = float(self.config.hidden_dropout_prob), float(self.config.attention_probs_dropout_prob)
+        return (hp, rt.next_dropout_seed() if hp > 0 else 0, rt.next_dropout_seed() if hp > 0 else 0,
+                ap, rt.next_dropout_seed() if ap > 0 else 0)
 
     def forward(self, h32, h_t, key_bias, B, L):
         """h32 (B*L, H) fp32 residual stream, h_t the same in the operand dtype; returns the next pair."""
-        self._check_dropout()
-        dt = rt.compute_dtype()
-        sa, so = self.attention.self, self.attention.output
-        eps = self.config.layer_norm_eps
-        wqkv = self._ops.get("qkv_w", (sa.query.weight, sa.key.weight, sa.value.weight), dt)
-        bqkv = self._ops.get("qkv_b", (sa.query.bias, sa.key.bias, sa.value.bias), torch.float32)
-        qkv = hip.gemm(h_t, wqkv, bias=bqkv)
-        ctx = hip.attn(qkv, B, L, sa.num_attention_heads, 1.0 / math.sqrt(sa.attention_head_size), key_bias)
-        s1 = hip.gemm(ctx, self._ops.get("ao_w", so.dense.weight, dt), bias=so.dense.bias, out_dtype=torch.float32, residual=h32)
-        a_t, a32 = hip.layernorm(s1, so.LayerNorm.weight, so.LayerNorm.bias, eps, dt, out32=True)
-        it = hip.gemm(a_t, self._ops.get("i_w", self.intermediate.dense.weight, dt), bias=self.intermediate.dense.bias, act=hip.ACT_GELU)
-        s2 = hip.gemm(it, self._ops.get("o_w", self.output.dense.weight, dt), bias=self.output.dense.bias, out_dtype=torch.float32, residual=a32)
-        o_t, o32 = hip.layernorm(s2, self.output.LayerNorm.weight, self.output.LayerNorm.bias, eps, dt, out32=True)
+        o32, o_t, _ = self.forward_train(h32, h_t, key_bias, B, L, save=False)
         return o32, o_t
 
-
     # ---- training path ---------------------------------------------------------------------------------
-    def forward_train(self, h32, h_t, key_bias, B, L):
-        self._check_dropout()
+    def forward_train(self, h32, h_t, key_bias, B, L, save=True):
+        hp, seed1, seed2, ap, seed_a = self._drop()
         dt = rt.compute_dtype()
         sa, so = self.attention.self, self.attention.output
         eps = self.config.layer_norm_eps
@@ -132,14 +123,17 @@ class BertLayer(nn.Module):
         wqkv = self._ops.get("qkv_w", (sa.query.weight, sa.key.weight, sa.value.weight), dt)
         bqkv = self._ops.get("qkv_b", (sa.query.bias, sa.key.bias, sa.value.bias), torch.float32)
         qkv = hip.gemm(h_t, wqkv, bias=bqkv)
-        ctx, lse = hip.attn(qkv, B, L, H, scale, key_bias, want_lse=True)
-        s1 = hip.gemm(ctx, self._ops.get("ao_w", so.dense.weight, dt), bias=so.dense.bias, out_dtype=torch.float32, residual=h32)
+        ctx, lse = hip.attn(qkv, B, L, H, scale, key_bias, want_lse=True, drop_p=ap, drop_seed=seed_a)
+        s1 = hip.gemm(ctx, self._ops.get("ao_w", so.dense.weight, dt), bias=so.dense.bias, out_dtype=torch.float32, residual=h32,
+                      drop_p=hp, drop_seed=seed1)
         a_t, a32 = hip.layernorm(s1, so.LayerNorm.weight, so.LayerNorm.bias, eps, dt, out32=True)
-        u = torch.empty((h_t.shape[0], self.intermediate.dense.out_features), dtype=dt, device=h_t.device)
+        u = torch.empty((h_t.shape[0], self.intermediate.dense.out_features), dtype=dt, device=h_t.device) if save else None
         it = hip.gemm(a_t, self._ops.get("i_w", self.intermediate.dense.weight, dt), bias=self.intermediate.dense.bias, act=hip.ACT_GELU, pre_act=u)
-        s2 = hip.gemm(it, self._ops.get("o_w", self.output.dense.weight, dt), bias=self.output.dense.bias, out_dtype=torch.float32, residual=a32)
+        s2 = hip.gemm(it, self._ops.get("o_w", self.output.dense.weight, dt), bias=self.output.dense.bias, out_dtype=torch.float32, residual=a32,
+                      drop_p=hp, drop_seed=seed2)
         o_t, o32 = hip.layernorm(s2, self.output.LayerNorm.weight, self.output.LayerNorm.bias, eps, dt, out32=True)
-        sv = dict(h_t=h_t, qkv=qkv, ctx=ctx, lse=lse, s1=s1, a_t=a_t, u=u, it=it, s2=s2, kb=key_bias, dims=(B, L, H, scale), dt=dt)
+        sv = dict(h_t=h_t, qkv=qkv, ctx=ctx, lse=lse, s1=s1, a_t=a_t, u=u, it=it, s2=s2, kb=key_bias, dims=(B, L, H, scale), dt=dt,
+                  drop=(hp, seed1, seed2, ap, seed_a)) if save else None
         return o32, o_t, sv
 
     def backward(self, sv, do32, do_t):
@@ -160,17 +154,18 @@ class BertLayer(nn.Module):
             hip.layernorm_bwd(dy_t, x, ln.weight, eps, dx, g, b_, dy2=dy32, accumulate=False)
             return dx
 
+        hp, seed1, seed2, ap, seed_a = sv["drop"]
         ds2 = ln_bwd(self.output.LayerNorm, sv["s2"], do_t, do32)          # also d(a32): identity residual
-        ds2_t = hip.gather_cast(ds2, dt)
+        ds2_t = hip.gather_cast(ds2, dt, drop_p=hp, drop_seed=seed2)     # through the FFN-output dropout
         tr.wgrad(ds2_t, sv["it"], self.output.dense.weight, self.output.dense.bias)
         du = hip.gelu_bwd(tr.dgrad(ds2_t, tr.transposed_operand(self._ops, "o_w^T", self.output.dense.weight, dt)), sv["u"])
         tr.wgrad(du, sv["a_t"], self.intermediate.dense.weight, self.intermediate.dense.bias)
         da_t = tr.dgrad(du, tr.transposed_operand(self._ops, "i_w^T", self.intermediate.dense.weight, dt))
         ds1 = ln_bwd(so.LayerNorm, sv["s1"], da_t, ds2)                     # also d(h32): identity residual
-        ds1_t = hip.gather_cast(ds1, dt)
+        ds1_t = hip.gather_cast(ds1, dt, drop_p=hp, drop_seed=seed1)     # through the attention-output dropout
         tr.wgrad(ds1_t, sv["ctx"], so.dense.weight, so.dense.bias)
         dctx = tr.dgrad(ds1_t, tr.transposed_operand(self._ops, "ao_w^T", so.dense.weight, dt))
-        dqkv = hip.attn_bwd(sv["qkv"], sv["ctx"], dctx, sv["lse"], B, L, H, scale, sv["kb"])
+        dqkv = hip.attn_bwd(sv["qkv"], sv["ctx"], dctx, sv["lse"], B, L, H, scale, sv["kb"], drop_p=ap, drop_seed=seed_a)
         # fused q/k/v projection: the three weight gradients come from the three column blocks of dqkv
         Hd = sa.all_head_size
         for i, lin in enumerate((sa.query, sa.key, sa.value)):
@@ -272,10 +267,10 @@ class BertModel(BertPreTrainedModel):
         if encoder_embeds is None:
             B, L = input_ids.shape
             emb = self.embeddings
-            if emb.training and cfg.hidden_dropout_prob > 0:
-                raise RuntimeError("BertEmbeddings dropout in train() mode is not implemented on the HIP path yet")
+            ep = float(cfg.hidden_dropout_prob) if emb.training else 0.0
             h32, h_t = hip.bert_embed(input_ids.contiguous(), emb.word_embeddings.weight, emb.position_embeddings.weight,
-                                      emb.token_type_embeddings.weight, emb.LayerNorm.weight, emb.LayerNorm.bias, cfg.layer_norm_eps, dt)
+                                      emb.token_type_embeddings.weight, emb.LayerNorm.weight, emb.LayerNorm.bias, cfg.layer_norm_eps, dt,
+                                      drop_p=ep, drop_seed=rt.next_dropout_seed() if ep > 0 else 0)
         else:
             B, L, Hd = encoder_embeds.shape
             h32 = encoder_embeds.reshape(B * L, Hd).contiguous().float()
@@ -305,13 +300,14 @@ class _BertRun:
         emb = m.embeddings
         if encoder_embeds is None:
             B, L = self.ids.shape
-            if emb.training and cfg.hidden_dropout_prob > 0:
-                raise RuntimeError("BertEmbeddings dropout in train() mode is not implemented on the HIP path yet")
             self.ids = self.ids.contiguous()
             word = emb.word_embeddings.weight
+            ep = float(cfg.hidden_dropout_prob) if emb.training else 0.0
+            self.emb_drop = (ep, rt.next_dropout_seed() if ep > 0 else 0)
             # pre-LayerNorm sum is needed by the LN backward: recompute it there from the tables (cheap gather)
             h32, h_t = hip.bert_embed(self.ids, word, emb.position_embeddings.weight, emb.token_type_embeddings.weight,
-                                      emb.LayerNorm.weight, emb.LayerNorm.bias, cfg.layer_norm_eps, dt)
+                                      emb.LayerNorm.weight, emb.LayerNorm.bias, cfg.layer_norm_eps, dt,
+                                      drop_p=self.emb_drop[0], drop_seed=self.emb_drop[1])
         else:
             B, L, Hd = encoder_embeds.shape
             h32 = encoder_embeds.reshape(B * L, Hd).contiguous().float()
@@ -344,7 +340,8 @@ class _BertRun:
                + emb.position_embeddings.weight.detach()[:L].repeat(B, 1)).contiguous()
         de = torch.empty_like(pre)
         g, b_ = tr.grad_buffer(emb.LayerNorm.weight, zero=True)[0], tr.grad_buffer(emb.LayerNorm.bias, zero=True)[0]
-        hip.layernorm_bwd(d_t, pre, emb.LayerNorm.weight, cfg.layer_norm_eps, de, g, b_, dy2=d32, accumulate=False)
+        hip.layernorm_bwd(d_t, pre, emb.LayerNorm.weight, cfg.layer_norm_eps, de, g, b_, dy2=d32, accumulate=False,
+                          drop_p=self.emb_drop[0], drop_seed=self.emb_drop[1])
         gw = tr.grad_buffer(emb.word_embeddings.weight, zero=True)[0] if emb.word_embeddings.weight.grad is None else emb.word_embeddings.weight.grad
         hip.scatter_add_rows(de, self.ids.view(-1), gw)
         gp = tr.grad_buffer(emb.position_embeddings.weight, zero=True)[0] if emb.position_embeddings.weight.grad is None else emb.position_embeddings.weight.grad

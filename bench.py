@@ -145,7 +145,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="visual_fwd", choices=["visual_fwd", "pretrain_fwd", "pretrain_step"])
-    ap.add_argument("--bert-dropout", type=float, default=0.0, help="hidden/attention dropout of the BERT half in pretrain_step")
+    ap.add_argument("--bert-dropout", type=float, default=0.1, help="hidden/attention dropout of the BERT half in pretrain_step")
     ap.add_argument("--batch", type=int, default=None)
     ap.add_argument("--frames", type=int, default=8)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "fp32"])

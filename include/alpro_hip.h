@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define ALPRO_HIP_ABI_VERSION 2
+#define ALPRO_HIP_ABI_VERSION 3
 
 enum { ALPRO_OK = 0, ALPRO_ERR_INVALID = 1, ALPRO_ERR_LAUNCH = 2 };
 enum { ALPRO_F32 = 0, ALPRO_BF16 = 1, ALPRO_F16 = 2 };
@@ -75,6 +75,8 @@ typedef struct {
   int64_t ld_side;
   void* C2;               /* optional (M, N) `dtype` copy of the pre-activation alpha*acc+bias (kept for the GELU backward) */
   int64_t ldc2;
+  float drop_p;           /* dropout on the value BEFORE the residual add (xbert.py:358,436): keep iff hash(seed, m*N+n) */
+  uint32_t drop_seed;     /* passes, kept values scaled by 1/(1-p); 0 = off.  Identity map only. */
 } alpro_gemm_desc_t;
 
 int alpro_gemm(const alpro_gemm_desc_t* d, void* stream);
@@ -100,7 +102,8 @@ int alpro_attn_temporal_fwd(const void* qkv, void* out, int dtype, int64_t rows,
  * (1 - mask) * -10000 of xbert.py:936-937 (NULL = no mask).  K/V of one (sequence, head) stay
  * resident in LDS; QK^T and PV run on MFMA; softmax in fp32 registers.  lse (batch, H, L) optional. */
 int alpro_attn_fwd(const void* qkv, void* out, int dtype, int batch, int L, int H, float scale,
-                   const float* key_bias, float* lse, void* stream);
+                   const float* key_bias, float* lse, float drop_p, uint32_t drop_seed, void* stream);
+/* drop_p > 0: dropout on the attention probabilities (xbert.py:331), mask = hash(seed, ((b*H+h)*L+q)*L+key). */
 
 /* out[(b*T+t)*N + n, c*256 + i*16 + j] = img[b, t, c, ph*16 + i, pw*16 + j], n = ph*(W/16) + pw:
  * the im2col rows of the stride-16 Conv2d (vit.py:230-238), cast to `dtype`. */
@@ -118,7 +121,9 @@ int alpro_vit_final_pool(const float* x, const float* gamma, const float* beta, 
 /* BERT embeddings (xbert.py:186-213): word[ids] + type[0] + pos[l] -> LayerNorm -> y32 (+ y_t). */
 int alpro_bert_embed_fwd(const int64_t* ids, const float* word, const float* pos, const float* type0,
                          const float* gamma, const float* beta, float eps, float* y32, void* y_t, int dtype,
-                         float* mean, float* rstd, int rows, int L, int D, void* stream);
+                         float* mean, float* rstd, int rows, int L, int D, float drop_p, uint32_t drop_seed,
+                         void* stream);
+/* drop_p > 0: the embedding dropout of xbert.py:212 on the LayerNorm output, mask = hash(seed, m*D+n). */
 
 /* dst[i] = (dtype) src[i]: parameter / activation cast used when the storage dtype is 16-bit. */
 int alpro_cast_from_f32(const float* src, void* dst, int dtype, int64_t n, void* stream);
@@ -129,7 +134,8 @@ int alpro_cast_from_f32(const float* src, void* dst, int dtype, int64_t n, void*
 /* dQKV (rows, 3*H*64) from dO (rows, H*64), the saved qkv / out and the row log-sum-exp of the forward.
  * P is recomputed on MFMA; delta = rowsum(dO o O); see attention_bwd.hip. */
 int alpro_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, int dtype,
-                   int batch, int L, int H, float scale, const float* key_bias, void* stream);
+                   int batch, int L, int H, float scale, const float* key_bias, float drop_p, uint32_t drop_seed,
+                   void* stream);
 int alpro_attn_temporal_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, int dtype,
                             int64_t rows, int T, int H, float scale, void* stream);
 
@@ -138,7 +144,10 @@ int alpro_attn_temporal_bwd(const void* qkv, const void* out, const void* dout, 
  * row under FRAME_TOKENS) are accumulated atomically, so that map requires accumulate = 1. */
 int alpro_layernorm_bwd(const void* dy, int dy_dtype, int64_t ld_dy, const float* dy2, const float* x, int64_t ldx,
                         const float* gamma, float eps, float* dx, int64_t ld_dx, int accumulate, float* dgamma,
-                        float* dbeta, int rows, int D, int map_mode, int map_p0, int map_p1, void* stream);
+                        float* dbeta, int rows, int D, int map_mode, int map_p0, int map_p1, float drop_p,
+                        uint32_t drop_seed, void* stream);
+/* drop_p > 0: the incoming gradient dy (+dy2) is first multiplied by the dropout mask hash(seed, m*D+n)/(1-p) that the
+ * forward applied to this LayerNorm's OUTPUT (embedding dropout). */
 
 /* out[c, r] = in[r, c] (r < R), 0 for R <= r < Rpad: puts the token dimension last so that dgrad / wgrad run on
  * the NT GEMM (dX = dY (W^T)^T, dW = dY^T (X^T)^T).  `in` is fp32 or out_dtype.  colsum (C) fp32, optional:
@@ -150,7 +159,9 @@ int alpro_transpose(const void* in, int in_dtype, int64_t ld_in, void* out, int 
  * the operand rows of the backward GEMMs (inverse of the forward scatter maps, drop-path scale re-applied).  Under
  * FRAME_TOKENS the j == 0 rows read the clip's CLS row times cls_scale (= 1/T, the frame mean of vit.py:187). */
 int alpro_gather_cast(const float* src, int64_t ld, void* out, int dtype, int rows, int D, int map_mode, int map_p0,
-                      int map_p1, const float* row_scale, int row_scale_group, float cls_scale, void* stream);
+                      int map_p1, const float* row_scale, int row_scale_group, float cls_scale, float drop_p,
+                      uint32_t drop_seed, void* stream);
+/* drop_p > 0: additionally re-applies the GEMM-epilogue dropout mask hash(seed, m*D+n)/(1-p) (backward of alpro_gemm's drop_p). */
 
 /* du = dh * gelu'(u) with the erf GELU (vit.py:61 / xbert.py:423 backward). */
 int alpro_gelu_bwd(const void* dh, const void* u, void* du, int dtype, int64_t n, void* stream);

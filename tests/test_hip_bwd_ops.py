@@ -197,3 +197,72 @@ def test_gemm_tn_acc(dt, M, N, K):
     cs = torch.ones(ldn).cuda()
     hip.colsum_acc(a.to(dt).cuda(), cs)
     close(cs[:N], 1 + a[:, :N].to(dt).double().sum(0), 1e-5, 1e-3, "colsum_acc")
+
+
+def _keep_mask(seed, n, p):
+    """numpy restatement of common.hpp::drop_keep for indices 0..n-1."""
+    import numpy as np
+    idx = np.arange(n, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        h = (np.uint32(seed) ^ (idx.astype(np.uint32) * np.uint32(0x9E3779B1)) ^ ((idx >> np.uint64(32)).astype(np.uint32) * np.uint32(0x85EBCA77))).astype(np.uint32)
+        h ^= h >> np.uint32(16); h *= np.uint32(0x7FEB352D); h ^= h >> np.uint32(15); h *= np.uint32(0x846CA68B); h ^= h >> np.uint32(16)
+    return torch.from_numpy(((h >> np.uint32(8)) >= np.uint32(int(p * 16777216.0 + 0.5))).astype("float32"))
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_dropout_gemm_and_backward_mask(dt):
+    """Fused hidden dropout (xbert.py:358,436): GEMM epilogue mask == gather_cast mask == the hash restated in numpy."""
+    hip = _hip()
+    M, N, K, p, seed = 520, 768, 768, 0.1, 12345
+    a, w, b, r = rnd(M, K, seed=130), rnd(N, K, seed=131, scale=0.05), rnd(N, seed=132), rnd(M, N, seed=133)
+    keep = _keep_mask(seed, M * N, p).view(M, N)
+    assert 0.88 < float(keep.mean()) < 0.92
+    out = hip.gemm(a.to(dt).cuda(), w.to(dt).cuda(), bias=b.cuda(), out_dtype=torch.float32, residual=r.cuda(), drop_p=p, drop_seed=seed)
+    ref = r.double() + keep.double() / (1 - p) * (a.to(dt).double() @ w.to(dt).double().T + b.double())
+    close(out, ref, 2e-5, 3e-4, "dropout gemm f32 out")
+    if dt != torch.float32:
+        out16 = hip.gemm(a.to(dt).cuda(), w.to(dt).cuda(), bias=b.cuda(), drop_p=p, drop_seed=seed)
+        close(out16, keep.double() / (1 - p) * (a.to(dt).double() @ w.to(dt).double().T + b.double()), 1e-2, 1e-2, "dropout gemm 16-bit out")
+    g = rnd(M, N, seed=134)
+    gc = hip.gather_cast(g.cuda(), torch.float32, drop_p=p, drop_seed=seed)
+    close(gc, g.double() * keep.double() / (1 - p), 1e-6, 1e-6, "gather_cast dropout mask")
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_attention_dropout_fwd_bwd(dt):
+    """Attention-probability dropout (xbert.py:331) forward and backward against autograd with the same mask."""
+    hip = _hip()
+    batch, L, H, p, seed = 2, 70, 12, 0.1, 777
+    qkv = (rnd(batch * L, 3 * H * 64, seed=140) * 0.7).to(dt)
+    dout = rnd(batch * L, H * 64, seed=141).to(dt)
+    keep = _keep_mask(seed, batch * H * L * L, p).view(batch, H, L, L).double()
+    q64 = qkv.double().requires_grad_(True)
+    t = q64.view(batch, L, 3, H, 64).permute(2, 0, 3, 1, 4)
+    pr = ((t[0] @ t[1].transpose(-1, -2)) * 0.125).softmax(-1) * keep / (1 - p)
+    ref = (pr @ t[2]).transpose(1, 2).reshape(batch * L, H * 64)
+    ref.backward(dout.double())
+    out, lse = hip.attn(qkv.cuda(), batch, L, H, 0.125, want_lse=True, drop_p=p, drop_seed=seed)
+    tol = (2e-5, 2e-5) if dt == torch.float32 else (2e-2, 2e-2)
+    close(out, ref, *tol, "attn dropout fwd")
+    dqkv = hip.attn_bwd(qkv.cuda(), out, dout.cuda(), lse, batch, L, H, 0.125, drop_p=p, drop_seed=seed)
+    close(dqkv, q64.grad, *GRAD_TOL[dt], "attn dropout bwd")
+
+
+def test_embedding_dropout_and_ln_bwd_mask():
+    hip = _hip()
+    D, p, seed = 768, 0.1, 999
+    ids = torch.randint(0, 300, (3, 40))
+    word, pos, typ = rnd(300, D, seed=150), rnd(64, D, seed=151), rnd(2, D, seed=152)
+    g, b = 1 + 0.1 * rnd(D, seed=153), 0.1 * rnd(D, seed=154)
+    keep = _keep_mask(seed, 120 * D, p).view(120, D).double()
+    y32, _ = hip.bert_embed(ids.cuda(), word.cuda(), pos.cuda(), typ.cuda(), g.cuda(), b.cuda(), 1e-12, torch.float32, drop_p=p, drop_seed=seed)
+    e = (word[ids].double() + typ[0].double() + pos[:40].double()).view(120, D)
+    e64 = e.clone().requires_grad_(True)
+    ref = torch.nn.functional.layer_norm(e64, (D,), g.double(), b.double(), 1e-12) * keep / (1 - p)
+    close(y32, ref, 1e-5, 1e-5, "embedding dropout")
+    dy = rnd(120, D, seed=155)
+    (ref * dy.double()).sum().backward()
+    dx = torch.empty(120, D).cuda()
+    hip.layernorm_bwd(dy.cuda(), e.float().cuda(), g.cuda(), 1e-12, dx, torch.zeros(D).cuda(), torch.zeros(D).cuda(), accumulate=False,
+                      drop_p=p, drop_seed=seed)
+    close(dx, e64.grad, 1e-4, 2e-4, "ln bwd through dropout")
