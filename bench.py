@@ -1,6 +1,9 @@
 """Benchmark of the ALPRO hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W [--workload visual_fwd|pretrain_fwd] [--batch B] [--dtype bf16]
+    python bench.py --gpus N --steps K --warmup W [--workload pretrain_step|visual_fwd|pretrain_fwd] [--batch B] [--dtype bf16]
+
+Default workload: pretrain_step -- the configuration BASELINE.json's metric ("video-text pairs/sec at 1/2/4/8 MI355X") is
+quoted on (configs[2] on one GPU, configs[3] under DP); visual_fwd is configs[1] (encoder-only isolation run).
 
 N > 1 is launched by the driver as `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`
 (one rank per GPU over RCCL).  Rank 0 prints ONE JSON line.  A "step" is one pass of the hot path over one
@@ -119,13 +122,52 @@ class KernelTimer:
         return {n: {"launches": c, "flops": f, "ms": ms} for n, (c, f, ms) in agg.items()}
 
 
+def cpu_baseline_train(T):
+    """The oracle's full pretraining step (VTC+VTM+MLM+MPM forward + autograd backward, fp32) on the host cores: ONE step
+    of B=2 pairs after a warm-up forward -- a bounded sample (~20-40 s of CPU work)."""
+    from oracle import alpro_oracle as ao
+    from oracle.det_init import det_batch
+    threads = min(os.cpu_count() or 1, 32)
+    torch.set_num_threads(threads)
+    spec = ao.alpro_state_spec("pretrain", BERT_CFG, T)
+    skip = ("prompter.text_encoder.", "prompter.itm_head", "prompter.text_proj", "visual_encoder.model.head", "prompter.visual_encoder.model.head")
+    g = torch.Generator().manual_seed(0)
+    p = {}
+    for k, s in spec.items():
+        if k.startswith(skip) or "decoder" in k:
+            continue
+        if k.endswith("position_ids"):
+            p[k] = torch.arange(s[1]).view(1, -1)
+        elif k.endswith(("norm1.weight", "norm2.weight", "norm.weight", "LayerNorm.weight")):
+            p[k] = torch.ones(*s)
+        elif k.endswith("temp"):
+            p[k] = torch.tensor(0.07)
+        else:
+            p[k] = torch.randn(*s, generator=g) * 0.02
+    for k, v in p.items():
+        if v.is_floating_point() and not k.startswith("prompter."):
+            v.requires_grad_(True)
+    orc = ao.AlproOracle(p, BERT_CFG, T)
+    Bc = 2
+    batch = det_batch(Bc, T, seed_name="cpu_baseline")
+    with torch.no_grad():
+        orc.visual_embeds(batch["visual_inputs"][:1])  # warm-up (thread pool, allocator)
+    t0 = time.time()
+    out = orc.forward_pretrain(batch)
+    (out["mlm_loss"] + out["itm_loss"] + out["itc_loss"] + out["mpm_loss"]).backward()
+    dt = time.time() - t0
+    return {"value": Bc / dt, "unit": "pairs/s", "cores": threads, "kind": "port",
+            "sample": "oracle AlproForPretrain fwd+bwd (no optimizer), 1 step of %d pairs x %df x 224^2 + 40 tok, fp32, torch %d threads, %.1f s" % (Bc, T, threads, dt)}
+
+
 def cpu_baseline(T, seconds_budget=25.0):
     """The oracle (CPU restatement of the reference, fp32) timed on this box's host cores: visual encoder forward."""
     from oracle import alpro_oracle as ao
     spec = ao.alpro_state_spec("retrieval", BERT_CFG, T)
     g = torch.Generator().manual_seed(0)
     p = {k: torch.randn(*s, generator=g) * 0.02 for k, s in spec.items() if k.startswith("visual_encoder") and "head" not in k}
-    threads = torch.get_num_threads()
+    threads = min(os.cpu_count() or 1, 32)
+    torch.set_num_threads(threads)
     Bc = 2
     x = torch.randn(Bc, 3, T, 224, 224, generator=g)
     with torch.no_grad():
@@ -144,7 +186,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="visual_fwd", choices=["visual_fwd", "pretrain_fwd", "pretrain_step"])
+    ap.add_argument("--workload", default="pretrain_step", choices=["visual_fwd", "pretrain_fwd", "pretrain_step"])
     ap.add_argument("--bert-dropout", type=float, default=0.1, help="hidden/attention dropout of the BERT half in pretrain_step")
     ap.add_argument("--batch", type=int, default=None)
     ap.add_argument("--frames", type=int, default=8)
@@ -240,6 +282,16 @@ def main():
             for k_ in ("launches", "flops", "ms"):
                 gemm[k_] += ks["gemm_tn_acc"][k_]
         ach = gemm["flops"] / (gemm["ms"] * 1e-3) / 1e12
+        traffic, traffic_src = None, None
+        prof = os.path.join(ROOT, "profiles", "r1_pretrain_step_B64_pmc_traffic.json")
+        if train and B == 64 and T == 8 and args.dtype == "bf16" and os.path.exists(prof):
+            # HBM bytes per GEMM launch from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command
+            # (tools/pmc_summary.py; FETCH_SIZE doubled per MI355X_MICROARCH.md): launch-weighted mean over the GEMM kernels
+            pm = json.load(open(prof))
+            gk = {k: v for k, v in pm.items() if k.startswith("gemm_")}
+            n = sum(v["launches"] for v in gk.values())
+            traffic = round(sum(v["launches"] * (v["read_bytes_corrected_per_launch"] + v["write_bytes_per_launch"]) for v in gk.values()) / n)
+            traffic_src = "profiles/r1_pretrain_step_B64_pmc_traffic.json"
         peak = MFMA_PEAK_TFLOPS[args.dtype]
         result = {
             "metric": "video-text pairs/sec (8f x 224^2, 40-tok)", "value": round(value, 3), "unit": unit, "n_gpus": world,
@@ -250,11 +302,12 @@ def main():
             "roofline": {"bound": "mfma", "kernel": "gemm_nt*/gemm_tn kernels<%s> (all %d GEMM launches of one step)" % (args.dtype, gemm["launches"]),
                          "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                          "avg_launch_ms": round(gemm["ms"] / gemm["launches"], 4),
-                         "gflop_per_launch": round(gemm["flops"] / gemm["launches"] / 1e9, 2), "traffic": None},
+                         "gflop_per_launch": round(gemm["flops"] / gemm["launches"] / 1e9, 2), "traffic": traffic,
+                         "traffic_unit": "HBM bytes per GEMM launch (PMC)", "traffic_source": traffic_src},
             "kernel_ms_per_step": {k: round(v["ms"], 3) for k, v in ks.items()},
         }
         if not args.no_cpu_baseline:
-            result["cpu_baseline"] = cpu_baseline(T)
+            result["cpu_baseline"] = cpu_baseline_train(T) if train else cpu_baseline(T)
         print(json.dumps(result))
     dist.barrier()
     return result
