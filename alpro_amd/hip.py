@@ -21,7 +21,7 @@ _CODE = {v: k for k, v in _TORCH_DTYPE.items()}
 EXPORTS = ["alpro_hip_last_error", "alpro_hip_abi_version", "alpro_gemm", "alpro_layernorm_fwd",
            "alpro_attn_temporal_fwd", "alpro_attn_fwd", "alpro_patchify", "alpro_cls_mean_residual",
            "alpro_vit_final_pool", "alpro_bert_embed_fwd", "alpro_cast_from_f32", "alpro_attn_bwd", "alpro_attn_temporal_bwd",
-           "alpro_layernorm_bwd", "alpro_transpose", "alpro_gelu_bwd", "alpro_cls_mean_bwd", "alpro_scatter_add_rows", "alpro_gather_cast", "alpro_sumsq", "alpro_adamw_step", "alpro_gemm_tn_acc", "alpro_colsum_acc"]
+           "alpro_layernorm_bwd", "alpro_transpose", "alpro_gelu_bwd", "alpro_cls_mean_bwd", "alpro_scatter_add_rows", "alpro_gather_cast", "alpro_sumsq", "alpro_adamw_step", "alpro_gemm_tn_acc", "alpro_colsum_acc", "alpro_softmax_xent"]
 
 
 class GemmDesc(ctypes.Structure):
@@ -64,6 +64,7 @@ def load():
     lib.alpro_transpose.argtypes = [vp, i32, i64, vp, i32, i64, i32, i32, i32, vp, vp]
     lib.alpro_gelu_bwd.argtypes = [vp, vp, vp, i32, i64, vp]
     lib.alpro_sumsq.argtypes = [vp, i64, vp, vp]
+    lib.alpro_softmax_xent.argtypes = [vp, i64, vp, i32, vp, vp, i32, i64, vp, i32, i32, i32, vp]
     lib.alpro_gemm_tn_acc.argtypes = [vp, i64, vp, i64, vp, i64, i32, i32, i32, i32, vp]
     lib.alpro_colsum_acc.argtypes = [vp, i64, vp, i32, i32, i32, vp]
     lib.alpro_adamw_step.argtypes = [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, f32, vp, f32, f32, vp]
@@ -360,3 +361,19 @@ def colsum_acc(a, out):
     _dev(a); _dev(out, torch.float32)
     _check(lib.alpro_colsum_acc(_ptr(a), a.stride(0), _ptr(out), _CODE[a.dtype], a.shape[0], a.shape[1], _stream()), "alpro_colsum_acc")
     return out
+
+
+def softmax_xent(logits, labels, grad_dtype=None, grad_scale=None, ignore_index=-100, pad_to=64):
+    """logits (M, V) fp32, labels (M,) int64 -> loss_rows (M,) [, dlogits (M, Vpad) in grad_dtype scaled by *grad_scale]."""
+    lib = load()
+    _dev(logits, torch.float32); _dev(labels, torch.int64)
+    M, V = logits.shape
+    loss_rows = torch.empty(M, dtype=torch.float32, device=logits.device)
+    dl, Vp = None, (V + pad_to - 1) // pad_to * pad_to
+    if grad_dtype is not None:
+        dl = torch.empty((M, Vp), dtype=grad_dtype, device=logits.device)
+        _dev(grad_scale, torch.float32)
+    _check(lib.alpro_softmax_xent(_ptr(logits), logits.stride(0), _ptr(labels), ignore_index, _ptr(loss_rows), _ptr(dl),
+                                  _CODE[grad_dtype] if grad_dtype is not None else 0, Vp, _ptr(grad_scale), M, V, Vp, _stream()),
+           "alpro_softmax_xent")
+    return (loss_rows, dl) if dl is not None else loss_rows

@@ -199,8 +199,7 @@ class AlproForPretrain(AlproBaseModel):
         text_embeds = self._text_embeds(input_ids, text_input_mask)
         out = self._fusion(torch.cat([text_embeds, video_embeds], dim=1), torch.cat([text_input_mask, video_atts], dim=1))
         txt_len = text_input_mask.shape[1]
-        mlm_logits = self.text_encoder.cls(out[:, :txt_len])
-        mlm_loss = F.cross_entropy(mlm_logits.view(-1, self.bert_config.vocab_size), mlm_labels.view(-1))
+        mlm_logits, mlm_loss = self.text_encoder.cls.predictions.forward_with_loss(out[:, :txt_len], mlm_labels)
         return mlm_loss, mlm_logits, mlm_labels
 
     def compute_mpm_with_encoder_out(self, encoder_outputs, text_atts, soft_labels, ignore_masks, patch_masks):

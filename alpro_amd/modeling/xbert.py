@@ -381,12 +381,26 @@ class BertLMPredictionHead(nn.Module):
         logits = hip.gemm(n, self._ops.get("dec_w", self.decoder.weight, dt), bias=self.bias, out_dtype=torch.float32)
         return logits.view(*shp[:-1], -1)
 
+    def forward_with_loss(self, hidden_states, labels, ignore_index=-100):
+        """(logits, mean cross-entropy over labels != ignore_index): BertLMPredictionHead + CrossEntropyLoss of
+        alpro_models.py:368-371 as ONE autograd node -- alpro_softmax_xent writes (softmax - onehot)/n straight in the
+        operand dtype, so the (B*Lt, vocab) fp32 gradient is never materialised.  NaN when no label is valid, like the
+        reference."""
+        run = _LMHeadRun(self, labels.reshape(-1).contiguous(), ignore_index)
+        need = torch.is_grad_enabled() and (hidden_states.requires_grad or any(p.requires_grad for p in self.parameters()))
+        if need:
+            logits, loss = tr.run_anchored(run, [hidden_states], list(self.parameters()))
+        else:
+            with torch.no_grad():
+                logits, loss = run.forward(hidden_states)
+        return logits, loss
+
 
 class _LMHeadRun:
     """Forward/backward of BertLMPredictionHead for tr.Anchor; the decoder weight is the word-embedding table."""
 
-    def __init__(self, head):
-        self.h = head
+    def __init__(self, head, labels=None, ignore_index=-100):
+        self.h, self.labels, self.ignore = head, labels, ignore_index
 
     def forward(self, hidden):
         hd, dt = self.h, rt.compute_dtype()
@@ -398,15 +412,31 @@ class _LMHeadRun:
         n = hip.layernorm(g, t.LayerNorm.weight, t.LayerNorm.bias, hd.config.layer_norm_eps, dt)
         logits = hip.gemm(n, hd._ops.get("dec_w", hd.decoder.weight, dt), bias=hd.bias, out_dtype=torch.float32)
         self.x, self.u, self.g, self.n, self.dt = x, u, g, n, dt
-        return logits.view(*self.shape[:-1], -1)
+        if self.labels is None:
+            return logits.view(*self.shape[:-1], -1)
+        inv_n = (1.0 / (self.labels != self.ignore).sum().to(torch.float32)).reshape(1)
+        want_grad = any(p.requires_grad for p in hd.parameters())
+        if want_grad:
+            loss_rows, self.dl = hip.softmax_xent(logits, self.labels, grad_dtype=dt, grad_scale=inv_n, ignore_index=self.ignore)
+        else:
+            loss_rows, self.dl = hip.softmax_xent(logits, self.labels, ignore_index=self.ignore), None
+        return logits.view(*self.shape[:-1], -1), (loss_rows.sum() * inv_n).reshape(())
 
-    def backward(self, dlogits):
+    def backward(self, dlogits, dloss=None):
         hd, dt = self.h, self.dt
         t = hd.transform
-        M, V = self.x.shape[0], dlogits.shape[-1]
+        M, V = self.x.shape[0], hd.decoder.weight.shape[0]
         Vp = (V + 63) // 64 * 64
-        dl = torch.zeros((M, Vp), dtype=dt, device=dlogits.device)
-        dl[:, :V] = dlogits.reshape(M, V)
+        if self.labels is not None:
+            dl = self.dl                       # (softmax - onehot) / n_valid, already in the operand dtype
+            if dloss is not None:
+                dl = dl * dloss.to(dl.dtype)   # upstream scale of the loss (1 in the reference's sum of losses)
+            if dlogits is not None:            # someone also differentiated through mlm_scores
+                dl = dl.clone()
+                dl[:, :V] += dlogits.reshape(M, V).to(dt)
+        else:
+            dl = torch.zeros((M, Vp), dtype=dt, device=dlogits.device)
+            dl[:, :V] = dlogits.reshape(M, V)
         dn = tr.dgrad(dl, tr.transposed_operand(hd._ops, "dec_w^T", hd.decoder.weight, dt))
         # decoder weight is the (tied) word-embedding table: dW (V, H) += dl^T n ; bias += colsum(dl)
         gw = tr.grad_buffer(hd.decoder.weight, zero=True)[0]

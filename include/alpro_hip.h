@@ -181,6 +181,14 @@ int alpro_gemm_tn_acc(const void* A, int64_t lda, const void* B, int64_t ldb, fl
 /* out[n] (fp32) += sum_m A[m, n]: bias gradients. */
 int alpro_colsum_acc(const void* A, int64_t lda, float* out, int dtype, int M, int N, void* stream);
 
+/* Masked-LM cross entropy (alpro_models.py:368-371: CrossEntropyLoss over (B*Lt, vocab), ignore_index -100):
+ * loss_rows[m] = logsumexp(logits[m]) - logits[m, label] (0 for ignored rows) and, if dlogits != NULL,
+ * dlogits[m, :Vpad] = (softmax - onehot) * *grad_scale in `dtype` (zero for ignored rows and for columns >= V), i.e.
+ * already the operand of the decoder's backward GEMMs.  *grad_scale is a device scalar (1 / #valid rows). */
+int alpro_softmax_xent(const float* logits, int64_t ld, const int64_t* labels, int ignore_index, float* loss_rows,
+                       void* dlogits, int dtype, int64_t ldd, const float* grad_scale, int M, int V, int Vpad,
+                       void* stream);
+
 /* ---- step epilogue on flat fp32 buffers (run_pretrain_sparse.py:633-648, src/optimization/adamw.py:40-103) ---- */
 
 /* *out += sum(x[i]^2): global gradient norm for clip_grad_norm_. */

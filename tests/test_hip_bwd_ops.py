@@ -266,3 +266,22 @@ def test_embedding_dropout_and_ln_bwd_mask():
     hip.layernorm_bwd(dy.cuda(), e.float().cuda(), g.cuda(), 1e-12, dx, torch.zeros(D).cuda(), torch.zeros(D).cuda(), accumulate=False,
                       drop_p=p, drop_seed=seed)
     close(dx, e64.grad, 1e-4, 2e-4, "ln bwd through dropout")
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_softmax_xent(dt):
+    hip = _hip()
+    M, V = 83, 30522
+    logits = rnd(M, V, seed=160) * 2
+    labels = torch.randint(0, V, (M,))
+    labels[::3] = -100
+    l64 = logits.double().requires_grad_(True)
+    ref = torch.nn.functional.cross_entropy(l64, labels, reduction="none", ignore_index=-100)
+    n = (labels != -100).sum()
+    (ref.sum() / n).backward()
+    inv_n = (1.0 / n.float()).reshape(1).cuda()
+    loss_rows, dl = hip.softmax_xent(logits.cuda(), labels.cuda(), grad_dtype=dt, grad_scale=inv_n)
+    close(loss_rows, ref.detach(), 1e-5, 1e-5, "xent rows")
+    assert dl.shape == (M, 30528) and float(dl[:, V:].abs().sum()) == 0
+    tol = (1e-5, 1e-8) if dt == torch.float32 else (1e-2, 1e-7)
+    close(dl[:, :V], l64.grad, *tol, "xent grad")
