@@ -16,10 +16,11 @@
 namespace alpro {
 namespace {
 
-constexpr int TM = 64;          // tokens per stage
+constexpr int TM = 32;          // tokens per stage
+constexpr int NSTAGE = 4;       // stages in LDS (3 in flight while one is consumed)
 constexpr int TW = 256;         // tile width (columns of A -> rows of C; columns of B -> columns of C)
 constexpr int ROW_BYTES = TW * 2;
-constexpr int IMG_BYTES = TM * ROW_BYTES;  // 32 KiB
+constexpr int IMG_BYTES = TM * ROW_BYTES;  // 16 KiB
 constexpr int NT3 = 512;
 
 __device__ u32x4 g_zero_page[4];
@@ -46,44 +47,69 @@ __device__ __forceinline__ u32x4 frag8(const char* img, int ks, int col0, int la
   return mk4(ax, ay, bx, by);
 }
 
+// global -> LDS DMA issued from inline asm: hipcc makes every LDS read wait for ALL outstanding global_load_lds it
+// knows about (it cannot prove the stage being filled is not the one being read), which serialises copy and
+// compute.  Hidden from the compiler, the copies are tracked by hand with s_waitcnt vmcnt(N) below.
+__device__ __forceinline__ void dma16(const void* src, uint32_t lds_addr) {
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(lds_addr) : "memory", "m0");
+}
+
 template <typename T>
-__global__ __launch_bounds__(NT3, 2) void gemm_tn_kernel(const T* __restrict__ A, int64_t lda, const T* __restrict__ B, int64_t ldb,
-                                                         float* __restrict__ C, int64_t ldc, int M, int N, int K, int steps_per_split) {
+__global__ __launch_bounds__(NT3, 1) void gemm_tn_kernel(const T* __restrict__ A, int64_t lda, const T* __restrict__ B, int64_t ldb,
+                                                         float* __restrict__ C, int64_t ldc, int M, int N, int K, int steps_per_split,
+                                                         int tn_cnt, int tk_cnt) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 2, wc = wave & 3;
-  const int n0 = blockIdx.x * TW, k0 = blockIdx.y * TW;
+  // XCD-aware decode of the 1-D grid: all (n-tile, k-tile) workgroups of one token slice run on ONE XCD (blockIdx % 8)
+  // back to back, so each token row of dY and X is fetched from HBM once and re-used out of that XCD's L2 by the
+  // other tiles of the slice (without this the operands are re-read N/256 resp. K/256 times).
+  const int tiles = tn_cnt * tk_cnt;
+  const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+  const int slice = (idx / tiles) * 8 + xcd;
+  const int tile = idx - (idx / tiles) * tiles;
+  const int n0 = (tile % tn_cnt) * TW, k0 = (tile / tn_cnt) * TW;
   const int total_steps = (M + TM - 1) / TM;
-  const int s0 = blockIdx.z * steps_per_split;
+  const int s0 = slice * steps_per_split;
   const int s1 = min(s0 + steps_per_split, total_steps);
   if (s0 >= s1) return;
 
-  // DMA pieces: 1 KiB = 2 token rows x 512 B; wave w moves pieces w, w+8, w+16, w+24 of each image per stage.
-  // LDS slot (row, chunk') receives source chunk chunk' ^ ((row & 3) << 2).
-  int rowA[4], colA[4];  // token row within stage, source column (elements) within tile
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int row = (wave + 8 * i) * 2 + (lane >> 5);
-    const int ch = (lane & 31) ^ ((row & 3) << 2);
-    rowA[i] = row;
-    colA[i] = ch * 8;
-  }
-  typedef __attribute__((address_space(3))) void* lds_ptr;
-  typedef const __attribute__((address_space(1))) void* gbl_ptr;
+  // DMA pieces: 1 KiB = 2 token rows x 512 B; wave w moves pieces w and w+8 of each image per stage.
+  // LDS slot (row, chunk') receives source chunk chunk' ^ ((row & 3) << 2).  Each lane keeps a byte cursor per piece
+  // that advances by one stage (TM rows) per issue; lanes whose column is outside the matrix, and rows past the end
+  // of the slice, read the zero page instead (cursor stride 0), so the loop body has no 64-bit address arithmetic
+  // beyond one add per cursor.
   const char* zero = (const char*)g_zero_page;
-  auto stage = [&](int step, int buf) {
-    char* dA = smem + buf * 2 * IMG_BYTES;
-    char* dB = dA + IMG_BYTES;
-    const int64_t m_base = (int64_t)step * TM;
+  const int rows_end = min(s1 * TM, M);
+  const char* curA[2];
+  const char* curB[2];
+  int mrow[2];
+  int64_t strA[2], strB[2];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int64_t m = m_base + rowA[i];
-      const bool mv = m < M;
-      const char* sa = (mv && n0 + colA[i] < N) ? (const char*)(A + m * lda + n0 + colA[i]) : zero;
-      const char* sb = (mv && k0 + colA[i] < K) ? (const char*)(B + m * ldb + k0 + colA[i]) : zero;
-      __builtin_amdgcn_global_load_lds((gbl_ptr)sa, (lds_ptr)(dA + (wave + 8 * i) * 1024), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((gbl_ptr)sb, (lds_ptr)(dB + (wave + 8 * i) * 1024), 16, 0, 0);
-    }
+  for (int i = 0; i < 2; ++i) {
+    const int row = (wave + 8 * i) * 2 + (lane >> 5);
+    const int col = ((lane & 31) ^ ((row & 3) << 2)) * 8;
+    const int64_t m = (int64_t)s0 * TM + row;
+    const bool ca = n0 + col < N, cb = k0 + col < K;
+    mrow[i] = s0 * TM + row;
+    curA[i] = ca ? (const char*)(A + m * lda + n0 + col) : zero;
+    curB[i] = cb ? (const char*)(B + m * ldb + k0 + col) : zero;
+    strA[i] = ca ? (int64_t)TM * lda * (int64_t)sizeof(T) : 0;
+    strB[i] = cb ? (int64_t)TM * ldb * (int64_t)sizeof(T) : 0;
+  }
+  const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+  const uint32_t lds_piece[2] = {lds_base + wave * 1024u, lds_base + (wave + 8) * 1024u};
+  // copy d = 0..3 of a stage: (A, piece 0), (B, piece 0), (A, piece 1), (B, piece 1) into stage buffer `buf`
+  auto copy = [&](int d, int buf) {
+    const int i = d >> 1;
+    const char* src = (d & 1) ? curB[i] : curA[i];
+    src = mrow[i] < rows_end ? src : zero;
+    dma16(src, __builtin_amdgcn_readfirstlane(lds_piece[i] + buf * 2 * IMG_BYTES + (d & 1) * IMG_BYTES));
+  };
+  auto advance = [&](int i) {  // piece i's cursors -> next stage
+    curA[i] += strA[i];
+    curB[i] += strB[i];
+    mrow[i] += TM;
   };
 
   f32x16 acc[4][2];
@@ -94,28 +120,67 @@ __global__ __launch_bounds__(NT3, 2) void gemm_tn_kernel(const T* __restrict__ A
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  stage(s0, 0);
-  __syncthreads();
-  int cur = 0;
-  for (int st = s0; st < s1; ++st) {
-    if (st + 1 < s1) stage(st + 1, cur ^ 1);
-    const char* cA = smem + cur * 2 * IMG_BYTES;
-    const char* cB = cA + IMG_BYTES;
+  // Software pipeline (4 stage buffers, fragments double-buffered in registers).  Step st:
+  //   first half : F1 <- LDS (stage st, tokens 16..31);  8 MFMAs on F0, with copies 2,3 of stage st+3 in the gaps
+  //   middle     : F1 landed (lgkmcnt 0) -> this wave is done reading stage st;  stage st+1 landed (vmcnt <= 8:
+  //                stages st+2, st+3 stay in flight);  barrier
+  //   second half: F0 <- LDS (stage st+1, tokens 0..15);  8 MFMAs on F1, with copies 0,1 of stage st+4 in the gaps
+  //                (they overwrite stage st's buffer, which every wave has finished reading at the barrier)
+  // so no MFMA waits on an LDS read issued in the same half, and every wave issues exactly 4 copies per step
+  // (out-of-range stages read the zero page), which is what makes the vmcnt arithmetic exact.
+  // A copy stalls its wave for ~60-150 issue cycles (the CU's address unit takes 1 KiB per ~16 clk): the two waves
+  // that share a SIMD (w, w+4) use alternating slots so that the partner's MFMAs cover it.
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      u32x4 fa[4], fb[2];
+  for (int p = 0; p < 3; ++p) {
 #pragma unroll
-      for (int j = 0; j < 2; ++j) fb[j] = frag8(cB, ks, wc * 64 + j * 32, lane);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) fa[i] = frag8(cA, ks, wr * 128 + i * 32, lane);
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) mma_chunk<T>(acc[i][j], fa[i], fb[j]);
-    }
-    __syncthreads();
-    cur ^= 1;
+    for (int d = 0; d < 4; ++d) copy(d, p);
+    advance(0);
+    advance(1);
   }
+  copy(0, 3);
+  copy(1, 3);  // piece 0 of stage s0+3; piece 1 follows in the first half of step s0
+  advance(0);
+  const int pos = wave >> 2;
+  auto load_frags = [&](u32x4* fa, u32x4* fb, const char* cA, const char* cB, int ks) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) fb[j] = frag8(cB, ks, wc * 64 + j * 32, lane);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) fa[i] = frag8(cA, ks, wr * 128 + i * 32, lane);
+  };
+  u32x4 fa0[4], fb0[2], fa1[4], fb1[2];
+  asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  load_frags(fa0, fb0, smem, smem + IMG_BYTES, 0);
+  for (int st = s0; st < s1; ++st) {
+    const int cur = (st - s0) & (NSTAGE - 1);
+    const int b3 = (cur + 3) & (NSTAGE - 1), b1 = (cur + 1) & (NSTAGE - 1);
+    const char* cA = smem + cur * 2 * IMG_BYTES;
+    load_frags(fa1, fb1, cA, cA + IMG_BYTES, 1);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        mma_chunk<T>(acc[i][j], fa0[i], fb0[j]);
+        if (j == 1 && (i & 1) == pos) copy(2 + (i >> 1), b3);  // piece 1 (A, B) of stage st+3
+      }
+    advance(1);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    const char* nA = smem + b1 * 2 * IMG_BYTES;
+    load_frags(fa0, fb0, nA, nA + IMG_BYTES, 0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        mma_chunk<T>(acc[i][j], fa1[i], fb1[j]);
+        if (j == 1 && (i & 1) == pos) copy(i >> 1, cur);  // piece 0 (A, B) of stage st+4
+      }
+    advance(0);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the tail copies (zero page) before the wave exits
   // C[n, k] += acc: lane owns column k = k0 + wc*64 + j*32 + (lane & 31); hardware fp32 atomics
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
@@ -190,23 +255,36 @@ extern "C" int alpro_gemm_tn_acc(const void* A, int64_t lda, const void* B, int6
               "alpro_gemm_tn_acc: lda/ldb must be multiples of 8 covering N/K rounded up to 8 (16-byte chunks are read whole)");
   ALPRO_CHECK(((uintptr_t)A % 16) == 0 && ((uintptr_t)B % 16) == 0, "alpro_gemm_tn_acc: operands must be 16-byte aligned");
   const int tn = (N + TW - 1) / TW, tk = (K + TW - 1) / TW;
+  const int tiles = tn * tk;
   const int total_steps = (M + TM - 1) / TM;
-  // enough slices to put ~2 waves of workgroups on the 256 CUs, at least 8 stages per slice
-  int splits = (512 + tn * tk - 1) / (tn * tk);
-  if (splits > (total_steps + 7) / 8) splits = (total_steps + 7) / 8;
-  if (splits < 1) splits = 1;
+  // Token slices: a multiple of 8 (slice s runs on XCD s % 8 -- see the kernel), s8 per XCD.  Pick the s8 whose
+  // workgroups (tiles * s8 per XCD, 32 CUs, one workgroup per CU) quantise best against the fixed per-workgroup cost
+  // (pipeline fill + the 256 KiB atomic epilogue, ~26 us measured, vs ~1.15 us per 32-token stage).
+  int best = 1;
+  double best_t = 1e30;
+  for (int s8 = 1; s8 <= 32; ++s8) {
+    const int per_try = (total_steps + 8 * s8 - 1) / (8 * s8);
+    if (per_try < 8 && s8 > 1) break;
+    const int units = tiles * s8;
+    const double t = (double)((units + 31) / 32) * (26.0 + 1.15 * per_try);
+    if (t < best_t * 0.98) { best_t = t; best = s8; }
+  }
+  int splits = 8 * best;
+  if (const char* e = getenv("ALPRO_TN_SPLITS")) splits = atoi(e);
   const int per = (total_steps + splits - 1) / splits;
   splits = (total_steps + per - 1) / per;
-  const size_t lds = 4 * IMG_BYTES;
+  const int slices8 = (splits + 7) / 8 * 8;  // grid covers a multiple of 8 slices (one per XCD per pass); empty ones exit
+  const unsigned grid = (unsigned)(slices8 * tiles);
+  const size_t lds = (size_t)NSTAGE * 2 * IMG_BYTES;
   hipStream_t st = (hipStream_t)stream;
   if (dtype == ALPRO_BF16) {
     static bool set = false;
     if (!set) { (void)hipFuncSetAttribute((const void*)gemm_tn_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); set = true; }
-    hipLaunchKernelGGL(gemm_tn_kernel<bf16_t>, dim3(tn, tk, splits), dim3(NT3), lds, st, (const bf16_t*)A, lda, (const bf16_t*)B, ldb, C, ldc, M, N, K, per);
+    hipLaunchKernelGGL(gemm_tn_kernel<bf16_t>, dim3(grid), dim3(NT3), lds, st, (const bf16_t*)A, lda, (const bf16_t*)B, ldb, C, ldc, M, N, K, per, tn, tk);
   } else {
     static bool set = false;
     if (!set) { (void)hipFuncSetAttribute((const void*)gemm_tn_kernel<f16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); set = true; }
-    hipLaunchKernelGGL(gemm_tn_kernel<f16_t>, dim3(tn, tk, splits), dim3(NT3), lds, st, (const f16_t*)A, lda, (const f16_t*)B, ldb, C, ldc, M, N, K, per);
+    hipLaunchKernelGGL(gemm_tn_kernel<f16_t>, dim3(grid), dim3(NT3), lds, st, (const f16_t*)A, lda, (const f16_t*)B, ldb, C, ldc, M, N, K, per, tn, tk);
   }
   return check_launch("alpro_gemm_tn_acc");
 }
