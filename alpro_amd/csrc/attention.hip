@@ -248,6 +248,171 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qkv
 }
 
 // ================================================================================================
+// full attention, 16-bit storage, throughput form.  Same math as attn_fwd_kernel; what changes is the schedule:
+//  * <= 256 registers and ~75 KiB of LDS per workgroup, so TWO workgroups (8 waves, 2 per SIMD) share a CU and one
+//    workgroup's K/V staging and softmax VALU work overlap the other's MFMAs (the fp32-capable kernel above needs
+//    350 registers at 7 key tiles = one wave per SIMD, every phase exposed);
+//  * K and V go global -> LDS by DMA (no VGPR round trip); the bank swizzle is applied on the source side;
+//  * softmax in the log2 domain: p = exp2(s * scale*log2(e) - m) is one FMA + one v_exp_f32 per score on fully valid
+//    key tiles, the row maximum is taken on the raw scores, and the 1/sum normalisation is applied to the 32x64
+//    output tile instead of the 32xL probabilities;
+//  * the next query tile's Q fragments are prefetched under the current tile's softmax;
+//  * O^T is transposed through 4 KiB of wave-private LDS so that a row's 128 bytes leave in 16-byte stores.
+__device__ u32x4 g_attn_zero[4];
+constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
+
+template <typename T, int NKT, bool HAS_BIAS>
+__global__ __launch_bounds__(256, NKT == 8 ? 1 : 2) void attn_fwd16_kernel(const T* __restrict__ qkv, T* __restrict__ out, int L, int H, float scale,
+                                                            const float* __restrict__ key_bias, float* __restrict__ lse, float drop_p,
+                                                            uint32_t drop_seed) {
+  static_assert(sizeof(T) == 2, "16-bit storage only");
+  constexpr int LP = NKT * 32, RB = 128;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* Ks = smem;
+  char* Vs = smem + LP * RB;
+  char* Os = smem + 2 * LP * RB;
+  float* Bs = (float*)(Os + 4 * 4096);  // additive key bias * log2(e); -inf on the padded keys
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int b = blockIdx.x / H, h = blockIdx.x - b * H;
+  for (int c = tid; c < LP; c += 256) Bs[c] = c < L ? (HAS_BIAS ? key_bias[(int64_t)b * L + c] * LOG2E : 0.f) : -INFINITY;
+  const int64_t ldq = 3 * (int64_t)H * HD;  // elements per token row of qkv
+  const T* base = qkv + (int64_t)b * L * ldq + h * HD;
+
+  // K (chunk ^ ((row >> 1) & 7)) and V (chunk ^ 4*bit1(row)) images: 1 KiB pieces of 8 rows; padded rows <- zero page
+  {
+    const uint32_t k_lds = lds_addr_of(Ks), v_lds = lds_addr_of(Vs);
+    const char* zero = (const char*)g_attn_zero;
+#pragma unroll
+    for (int i = 0; i < NKT; ++i) {
+      const int piece = wave + 4 * i;
+      const int row = piece * 8 + (lane >> 3), slot = lane & 7;
+      const T* src = base + (int64_t)row * ldq;
+      const char* ks = row < L ? (const char*)(src + H * HD + ((slot ^ ((row >> 1) & 7)) << 3)) : zero;
+      const char* vs = row < L ? (const char*)(src + 2 * H * HD + ((slot ^ (((row >> 1) & 1) << 2)) << 3)) : zero;
+      dma16(ks, __builtin_amdgcn_readfirstlane(k_lds + piece * 1024));
+      dma16(vs, __builtin_amdgcn_readfirstlane(v_lds + piece * 1024));
+    }
+  }
+  const int nqt = (L + 31) >> 5;
+  const int g = lane >> 5, ql = lane & 31;
+  auto load_q = [&](int qt, u32x4(&qf)[4]) {
+    const int qc = min(qt * 32 + ql, L - 1);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const u32x4*)(base + (int64_t)qc * ldq + (2 * ks + g) * 8);
+  };
+  u32x4 qf[4];
+  load_q(min(wave, nqt - 1), qf);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  const float sl = scale * LOG2E;
+  char* Ow = Os + wave * 4096;
+  for (int qt = wave; qt < nqt; qt += 4) {
+    const int q = qt * 32 + ql;
+    f32x16 s[NKT];
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[kt][r] = 0.f;
+      const int krow = kt * 32 + ql;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const u32x4 a = *(const u32x4*)(Ks + krow * RB + (((2 * ks + g) ^ ((krow >> 1) & 7)) << 4));
+        mma_chunk<T>(s[kt], a, qf[ks]);
+      }
+    }
+    u32x4 qn[4];
+    load_q(min(qt + 4, nqt - 1), qn);  // lands under the softmax
+
+    // ---- softmax (log2 domain); tiles with all 32 keys valid and no bias skip the bias FMA
+    float m = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+      if (!HAS_BIAS && (kt + 1) * 32 <= L) {
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) m = fmaxf(fmaxf(m, s[kt][r]), s[kt][r + 1]);
+      }
+    }
+    m *= sl;  // scale > 0
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+      if (HAS_BIAS || (kt + 1) * 32 > L) {
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq) {
+          const float4 bq = *(const float4*)(Bs + kt * 32 + 8 * rq + 4 * g);
+          const float bb[4] = {bq.x, bq.y, bq.z, bq.w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float v = fmaf(s[kt][4 * rq + e], sl, bb[e]);
+            s[kt][4 * rq + e] = v;
+            m = fmaxf(m, v);
+          }
+        }
+      }
+    }
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+      if (!HAS_BIAS && (kt + 1) * 32 <= L) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float pr = __builtin_amdgcn_exp2f(fmaf(s[kt][r], sl, -m));
+          s[kt][r] = pr;
+          sum += pr;
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float pr = __builtin_amdgcn_exp2f(s[kt][r] - m);  // exp2(-inf) == 0 for masked keys
+          s[kt][r] = pr;
+          sum += pr;
+        }
+      }
+    }
+    sum += __shfl_xor(sum, 32, 64);
+    const float inv = 1.0f / sum;
+    if (lse && g == 0 && q < L) lse[((int64_t)b * H + h) * L + q] = (m + __builtin_amdgcn_logf(sum)) * LN2;
+    if (drop_seed) {  // attention-probability dropout (xbert.py:331): mask is a pure function of (b, h, q, key)
+      const uint32_t th = drop_thresh24(drop_p);
+      const float ks = 1.0f / (1.0f - drop_p);
+      const uint64_t base_i = (((uint64_t)b * H + h) * L + (uint64_t)min(q, L - 1)) * L;
+#pragma unroll
+      for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[kt][r] = drop_keep(drop_seed, base_i + kt * 32 + acc_row(r, lane), th) ? s[kt][r] * ks : 0.f;
+    }
+
+    f32x16 o[2];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
+    pv_tiles<T, NKT>(o, s, Vs, lane);
+
+    // ---- O^T (lane = query, 4 consecutive d per register quad) -> row-major rows through wave-private LDS
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int rq = 0; rq < 4; ++rq) {
+        const uint32_t lo = pack2(o[dt][4 * rq] * inv, o[dt][4 * rq + 1] * inv, (T*)0);
+        const uint32_t hi = pack2(o[dt][4 * rq + 2] * inv, o[dt][4 * rq + 3] * inv, (T*)0);
+        *(u32x2*)(Ow + ql * 128 + (((dt * 4 + rq) ^ ((ql >> 1) & 7)) << 4) + g * 8) = mk2(lo, hi);
+      }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // DS ops of one wave complete in order; nothing else touches Ow
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int row = p * 8 + (lane >> 3), slot = lane & 7;
+      const u32x4 v = *(const u32x4*)(Ow + row * 128 + ((slot ^ ((row >> 1) & 7)) << 4));
+      const int qq = qt * 32 + row;
+      if (qq < L) *(u32x4*)(out + ((int64_t)b * L + qq) * H * HD + h * HD + slot * 8) = v;
+    }
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) qf[ks] = qn[ks];
+  }
+}
+
+// ================================================================================================
 // temporal attention: one wave per (32 consecutive tokens, head); groups of Tn tokens
 template <typename T>
 __global__ __launch_bounds__(256) void attn_temporal_fwd_kernel(const T* __restrict__ qkv, T* __restrict__ out, int64_t rows, int Tn,
@@ -319,10 +484,33 @@ int launch_attn(const void* qkv, void* out, int batch, int L, int H, float scale
   return check_launch("alpro_attn_fwd");
 }
 
+template <typename T, int NKT, bool HAS_BIAS>
+int launch_attn16(const void* qkv, void* out, int batch, int L, int H, float scale, const float* key_bias, float* lse, float drop_p,
+                  uint32_t drop_seed, hipStream_t st) {
+  const size_t lds = 2 * (size_t)NKT * 32 * 128 + 4 * 4096 + (size_t)NKT * 32 * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)attn_fwd16_kernel<T, NKT, HAS_BIAS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((attn_fwd16_kernel<T, NKT, HAS_BIAS>), dim3(batch * H), dim3(256), lds, st, (const T*)qkv, (T*)out, L, H, scale, key_bias, lse, drop_p, drop_seed);
+  return check_launch("alpro_attn_fwd");
+}
+
 template <typename T>
 int dispatch_attn(const void* qkv, void* out, int batch, int L, int H, float scale, const float* key_bias, float* lse, float dp, uint32_t ds,
                   hipStream_t st) {
   const int nkt = (L + 31) / 32;
+  if constexpr (sizeof(T) == 2) {
+#define ALPRO_ATTN16(N)                                                                                       \
+  return key_bias ? launch_attn16<T, N, true>(qkv, out, batch, L, H, scale, key_bias, lse, dp, ds, st)         \
+                  : launch_attn16<T, N, false>(qkv, out, batch, L, H, scale, key_bias, lse, dp, ds, st)
+    if (nkt <= 2) ALPRO_ATTN16(2);
+    if (nkt <= 4) ALPRO_ATTN16(4);
+    if (nkt <= 7) ALPRO_ATTN16(7);
+    ALPRO_ATTN16(8);
+#undef ALPRO_ATTN16
+  }
   if (nkt <= 2) return launch_attn<T, 2>(qkv, out, batch, L, H, scale, key_bias, lse, dp, ds, st);
   if (nkt <= 4) return launch_attn<T, 4>(qkv, out, batch, L, H, scale, key_bias, lse, dp, ds, st);
   if (nkt <= 7) return launch_attn<T, 7>(qkv, out, batch, L, H, scale, key_bias, lse, dp, ds, st);

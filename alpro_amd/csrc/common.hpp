@@ -149,6 +149,16 @@ __device__ __forceinline__ bool drop_keep(uint32_t seed, uint64_t idx, uint32_t 
 }
 __host__ __device__ inline uint32_t drop_thresh24(float p) { return (uint32_t)(p * 16777216.0f + 0.5f); }
 
+// ---- global -> LDS DMA issued from inline asm ---------------------------------------------------------------
+// hipcc makes every LDS read wait for ALL outstanding global_load_lds it knows about (it cannot prove that the
+// buffer being filled is not the one being read), which serialises copy and compute.  Hidden from the compiler,
+// the copies are tracked by hand with s_waitcnt vmcnt(N).  lds_addr: wave-uniform LDS byte address of the 1 KiB
+// piece; lane l's 16 bytes land at lds_addr + 16 l.
+__device__ __forceinline__ void dma16(const void* src, uint32_t lds_addr) {
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(lds_addr) : "memory", "m0");
+}
+__device__ __forceinline__ uint32_t lds_addr_of(const void* p) { return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)p; }
+
 // ---- host side -----------------------------------------------------------------------------
 void set_error(const char* fmt, ...);
 #define ALPRO_CHECK(cond, ...)            \

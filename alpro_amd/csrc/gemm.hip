@@ -536,7 +536,9 @@ int launch_gemm_inst(const alpro_gemm_desc_t& g, hipStream_t st) {
   // at least one full wave of 256^2 tiles on the 256 CUs; the persistent kernel's pipeline needs >= 2 K-tiles
   const bool use256 = nk >= 2 && (force ? atoi(force) == 256 : big_tiles >= 256);
   if (use256) {
-    hipLaunchKernelGGL((gemm_nt256p_kernel<T, ACT, MAP>), dim3(big_tiles < 256 ? big_tiles : 256), dim3(NT2), 4 * TILE2_BYTES + EPI_BYTES, st, g);
+    int grid = big_tiles < 256 ? big_tiles : 256;
+    if (const char* e = getenv("ALPRO_GEMM_GRID")) grid = atoi(e) < grid ? atoi(e) : grid;  // tuning aid: cap the persistent grid
+    hipLaunchKernelGGL((gemm_nt256p_kernel<T, ACT, MAP>), dim3(grid), dim3(NT2), 4 * TILE2_BYTES + EPI_BYTES, st, g);
   } else {
     const int ntn = (g.N + BN - 1) / BN, ntm = (g.M + BM - 1) / BM;
     hipLaunchKernelGGL((gemm_nt_kernel<T, ACT, MAP>), dim3(ntn * ntm), dim3(NT), 4 * TILE_BYTES, st, g);

@@ -47,13 +47,6 @@ __device__ __forceinline__ u32x4 frag8(const char* img, int ks, int col0, int la
   return mk4(ax, ay, bx, by);
 }
 
-// global -> LDS DMA issued from inline asm: hipcc makes every LDS read wait for ALL outstanding global_load_lds it
-// knows about (it cannot prove the stage being filled is not the one being read), which serialises copy and
-// compute.  Hidden from the compiler, the copies are tracked by hand with s_waitcnt vmcnt(N) below.
-__device__ __forceinline__ void dma16(const void* src, uint32_t lds_addr) {
-  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(lds_addr) : "memory", "m0");
-}
-
 template <typename T>
 __global__ __launch_bounds__(NT3, 1) void gemm_tn_kernel(const T* __restrict__ A, int64_t lda, const T* __restrict__ B, int64_t ldb,
                                                          float* __restrict__ C, int64_t ldc, int M, int N, int K, int steps_per_split,
