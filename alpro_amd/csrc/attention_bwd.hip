@@ -279,6 +279,284 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_kernel(const T* __restrict__
   }
 }
 
+// ================================================================================================
+// 16-bit full-attention backward, throughput form (same two phases and MFMA orientations as attn_bwd_kernel):
+//  * tiles go global -> LDS by DMA with the swizzle applied on the source side; padded rows read a zero page;
+//  * exp2 with log2(e) folded into the score scale; LDS holds -lse*log2(e) (or -inf for padded queries, which makes
+//    their P rows exactly 0) and delta*scale, so a score costs FMA + v_exp_f32 and a dS costs FMA + MUL;
+//  * the next query tile's Q / dO / O fragments are prefetched under the current tile's work (phase 1);
+//  * dQ, dK, dV tiles are transposed through 4 KiB of wave-private LDS and leave as 16-byte row stores;
+//  * <= 256 registers and ~76 KiB of LDS: two workgroups per CU.
+__device__ u32x4 g_bwd_zero[4];
+constexpr float LOG2E_B = 1.4426950408889634f;
+
+// wave-private transpose: accumulator pair (column = token of this lane, rows = d) -> 32 row-major 128-byte rows
+template <typename T>
+__device__ __forceinline__ void store_rows_via_lds(char* Ow, const f32x16 (&o)[2], T* dst, int64_t ld, int row_base, int rows_valid, int lane) {
+  const int g = lane >> 5, ql = lane & 31;
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int rq = 0; rq < 4; ++rq) {
+      const uint32_t lo = pack2(o[dt][4 * rq], o[dt][4 * rq + 1], (T*)0);
+      const uint32_t hi = pack2(o[dt][4 * rq + 2], o[dt][4 * rq + 3], (T*)0);
+      *(u32x2*)(Ow + ql * 128 + (((dt * 4 + rq) ^ ((ql >> 1) & 7)) << 4) + g * 8) = mk2(lo, hi);
+    }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const int row = p * 8 + (lane >> 3), slot = lane & 7;
+    const u32x4 v = *(const u32x4*)(Ow + row * 128 + ((slot ^ ((row >> 1) & 7)) << 4));
+    if (row_base + row < rows_valid) *(u32x4*)(dst + (int64_t)(row_base + row) * ld + slot * 8) = v;
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the staging rows may be rewritten right away
+}
+
+template <typename T, int NKT, bool HAS_BIAS>
+__global__ __launch_bounds__(256, NKT == 8 ? 1 : 2) void attn_bwd16_kernel(const T* __restrict__ qkv, const T* __restrict__ out,
+                                                                          const T* __restrict__ dout, const float* __restrict__ lse,
+                                                                          T* __restrict__ dqkv, int L, int H, float scale,
+                                                                          const float* __restrict__ key_bias, float drop_p, uint32_t drop_seed) {
+  static_assert(sizeof(T) == 2, "16-bit storage only");
+  constexpr int LP = NKT * 32, RB = 128;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* tA = smem;              // K, then Q
+  char* tB = smem + LP * RB;    // V, then dO
+  char* Os = smem + 2 * LP * RB;
+  float* Bs = (float*)(Os + 4 * 4096);  // key bias * log2(e); -inf on padded keys
+  float* Ls = Bs + LP;                   // -lse * log2(e); -inf on padded queries
+  float* Ds = Ls + LP;                   // delta * scale
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int b = blockIdx.x / H, h = blockIdx.x - b * H;
+  const int64_t row0 = (int64_t)b * L;
+  const int64_t ldq = 3 * (int64_t)H * HD, ldo = (int64_t)H * HD;
+  const T* qb = qkv + row0 * ldq + h * HD;
+  const T* ob = out + row0 * ldo + h * HD;
+  const T* dob = dout + row0 * ldo + h * HD;
+  T* db = dqkv + row0 * ldq + h * HD;
+  const float* lse_b = lse + ((int64_t)b * H + h) * L;
+  const uint32_t dth = drop_thresh24(drop_p);
+  const float dks = drop_seed ? 1.0f / (1.0f - drop_p) : 1.0f;
+  const uint64_t dbase = ((uint64_t)b * H + h) * (uint64_t)L;  // + q, then * L + key
+  const float sl = scale * LOG2E_B;
+  for (int c = tid; c < LP; c += 256) {
+    Bs[c] = c < L ? (HAS_BIAS ? key_bias[(int64_t)b * L + c] * LOG2E_B : 0.f) : -INFINITY;
+    Ls[c] = c < L ? -lse_b[c] * LOG2E_B : -INFINITY;
+  }
+  const uint32_t a_lds = lds_addr_of(tA), b_lds = lds_addr_of(tB);
+  const char* zero = (const char*)g_bwd_zero;
+  // two row-major (row, 64) tiles -> LDS images, chunk ^ (bit1(row) << 2 | (row >> 2) & 3)
+  auto stage2 = [&](const T* srcA, int64_t lda_, const T* srcB, int64_t ldb_) {
+#pragma unroll
+    for (int i = 0; i < NKT; ++i) {
+      const int piece = wave + 4 * i;
+      const int row = piece * 8 + (lane >> 3), slot = lane & 7;
+      const int ch = slot ^ ((((row >> 1) & 1) << 2) | ((row >> 2) & 3));
+      const char* pa = row < L ? (const char*)(srcA + (int64_t)row * lda_ + ch * 8) : zero;
+      const char* pb = row < L ? (const char*)(srcB + (int64_t)row * ldb_ + ch * 8) : zero;
+      dma16(pa, __builtin_amdgcn_readfirstlane(a_lds + piece * 1024));
+      dma16(pb, __builtin_amdgcn_readfirstlane(b_lds + piece * 1024));
+    }
+  };
+  stage2(qb + H * HD, ldq, qb + 2 * H * HD, ldq);
+
+  const int g = lane >> 5, ql = lane & 31;
+  const int ntile = (L + 31) >> 5;
+  char* Ow = Os + wave * 4096;
+  // ---------------------------------------------------------------- phase 1: dQ (lane = query)
+  auto load_q3 = [&](int qt, u32x4(&qf)[4], u32x4(&dof)[4], u32x4(&of)[4]) {
+    const int qc = min(qt * 32 + ql, L - 1);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int off = (2 * ks + g) * 8;
+      qf[ks] = *(const u32x4*)(qb + (int64_t)qc * ldq + off);
+      dof[ks] = *(const u32x4*)(dob + (int64_t)qc * ldo + off);
+      of[ks] = *(const u32x4*)(ob + (int64_t)qc * ldo + off);
+    }
+  };
+  u32x4 qf[4], dof[4], of[4];
+  load_q3(min(wave, ntile - 1), qf, dof, of);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (int qt = wave; qt < ntile; qt += 4) {
+    const int q = qt * 32 + ql;
+    const int qc = min(q, L - 1);
+    float delta = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      float a[8], c2[8];
+      unpack_chunk<T>(dof[ks], a);
+      unpack_chunk<T>(of[ks], c2);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) delta += a[e] * c2[e];
+    }
+    delta += __shfl_xor(delta, 32, 64);
+    const float nds = -delta * scale;
+    const float nlq = Ls[q];
+    if (g == 0) Ds[q] = nds;
+    u32x4 qn[4], don[4], on[4];
+    f32x16 dq[2];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dq[dt][r] = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+      if (kt < ntile) {
+        f32x16 s, dp;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = dp[r] = 0.f;
+        const int krow = kt * 32 + ql;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          const u32x4 ka = *(const u32x4*)(tA + tile_off<T>(krow, 2 * ks + g));
+          const u32x4 va = *(const u32x4*)(tB + tile_off<T>(krow, 2 * ks + g));
+          mma_chunk<T>(s, ka, qf[ks]);
+          mma_chunk<T>(dp, va, dof[ks]);
+        }
+        if (kt == 0) load_q3(min(qt + 4, ntile - 1), qn, don, on);  // lands under this tile's work
+        const bool plain = !HAS_BIAS && (kt + 1) * 32 <= L;          // all 32 keys valid, no bias
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq) {
+          float bb[4] = {nlq, nlq, nlq, nlq};
+          if (!plain) {
+            const float4 bq = *(const float4*)(Bs + kt * 32 + 8 * rq + 4 * g);
+            bb[0] += bq.x; bb[1] += bq.y; bb[2] += bq.z; bb[3] += bq.w;
+          }
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int r = 4 * rq + e;
+            const float p = __builtin_amdgcn_exp2f(fmaf(s[r], sl, bb[e]));
+            float gd = dp[r];
+            if (drop_seed) gd = drop_keep(drop_seed, (dbase + qc) * L + kt * 32 + 8 * rq + 4 * g + e, dth) ? gd * dks : 0.f;
+            s[r] = p * fmaf(gd, scale, nds);  // dS^T = P o (dP - delta) * scale
+          }
+        }
+#pragma unroll
+        for (int cc = 0; cc < 2; ++cc) {
+          float v[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = s[cc * 8 + e];
+          const u32x4 bop = pack_chunk<T>(v);
+#pragma unroll
+          for (int dt = 0; dt < 2; ++dt) mma_chunk<T>(dq[dt], load_t_chunk<T>(tA, kt * 32, cc, lane, dt), bop);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    store_rows_via_lds<T>(Ow, dq, db, ldq, qt * 32, L, lane);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      qf[ks] = qn[ks];
+      dof[ks] = don[ks];
+      of[ks] = on[ks];
+    }
+  }
+  __syncthreads();
+  // ---------------------------------------------------------------- phase 2: dK, dV (lane = key)
+  stage2(qb, ldq, dob, ldo);
+  u32x4 kf[4], vf[4];
+  {
+    const int kc = min(min(wave, ntile - 1) * 32 + ql, L - 1);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int off = (2 * ks + g) * 8;
+      kf[ks] = *(const u32x4*)(qb + (int64_t)kc * ldq + H * HD + off);
+      vf[ks] = *(const u32x4*)(qb + (int64_t)kc * ldq + 2 * H * HD + off);
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (int kt = wave; kt < ntile; kt += 4) {
+    const int key = kt * 32 + ql;
+    if (kt != wave) {
+      const int kc = min(key, L - 1);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const int off = (2 * ks + g) * 8;
+        kf[ks] = *(const u32x4*)(qb + (int64_t)kc * ldq + H * HD + off);
+        vf[ks] = *(const u32x4*)(qb + (int64_t)kc * ldq + 2 * H * HD + off);
+      }
+    }
+    const float kb = HAS_BIAS ? Bs[key] : 0.f;
+    f32x16 dk[2], dv[2];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dk[dt][r] = dv[dt][r] = 0.f;
+#pragma unroll 1
+    for (int qt = 0; qt < ntile; ++qt) {
+      f32x16 s, dp;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[r] = dp[r] = 0.f;
+      const int qrow = qt * 32 + ql;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const u32x4 qa = *(const u32x4*)(tA + tile_off<T>(qrow, 2 * ks + g));
+        const u32x4 da = *(const u32x4*)(tB + tile_off<T>(qrow, 2 * ks + g));
+        mma_chunk<T>(s, qa, kf[ks]);
+        mma_chunk<T>(dp, da, vf[ks]);
+      }
+#pragma unroll
+      for (int rq = 0; rq < 4; ++rq) {
+        const float4 lq = *(const float4*)(Ls + qt * 32 + 8 * rq + 4 * g);
+        const float4 dq4 = *(const float4*)(Ds + qt * 32 + 8 * rq + 4 * g);
+        float ll[4] = {lq.x, lq.y, lq.z, lq.w};
+        const float dd[4] = {dq4.x, dq4.y, dq4.z, dq4.w};
+        if (HAS_BIAS) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) ll[e] += kb;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int r = 4 * rq + e;
+          const float p = __builtin_amdgcn_exp2f(fmaf(s[r], sl, ll[e]));
+          float gd = dp[r], pm = p;
+          if (drop_seed) {
+            const int qq = qt * 32 + 8 * rq + 4 * g + e;
+            const bool keep = drop_keep(drop_seed, (dbase + (qq < L ? qq : L - 1)) * L + key, dth);
+            pm = keep ? p * dks : 0.f;
+            gd = keep ? gd * dks : 0.f;
+          }
+          s[r] = pm;                          // dropped P (feeds dV)
+          dp[r] = p * fmaf(gd, scale, dd[e]);  // dS
+        }
+      }
+#pragma unroll
+      for (int cc = 0; cc < 2; ++cc) {
+        float pv[8], sv[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          pv[e] = s[cc * 8 + e];
+          sv[e] = dp[cc * 8 + e];
+        }
+        const u32x4 pb = pack_chunk<T>(pv), sb = pack_chunk<T>(sv);
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          mma_chunk<T>(dv[dt], load_t_chunk<T>(tB, qt * 32, cc, lane, dt), pb);
+          mma_chunk<T>(dk[dt], load_t_chunk<T>(tA, qt * 32, cc, lane, dt), sb);
+        }
+      }
+    }
+    store_rows_via_lds<T>(Ow, dk, db + H * HD, ldq, kt * 32, L, lane);
+    store_rows_via_lds<T>(Ow, dv, db + 2 * H * HD, ldq, kt * 32, L, lane);
+  }
+}
+
+template <typename T, int NKT, bool HAS_BIAS>
+int launch_bwd16(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, int batch, int L, int H, float scale,
+                 const float* key_bias, float dp, uint32_t ds, hipStream_t st) {
+  const size_t lds = 2 * (size_t)NKT * 32 * 128 + 4 * 4096 + 3 * (size_t)NKT * 32 * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)attn_bwd16_kernel<T, NKT, HAS_BIAS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((attn_bwd16_kernel<T, NKT, HAS_BIAS>), dim3((unsigned)(batch * H)), dim3(256), lds, st, (const T*)qkv, (const T*)out, (const T*)dout,
+                     lse, (T*)dqkv, L, H, scale, key_bias, dp, ds);
+  return check_launch("alpro_attn_bwd");
+}
+
 template <typename T, int NKT, int NW, bool GROUPED>
 int launch_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, int64_t nblocks_b, int L, int H, float scale,
                const float* key_bias, int Tn, int64_t total_rows, float dp, uint32_t ds, hipStream_t st) {
@@ -298,6 +576,16 @@ int dispatch_bwd(const void* qkv, const void* out, const void* dout, const float
                  const float* key_bias, float dp, uint32_t ds, hipStream_t st) {
   const int nkt = (L + 31) / 32;
   const int64_t rows = (int64_t)batch * L;
+  if constexpr (sizeof(T) == 2) {
+#define ALPRO_BWD16(N)                                                                                              \
+  return key_bias ? launch_bwd16<T, N, true>(qkv, out, dout, lse, dqkv, batch, L, H, scale, key_bias, dp, ds, st)   \
+                  : launch_bwd16<T, N, false>(qkv, out, dout, lse, dqkv, batch, L, H, scale, key_bias, dp, ds, st)
+    if (nkt <= 2) ALPRO_BWD16(2);
+    if (nkt <= 4) ALPRO_BWD16(4);
+    if (nkt <= 7) ALPRO_BWD16(7);
+    ALPRO_BWD16(8);
+#undef ALPRO_BWD16
+  }
   if (nkt <= 2) return launch_bwd<T, 2, 4, false>(qkv, out, dout, lse, dqkv, batch, L, H, scale, key_bias, 0, rows, dp, ds, st);
   if (nkt <= 4) return launch_bwd<T, 4, 4, false>(qkv, out, dout, lse, dqkv, batch, L, H, scale, key_bias, 0, rows, dp, ds, st);
   if (nkt <= 7) return launch_bwd<T, 7, 4, false>(qkv, out, dout, lse, dqkv, batch, L, H, scale, key_bias, 0, rows, dp, ds, st);
