@@ -168,30 +168,32 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
 
 // ---- out[m, :] = (T)(scale(m) * src[row(m), :]): gathers fp32 token-gradient rows into a GEMM operand ---------------
 // row(m) follows the forward maps; under FRAME_TOKENS the j == 0 rows read the clip's CLS row times cls_scale (1/T).
-template <typename T>
-__global__ __launch_bounds__(256) void gather_cast_kernel(const float* __restrict__ src, int64_t ld, T* __restrict__ out, int64_t rows, int mode,
+template <typename T, int NW>
+__global__ __launch_bounds__(NW * 64) void gather_cast_kernel(const float* __restrict__ src, int64_t ld, T* __restrict__ out, int64_t rows, int mode,
                                                           int p0, int p1, const float* __restrict__ row_scale, int group, float cls_scale,
-                                                          float drop_p, uint32_t drop_seed) {
+                                                          float drop_p, uint32_t drop_seed, float* __restrict__ colsum) {
+  __shared__ float red[NW][LN_D];
   const int lane = threadIdx.x & 63;
-  const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  const int64_t nwaves = (int64_t)gridDim.x * 4;
-  for (int64_t m = wave; m < rows; m += nwaves) {
-    int64_t r;
-    float sc = row_scale ? row_scale[m / group] : 1.0f;
+  const int64_t wave = (int64_t)blockIdx.x * NW + (threadIdx.x >> 6);
+  const int64_t nwaves = (int64_t)gridDim.x * NW;
+  float cs[12];
+#pragma unroll
+  for (int i = 0; i < 12; ++i) cs[i] = 0.f;
+  auto src_row = [&](int64_t m, float& sc) -> int64_t {
+    sc = row_scale ? row_scale[m / group] : 1.0f;
     if (mode == ALPRO_MAP_PATCH_EMBED) {
       const int T_ = p0, N = p1;
       const int64_t bt = m / N;
       const int n = (int)(m - bt * N);
       const int64_t b = bt / T_;
       const int t = (int)(bt - b * T_);
-      r = b * (1 + (int64_t)N * T_) + 1 + (int64_t)n * T_ + t;
-    } else {
-      const SrcRow s = ln_src_row(mode, p0, p1, m);
-      r = s.row;
-      if (s.shared) sc *= cls_scale;
+      return b * (1 + (int64_t)N * T_) + 1 + (int64_t)n * T_ + t;
     }
-    float v[12];
-    ld12(src + r * ld, lane, v);
+    const SrcRow s = ln_src_row(mode, p0, p1, m);
+    if (s.shared) sc *= cls_scale;
+    return s.row;
+  };
+  auto emit = [&](int64_t m, float (&v)[12], float sc) {
     if (drop_seed) {
       const uint32_t th = drop_thresh24(drop_p);
       const float ks = 1.0f / (1.0f - drop_p);
@@ -202,16 +204,49 @@ __global__ __launch_bounds__(256) void gather_cast_kernel(const float* __restric
       }
     }
 #pragma unroll
+    for (int i = 0; i < 12; ++i) {
+      v[i] *= sc;
+      cs[i] += v[i];
+    }
+#pragma unroll
     for (int i = 0; i < 3; ++i) {
       T* p = out + m * LN_D + i * 256 + lane * 4;
       if constexpr (sizeof(T) == 4) {
-        *(float4*)p = make_float4(v[4 * i] * sc, v[4 * i + 1] * sc, v[4 * i + 2] * sc, v[4 * i + 3] * sc);
+        *(float4*)p = make_float4(v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]);
       } else {
         u32x2 u;
-        u.x = pack2(v[4 * i] * sc, v[4 * i + 1] * sc, (T*)0);
-        u.y = pack2(v[4 * i + 2] * sc, v[4 * i + 3] * sc, (T*)0);
+        u.x = pack2(v[4 * i], v[4 * i + 1], (T*)0);
+        u.y = pack2(v[4 * i + 2], v[4 * i + 3], (T*)0);
         *(u32x2*)p = u;
       }
+    }
+  };
+  // two rows per wave iteration: both rows' loads are in flight before either is converted (the colsum launch uses a
+  // small grid, so each wave walks ~25 rows and would otherwise expose one HBM round trip per row)
+  for (int64_t m = wave; m < rows; m += 2 * nwaves) {
+    const int64_t m2 = m + nwaves;
+    const bool has2 = m2 < rows;
+    float sc, sc2 = 0.f;
+    const int64_t r = src_row(m, sc);
+    const int64_t r2 = has2 ? src_row(m2, sc2) : r;
+    float v[12], v2[12];
+    ld12(src + r * ld, lane, v);
+    ld12(src + r2 * ld, lane, v2);
+    emit(m, v, sc);
+    if (has2) emit(m2, v2, sc2);
+  }
+  if (colsum) {  // bias gradient of the Linear these rows are the dY of: 4-wave LDS fold, one atomic per column per block
+    const int w = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) red[w][i * 256 + lane * 4 + e] = cs[4 * i + e];
+    __syncthreads();
+    for (int c = threadIdx.x; c < LN_D; c += NW * 64) {
+      float t = 0.f;
+#pragma unroll
+      for (int k = 0; k < NW; ++k) t += red[k][c];
+      unsafeAtomicAdd(colsum + c, t);
     }
   }
 }
@@ -308,12 +343,19 @@ extern "C" int alpro_layernorm_bwd(const void* dy, int dy_dtype, int64_t ld_dy, 
 }
 
 extern "C" int alpro_gather_cast(const float* src, int64_t ld, void* out, int dtype, int rows, int D, int map_mode, int map_p0, int map_p1,
-                                 const float* row_scale, int row_scale_group, float cls_scale, float drop_p, uint32_t drop_seed, void* stream) {
+                                 const float* row_scale, int row_scale_group, float cls_scale, float drop_p, uint32_t drop_seed, float* colsum,
+                                 void* stream) {
   ALPRO_CHECK(src && out && rows > 0, "alpro_gather_cast: bad args");
   ALPRO_CHECK(D == LN_D, "alpro_gather_cast: D=%d unsupported", D);
   ALPRO_CHECK(map_mode >= 0 && map_mode <= ALPRO_MAP_PATCH_EMBED, "alpro_gather_cast: bad map_mode %d", map_mode);
   ALPRO_CHECK(!row_scale || row_scale_group > 0, "alpro_gather_cast: row_scale_group must be > 0");
-  ALPRO_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL(gather_cast_kernel<T>, dim3(grid_for(rows, 4, 256 * 32)), dim3(256), 0, (hipStream_t)stream, src, ld, (T*)out, (int64_t)rows, map_mode, map_p0, map_p1, row_scale, row_scale_group, cls_scale, drop_p, drop_seed));
+  // with a colsum target: few, fat workgroups (16 waves) -- every workgroup ends with 768 same-address atomics, and those
+  // serialise at the memory side (3072 workgroups cost 2x the whole cast); plain casts use many small workgroups
+  if (colsum) {
+    ALPRO_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((gather_cast_kernel<T, 16>), dim3(grid_for(rows, 32, 512)), dim3(1024), 0, (hipStream_t)stream, src, ld, (T*)out, (int64_t)rows, map_mode, map_p0, map_p1, row_scale, row_scale_group, cls_scale, drop_p, drop_seed, colsum));
+  } else {
+    ALPRO_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((gather_cast_kernel<T, 4>), dim3(grid_for(rows, 8, 256 * 32)), dim3(256), 0, (hipStream_t)stream, src, ld, (T*)out, (int64_t)rows, map_mode, map_p0, map_p1, row_scale, row_scale_group, cls_scale, drop_p, drop_seed, colsum));
+  }
   return check_launch("alpro_gather_cast");
 }
 

@@ -137,6 +137,21 @@ template <typename T> __device__ __forceinline__ float gelu_fast(float x) {
   else return 0.5f * x * (1.0f + erf_as(x * 0.70710678118654752440f));
 }
 
+// gelu'(x) = Phi(x) + x phi(x); 16-bit storage shares one exp between the A-S erf and the density
+template <typename T> __device__ __forceinline__ float gelu_grad(float x) {
+  if constexpr (sizeof(T) == 4) {
+    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+    return cdf + x * 0.39894228040143267794f * __expf(-0.5f * x * x);
+  } else {
+    const float ax = fabsf(x) * 0.70710678118654752440f;
+    const float t = __frcp_rn(1.0f + 0.3275911f * ax);
+    const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+    const float e = __expf(-ax * ax);                       // exp(-x^2 / 2)
+    const float cdf = 0.5f + copysignf(0.5f - 0.5f * poly * e, x);
+    return cdf + x * 0.39894228040143267794f * e;
+  }
+}
+
 // ---- counter-based dropout mask: a pure function of (seed, element index), so the backward regenerates it ------
 __device__ __forceinline__ uint32_t mix32(uint32_t h) {  // "lowbias32" finalizer
   h ^= h >> 16; h *= 0x7FEB352Du; h ^= h >> 15; h *= 0x846CA68Bu; h ^= h >> 16;

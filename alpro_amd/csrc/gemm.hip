@@ -118,12 +118,34 @@ __device__ __forceinline__ void epi_rows16(const alpro_gemm_desc_t& g, const flo
     const float rs = g.row_scale ? g.row_scale[(m_base + row) / g.row_scale_group] : 1.0f;
 #pragma unroll
     for (int e = 0; e < 4; ++e) v[e] = g.alpha * v[e] + bias[e];
-    if (ACT != ALPRO_ACT_NONE && g.C2) {  // pre-activation copy (host guarantees vector alignment for C2)
+    if ((ACT == ALPRO_ACT_GELU || ACT == ALPRO_ACT_RELU) && g.C2) {  // pre-activation copy (host guarantees vector alignment for C2)
       if constexpr (sizeof(T) == 2) {
         *(u32x2*)((T*)g.C2 + orow[p] * g.ldc2 + n) = mk2(pack2(v[0], v[1], (T*)0), pack2(v[2], v[3], (T*)0));
       } else {
         *(float4*)((float*)g.C2 + orow[p] * g.ldc2 + n) = make_float4(v[0], v[1], v[2], v[3]);
       }
+    }
+    if (ACT == ALPRO_ACT_GELU_BWD) {  // v *= gelu'(saved pre-activation)
+      const T* pp = (const T*)g.C2 + orow[p] * g.ldc2 + n;
+      float pre[4];
+      if (FAST) {
+        if constexpr (sizeof(T) == 2) {
+          const u32x2 u = *(const u32x2*)pp;
+          const uint32_t ux = u.x, uy = u.y;
+          pre[0] = to_f32(T{(uint16_t)(ux & 0xFFFFu)});
+          pre[1] = to_f32(T{(uint16_t)(ux >> 16)});
+          pre[2] = to_f32(T{(uint16_t)(uy & 0xFFFFu)});
+          pre[3] = to_f32(T{(uint16_t)(uy >> 16)});
+        } else {
+          const float4 f = *(const float4*)pp;
+          pre[0] = f.x; pre[1] = f.y; pre[2] = f.z; pre[3] = f.w;
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) pre[e] = (n + e < g.N) ? to_f32(pp[e]) : 0.f;
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] *= gelu_grad<T>(pre[e]);
     }
 #pragma unroll
     for (int e = 0; e < 4; ++e) v[e] = apply_act<T, ACT>(v[e]) * rs;
@@ -174,7 +196,13 @@ __device__ __forceinline__ void epi_rows16_c16(const alpro_gemm_desc_t& g, const
     const float rs = g.row_scale ? g.row_scale[m / g.row_scale_group] : 1.0f;
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] = g.alpha * v[e] + bias[e];
-    if (ACT != ALPRO_ACT_NONE && g.C2) *(u32x4*)((T*)g.C2 + m * g.ldc2 + n) = pack_chunk<T>(v);
+    if ((ACT == ALPRO_ACT_GELU || ACT == ALPRO_ACT_RELU) && g.C2) *(u32x4*)((T*)g.C2 + m * g.ldc2 + n) = pack_chunk<T>(v);
+    if (ACT == ALPRO_ACT_GELU_BWD) {
+      float pre[8];
+      unpack_chunk<T>(*(const u32x4*)((const T*)g.C2 + m * g.ldc2 + n), pre);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] *= gelu_grad<T>(pre[e]);
+    }
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] = apply_act<T, ACT>(v[e]) * rs;
     if (g.drop_seed) {
@@ -381,15 +409,17 @@ __global__ __launch_bounds__(NT2, 2) void gemm_nt256p_kernel(const alpro_gemm_de
       w_src[i] = (const char*)g.W + min(n0 + row, g.N - 1) * ldw_b + ch * 16;
     }
   };
+  const uint32_t lds_base = lds_addr_of(smem);
+  // copy c = 0..7 of K-tile kt into stage buffer buf: (A, W) x 4 pieces of 1 KiB per wave.  Issued from inline asm
+  // (common.hpp dma16) and tracked by the hand-placed vmcnt waits below.
+  auto copy_piece = [&](int c, int kt, int buf) {
+    const int i = c >> 1;
+    const char* src = ((c & 1) ? w_src[i] : a_src[i]) + (int64_t)kt * ROWB;
+    dma16(src, __builtin_amdgcn_readfirstlane(lds_base + buf * 2 * TILE2_BYTES + (c & 1) * TILE2_BYTES + (wave + 8 * i) * 1024));
+  };
   auto stage_tile = [&](int kt, int buf) {
-    char* dA = smem + buf * 2 * TILE2_BYTES;
-    char* dW = dA + TILE2_BYTES;
-    const int64_t ko = (int64_t)kt * ROWB;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      __builtin_amdgcn_global_load_lds((gbl_ptr)(a_src[i] + ko), (lds_ptr)(dA + (wave + 8 * i) * 1024), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((gbl_ptr)(w_src[i] + ko), (lds_ptr)(dW + (wave + 8 * i) * 1024), 16, 0, 0);
-    }
+    for (int c = 0; c < 8; ++c) copy_piece(c, kt, buf);
   };
   int a_row[4], b_row[2];
 #pragma unroll
@@ -403,6 +433,7 @@ __global__ __launch_bounds__(NT2, 2) void gemm_nt256p_kernel(const alpro_gemm_de
   if (tile >= nblk) return;
   // Invariant at the top of every tile: K-tiles 0 and 1 are in buffers s0 and s0^1 and this wave has no DMA in flight,
   // so the first two K-steps need no vmcnt wait -- the previous tile's output stores drain underneath them.
+  const int pos = wave >> 2;
   auto wait_vm0 = [] { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
   auto block_sync = [] {  // barrier that does NOT drain vmcnt (a __syncthreads() would wait for the output stores)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -429,13 +460,16 @@ __global__ __launch_bounds__(NT2, 2) void gemm_nt256p_kernel(const alpro_gemm_de
       const int cur = s0 ^ (kt & 1);
       if (kt >= 2) wait_vm0();  // own pieces of K-tile kt (issued one step ago); at kt == 2 also the previous tile's stores
       block_sync();             // K-tile kt visible to everyone; everyone is done with K-tile kt-1
-      if (kt >= 1) {            // the buffer of K-tile kt-1 is free
-        if (kt + 1 < nk) {
-          stage_tile(kt + 1, cur ^ 1);
-        } else if (more) {      // last step: start the NEXT tile's first K-tile
-          setup(next);
-          stage_tile(0, cur ^ 1);
-        }
+      // The buffer of K-tile kt-1 is free from here on: its 8 copies (K-tile kt+1, or K-tile 0 of the NEXT tile on the
+      // last step) are issued BETWEEN this step's 32 MFMAs, and the two waves that share a SIMD (w, w+4) use alternating
+      // slots -- a copy stalls its wave ~60-150 cycles at issue, which the partner's MFMAs cover; issued back to back by
+      // all 8 waves right after the barrier they idle the whole CU for several hundred cycles per K-step.
+      int ckt = kt + 1;
+      bool do_copy = kt >= 1 && kt + 1 < nk;
+      if (kt >= 1 && kt + 1 == nk && more) {  // last step: start the NEXT tile's first K-tile
+        setup(next);
+        ckt = 0;
+        do_copy = true;
       }
       const char* cA = smem + cur * 2 * TILE2_BYTES;
       const char* cW = cA + TILE2_BYTES;
@@ -455,7 +489,11 @@ __global__ __launch_bounds__(NT2, 2) void gemm_nt256p_kernel(const alpro_gemm_de
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-          for (int j = 0; j < 2; ++j) mma_chunk<T>(acc[i][j], fa[s & 1][i], fb[s & 1][j]);
+          for (int j = 0; j < 2; ++j) {
+            mma_chunk<T>(acc[i][j], fa[s & 1][i], fb[s & 1][j]);
+            const int q = s * 8 + i * 2 + j;  // 0..31; copy c = q >> 2 goes after MFMA 4c+1 (waves 0-3) / 4c+3 (waves 4-7)
+            if ((q & 1) && do_copy && ((q >> 1) & 1) == pos) copy_piece(q >> 2, ckt, cur ^ 1);
+          }
       }
     }
     block_sync();  // everyone is done with the last K-tile: its buffer takes the next tile's K-tile 1
@@ -491,7 +529,7 @@ __global__ __launch_bounds__(NT2, 2) void gemm_nt256p_kernel(const alpro_gemm_de
             epi_rows16<T, ACT, MAP, FAST, 2>(g, st, mb + i * 32 + q * 8, nb, lane, bias);
           }
         }
-      };
+            };
       const bool fast = epi_fast_ok(g, mb, 128, nb);
       bool c16 = false;
       if constexpr (sizeof(T) == 2 && MAP == ALPRO_MAP_IDENTITY)
@@ -519,6 +557,7 @@ __global__ __launch_bounds__(NT2, 2) void gemm_nt256p_kernel(const alpro_gemm_de
     }
     if (!more) break;
     tile = next;
+    setup(tile);  // recomputed (not kept live): frees the 16 source-pointer registers across the epilogue
   }
 }
 
@@ -555,6 +594,7 @@ int launch_gemm(const alpro_gemm_desc_t& g, hipStream_t st) {
       set_error("alpro_gemm: an activation cannot be combined with a row map");
       return ALPRO_ERR_INVALID;
     }
+    if (g.act == ALPRO_ACT_GELU_BWD) return launch_gemm_inst<T, ALPRO_ACT_GELU_BWD, ALPRO_MAP_IDENTITY>(g, st);
     return g.act == ALPRO_ACT_GELU ? launch_gemm_inst<T, ALPRO_ACT_GELU, ALPRO_MAP_IDENTITY>(g, st)
                                    : launch_gemm_inst<T, ALPRO_ACT_RELU, ALPRO_MAP_IDENTITY>(g, st);
   }
@@ -578,7 +618,8 @@ extern "C" int alpro_gemm(const alpro_gemm_desc_t* d, void* stream) {
   ALPRO_CHECK(((uintptr_t)d->A % 16) == 0 && ((uintptr_t)d->W % 16) == 0, "alpro_gemm: A/W must be 16-byte aligned");
   ALPRO_CHECK(d->c_dtype == d->dtype || d->c_dtype == ALPRO_F32, "alpro_gemm: c_dtype must be dtype or F32");
   ALPRO_CHECK(d->map_mode >= 0 && d->map_mode <= 3, "alpro_gemm: bad map_mode %d", d->map_mode);
-  ALPRO_CHECK(d->act >= 0 && d->act <= 2, "alpro_gemm: bad act %d", d->act);
+  ALPRO_CHECK(d->act >= 0 && d->act <= ALPRO_ACT_GELU_BWD, "alpro_gemm: bad act %d", d->act);
+  ALPRO_CHECK(d->act != ALPRO_ACT_GELU_BWD || (d->C2 && d->N % 8 == 0 && d->ldc2 % 8 == 0), "alpro_gemm: GELU_BWD needs the saved pre-activation in C2 (N, ldc2 multiples of 8)");
   ALPRO_CHECK(!d->drop_seed || (d->map_mode == ALPRO_MAP_IDENTITY && d->drop_p > 0.f && d->drop_p < 1.f), "alpro_gemm: dropout needs the identity map and 0 < p < 1");
   ALPRO_CHECK(!d->C2 || (d->N % 4 == 0 && d->ldc2 % 4 == 0 && d->ldc % 4 == 0), "alpro_gemm: C2 needs N, ldc, ldc2 multiples of 4");
   ALPRO_CHECK(d->map_mode != ALPRO_MAP_FRAME_TOKENS || d->side, "alpro_gemm: FRAME_TOKENS needs a side buffer");

@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libalpro_hip.so")
 
 F32, BF16, F16 = 0, 1, 2
-ACT_NONE, ACT_GELU, ACT_RELU = 0, 1, 2
+ACT_NONE, ACT_GELU, ACT_RELU, ACT_GELU_BWD = 0, 1, 2, 3
 MAP_IDENTITY, MAP_SKIP_CLS, MAP_FRAME_TOKENS, MAP_PATCH_EMBED = 0, 1, 2, 3
 
 _TORCH_DTYPE = {F32: torch.float32, BF16: torch.bfloat16, F16: torch.float16}
@@ -68,7 +68,7 @@ def load():
     lib.alpro_gemm_tn_acc.argtypes = [vp, i64, vp, i64, vp, i64, i32, i32, i32, i32, vp]
     lib.alpro_colsum_acc.argtypes = [vp, i64, vp, i32, i32, i32, vp]
     lib.alpro_adamw_step.argtypes = [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, f32, vp, f32, f32, vp]
-    lib.alpro_gather_cast.argtypes = [vp, i64, vp, i32, i32, i32, i32, i32, i32, vp, i32, f32, f32, u32, vp]
+    lib.alpro_gather_cast.argtypes = [vp, i64, vp, i32, i32, i32, i32, i32, i32, vp, i32, f32, f32, u32, vp, vp]
     lib.alpro_cls_mean_bwd.argtypes = [vp, i64, vp, i32, i32, i32, vp]
     lib.alpro_scatter_add_rows.argtypes = [vp, vp, vp, i32, i32, i32, vp]
     lib.alpro_attn_fwd.argtypes = [vp, vp, i32, i32, i32, i32, f32, vp, vp, f32, u32, vp]
@@ -77,7 +77,7 @@ def load():
     lib.alpro_vit_final_pool.argtypes = [vp, vp, vp, f32, vp, vp, i32, i32, i32, i32, i32, vp]
     lib.alpro_bert_embed_fwd.argtypes = [vp, vp, vp, vp, vp, vp, f32, vp, vp, i32, vp, vp, i32, i32, i32, f32, u32, vp]
     lib.alpro_cast_from_f32.argtypes = [vp, vp, i32, i64, vp]
-    if lib.alpro_hip_abi_version() != 3:
+    if lib.alpro_hip_abi_version() != 4:
         raise RuntimeError("libalpro_hip.so ABI version mismatch")
     _lib = lib
     return lib
@@ -117,7 +117,8 @@ def torch_dtype(code):
 # ------------------------------------------------------------------------------------------------
 def gemm(a, w, out=None, bias=None, act=ACT_NONE, out_dtype=None, alpha=1.0, row_scale=None, row_scale_group=1,
          residual=None, map_mode=MAP_IDENTITY, map_p0=0, map_p1=0, side=None, out_rows=None, pre_act=None, drop_p=0.0, drop_seed=0):
-    """out[map(m)] = residual[map(m)] + row_scale * act(alpha * a @ w.T + bias)   (see alpro_gemm)."""
+    """out[map(m)] = residual[map(m)] + row_scale * act(alpha * a @ w.T + bias)   (see alpro_gemm).
+    act=ACT_GELU_BWD: out = (alpha * a @ w.T + bias) * gelu'(pre_act) (pre_act read only)."""
     lib = load()
     _dev(a); _dev(w, a.dtype)
     M, K = a.shape
@@ -225,15 +226,16 @@ def transpose(x, out_dtype=None, pad_to=64, colsum=None):
 
 
 def gather_cast(src, dtype, rows=None, map_mode=MAP_IDENTITY, map_p0=0, map_p1=0, row_scale=None, row_scale_group=1, cls_scale=1.0,
-                drop_p=0.0, drop_seed=0):
-    """fp32 (..., 768) token-gradient rows -> (rows, 768) GEMM operand in `dtype` (see alpro_gather_cast)."""
+                drop_p=0.0, drop_seed=0, colsum=None):
+    """fp32 (..., 768) token-gradient rows -> (rows, 768) GEMM operand in `dtype` (see alpro_gather_cast); colsum (768,) fp32 += out.sum(0)."""
     lib = load()
     _dev(src, torch.float32)
     D = src.shape[-1]
     rows = rows if rows is not None else src.numel() // D
     out = torch.empty((rows, D), dtype=dtype, device=src.device)
     _check(lib.alpro_gather_cast(_ptr(src), D, _ptr(out), _CODE[dtype], rows, D, map_mode, map_p0, map_p1,
-                                 _ptr(_dev(row_scale, torch.float32)) if row_scale is not None else None, row_scale_group, cls_scale, drop_p, drop_seed, _stream()),
+                                 _ptr(_dev(row_scale, torch.float32)) if row_scale is not None else None, row_scale_group, cls_scale, drop_p, drop_seed,
+                                 _ptr(_dev(colsum, torch.float32)) if colsum is not None else None, _stream()),
            "alpro_gather_cast")
     return out
 

@@ -43,10 +43,18 @@ def transposed_operand(cache, key, weight, dt):
     return out
 
 
-def wgrad(dy_t, x_t, weight, bias):
-    """weight.grad += dy^T x ; bias.grad += colsum(dy).  dy_t (M, N), x_t (M, K) operand-dtype activations.
-    16-bit operands: alpro_gemm_tn_acc reads both in place (split over tokens, fp32 atomics); fp32 (exact mode):
-    transposed copies + the NT GEMM."""
+def bias_grad(bias):
+    """fp32 .grad buffer of a bias (zero-initialised on first use): the `colsum` target of the kernel that PRODUCES the
+    Linear's output gradient (alpro_gather_cast / alpro_gemm epilogue), so dY is not read a second time for it."""
+    return grad_buffer(bias, zero=True)[0]
+
+
+def wgrad(dy_t, x_t, weight, bias, bias_done=False):
+    """weight.grad += dy^T x ; bias.grad += colsum(dy) unless the producer of dy already did (bias_done).
+    dy_t (M, N), x_t (M, K) operand-dtype activations.  16-bit operands: alpro_gemm_tn_acc reads both in place (split
+    over tokens, fp32 atomics); fp32 (exact mode): transposed copies + the NT GEMM."""
+    if bias_done:
+        bias = None
     if bias is not None:
         gb = grad_buffer(bias, zero=True)[0]
     gw, existed = grad_buffer(weight, zero=True)
@@ -60,8 +68,10 @@ def wgrad(dy_t, x_t, weight, bias):
     hip.gemm(dyT, hip.transpose(x_t), out=gw2, out_dtype=torch.float32, residual=gw2)
 
 
-def dgrad(dy_t, wT, out_dtype=None, row_scale=None, row_scale_group=1):
-    """dX = dy @ W using the cached transposed operand wT (K, N64); dy_t (M, N)."""
+def dgrad(dy_t, wT, out_dtype=None, row_scale=None, row_scale_group=1, gelu_pre=None):
+    """dX = dy @ W using the cached transposed operand wT (K, N64); dy_t (M, N).
+    gelu_pre: saved pre-activation of the GELU that produced this Linear's input -> dX *= gelu'(pre) in the epilogue
+    (the elementwise GELU backward never runs as its own pass)."""
     n = dy_t.shape[1]
     w = wT if wT.shape[1] == n else wT[:, :n]
     if not w.is_contiguous() or n % (64 if dy_t.dtype != torch.float32 else 32) != 0:
@@ -69,7 +79,8 @@ def dgrad(dy_t, wT, out_dtype=None, row_scale=None, row_scale_group=1):
         pad = wT.shape[1] - n
         dy_t = torch.nn.functional.pad(dy_t, (0, pad))
         w = wT
-    return hip.gemm(dy_t, w, out_dtype=out_dtype or dy_t.dtype, row_scale=row_scale, row_scale_group=row_scale_group)
+    return hip.gemm(dy_t, w, out_dtype=out_dtype or dy_t.dtype, row_scale=row_scale, row_scale_group=row_scale_group,
+                    act=hip.ACT_GELU_BWD if gelu_pre is not None else hip.ACT_NONE, pre_act=gelu_pre)
 
 
 class Anchor(torch.autograd.Function):

@@ -156,14 +156,15 @@ class BertLayer(nn.Module):
 
         hp, seed1, seed2, ap, seed_a = sv["drop"]
         ds2 = ln_bwd(self.output.LayerNorm, sv["s2"], do_t, do32)          # also d(a32): identity residual
-        ds2_t = hip.gather_cast(ds2, dt, drop_p=hp, drop_seed=seed2)     # through the FFN-output dropout
-        tr.wgrad(ds2_t, sv["it"], self.output.dense.weight, self.output.dense.bias)
-        du = hip.gelu_bwd(tr.dgrad(ds2_t, tr.transposed_operand(self._ops, "o_w^T", self.output.dense.weight, dt)), sv["u"])
+        # through the FFN-output dropout; bias gradients are column sums taken by the kernel that produces each dY
+        ds2_t = hip.gather_cast(ds2, dt, drop_p=hp, drop_seed=seed2, colsum=tr.bias_grad(self.output.dense.bias))
+        tr.wgrad(ds2_t, sv["it"], self.output.dense.weight, self.output.dense.bias, bias_done=True)
+        du = tr.dgrad(ds2_t, tr.transposed_operand(self._ops, "o_w^T", self.output.dense.weight, dt), gelu_pre=sv["u"])
         tr.wgrad(du, sv["a_t"], self.intermediate.dense.weight, self.intermediate.dense.bias)
         da_t = tr.dgrad(du, tr.transposed_operand(self._ops, "i_w^T", self.intermediate.dense.weight, dt))
         ds1 = ln_bwd(so.LayerNorm, sv["s1"], da_t, ds2)                     # also d(h32): identity residual
-        ds1_t = hip.gather_cast(ds1, dt, drop_p=hp, drop_seed=seed1)     # through the attention-output dropout
-        tr.wgrad(ds1_t, sv["ctx"], so.dense.weight, so.dense.bias)
+        ds1_t = hip.gather_cast(ds1, dt, drop_p=hp, drop_seed=seed1, colsum=tr.bias_grad(so.dense.bias))  # through the attention-output dropout
+        tr.wgrad(ds1_t, sv["ctx"], so.dense.weight, so.dense.bias, bias_done=True)
         dctx = tr.dgrad(ds1_t, tr.transposed_operand(self._ops, "ao_w^T", so.dense.weight, dt))
         dqkv = hip.attn_bwd(sv["qkv"], sv["ctx"], dctx, sv["lse"], B, L, H, scale, sv["kb"], drop_p=ap, drop_seed=seed_a)
         # fused q/k/v projection: the three weight gradients come from the three column blocks of dqkv

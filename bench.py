@@ -79,7 +79,7 @@ class KernelTimer:
         self.hip, self.rec, self.orig = hip, [], {}
 
     def __enter__(self):
-        def wrap(name, flops_fn):
+        def wrap(name, flops_fn, key_fn=None):
             fn = getattr(self.hip, name)
             self.orig[name] = fn
 
@@ -88,10 +88,15 @@ class KernelTimer:
                 e0.record()
                 out = fn(*a, **k)
                 e1.record()
-                self.rec.append((name, flops_fn(*a, **k), e0, e1))
+                self.rec.append((name, flops_fn(*a, **k), e0, e1, key_fn(*a, **k) if key_fn else ""))
                 return out
             setattr(self.hip, name, timed)
-        wrap("gemm", lambda a, w, *r, **k: 2.0 * a.shape[0] * a.shape[1] * w.shape[0])
+
+        def gemm_key(a, w, *r, **k):
+            od = k.get("out_dtype")
+            return "M=%d N=%d K=%d act=%s res=%d out=%s map=%s" % (a.shape[0], w.shape[0], a.shape[1], k.get("act", 0), k.get("residual") is not None,
+                                                              str(od).replace("torch.", "") if od is not None else "-", k.get("map_mode", 0))
+        wrap("gemm", lambda a, w, *r, **k: 2.0 * a.shape[0] * a.shape[1] * w.shape[0], gemm_key)
         wrap("attn", lambda qkv, batch, L, H, *r, **k: 4.0 * batch * H * L * L * 64)
         wrap("attn_temporal", lambda qkv, T, H, *r, **k: 4.0 * qkv.shape[0] * T * H * 64)
         wrap("layernorm", lambda *a, **k: 0.0)
@@ -101,7 +106,8 @@ class KernelTimer:
         wrap("transpose", lambda *a, **k: 0.0)
         wrap("gather_cast", lambda *a, **k: 0.0)
         wrap("gelu_bwd", lambda *a, **k: 0.0)
-        wrap("gemm_tn_acc", lambda a, b, c, *r, **k: 2.0 * a.shape[0] * a.shape[1] * b.shape[1])
+        wrap("gemm_tn_acc", lambda a, b, c, *r, **k: 2.0 * a.shape[0] * a.shape[1] * b.shape[1],
+             lambda a, b, c, *r, **k: "M=%d N=%d K=%d" % (a.shape[0], a.shape[1], b.shape[1]))
         wrap("colsum_acc", lambda *a, **k: 0.0)
         wrap("adamw_step", lambda *a, **k: 0.0)
         wrap("sumsq", lambda *a, **k: 0.0)
@@ -114,11 +120,20 @@ class KernelTimer:
     def summary(self):
         torch.cuda.synchronize()
         agg = {}
-        for name, fl, e0, e1 in self.rec:
+        shapes = {}
+        for name, fl, e0, e1, key in self.rec:
             d = agg.setdefault(name, [0, 0.0, 0.0])
             d[0] += 1
             d[1] += fl
             d[2] += e0.elapsed_time(e1)
+            if key:
+                sd = shapes.setdefault((name, key), [0, 0.0, 0.0])
+                sd[0] += 1
+                sd[1] += fl
+                sd[2] += e0.elapsed_time(e1)
+        if os.environ.get("ALPRO_BENCH_SHAPES"):  # per-shape GEMM table (tuning aid), to stderr
+            for (name, key), (c, f, ms) in sorted(shapes.items(), key=lambda kv: -kv[1][2]):
+                sys.stderr.write("%-12s %-70s n=%3d  %8.3f ms  %6.0f TF/s\n" % (name, key, c, ms, f / ms / 1e9))
         return {n: {"launches": c, "flops": f, "ms": ms} for n, (c, f, ms) in agg.items()}
 
 

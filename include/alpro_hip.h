@@ -24,11 +24,13 @@
 extern "C" {
 #endif
 
-#define ALPRO_HIP_ABI_VERSION 3
+#define ALPRO_HIP_ABI_VERSION 4
 
 enum { ALPRO_OK = 0, ALPRO_ERR_INVALID = 1, ALPRO_ERR_LAUNCH = 2 };
 enum { ALPRO_F32 = 0, ALPRO_BF16 = 1, ALPRO_F16 = 2 };
-enum { ALPRO_ACT_NONE = 0, ALPRO_ACT_GELU = 1, ALPRO_ACT_RELU = 2 };
+/* GELU_BWD (backward of a GELU Linear, vit.py:61 / xbert.py:423): C = (alpha*acc + bias) * gelu'(C2[m, n]) where C2 is
+ * the READ-ONLY pre-activation the forward GEMM saved; fuses the elementwise backward into the dgrad GEMM. */
+enum { ALPRO_ACT_NONE = 0, ALPRO_ACT_GELU = 1, ALPRO_ACT_RELU = 2, ALPRO_ACT_GELU_BWD = 3 };
 
 /* Row maps: how GEMM/LayerNorm row m addresses the (B, 1 + N*T, D) token tensor whose patch token
  * (n, t) lives at row 1 + n*T + t of its clip (vit.py:147 'b (h w t) m').
@@ -73,7 +75,8 @@ typedef struct {
   int map_mode, map_p0, map_p1; /* ALPRO_MAP_* applied to C rows and residual rows */
   float* side;            /* FRAME_TOKENS: (B*T, N) fp32 buffer receiving the j == 0 rows (no residual) */
   int64_t ld_side;
-  void* C2;               /* optional (M, N) `dtype` copy of the pre-activation alpha*acc+bias (kept for the GELU backward) */
+  void* C2;               /* GELU/RELU: optional (M, N) `dtype` copy of the pre-activation alpha*acc+bias (kept for the
+                             backward).  GELU_BWD: the saved pre-activation, read only (required). */
   int64_t ldc2;
   float drop_p;           /* dropout on the value BEFORE the residual add (xbert.py:358,436): keep iff hash(seed, m*N+n) */
   uint32_t drop_seed;     /* passes, kept values scaled by 1/(1-p); 0 = off.  Identity map only. */
@@ -160,8 +163,9 @@ int alpro_transpose(const void* in, int in_dtype, int64_t ld_in, void* out, int 
  * FRAME_TOKENS the j == 0 rows read the clip's CLS row times cls_scale (= 1/T, the frame mean of vit.py:187). */
 int alpro_gather_cast(const float* src, int64_t ld, void* out, int dtype, int rows, int D, int map_mode, int map_p0,
                       int map_p1, const float* row_scale, int row_scale_group, float cls_scale, float drop_p,
-                      uint32_t drop_seed, void* stream);
-/* drop_p > 0: additionally re-applies the GEMM-epilogue dropout mask hash(seed, m*D+n)/(1-p) (backward of alpro_gemm's drop_p). */
+                      uint32_t drop_seed, float* colsum, void* stream);
+/* drop_p > 0: additionally re-applies the GEMM-epilogue dropout mask hash(seed, m*D+n)/(1-p) (backward of alpro_gemm's drop_p).
+ * colsum (optional, (D) fp32): colsum[n] += sum_m out[m, n] -- the bias gradient of the Linear these rows are the dY of. */
 
 /* du = dh * gelu'(u) with the erf GELU (vit.py:61 / xbert.py:423 backward). */
 int alpro_gelu_bwd(const void* dh, const void* u, void* du, int dtype, int64_t n, void* stream);

@@ -285,3 +285,35 @@ def test_softmax_xent(dt):
     assert dl.shape == (M, 30528) and float(dl[:, V:].abs().sum()) == 0
     tol = (1e-5, 1e-8) if dt == torch.float32 else (1e-2, 1e-7)
     close(dl[:, :V], l64.grad, *tol, "xent grad")
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("M,N,K,tile", [(300, 3072, 768, "128"), (70000, 768, 768, "256"), (1000, 256, 768, "256")])
+def test_gemm_gelu_bwd_epilogue(dt, M, N, K, tile, monkeypatch):
+    """alpro_gemm with ACT_GELU_BWD (dX *= gelu'(saved pre-activation)) on both tile kernels incl. partial edge tiles."""
+    hip = _hip()
+    monkeypatch.setenv("ALPRO_GEMM_TILE", tile)
+    dy = rnd(M, K, seed=300, scale=0.5).to(dt)
+    w = rnd(N, K, seed=301, scale=0.05).to(dt)
+    pre = rnd(M, N, seed=302).to(dt)
+    out = hip.gemm(dy.cuda(), w.cuda(), act=hip.ACT_GELU_BWD, pre_act=pre.cuda())
+    p64 = pre.double().requires_grad_(True)
+    torch.nn.functional.gelu(p64).sum().backward()
+    ref = (dy.double() @ w.double().T) * p64.grad
+    rt, at = {torch.float32: (1e-4, 1e-4), torch.bfloat16: (1.5e-2, 1.5e-2), torch.float16: (3e-3, 3e-3)}[dt]
+    close(out, ref, rt, at, "gelu-bwd epilogue")
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_gather_cast_colsum(dt):
+    hip = _hip()
+    B, T, N = 2, 4, 9
+    dx = rnd(B, 1 + N * T, 768, seed=310)
+    cs = torch.ones(768).cuda()
+    rs = torch.rand(B * T).cuda()
+    out = hip.gather_cast(dx.cuda(), dt, rows=B * T * (N + 1), map_mode=hip.MAP_FRAME_TOKENS, map_p0=T, map_p1=N, row_scale=rs,
+                          row_scale_group=N + 1, cls_scale=1.0 / T, colsum=cs)
+    ref = hip.gather_cast(dx.cuda(), torch.float32, rows=B * T * (N + 1), map_mode=hip.MAP_FRAME_TOKENS, map_p0=T, map_p1=N, row_scale=rs,
+                          row_scale_group=N + 1, cls_scale=1.0 / T)
+    close(out, ref.cpu().double(), *((1e-6, 1e-6) if dt == torch.float32 else (1e-2, 1e-2)), "gather_cast")
+    close(cs, 1 + ref.cpu().double().sum(0), 1e-4, 1e-4, "gather_cast colsum")
