@@ -561,210 +561,6 @@ __global__ __launch_bounds__(NT2, 2) void gemm_nt256p_kernel(const alpro_gemm_de
   }
 }
 
-// ------------------------------------------------------------------------------------------------
-// Two-workgroups-per-CU form (16-bit storage).  256x128 tile, 4 waves (2 x 2, 128x64 each = 4x2 MFMA accumulators), 80 KiB
-// of LDS and <= 256 registers, so TWO persistent workgroups share a CU (one wave of each per SIMD) and de-phase: one
-// workgroup's epilogue (LDS transposes, VALU activation, the store path at ~11 B/clk/CU) and its barrier / copy-issue
-// stalls run under the other's MFMAs, which the one-workgroup 256x256 kernel cannot overlap with anything.
-//  * K-stage = 32 elements (64-byte rows): 3 stages x (A 16 KiB + W 8 KiB) ring + 2 KiB epilogue staging per wave;
-//    LDS slot (row, c') holds source chunk c' ^ ((row >> 2) & 3) -> conflict-free ds_read_b128 fragments;
-//  * copies are issued from inline asm (dma16) by a "copy cursor" that runs three stages ahead of the MFMAs and simply
-//    continues into the next tile's K-loop (and into zero-page dummies at the very end), so every wave issues exactly 6
-//    copies per step and `s_waitcnt vmcnt(6)` is exact; 3 copies go in each half step, between the MFMAs;
-//  * fragments are double buffered across a mid-step barrier (first 16 k of stage g+1 are fetched while the second 16 k of
-//    stage g are multiplied), so no MFMA waits on an LDS read issued in the same half step.
-constexpr int BM3 = 256, BN3 = 128, NT4 = 256, ROWB3 = 64;
-constexpr int STG3_A = BM3 * ROWB3, STG3_W = BN3 * ROWB3, STG3 = STG3_A + STG3_W;  // 16 + 8 = 24 KiB per stage
-constexpr int NSTG3 = 3;
-constexpr int LDS3_BYTES = NSTG3 * STG3 + 4 * 2048;  // 80 KiB
-__device__ __forceinline__ int lds_off3(int row, int chunk) { return row * ROWB3 + ((chunk ^ ((row >> 2) & 3)) << 4); }
-__device__ u32x4 g_gemm_zero[4];
-
-template <typename T, int ACT, int MAP>
-__global__ __launch_bounds__(NT4, 2) void gemm_nt2_kernel(const alpro_gemm_desc_t g) {
-  static_assert(sizeof(T) == 2, "16-bit storage only");
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wr = wave >> 1, wc = wave & 1;
-  const int ntn = (g.N + BN3 - 1) / BN3, ntm = (g.M + BM3 - 1) / BM3;
-  const int nblk = ntn * ntm;
-  const int64_t lda_b = g.lda * 2, ldw_b = g.ldw * 2;
-  const int nk = (g.K * 2) / ROWB3;
-  const int per_xcd = (gridDim.x + 7) >> 3;
-  const int slot = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);  // XCD-contiguous walk
-  if (slot >= nblk) return;
-  const uint32_t lds_base = lds_addr_of(smem);
-  const char* zero = (const char*)g_gemm_zero;
-
-  // ---- copy cursor: (tile, stage) being copied, three stages ahead of the MFMAs
-  const char* src[6];  // per-lane source of copy c at stage 0 of the cursor tile: c < 4 -> A piece wave+4c, else W piece wave+4(c-4)
-  int c_tile = slot, c_kt = 0, c_buf = 0;
-  int64_t c_off = 0, c_stride = ROWB3;
-  auto cursor_setup = [&](int tile) {
-    if (tile < nblk) {
-      const int tm = tile / ntn, tn = tile - tm * ntn;
-#pragma unroll
-      for (int c = 0; c < 6; ++c) {
-        const int piece = wave + 4 * (c < 4 ? c : c - 4);
-        const int row = piece * 16 + (lane >> 2);
-        const int ch = (lane & 3) ^ ((row >> 2) & 3);
-        src[c] = c < 4 ? (const char*)g.A + min(tm * BM3 + row, g.M - 1) * lda_b + ch * 16
-                       : (const char*)g.W + min(tn * BN3 + row, g.N - 1) * ldw_b + ch * 16;
-      }
-      c_stride = ROWB3;
-    } else {  // past the last tile: dummy copies keep the per-step copy count (and with it the vmcnt arithmetic) uniform
-#pragma unroll
-      for (int c = 0; c < 6; ++c) src[c] = zero;
-      c_stride = 0;
-    }
-    c_off = 0;
-    c_kt = 0;
-  };
-  auto copy1 = [&](int c) {
-    const uint32_t dst = lds_base + c_buf * STG3 + (c < 4 ? (wave + 4 * c) * 1024 : STG3_A + (wave + 4 * (c - 4)) * 1024);
-    dma16(src[c] + c_off, __builtin_amdgcn_readfirstlane(dst));
-  };
-  auto cursor_advance = [&] {
-    c_buf = c_buf == NSTG3 - 1 ? 0 : c_buf + 1;
-    c_off += c_stride;
-    if (++c_kt == nk) {
-      c_tile += gridDim.x;
-      cursor_setup(c_tile);
-    }
-  };
-
-  int a_row[4], b_row[2];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) a_row[i] = wr * 128 + i * 32 + (lane & 31);
-#pragma unroll
-  for (int j = 0; j < 2; ++j) b_row[j] = wc * 64 + j * 32 + (lane & 31);
-  const int khalf = lane >> 5;
-  float* stage = (float*)(smem + NSTG3 * STG3 + wave * 2048);
-  auto load_frags = [&](u32x4(&fa)[4], u32x4(&fb)[2], int buf, int ks) {
-    const char* cA = smem + buf * STG3;
-    const char* cW = cA + STG3_A;
-#pragma unroll
-    for (int j = 0; j < 2; ++j) fb[j] = *(const u32x4*)(cW + lds_off3(b_row[j], 2 * ks + khalf));
-#pragma unroll
-    for (int i = 0; i < 4; ++i) fa[i] = *(const u32x4*)(cA + lds_off3(a_row[i], 2 * ks + khalf));
-  };
-
-  // ---- prologue: stages 0 and 1 whole, first half of stage 2
-  cursor_setup(slot);
-#pragma unroll
-  for (int p = 0; p < 2; ++p) {
-#pragma unroll
-    for (int c = 0; c < 6; ++c) copy1(c);
-    cursor_advance();
-  }
-#pragma unroll
-  for (int c = 0; c < 3; ++c) copy1(c);
-  asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  asm volatile("" ::: "memory");
-  u32x4 fa0[4], fb0[2], fa1[4], fb1[2];
-  load_frags(fa0, fb0, 0, 0);
-
-  int tile = slot, cb = 0;
-  bool after_epilogue = false;
-  while (true) {
-    const int tm = tile / ntn, tn = tile - tm * ntn;
-    const int tm0 = tm * BM3, tn0 = tn * BN3;
-    const bool more = tile + (int)gridDim.x < nblk;
-    f32x16 acc[4][2];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    for (int kt = 0; kt < nk; ++kt) {
-      // first half: second 16 k of this stage -> F1; MFMAs on F0; copies 3..5 of the cursor stage
-      load_frags(fa1, fb1, cb, 1);
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          mma_chunk<T>(acc[i][j], fa0[i], fb0[j]);
-          const int q = i * 2 + j;
-          if (q == 1 || q == 3 || q == 5) copy1(3 + (q >> 1));
-        }
-      cursor_advance();
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave is done reading stage buffer cb
-      // stage g+1 landed: everything but the 6 copies of stage g+2 (right after an epilogue its wait-for-all already
-      // covered stage g+1, and waiting here would only drain the tile's output stores)
-      if (!(kt == 0 && after_epilogue)) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      asm volatile("" ::: "memory");
-      // second half: first 16 k of the next stage -> F0; MFMAs on F1; copies 0..2 of the cursor stage (into buffer cb)
-      const int nb = cb == NSTG3 - 1 ? 0 : cb + 1;
-      load_frags(fa0, fb0, nb, 0);
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          mma_chunk<T>(acc[i][j], fa1[i], fb1[j]);
-          const int q = i * 2 + j;
-          if (q == 1 || q == 3 || q == 5) copy1(q >> 1);
-        }
-      cb = nb;
-    }
-    // ---- epilogue (the copies in flight are waited for first, so that afterwards vmcnt only has to account for this
-    // tile's stores, which are older than anything the next steps wait on)
-    {
-      const int mb = tm0 + wr * 128, nbc = tn0 + wc * 64;
-      float bias[4];
-      load_bias4(g, nbc + (lane & 15) * 4, bias);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      auto stage_chunk = [&](const f32x16& a0, const f32x16& a1, int q) {
-#pragma unroll
-        for (int r4 = 0; r4 < 4; ++r4) {
-          const int row = r4 + 4 * (lane >> 5);
-          stage[row * 64 + (lane & 31)] = a0[4 * q + r4];
-          stage[row * 64 + 32 + (lane & 31)] = a1[4 * q + r4];
-        }
-      };
-      auto run_epilogue = [&](auto fast_tag) {
-        constexpr bool FAST = decltype(fast_tag)::value;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            stage_chunk(acc[i][0], acc[i][1], q);
-            epi_rows16<T, ACT, MAP, FAST, 2>(g, stage, mb + i * 32 + q * 8, nbc, lane, bias);
-          }
-        }
-      };
-      const bool fast = epi_fast_ok(g, mb, 128, nbc);
-      bool c16 = false;
-      if constexpr (MAP == ALPRO_MAP_IDENTITY) c16 = fast && g.c_dtype != ALPRO_F32 && ((g.ldc & 7) == 0) && (!g.C2 || (g.ldc2 & 7) == 0);
-      if (c16) {
-        if constexpr (MAP == ALPRO_MAP_IDENTITY) {
-          float bias8[8];
-#pragma unroll
-          for (int e = 0; e < 8; ++e) bias8[e] = g.bias ? g.bias[nbc + (lane & 7) * 8 + e] : 0.f;
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              stage_chunk(acc[i][0], acc[i][1], q);
-              epi_rows16_c16<T, ACT, 1>(g, stage, mb + i * 32 + q * 8, nbc, lane, bias8);
-            }
-          }
-        }
-      } else if (fast) {
-        run_epilogue(std::true_type{});
-      } else {
-        run_epilogue(std::false_type{});
-      }
-    }
-    if (!more) break;
-    tile += gridDim.x;
-    after_epilogue = true;
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the trailing dummy copies before the LDS is released
-}
-
 template <typename T, int ACT, int MAP>
 int launch_gemm_inst(const alpro_gemm_desc_t& g, hipStream_t st) {
   static bool attr_set = false;
@@ -775,23 +571,6 @@ int launch_gemm_inst(const alpro_gemm_desc_t& g, hipStream_t st) {
   }
   const int big_tiles = ((g.N + BN2 - 1) / BN2) * ((g.M + BM2 - 1) / BM2);
   const char* force = getenv("ALPRO_GEMM_TILE");
-  if constexpr (sizeof(T) == 2) {
-    // two-workgroups-per-CU kernel: 16-bit storage, K a multiple of 32 with >= 2 stages, at least one tile per CU
-    const int tiles2 = ((g.N + BN3 - 1) / BN3) * ((g.M + BM3 - 1) / BM3);
-    const int nk3 = (g.K * 2) / ROWB3;
-    const bool ok2 = (g.K * 2) % ROWB3 == 0 && nk3 >= 2;
-    if (ok2 && (force ? atoi(force) == 2 : false)) {
-      static bool set2 = false;
-      if (!set2) {
-        (void)hipFuncSetAttribute((const void*)gemm_nt2_kernel<T, ACT, MAP>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS3_BYTES);
-        set2 = true;
-      }
-      int grid2 = tiles2 < 512 ? (tiles2 + 7) / 8 * 8 : 512;  // multiple of 8: the XCD-contiguous slot map must be a bijection
-      if (const char* e = getenv("ALPRO_GEMM_GRID")) grid2 = atoi(e) < grid2 ? (atoi(e) + 7) / 8 * 8 : grid2;
-      hipLaunchKernelGGL((gemm_nt2_kernel<T, ACT, MAP>), dim3(grid2), dim3(NT4), LDS3_BYTES, st, g);
-      return check_launch("alpro_gemm");
-    }
-  }
   const int nk = (g.K * (int)sizeof(T)) / ROWB;
   // at least one full wave of 256^2 tiles on the 256 CUs; the persistent kernel's pipeline needs >= 2 K-tiles
   const bool use256 = nk >= 2 && (force ? atoi(force) == 256 : big_tiles >= 256);
