@@ -572,11 +572,11 @@ int launch_gemm_inst(const alpro_gemm_desc_t& g, hipStream_t st) {
   const int big_tiles = ((g.N + BN2 - 1) / BN2) * ((g.M + BM2 - 1) / BM2);
   const char* force = getenv("ALPRO_GEMM_TILE");
   const int nk = (g.K * (int)sizeof(T)) / ROWB;
-  // at least one full wave of 256^2 tiles on the 256 CUs; the persistent kernel's pipeline needs >= 2 K-tiles
-  const bool use256 = nk >= 2 && (force ? atoi(force) == 256 : big_tiles >= 256);
+  // the persistent 256^2 kernel wins from ~160 tiles up (measured, tools/gemm_bert_bench.py: M=15168 N=768 = 180 tiles is 15-25 % faster than on the 128^2 kernel; M=2560 N=3072 = 120 tiles is not); its pipeline needs >= 2 K-tiles
+  const bool use256 = nk >= 2 && (force ? atoi(force) == 256 : big_tiles >= 160);
   if (use256) {
-    int grid = big_tiles < 256 ? big_tiles : 256;
-    if (const char* e = getenv("ALPRO_GEMM_GRID")) grid = atoi(e) < grid ? atoi(e) : grid;  // tuning aid: cap the persistent grid
+    int grid = big_tiles < 256 ? (big_tiles + 7) / 8 * 8 : 256;  // multiple of 8: the XCD-contiguous slot map must be a bijection
+    if (const char* e = getenv("ALPRO_GEMM_GRID")) grid = atoi(e) < grid ? (atoi(e) + 7) / 8 * 8 : grid;  // tuning aid: cap the persistent grid
     hipLaunchKernelGGL((gemm_nt256p_kernel<T, ACT, MAP>), dim3(grid), dim3(NT2), 4 * TILE2_BYTES + EPI_BYTES, st, g);
   } else {
     const int ntn = (g.N + BN - 1) / BN, ntm = (g.M + BM - 1) / BM;
