@@ -50,7 +50,7 @@ __device__ __forceinline__ u32x4 frag8(const char* img, int ks, int col0, int la
 template <typename T>
 __global__ __launch_bounds__(NT3, 1) void gemm_tn_kernel(const T* __restrict__ A, int64_t lda, const T* __restrict__ B, int64_t ldb,
                                                          float* __restrict__ C, int64_t ldc, int M, int N, int K, int steps_per_split,
-                                                         int tn_cnt, int tk_cnt) {
+                                                         int tn_cnt, int tk_cnt, float* __restrict__ colsum) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 2, wc = wave & 3;
@@ -140,6 +140,19 @@ __global__ __launch_bounds__(NT3, 1) void gemm_tn_kernel(const T* __restrict__ A
 #pragma unroll
     for (int i = 0; i < 4; ++i) fa[i] = frag8(cA, ks, wr * 128 + i * 32, lane);
   };
+  // Bias gradient for free: colsum[n] += sum over tokens of A[m, n].  The A fragments already sit in registers (lane = one
+  // column, 8 tokens per fragment), so the waves of the first k-tile column (k0 == 0, wc == 0) add them up on the VALU
+  // while the MFMA pipe runs -- the separate pass over dY that torch / alpro_colsum_acc would make never happens.
+  const bool do_cs = colsum != nullptr && k0 == 0 && wc == 0;
+  float cs[4] = {0.f, 0.f, 0.f, 0.f};
+  auto add_cols = [&](const u32x4* fa) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float f[8];
+      unpack_chunk<T>(fa[i], f);
+      cs[i] += ((f[0] + f[1]) + (f[2] + f[3])) + ((f[4] + f[5]) + (f[6] + f[7]));
+    }
+  };
   u32x4 fa0[4], fb0[2], fa1[4], fb1[2];
   asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
   __builtin_amdgcn_s_barrier();
@@ -157,6 +170,7 @@ __global__ __launch_bounds__(NT3, 1) void gemm_tn_kernel(const T* __restrict__ A
         mma_chunk<T>(acc[i][j], fa0[i], fb0[j]);
         if (j == 1 && (i & 1) == pos) copy(2 + (i >> 1), b3);  // piece 1 (A, B) of stage st+3
       }
+    if (do_cs) add_cols(fa0);
     advance(1);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
@@ -171,7 +185,16 @@ __global__ __launch_bounds__(NT3, 1) void gemm_tn_kernel(const T* __restrict__ A
         mma_chunk<T>(acc[i][j], fa1[i], fb1[j]);
         if (j == 1 && (i & 1) == pos) copy(i >> 1, cur);  // piece 0 (A, B) of stage st+4
       }
+    if (do_cs) add_cols(fa1);
     advance(0);
+  }
+  if (do_cs) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float t = cs[i] + __shfl_xor(cs[i], 32, 64);  // the two token halves of the fragment
+      const int n = n0 + wr * 128 + i * 32 + (lane & 31);
+      if (lane < 32 && n < N) unsafeAtomicAdd(colsum + n, t);
+    }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the tail copies (zero page) before the wave exits
   // C[n, k] += acc: lane owns column k = k0 + wc*64 + j*32 + (lane & 31); hardware fp32 atomics
@@ -241,7 +264,7 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ A, in
 using namespace alpro;
 
 extern "C" int alpro_gemm_tn_acc(const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc, int dtype, int M, int N,
-                                 int K, void* stream) {
+                                 int K, float* colsum, void* stream) {
   ALPRO_CHECK(A && B && C && M > 0 && N > 0 && K > 0, "alpro_gemm_tn_acc: bad args");
   ALPRO_CHECK(dtype == ALPRO_BF16 || dtype == ALPRO_F16, "alpro_gemm_tn_acc: 16-bit operands only (fp32 mode uses alpro_transpose + alpro_gemm)");
   ALPRO_CHECK(lda % 8 == 0 && ldb % 8 == 0 && lda >= (N + 7) / 8 * 8 && ldb >= (K + 7) / 8 * 8,
@@ -273,11 +296,11 @@ extern "C" int alpro_gemm_tn_acc(const void* A, int64_t lda, const void* B, int6
   if (dtype == ALPRO_BF16) {
     static bool set = false;
     if (!set) { (void)hipFuncSetAttribute((const void*)gemm_tn_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); set = true; }
-    hipLaunchKernelGGL(gemm_tn_kernel<bf16_t>, dim3(grid), dim3(NT3), lds, st, (const bf16_t*)A, lda, (const bf16_t*)B, ldb, C, ldc, M, N, K, per, tn, tk);
+    hipLaunchKernelGGL(gemm_tn_kernel<bf16_t>, dim3(grid), dim3(NT3), lds, st, (const bf16_t*)A, lda, (const bf16_t*)B, ldb, C, ldc, M, N, K, per, tn, tk, colsum);
   } else {
     static bool set = false;
     if (!set) { (void)hipFuncSetAttribute((const void*)gemm_tn_kernel<f16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); set = true; }
-    hipLaunchKernelGGL(gemm_tn_kernel<f16_t>, dim3(grid), dim3(NT3), lds, st, (const f16_t*)A, lda, (const f16_t*)B, ldb, C, ldc, M, N, K, per, tn, tk);
+    hipLaunchKernelGGL(gemm_tn_kernel<f16_t>, dim3(grid), dim3(NT3), lds, st, (const f16_t*)A, lda, (const f16_t*)B, ldb, C, ldc, M, N, K, per, tn, tk, colsum);
   }
   return check_launch("alpro_gemm_tn_acc");
 }

@@ -65,7 +65,7 @@ def load():
     lib.alpro_gelu_bwd.argtypes = [vp, vp, vp, i32, i64, vp]
     lib.alpro_sumsq.argtypes = [vp, i64, vp, vp]
     lib.alpro_softmax_xent.argtypes = [vp, i64, vp, i32, vp, vp, i32, i64, vp, i32, i32, i32, vp]
-    lib.alpro_gemm_tn_acc.argtypes = [vp, i64, vp, i64, vp, i64, i32, i32, i32, i32, vp]
+    lib.alpro_gemm_tn_acc.argtypes = [vp, i64, vp, i64, vp, i64, i32, i32, i32, i32, vp, vp]
     lib.alpro_colsum_acc.argtypes = [vp, i64, vp, i32, i32, i32, vp]
     lib.alpro_adamw_step.argtypes = [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, f32, vp, f32, f32, vp]
     lib.alpro_gather_cast.argtypes = [vp, i64, vp, i32, i32, i32, i32, i32, i32, vp, i32, f32, f32, u32, vp, vp]
@@ -348,13 +348,17 @@ def adamw_step(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step_size, gnorm
                                 _ptr(gnorm_sq), max_norm, grad_scale, _stream()), "alpro_adamw_step")
 
 
-def gemm_tn_acc(a, b, c):
-    """c (N, K) fp32 += a(M, N)^T @ b(M, K) with 16-bit a, b in their natural row-major layout (alpro_gemm_tn_acc)."""
+def gemm_tn_acc(a, b, c, colsum=None):
+    """c (N, K) fp32 += a(M, N)^T @ b(M, K) with 16-bit a, b in their natural row-major layout (alpro_gemm_tn_acc);
+    colsum (N,) fp32 += a.sum(0) (the bias gradient) from the same pass."""
     lib = load()
     _dev(a); _dev(b, a.dtype); _dev(c, torch.float32)
     assert a.shape[0] == b.shape[0] and tuple(c.shape) == (a.shape[1], b.shape[1])
+    if colsum is not None:
+        _dev(colsum, torch.float32)
+        assert colsum.numel() >= a.shape[1]
     _check(lib.alpro_gemm_tn_acc(_ptr(a), a.stride(0), _ptr(b), b.stride(0), _ptr(c), c.stride(0), _CODE[a.dtype], a.shape[0], a.shape[1],
-                                 b.shape[1], _stream()), "alpro_gemm_tn_acc")
+                                 b.shape[1], _ptr(colsum), _stream()), "alpro_gemm_tn_acc")
     return c
 
 

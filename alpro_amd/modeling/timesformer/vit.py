@@ -187,9 +187,8 @@ class Block(nn.Module):
         dt = sv["dt"]
         ta, sa = self.temporal_attn, self.attn
         # ---- MLP: out = x2 + drop_m * (fc2(gelu(fc1(LN2(x2)))))
-        # (bias gradients = column sums of each dY, taken by the kernel that produces the dY)
-        dz = hip.gather_cast(dx, dt, row_scale=sv["drop_m"], row_scale_group=S, colsum=tr.bias_grad(self.mlp.fc2.bias))
-        tr.wgrad(dz, sv["f1"], self.mlp.fc2.weight, self.mlp.fc2.bias, bias_done=True)
+        dz = hip.gather_cast(dx, dt, row_scale=sv["drop_m"], row_scale_group=S)
+        tr.wgrad(dz, sv["f1"], self.mlp.fc2.weight, self.mlp.fc2.bias)
         du = tr.dgrad(dz, self._wt("fc2", self.mlp.fc2, dt), gelu_pre=sv["u"])
         tr.wgrad(du, sv["h2"], self.mlp.fc1.weight, self.mlp.fc1.bias)
         dh2 = tr.dgrad(du, self._wt("fc1", self.mlp.fc1, dt))
@@ -197,8 +196,8 @@ class Block(nn.Module):
         hip.layernorm_bwd(dh2, sv["x2"], self.norm2.weight, VIT_EPS, dx, g, b_)
         # ---- spatial: x2 = scatter(xt + drop_s * proj(attn(qkv(LN1(gather(xt)))))), CLS averaged over frames
         dpo = hip.gather_cast(dx, dt, rows=B * T * (N + 1), map_mode=hip.MAP_FRAME_TOKENS, map_p0=T, map_p1=N,
-                              row_scale=sv["drop_s"], row_scale_group=N + 1, cls_scale=1.0 / T, colsum=tr.bias_grad(sa.proj.bias))
-        tr.wgrad(dpo, sv["a_s"], sa.proj.weight, sa.proj.bias, bias_done=True)
+                              row_scale=sv["drop_s"], row_scale_group=N + 1, cls_scale=1.0 / T)
+        tr.wgrad(dpo, sv["a_s"], sa.proj.weight, sa.proj.bias)
         da = tr.dgrad(dpo, self._wt("s_proj", sa.proj, dt))
         dqkv = hip.attn_bwd(sv["qkv_s"], sv["a_s"], da, sv["lse_s"], B * T, N + 1, H, sa.scale)
         tr.wgrad(dqkv, sv["hs"], sa.qkv.weight, sa.qkv.bias)
@@ -207,8 +206,8 @@ class Block(nn.Module):
         hip.layernorm_bwd(dhs, sv["xt"], self.norm1.weight, VIT_EPS, dx, g, b_, rows=B * T * (N + 1),
                           map_mode=hip.MAP_FRAME_TOKENS, map_p0=T, map_p1=N)
         # ---- temporal: xt[:, 1:] = x[:, 1:] + fc(drop_t * proj(attn(qkv(LN_t(x[:, 1:])))))
-        dfo = hip.gather_cast(dx, dt, rows=B * N * T, map_mode=hip.MAP_SKIP_CLS, map_p0=N * T, colsum=tr.bias_grad(self.temporal_fc.bias))
-        tr.wgrad(dfo, sv["pr"], self.temporal_fc.weight, self.temporal_fc.bias, bias_done=True)
+        dfo = hip.gather_cast(dx, dt, rows=B * N * T, map_mode=hip.MAP_SKIP_CLS, map_p0=N * T)
+        tr.wgrad(dfo, sv["pr"], self.temporal_fc.weight, self.temporal_fc.bias)
         dpp = tr.dgrad(dfo, self._wt("t_fc", self.temporal_fc, dt), row_scale=sv["drop_t"], row_scale_group=T)
         tr.wgrad(dpp, sv["a_t"], ta.proj.weight, ta.proj.bias)
         da = tr.dgrad(dpp, self._wt("t_proj", ta.proj, dt))
@@ -306,9 +305,13 @@ class VisionTransformer(nn.Module):
         D = self.embed_dim
         drows = hip.gather_cast(dtok, dt, rows=B * T * N, map_mode=hip.MAP_PATCH_EMBED, map_p0=T, map_p1=N)
         pe = self.patch_embed.proj
-        gw, existed = tr.grad_buffer(pe.weight)
-        gw2 = gw.view(D, -1)
-        hip.gemm(hip.transpose(drows), hip.transpose(rows), out=gw2, out_dtype=torch.float32, residual=gw2 if existed else None)
+        if dt != torch.float32:  # 16-bit operands: in-place TN weight gradient (contraction over the B*T*N patch rows)
+            gw = tr.grad_buffer(pe.weight, zero=True)[0]
+            hip.gemm_tn_acc(drows, rows, gw.view(D, -1))
+        else:
+            gw, existed = tr.grad_buffer(pe.weight)
+            gw2 = gw.view(D, -1)
+            hip.gemm(hip.transpose(drows), hip.transpose(rows), out=gw2, out_dtype=torch.float32, residual=gw2 if existed else None)
         dtable = dtok[:, 1:].sum(0).view(N, T, D)  # small (N*T, D) reductions: parameter-sized, stay in torch
         tr.add_grad(pe.bias, dtable.sum((0, 1)))
         dcls = dtok[:, 0].sum(0)

@@ -52,7 +52,8 @@ def bias_grad(bias):
 def wgrad(dy_t, x_t, weight, bias, bias_done=False):
     """weight.grad += dy^T x ; bias.grad += colsum(dy) unless the producer of dy already did (bias_done).
     dy_t (M, N), x_t (M, K) operand-dtype activations.  16-bit operands: alpro_gemm_tn_acc reads both in place (split
-    over tokens, fp32 atomics); fp32 (exact mode): transposed copies + the NT GEMM."""
+    over tokens, fp32 atomics) and takes the bias gradient from the dY fragments it holds; fp32 (exact mode): transposed
+    copies + the NT GEMM, bias gradient fused into the transpose."""
     if bias_done:
         bias = None
     if bias is not None:
@@ -60,9 +61,7 @@ def wgrad(dy_t, x_t, weight, bias, bias_done=False):
     gw, existed = grad_buffer(weight, zero=True)
     gw2 = gw.view(gw.shape[0], -1)
     if dy_t.dtype != torch.float32:
-        if bias is not None:
-            hip.colsum_acc(dy_t, gb)
-        hip.gemm_tn_acc(dy_t, x_t, gw2)
+        hip.gemm_tn_acc(dy_t, x_t, gw2, colsum=gb if bias is not None else None)  # bias gradient from the same pass over dy
         return
     dyT = hip.transpose(dy_t, colsum=gb if bias is not None else None)
     hip.gemm(dyT, hip.transpose(x_t), out=gw2, out_dtype=torch.float32, residual=gw2)

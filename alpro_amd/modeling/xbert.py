@@ -156,15 +156,14 @@ class BertLayer(nn.Module):
 
         hp, seed1, seed2, ap, seed_a = sv["drop"]
         ds2 = ln_bwd(self.output.LayerNorm, sv["s2"], do_t, do32)          # also d(a32): identity residual
-        # through the FFN-output dropout; bias gradients are column sums taken by the kernel that produces each dY
-        ds2_t = hip.gather_cast(ds2, dt, drop_p=hp, drop_seed=seed2, colsum=tr.bias_grad(self.output.dense.bias))
-        tr.wgrad(ds2_t, sv["it"], self.output.dense.weight, self.output.dense.bias, bias_done=True)
+        ds2_t = hip.gather_cast(ds2, dt, drop_p=hp, drop_seed=seed2)     # through the FFN-output dropout
+        tr.wgrad(ds2_t, sv["it"], self.output.dense.weight, self.output.dense.bias)
         du = tr.dgrad(ds2_t, tr.transposed_operand(self._ops, "o_w^T", self.output.dense.weight, dt), gelu_pre=sv["u"])
         tr.wgrad(du, sv["a_t"], self.intermediate.dense.weight, self.intermediate.dense.bias)
         da_t = tr.dgrad(du, tr.transposed_operand(self._ops, "i_w^T", self.intermediate.dense.weight, dt))
         ds1 = ln_bwd(so.LayerNorm, sv["s1"], da_t, ds2)                     # also d(h32): identity residual
-        ds1_t = hip.gather_cast(ds1, dt, drop_p=hp, drop_seed=seed1, colsum=tr.bias_grad(so.dense.bias))  # through the attention-output dropout
-        tr.wgrad(ds1_t, sv["ctx"], so.dense.weight, so.dense.bias, bias_done=True)
+        ds1_t = hip.gather_cast(ds1, dt, drop_p=hp, drop_seed=seed1)     # through the attention-output dropout
+        tr.wgrad(ds1_t, sv["ctx"], so.dense.weight, so.dense.bias)
         dctx = tr.dgrad(ds1_t, tr.transposed_operand(self._ops, "ao_w^T", so.dense.weight, dt))
         dqkv = hip.attn_bwd(sv["qkv"], sv["ctx"], dctx, sv["lse"], B, L, H, scale, sv["kb"], drop_p=ap, drop_seed=seed_a)
         # fused q/k/v projection: the three weight gradients come from the three column blocks of dqkv
@@ -443,8 +442,7 @@ class _LMHeadRun:
         gw = tr.grad_buffer(hd.decoder.weight, zero=True)[0]
         cs = torch.zeros(Vp, dtype=torch.float32, device=dl.device)
         if dt != torch.float32:
-            hip.colsum_acc(dl, cs)
-            hip.gemm_tn_acc(dl[:, :V], self.n, gw)
+            hip.gemm_tn_acc(dl[:, :V], self.n, gw, colsum=cs)
         else:
             dlT = hip.transpose(dl, colsum=cs)
             hip.gemm(dlT[:V], hip.transpose(self.n), out=gw, out_dtype=torch.float32, residual=gw)

@@ -178,9 +178,11 @@ int alpro_scatter_add_rows(const float* src, const int64_t* idx, float* dst, int
 
 /* Weight gradient without transposed copies: C[N, K] (fp32, ATOMICALLY accumulated) += A[M, N]^T B[M, K], A = dY and
  * B = X row-major in a 16-bit dtype, contraction over tokens split across the grid (gemm_tn.hip).  C must be
- * initialised (zero or the running gradient).  fp32 operands: use alpro_transpose + alpro_gemm. */
+ * initialised (zero or the running gradient).  fp32 operands: use alpro_transpose + alpro_gemm.
+ * colsum (optional, (N) fp32, atomically accumulated): colsum[n] += sum_m A[m, n] -- the bias gradient of the same Linear,
+ * taken from the dY fragments the kernel already holds (nn.Linear backward: grad_bias = grad_output.sum(0)). */
 int alpro_gemm_tn_acc(const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc, int dtype, int M,
-                      int N, int K, void* stream);
+                      int N, int K, float* colsum, void* stream);
 
 /* out[n] (fp32) += sum_m A[m, n]: bias gradients. */
 int alpro_colsum_acc(const void* A, int64_t lda, float* out, int dtype, int M, int N, void* stream);

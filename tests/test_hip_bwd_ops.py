@@ -191,9 +191,12 @@ def test_gemm_tn_acc(dt, M, N, K):
     b = rnd(M, K, seed=121)
     c0 = rnd(N, K, seed=122)
     c = c0.clone().cuda()
-    hip.gemm_tn_acc(a.to(dt).cuda()[:, :N], b.to(dt).cuda(), c)
+    bg = torch.full((ldn,), 2.0).cuda()
+    hip.gemm_tn_acc(a.to(dt).cuda()[:, :N], b.to(dt).cuda(), c, colsum=bg)
     ref = c0.double() + a[:, :N].to(dt).double().T @ b.to(dt).double()
     close(c, ref, 2e-5, 2e-3 * math.sqrt(M / 1000.0), "gemm_tn_acc")
+    close(bg[:N], 2 + a[:, :N].to(dt).double().sum(0), 1e-5, 1e-3, "gemm_tn_acc fused bias gradient")
+    assert float((bg[N:] - 2).abs().max()) == 0 if ldn > N else True
     cs = torch.ones(ldn).cuda()
     hip.colsum_acc(a.to(dt).cuda(), cs)
     close(cs[:N], 1 + a[:, :N].to(dt).double().sum(0), 1e-5, 1e-3, "colsum_acc")
