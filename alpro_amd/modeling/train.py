@@ -49,6 +49,22 @@ def bias_grad(bias):
     return grad_buffer(bias, zero=True)[0]
 
 
+def fused_grad_view(params):
+    """If the fp32 .grad buffers of `params` (equal trailing shape) lie back to back in one storage (FlatAdamW's flat
+    gradient buffer), return a single (sum of rows, ...) view over them, else None."""
+    gs = [p.grad for p in params]
+    if any(g is None or not g.is_contiguous() for g in gs):
+        return None
+    base = gs[0]
+    off = base.data_ptr()
+    for g in gs:
+        if g.untyped_storage().data_ptr() != base.untyped_storage().data_ptr() or g.data_ptr() != off or g.shape[1:] != base.shape[1:]:
+            return None
+        off += g.numel() * 4
+    rows = sum(g.shape[0] for g in gs)
+    return torch.as_strided(base, (rows,) + tuple(base.shape[1:]), base.stride())
+
+
 def wgrad(dy_t, x_t, weight, bias, bias_done=False):
     """weight.grad += dy^T x ; bias.grad += colsum(dy) unless the producer of dy already did (bias_done).
     dy_t (M, N), x_t (M, K) operand-dtype activations.  16-bit operands: alpro_gemm_tn_acc reads both in place (split

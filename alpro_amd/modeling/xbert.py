@@ -168,8 +168,18 @@ class BertLayer(nn.Module):
         dqkv = hip.attn_bwd(sv["qkv"], sv["ctx"], dctx, sv["lse"], B, L, H, scale, sv["kb"], drop_p=ap, drop_seed=seed_a)
         # fused q/k/v projection: the three weight gradients come from the three column blocks of dqkv
         Hd = sa.all_head_size
-        for i, lin in enumerate((sa.query, sa.key, sa.value)):
-            tr.wgrad(dqkv[:, i * Hd:(i + 1) * Hd], sv["h_t"], lin.weight, lin.bias)
+        lins = (sa.query, sa.key, sa.value)
+        gw = gb = None
+        if dqkv.dtype != torch.float32:
+            for lin in lins:
+                tr.grad_buffer(lin.weight, zero=True)
+                tr.grad_buffer(lin.bias, zero=True)
+            gw, gb = tr.fused_grad_view([l.weight for l in lins]), tr.fused_grad_view([l.bias for l in lins])
+        if gw is not None and gb is not None:  # flat gradient buffer: one (3H, H) weight-gradient GEMM + bias gradient
+            hip.gemm_tn_acc(dqkv, sv["h_t"], gw, colsum=gb)
+        else:
+            for i, lin in enumerate(lins):
+                tr.wgrad(dqkv[:, i * Hd:(i + 1) * Hd], sv["h_t"], lin.weight, lin.bias)
         wT = self._ops._store.get("qkv_w^T")
         ver = (tr.param_epoch(),) + tuple((p.data_ptr(), p._version) for p in (sa.query.weight, sa.key.weight, sa.value.weight))
         if wT is None or wT[0] != ver or wT[1].dtype != dt:

@@ -41,6 +41,9 @@ class FlatAdamW:
                 live.append(p)
         if not live:
             raise RuntimeError("FlatAdamW.step() called before any backward pass")
+        # matrices first (original order), vectors after: BERT's query/key/value weights (and their biases) then sit back
+        # to back in the flat gradient buffer, so the fused-QKV weight gradient is ONE N=2304 GEMM into a (2304, 768) view
+        live.sort(key=lambda p: p.dim() < 2)
         dev = live[0].device
         offs, n = [], 0
         for p in live:

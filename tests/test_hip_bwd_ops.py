@@ -320,3 +320,39 @@ def test_gather_cast_colsum(dt):
                           row_scale_group=N + 1, cls_scale=1.0 / T)
     close(out, ref.cpu().double(), *((1e-6, 1e-6) if dt == torch.float32 else (1e-2, 1e-2)), "gather_cast")
     close(cs, 1 + ref.cpu().double().sum(0), 1e-4, 1e-4, "gather_cast colsum")
+
+
+def test_fused_qkv_wgrad_through_flat_gradient_buffer():
+    """Once FlatAdamW owns the gradients, BertLayer.backward takes the query/key/value weight+bias gradients with ONE
+    (3H, H) TN GEMM into a view of the flat buffer; the result must equal the three separate GEMMs."""
+    _hip()
+    import types
+    from alpro_amd import config as rt
+    from alpro_amd.modeling import train as tr
+    from alpro_amd.modeling.xbert import BertLayer
+    from alpro_amd.optim import FlatAdamW
+    from tests.conftest import BERT_CFG
+    cfg = types.SimpleNamespace(**dict(BERT_CFG, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0, chunk_size_feed_forward=0))
+    torch.manual_seed(3)
+    layer = BertLayer(cfg, 0).cuda().train()
+    B, L = 3, 40
+    h32 = rnd(B * L, 768, seed=400).cuda()
+    do32 = rnd(B * L, 768, seed=401).cuda()
+    lins = (layer.attention.self.query, layer.attention.self.key, layer.attention.self.value)
+
+    def run():
+        with rt.use_compute_dtype(torch.bfloat16), torch.no_grad():
+            _, _, sv = layer.forward_train(h32, h32.to(torch.bfloat16), None, B, L)
+            layer.backward(sv, do32.clone(), None)
+        return [l.weight.grad.clone() for l in lins] + [l.bias.grad.clone() for l in lins]
+
+    sep = run()                                   # separate .grad tensors -> three GEMMs
+    assert tr.fused_grad_view([l.weight for l in lins]) is None
+    opt = FlatAdamW(layer.parameters(), lr=0.0)   # lr 0: the step only moves the gradients into the flat buffer
+    opt.step()
+    opt.zero_grad()
+    assert tr.fused_grad_view([l.weight for l in lins]).shape == (3 * 768, 768)
+    assert tr.fused_grad_view([l.bias for l in lins]).shape == (3 * 768,)
+    fused = run()
+    for a, b in zip(sep, fused):
+        close(b, a.cpu().double(), 1e-5, 1e-4, "fused qkv wgrad")
