@@ -543,6 +543,152 @@ __global__ __launch_bounds__(256, NKT == 8 ? 1 : 2) void attn_bwd16_kernel(const
   }
 }
 
+// ================================================================================================
+// 16-bit temporal-attention backward: one WAVE per (32 consecutive tokens, head) unit, everything wave-private.
+// The four 4 KiB tiles K, V, Q, dO of the unit go global -> LDS by DMA (16 copies per unit, swizzled on the source side) and
+// every operand is then read from LDS; delta = rowsum(P o dP) (== rowsum(dO o O) for the recomputed P), so the saved
+// output is not read at all; dQ / dK / dV leave through the dead K / V tiles as 16-byte row stores.  No workgroup
+// barrier anywhere: 4 independent waves per workgroup, 2 workgroups per CU, units handed out grid-stride.
+template <typename T>
+__global__ __launch_bounds__(256, 2) void attn_temporal_bwd16_kernel(const T* __restrict__ qkv, const T* __restrict__ dout,
+                                                                    const float* __restrict__ lse, T* __restrict__ dqkv, int64_t rows, int Tn,
+                                                                    int H, float scale, int64_t units) {
+  static_assert(sizeof(T) == 2, "16-bit storage only");
+  constexpr int WB = 4 * 4096 + 256;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  char* base = smem + wave * WB;
+  char* tK = base;
+  char* tV = base + 4096;
+  char* tQ = base + 8192;
+  char* tD = base + 12288;
+  float* Ls = (float*)(base + 16384);  // -lse * log2(e); -inf on padded queries
+  float* Ds = Ls + 32;                  // -delta * scale
+  const uint32_t lds0 = lds_addr_of(base);
+  const char* zero = (const char*)g_bwd_zero;
+  const int64_t ldq = 3 * (int64_t)H * HD, ldo = (int64_t)H * HD;
+  const int g = lane >> 5, ql = lane & 31;
+  const float sl = scale * LOG2E_B;
+  const int qgrp = ql / Tn;
+  for (int64_t unit = (int64_t)blockIdx.x * 4 + wave; unit < units; unit += (int64_t)gridDim.x * 4) {
+    const int64_t chunk = unit / H;
+    const int h = (int)(unit - chunk * H);
+    const int64_t r0 = chunk * 32;
+    const int Le = (int)((rows - r0) < 32 ? (rows - r0) : 32);
+    const T* qb = qkv + r0 * ldq + h * HD;
+    const T* dob = dout + r0 * ldo + h * HD;
+    T* db = dqkv + r0 * ldq + h * HD;
+#pragma unroll
+    for (int piece = 0; piece < 4; ++piece) {
+      const int row = piece * 8 + (lane >> 3), slot = lane & 7;
+      const int ch = slot ^ ((((row >> 1) & 1) << 2) | ((row >> 2) & 3));
+      const bool ok = row < Le;
+      const T* src = qb + (int64_t)row * ldq + ch * 8;
+      dma16(ok ? (const char*)(src + H * HD) : zero, __builtin_amdgcn_readfirstlane(lds0 + piece * 1024));
+      dma16(ok ? (const char*)(src + 2 * H * HD) : zero, __builtin_amdgcn_readfirstlane(lds0 + 4096 + piece * 1024));
+      dma16(ok ? (const char*)src : zero, __builtin_amdgcn_readfirstlane(lds0 + 8192 + piece * 1024));
+      dma16(ok ? (const char*)(dob + (int64_t)row * ldo + ch * 8) : zero, __builtin_amdgcn_readfirstlane(lds0 + 12288 + piece * 1024));
+    }
+    if (lane < 32) Ls[lane] = lane < Le ? -lse[unit * 32 + lane] * LOG2E_B : -INFINITY;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // ------------------------------------------------------------ phase 1: dQ (lane = query)
+    u32x4 qf[4], dof[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      qf[ks] = *(const u32x4*)(tQ + tile_off<T>(ql, 2 * ks + g));
+      dof[ks] = *(const u32x4*)(tD + tile_off<T>(ql, 2 * ks + g));
+    }
+    f32x16 s, dp;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s[r] = dp[r] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      mma_chunk<T>(s, *(const u32x4*)(tK + tile_off<T>(ql, 2 * ks + g)), qf[ks]);
+      mma_chunk<T>(dp, *(const u32x4*)(tV + tile_off<T>(ql, 2 * ks + g)), dof[ks]);
+    }
+    const float nlq = Ls[ql];
+    float delta = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = (r & 3) + 8 * (r >> 2) + 4 * g;
+      const float p = (key / Tn == qgrp) ? __builtin_amdgcn_exp2f(fmaf(s[r], sl, nlq)) : 0.f;
+      s[r] = p;
+      delta = fmaf(p, dp[r], delta);
+    }
+    delta += __shfl_xor(delta, 32, 64);
+    const float nds = -delta * scale;
+    if (g == 0) Ds[ql] = nds;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s[r] *= fmaf(dp[r], scale, nds);  // dS^T
+    f32x16 acc[2];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[dt][r] = 0.f;
+#pragma unroll
+    for (int cc = 0; cc < 2; ++cc) {
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = s[cc * 8 + e];
+      const u32x4 bop = pack_chunk<T>(v);
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) mma_chunk<T>(acc[dt], load_t_chunk<T>(tK, 0, cc, lane, dt), bop);
+    }
+    // K / V rows of this lane's key as phase-2 B operands, then the K tile is dead: dQ leaves through it
+    u32x4 kf[4], vf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      kf[ks] = *(const u32x4*)(tK + tile_off<T>(ql, 2 * ks + g));
+      vf[ks] = *(const u32x4*)(tV + tile_off<T>(ql, 2 * ks + g));
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    store_rows_via_lds<T>(tK, acc, db, ldq, 0, Le, lane);
+    // ------------------------------------------------------------ phase 2: dK, dV (lane = key)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s[r] = dp[r] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      mma_chunk<T>(s, *(const u32x4*)(tQ + tile_off<T>(ql, 2 * ks + g)), kf[ks]);
+      mma_chunk<T>(dp, *(const u32x4*)(tD + tile_off<T>(ql, 2 * ks + g)), vf[ks]);
+    }
+#pragma unroll
+    for (int rq = 0; rq < 4; ++rq) {
+      const float4 lq = *(const float4*)(Ls + 8 * rq + 4 * g);
+      const float4 dq4 = *(const float4*)(Ds + 8 * rq + 4 * g);
+      const float ll[4] = {lq.x, lq.y, lq.z, lq.w}, dd[4] = {dq4.x, dq4.y, dq4.z, dq4.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int r = 4 * rq + e;
+        const float p = ((8 * rq + 4 * g + e) / Tn == qgrp) ? __builtin_amdgcn_exp2f(fmaf(s[r], sl, ll[e])) : 0.f;
+        s[r] = p;
+        dp[r] = p * fmaf(dp[r], scale, dd[e]);
+      }
+    }
+    f32x16 dk[2], dv[2];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dk[dt][r] = dv[dt][r] = 0.f;
+#pragma unroll
+    for (int cc = 0; cc < 2; ++cc) {
+      float pv[8], sv[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        pv[e] = s[cc * 8 + e];
+        sv[e] = dp[cc * 8 + e];
+      }
+      const u32x4 pb = pack_chunk<T>(pv), sb = pack_chunk<T>(sv);
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) {
+        mma_chunk<T>(dv[dt], load_t_chunk<T>(tD, 0, cc, lane, dt), pb);
+        mma_chunk<T>(dk[dt], load_t_chunk<T>(tQ, 0, cc, lane, dt), sb);
+      }
+    }
+    store_rows_via_lds<T>(tK, dk, db + H * HD, ldq, 0, Le, lane);
+    store_rows_via_lds<T>(tV, dv, db + 2 * H * HD, ldq, 0, Le, lane);
+  }
+}
+
 template <typename T, int NKT, bool HAS_BIAS>
 int launch_bwd16(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, int batch, int L, int H, float scale,
                  const float* key_bias, float dp, uint32_t ds, hipStream_t st) {
@@ -610,6 +756,26 @@ extern "C" int alpro_attn_temporal_bwd(const void* qkv, const void* out, const v
   ALPRO_CHECK(qkv && out && dout && lse && dqkv && rows > 0 && H > 0, "alpro_attn_temporal_bwd: bad args");
   ALPRO_CHECK(T > 0 && 32 % T == 0 && rows % T == 0, "alpro_attn_temporal_bwd: num_frm=%d must divide 32 and rows", T);
   const int64_t chunks = (rows + 31) / 32;
+  if (dtype != ALPRO_F32) {
+    const int64_t units = chunks * H;
+    int64_t grid = (units + 3) / 4;
+    if (grid > 512) grid = 512;
+    const size_t lds = 4 * (4 * 4096 + 256);
+    static bool attr_set = false;
+    if (!attr_set) {
+      (void)hipFuncSetAttribute((const void*)attn_temporal_bwd16_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      (void)hipFuncSetAttribute((const void*)attn_temporal_bwd16_kernel<f16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      attr_set = true;
+    }
+    if (dtype == ALPRO_BF16) {
+      hipLaunchKernelGGL(attn_temporal_bwd16_kernel<bf16_t>, dim3((unsigned)grid), dim3(256), lds, (hipStream_t)stream, (const bf16_t*)qkv, (const bf16_t*)dout, lse,
+                         (bf16_t*)dqkv, rows, T, H, scale, units);
+    } else {
+      hipLaunchKernelGGL(attn_temporal_bwd16_kernel<f16_t>, dim3((unsigned)grid), dim3(256), lds, (hipStream_t)stream, (const f16_t*)qkv, (const f16_t*)dout, lse,
+                         (f16_t*)dqkv, rows, T, H, scale, units);
+    }
+    return check_launch("alpro_attn_temporal_bwd");
+  }
   ALPRO_DISPATCH_DTYPE(dtype, T_, return (launch_bwd<T_, 1, 1, true>(qkv, out, dout, lse, dqkv, chunks, 32, H, scale, nullptr, T, rows, 0.f, 0u, (hipStream_t)stream)));
   return ALPRO_OK;
 }

@@ -27,3 +27,14 @@ for name, batch, L, bias, dp in [("vit spatial", 512, 197, False, 0.0), ("bert t
         do = torch.randn_like(out)
         ms = timeit(lambda: hip.attn_bwd(qkv, out, do, lse, batch, L, H, 0.125, key_bias=kb, drop_p=dp, drop_seed=(123 if dp else 0)))
         print("%-16s bwd batch=%d L=%d: %.3f ms  %.1f TF/s" % (name, batch, L, ms, 2.5 * fl / ms / 1e9))
+
+rows, T = 64 * 196 * 8, 8
+qkv = torch.randn(rows, 3 * H * 64, device="cuda").to(dt)
+if what in ("fwd", "all"):
+    ms = timeit(lambda: hip.attn_temporal(qkv, T, H, 0.125, want_lse=True))
+    print("vit temporal     fwd rows=%d T=%d: %.3f ms  %.0f GB/s" % (rows, T, ms, 4 * rows * 768 * 2 / ms / 1e6))
+if what in ("bwd", "all"):
+    out, lse = hip.attn_temporal(qkv, T, H, 0.125, want_lse=True)
+    do = torch.randn_like(out)
+    ms = timeit(lambda: hip.attn_temporal_bwd(qkv, out, do, lse, T, H, 0.125))
+    print("vit temporal     bwd rows=%d T=%d: %.3f ms  %.0f GB/s (q,k,v,dO read + dq,dk,dv written)" % (rows, T, ms, 7 * rows * 768 * 2 / ms / 1e6))
