@@ -283,23 +283,42 @@ class VisionTransformer(nn.Module):
         B, C, T, Hh, Ww = x.shape
         D = self.embed_dim
         N = (Hh // 16) * (Ww // 16)
-        if N + 1 != self.pos_embed.size(1) or T != self.time_embed.size(1):
-            raise RuntimeError("input grid (%d patches, %d frames) does not match pos_embed/time_embed (%d, %d); resize the "
-                               "checkpoint with load_state_dict_with_pos_embed_resizing first"
-                               % (N, T, self.pos_embed.size(1) - 1, self.time_embed.size(1)))
+        pidx, tidx = self._embed_index(N, T, Ww // 16)
         frames = x.transpose(1, 2).reshape(B * T, C, Hh, Ww).contiguous().float()
         rows = hip.patchify(frames, dt)
         w = self._ops.get("patch_w", self.patch_embed.proj.weight.view(D, -1), dt)
         # table[n*T + t] = conv bias + pos_embed[1 + n] + time_embed[t]
-        table = (self.patch_embed.proj.bias.detach()[None, None, :] + self.pos_embed.detach()[0, 1:, None, :]
-                 + self.time_embed.detach()[0, None, :, :]).reshape(N * T, D).contiguous()
+        pos_p, time_e = self.pos_embed.detach()[0, 1:], self.time_embed.detach()[0]
+        if pidx is not None:
+            pos_p = pos_p.index_select(0, pidx)
+        if tidx is not None:
+            time_e = time_e.index_select(0, tidx)
+        table = (self.patch_embed.proj.bias.detach()[None, None, :] + pos_p[:, None, :] + time_e[None, :, :]).reshape(N * T, D).contiguous()
         tok = torch.empty((B, 1 + N * T, D), dtype=torch.float32, device=x.device)
         tok[:, 0] = (self.cls_token.detach() + self.pos_embed.detach()[:, :1]).view(1, D)
         hip.gemm(rows, w, out=tok.view(-1, D), out_dtype=torch.float32, residual=table, map_mode=hip.MAP_PATCH_EMBED, map_p0=T, map_p1=N)
         self._last_rows = rows
         return tok, T, Ww // 16, N
 
-    def _embed_backward(self, rows, dtok, B, T, N):
+    def _embed_index(self, N, T, Wg):
+        """Nearest-neighbour resampling of pos_embed / time_embed when the input grid differs from the tables
+        (vit.py:328-340: the P x P patch table is resampled in 2-D to the (N / Wg) x Wg input grid; :350-357: the frame
+        table in 1-D).  Returns (patch index (N,) or None, frame index (T,) or None)."""
+        from alpro_amd.utils.load_save import nearest_index
+        dev = self.pos_embed.device
+        pidx = tidx = None
+        P2 = self.pos_embed.size(1) - 1
+        if N != P2:
+            P = int(P2 ** 0.5)
+            if P * P != P2 or N % Wg != 0:
+                raise RuntimeError("pos_embed holds %d patch slots (not a square grid) / input has %d patches in rows of %d" % (P2, N, Wg))
+            Hg = N // Wg
+            pidx = (nearest_index(P, Hg, dev)[:, None] * P + nearest_index(P, Wg, dev)[None, :]).reshape(-1)
+        if T != self.time_embed.size(1):
+            tidx = nearest_index(self.time_embed.size(1), T, dev)
+        return pidx, tidx
+
+    def _embed_backward(self, rows, dtok, B, T, N, Wg=None):
         """Gradients of patch_embed.proj / cls_token / pos_embed / time_embed from dtok (B, 1+N*T, D)."""
         dt = rows.dtype
         D = self.embed_dim
@@ -316,8 +335,14 @@ class VisionTransformer(nn.Module):
         tr.add_grad(pe.bias, dtable.sum((0, 1)))
         dcls = dtok[:, 0].sum(0)
         tr.add_grad(self.cls_token, dcls)
-        tr.add_grad(self.pos_embed, torch.cat([dcls[None], dtable.sum(1)], 0))
-        tr.add_grad(self.time_embed, dtable.sum(0))
+        pidx, tidx = self._embed_index(N, T, Wg) if Wg is not None else (None, None)
+        dpos, dtime = dtable.sum(1), dtable.sum(0)
+        if pidx is not None:  # resampled tables: scatter the gradients back onto the slots they were read from
+            dpos = torch.zeros((self.pos_embed.size(1) - 1, D), dtype=dpos.dtype, device=dpos.device).index_add_(0, pidx, dpos)
+        if tidx is not None:
+            dtime = torch.zeros((self.time_embed.size(1), D), dtype=dtime.dtype, device=dtime.device).index_add_(0, tidx, dtime)
+        tr.add_grad(self.pos_embed, torch.cat([dcls[None], dpos], 0))
+        tr.add_grad(self.time_embed, dtime)
 
     def forward_features(self, x, return_all_tokens=False):
         B = x.shape[0]
@@ -398,7 +423,7 @@ class _VisualRun:
         m = self.enc.model
         B = x.shape[0]
         tok, T, W, N = m._embed(x)
-        self.rows, self.dims = m._last_rows, (B, T, N)
+        self.rows, self.dims, self.Wg = m._last_rows, (B, T, N), W
         self.saved = []
         for blk in m.blocks:
             tok, sv = blk.forward_train(tok, B, T, W)
@@ -422,6 +447,6 @@ class _VisualRun:
         for blk, sv in zip(reversed(m.blocks), reversed(self.saved)):
             dtok = blk.backward(sv, dtok)
             sv.clear()
-        m._embed_backward(self.rows, dtok, B, T, N)
+        m._embed_backward(self.rows, dtok, B, T, N, self.Wg)
         self.saved = self.rows = self.tok = None
         return None  # pixels need no gradient

@@ -97,3 +97,42 @@ def test_dist_single_process_identity():
     assert dist.size() == 1 and dist.rank() == 0 and dist.local_rank() == 0
     assert dist.allgather(x) is x
     assert dist.allreduce_grads_([x]) == 0
+
+
+def test_nearest_index_matches_torch_interpolate():
+    """The resampling rule of the pos/time-embed resize (checkpoint loader and in-forward) is torch's 'nearest'."""
+    import torch.nn.functional as F
+    from alpro_amd.utils.load_save import nearest_index, resize_spatial_embedding, resize_temporal_embedding
+    for n_in, n_out in [(196, 576), (196, 49), (8, 4), (8, 16), (8, 3), (14, 24), (14, 7), (5, 5)]:
+        src = torch.arange(n_in, dtype=torch.float32).view(1, 1, n_in)
+        assert torch.equal(F.interpolate(src, size=n_out, mode="nearest").view(-1).long(), nearest_index(n_in, n_out))
+    sd = {"p": torch.randn(1, 197, 16), "t": torch.randn(1, 8, 16)}
+    new = resize_spatial_embedding(sd, "p", 576)
+    ref = torch.cat((sd["p"][:, :1], F.interpolate(sd["p"][:, 1:].transpose(1, 2), size=576, mode="nearest").transpose(1, 2)), 1)
+    assert torch.equal(new, ref)
+    assert torch.equal(resize_temporal_embedding(sd, "t", 4), F.interpolate(sd["t"].transpose(1, 2), size=4, mode="nearest").transpose(1, 2))
+
+
+def test_load_state_dict_with_pos_embed_resizing_host_logic():
+    from alpro_amd.utils.load_save import load_state_dict_with_pos_embed_resizing
+
+    class Tiny(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.visual_encoder = torch.nn.Module()
+            self.visual_encoder.model = torch.nn.Module()
+            self.visual_encoder.model.pos_embed = torch.nn.Parameter(torch.zeros(1, 1 + 9, 4))
+            self.visual_encoder.model.time_embed = torch.nn.Parameter(torch.zeros(1, 2, 4))
+            self.text_encoder = torch.nn.Linear(4, 4)
+            self.head = torch.nn.Linear(4, 3)
+
+    m = Tiny()
+    ck = {"visual_encoder.model.pos_embed": torch.randn(1, 1 + 4, 4), "visual_encoder.model.time_embed": torch.randn(1, 4, 4),
+          "text_encoder.bert.weight": torch.randn(4, 4), "text_encoder.bert.bias": torch.randn(4), "head.weight": torch.randn(7, 4), "extra": torch.zeros(1)}
+    mism = load_state_dict_with_pos_embed_resizing(m, ck, num_patches=9, num_frames=2, remove_text_encoder_prefix=True)
+    assert mism == ["head.weight"]
+    assert torch.equal(m.visual_encoder.model.pos_embed[0, 0], ck["visual_encoder.model.pos_embed"][0, 0])
+    assert torch.equal(m.visual_encoder.model.time_embed[0, 1], ck["visual_encoder.model.time_embed"][0, 2])
+    assert torch.equal(m.text_encoder.weight, ck["text_encoder.bert.weight"])
+    import src.utils.load_save as shim
+    assert shim.load_state_dict_with_pos_embed_resizing is load_state_dict_with_pos_embed_resizing

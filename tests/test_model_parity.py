@@ -139,3 +139,40 @@ def test_pretrain_gradients_vs_reference(bert_cfg, monkeypatch, mode, rtol):
             r = g[k].astype(np.float64)
             e = np.abs(pd[k[5:]].grad.float().cpu().numpy().astype(np.float64) - r).max()
             assert e <= rtol * max(np.abs(r).max(), 1e-6) + 1e-7, (k, e, np.abs(r).max())
+
+
+def test_embed_resamples_pos_and_time_tables_like_the_reference():
+    """Input grid != checkpoint grid (vit.py:328-340,350-357): pos_embed is resampled nearest-neighbour in 2-D, time_embed in
+    1-D; forward tokens and the gradients scattered back to the tables must equal the torch restatement."""
+    import torch.nn.functional as F
+    from alpro_amd import config as rt
+    from alpro_amd.modeling.timesformer.vit import TimeSformer
+    torch.manual_seed(5)
+    enc = TimeSformer(dict(VENC, num_frm=8), input_format="RGB").cuda()
+    m = enc.model
+    with torch.no_grad():
+        m.pos_embed.normal_(0, 0.5)
+        m.time_embed.normal_(0, 0.5)
+    B, T, Hh, Ww = 2, 4, 160, 192          # 10 x 12 patches, 4 frames against a 14 x 14 / 8-frame table
+    x = torch.randn(B, 3, T, Hh, Ww, device="cuda")
+    with rt.use_compute_dtype(torch.float32), torch.no_grad():
+        tok, T_, Wg, N = m._embed(x)
+    assert (T_, Wg, N) == (T, 12, 120)
+    D = m.embed_dim
+    pos, te = m.pos_embed.detach().clone().requires_grad_(True), m.time_embed.detach().clone().requires_grad_(True)
+    conv = F.conv2d(x.transpose(1, 2).reshape(B * T, 3, Hh, Ww), m.patch_embed.proj.weight.detach(), m.patch_embed.proj.bias.detach(), stride=16)
+    pt = conv.flatten(2).transpose(1, 2)                                                  # (B*T, N, D)
+    new_pos = F.interpolate(pos[0, 1:].t().reshape(1, D, 14, 14), size=(10, 12), mode="nearest").flatten(2).transpose(1, 2)
+    pt = pt + new_pos
+    pt = pt.view(B, T, N, D).permute(0, 2, 1, 3)                                           # (B, N, T, D)
+    pt = pt + F.interpolate(te.transpose(1, 2), size=T, mode="nearest").transpose(1, 2)[:, None]
+    ref = torch.cat([(m.cls_token.detach() + pos[:, :1]).expand(B, 1, D), pt.reshape(B, N * T, D)], 1)
+    assert (tok - ref.detach()).abs().max().item() < 2e-4
+    dtok = torch.randn_like(tok)
+    ref.backward(dtok)
+    for p in (m.pos_embed, m.time_embed, m.patch_embed.proj.weight, m.patch_embed.proj.bias, m.cls_token):
+        p.grad = None
+    with rt.use_compute_dtype(torch.float32), torch.no_grad():
+        m._embed_backward(m._last_rows, dtok, B, T, N, Wg)
+    assert (m.pos_embed.grad - pos.grad).abs().max().item() < 2e-3
+    assert (m.time_embed.grad - te.grad).abs().max().item() < 2e-3
