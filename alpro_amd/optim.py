@@ -31,6 +31,7 @@ class FlatAdamW:
         self.step_count = 0
         self.flat = None  # built at the first step(), when we know which parameters actually receive gradients
         self.last_grad_norm = None
+        self._pre_synced = None  # "sum" / "avg": synchronize() already ran for this step (hvd-style drivers call it themselves)
 
     # ---- flat buffers ---------------------------------------------------------------------------------
     def _build(self):
@@ -73,16 +74,27 @@ class FlatAdamW:
         else:
             self.flat["g"].zero_()
 
-    def synchronize(self):
-        """Sum gradients across ranks (averaging is folded into the AdamW kernel's grad_scale)."""
-        if self.flat is None or not self.allreduce or dist.size() == 1:
+    def synchronize(self, average=False):
+        """Sum gradients across ranks; step() folds the 1/world averaging into the AdamW kernel's grad_scale.
+        average=True (the hvd.DistributedOptimizer.synchronize() contract: callers clip the AVERAGED gradients before
+        step()) divides in place instead and makes the next step() skip both its own exchange and the scaling."""
+        if not self.allreduce or dist.size() == 1:
+            self._pre_synced = "avg" if average else None
+            return 0
+        if self.flat is None:  # first step: gradients are still separate tensors
+            dist.allreduce_grads_(self.params, average=average)
+            self._pre_synced = "avg" if average else "sum"
             return 0
         g, n = self.flat["g"], self.flat["n"]
         for s in range(0, n, self.bucket_elems):
             torch.distributed.all_reduce(g[s:min(n, s + self.bucket_elems)])
+        if average:
+            g.div_(dist.size())
+        self._pre_synced = "avg" if average else "sum"
         return n * 4
 
     def step(self):
+        pre, self._pre_synced = self._pre_synced, None
         if self.flat is None:
             self._build()
         f, grp = self.flat, self.param_groups[0]
@@ -90,8 +102,10 @@ class FlatAdamW:
                 or (p.grad is not None and p.grad.data_ptr() >= f["g"].data_ptr() + f["n"] * 4)]
         if late:
             raise RuntimeError("%d parameters started receiving gradients after the flat buffers were built" % len(late))
-        self.synchronize()
-        world = dist.size() if self.allreduce else 1
+        if pre is None:
+            self.synchronize()
+            self._pre_synced = None
+        world = dist.size() if (self.allreduce and pre != "avg") else 1
         self.step_count += 1
         lr, (b1, b2) = grp["lr"], grp["betas"]
         step_size = lr

@@ -70,7 +70,55 @@ def _worker(rank, world, port, out):
     dist.broadcast_parameters(lin)
     assert float(lin.weight[0, 0]) == 7.0
     dist.barrier()
+    _hvd_facade_checks(rank, world)
     out.put((rank, "ok"))
+
+
+def _hvd_facade_checks(rank, world):
+    """The horovod.torch / apex.amp stand-ins (alpro_amd/compat) driven the way run_pretrain_sparse.py:432-441,596-648 drives
+    them: DistributedOptimizer(...).synchronize() -> clip on AVERAGED gradients -> `with skip_synchronize(): step()`."""
+    import sys
+    import alpro_amd.compat
+    sys.path.insert(0, alpro_amd.compat.PATH)
+    from horovod import torch as hvd
+    from apex import amp
+    assert hvd.__file__.startswith(alpro_amd.compat.PATH)
+    hvd.init()
+    assert hvd.size() == world and hvd.rank() == rank
+    t = torch.full((4,), float(rank + 1))
+    assert torch.allclose(hvd.allreduce(t), torch.full((4,), 1.5)) and float(t[0]) == rank + 1     # out-of-place mean
+    hvd.allreduce_(t, average=False)
+    assert torch.allclose(t, torch.full((4,), 3.0))
+    b = torch.full((2,), float(rank))
+    hvd.broadcast_(b, root_rank=1)
+    assert float(b[0]) == 1.0
+    torch.manual_seed(100 + rank)                 # different initial weights per rank
+    model = torch.nn.Linear(3, 2)
+    opt = hvd.DistributedOptimizer(torch.optim.SGD(model.parameters(), lr=0.5, momentum=0.9), named_parameters=model.named_parameters(),
+                                   compression=hvd.Compression.none)
+    hvd.broadcast_parameters(model.state_dict(), root_rank=0)
+    hvd.broadcast_optimizer_state(opt, root_rank=0)
+    model, opt = amp.initialize(model, opt, enabled=0, opt_level="O1")
+    w0 = model.weight.detach().clone()
+    x = torch.full((1, 3), float(rank + 1))
+    loss = model(x).sum()
+    with amp.scale_loss(loss, opt, delay_unscale=False) as scaled:
+        scaled.backward()
+        opt.synchronize()
+    assert torch.allclose(model.weight.grad, torch.full((2, 3), 1.5))                             # mean of 1 and 2
+    torch.nn.utils.clip_grad_norm_(amp.master_params(opt), 100.0)
+    with opt.skip_synchronize():
+        opt.step()
+        opt.zero_grad()
+    assert torch.allclose(model.weight.detach(), w0 - 0.5 * 1.5)
+    both = hvd.allgather(model.weight.detach().reshape(1, -1))
+    assert torch.allclose(both[0], both[1])                                                       # replicas stay identical
+    # step() without an explicit synchronize() exchanges by itself
+    model(x).sum().backward()
+    opt.step()
+    both = hvd.allgather(model.weight.detach().reshape(1, -1))
+    assert torch.allclose(both[0], both[1])
+    assert amp.state_dict() == {}
 
 
 def test_world2_gloo():

@@ -356,3 +356,34 @@ def test_fused_qkv_wgrad_through_flat_gradient_buffer():
     fused = run()
     for a, b in zip(sep, fused):
         close(b, a.cpu().double(), 1e-5, 1e-4, "fused qkv wgrad")
+
+
+def test_flat_adamw_behind_the_hvd_facade():
+    """hvd.DistributedOptimizer(FlatAdamW) driven like run_pretrain_sparse.py:596-648 equals FlatAdamW.step() alone."""
+    _hip()
+    import sys
+    import alpro_amd.compat
+    sys.path.insert(0, alpro_amd.compat.PATH)
+    from horovod import torch as hvd
+    from alpro_amd.optim import FlatAdamW
+    torch.manual_seed(1)
+    a = [torch.nn.Parameter(torch.randn(9, 5).cuda()), torch.nn.Parameter(torch.randn(7).cuda())]
+    b = [torch.nn.Parameter(p.detach().clone()) for p in a]
+    oa = FlatAdamW(a, lr=1e-2, betas=(0.9, 0.98), eps=1e-6, weight_decay=0.01, max_grad_norm=1.0)
+    ob = hvd.DistributedOptimizer(FlatAdamW(b, lr=1e-2, betas=(0.9, 0.98), eps=1e-6, weight_decay=0.01, max_grad_norm=1.0))
+    for step in range(3):
+        gs = [torch.randn_like(p) for p in a]
+        for ps in (a, b):
+            for p, g in zip(ps, gs):
+                if p.grad is None:
+                    p.grad = g.clone()
+                else:
+                    p.grad.copy_(g)
+        oa.step()
+        ob.synchronize()
+        with ob.skip_synchronize():
+            ob.step()
+        for p, q_ in zip(a, b):
+            close(q_, p.detach().cpu().double(), 1e-6, 1e-7, "facade step %d" % step)
+        oa.zero_grad()
+        ob.zero_grad()
