@@ -323,6 +323,32 @@ class AlproForVideoTextRetrieval(AlproBaseModel):
         out = self._fusion(torch.cat([text_embeds, video_embeds], dim=1), torch.cat([text_input_mask, video_atts], dim=1))
         return dict(logits=_linear32(out[:, 0, :], self.itm_head), itc_scores=vtc_sim_scores)
 
+    # ---- retrieval evaluation with cached encoders.  The reference's eval loop
+    # (run_video_retrieval.py:642-690) calls forward_inference once per (video, caption mini-batch): the ViT runs
+    # #mini-batches times per video and the text encoder #videos times per caption.  The three methods below split
+    # forward_inference at its natural seams so a caller encodes every video and every caption ONCE and only the fusion
+    # pass runs per pair; alpro_amd/retrieval_eval.py drives them and reproduces the reference's result records.
+    @torch.no_grad()
+    def encode_video(self, visual_inputs):
+        """(1, T, C, H, W) -> (video_embeds (1, 1+N, D), video_feat (1, 256))."""
+        video_embeds = self._forward_visual_embeds(visual_inputs)
+        return video_embeds, self._video_feat(video_embeds)
+
+    @torch.no_grad()
+    def encode_text(self, text_input_ids, text_input_mask):
+        """(n, Lt) -> (text_embeds (n, Lt, D), text_feat (n, 256))."""
+        text_embeds = self._text_embeds(text_input_ids, text_input_mask)
+        return text_embeds, self._text_feat(text_embeds)
+
+    @torch.no_grad()
+    def score_pairs(self, video_embeds, video_feat, text_embeds, text_feat, text_input_mask):
+        """One cached video against n cached captions: the tail of forward_inference (alpro_models.py:893-914)."""
+        n = text_embeds.shape[0]
+        ve = video_embeds.repeat(n, 1, 1)
+        video_atts = torch.ones(ve.size()[:-1], dtype=torch.long, device=ve.device)
+        out = self._fusion(torch.cat([text_embeds, ve], dim=1), torch.cat([text_input_mask, video_atts], dim=1))
+        return dict(logits=_linear32(out[:, 0, :], self.itm_head), itc_scores=video_feat @ text_feat.t() / self.temp)
+
 
 class AlproForSequenceClassification(AlproBaseModel):
     """VideoQA head (alpro_models.py:633-724): same encoders + an MLP classifier.  Kept for API completeness;

@@ -136,3 +136,22 @@ def test_load_state_dict_with_pos_embed_resizing_host_logic():
     assert torch.equal(m.text_encoder.weight, ck["text_encoder.bert.weight"])
     import src.utils.load_save as shim
     assert shim.load_state_dict_with_pos_embed_resizing is load_state_dict_with_pos_embed_resizing
+
+
+def test_retrieval_metrics_known_answer():
+    """R@K / median / mean rank of the retrieval evaluation (run_video_retrieval.py:515-628) on a hand-made score matrix."""
+    import numpy as np
+    from alpro_amd.retrieval_eval import eval_retrieval, get_retrieval_metric_from_bool_matrix
+    bm = np.zeros((4, 12), dtype=bool)
+    for r, c in enumerate([0, 3, 7, 11]):
+        bm[r, c] = True
+    m = get_retrieval_metric_from_bool_matrix(bm)
+    assert (m["r1"], m["r5"], m["r10"], m["medianR"], m["meanR"]) == (25.0, 50.0, 75.0, 6.0, 6.25)
+    # 3 captions x 3 videos; caption t_i belongs to video v_i; t2 is ranked second for its video
+    scores = {("t0", "v0"): .9, ("t0", "v1"): .2, ("t0", "v2"): .1, ("t1", "v0"): .3, ("t1", "v1"): .8, ("t1", "v2"): .4,
+              ("t2", "v0"): .1, ("t2", "v1"): .7, ("t2", "v2"): .6}
+    recs = [dict(vid_id=v, txt_id=t, score=s, sim=0.0) for (t, v), s in scores.items()]
+    recs.append(dict(vid_id="v0", txt_id="t0", score=0.0, sim=0.0))  # duplicate pair: first record wins
+    out = eval_retrieval(recs, {"t0": "v0", "t1": "v1", "t2": "v2"})
+    assert abs(out["text2video"]["r1"] - 200 / 3) < 1e-9 and out["text2video"]["r5"] == 100.0 and out["text2video"]["meanR"] == 4 / 3
+    assert abs(out["video2text"]["r1"] - 100.0) < 1e-9

@@ -176,3 +176,28 @@ def test_embed_resamples_pos_and_time_tables_like_the_reference():
         m._embed_backward(m._last_rows, dtok, B, T, N, Wg)
     assert (m.pos_embed.grad - pos.grad).abs().max().item() < 2e-3
     assert (m.time_embed.grad - te.grad).abs().max().item() < 2e-3
+
+
+def test_cached_retrieval_eval_equals_forward_inference(retrieval):
+    """alpro_amd.retrieval_eval (every video / caption encoded once) reproduces the records the reference's loop builds from
+    forward_inference per (video, caption mini-batch) (run_video_retrieval.py:642-690)."""
+    from alpro_amd import config as rt
+    from alpro_amd.retrieval_eval import eval_retrieval, inference_retrieval_cached
+    m, batch, _ = retrieval
+    vids = [("v%d" % i, batch["visual_inputs"][i:i + 1]) for i in range(3)]
+    ids, mask = batch["text_input_ids"], batch["text_input_mask"]
+    cap_ids = ["t%d" % i for i in range(ids.shape[0])]
+    with rt.use_compute_dtype("fp32"), torch.no_grad():
+        got = inference_retrieval_cached(m, vids, ids, mask, cap_ids, eval_bsz=2)
+        ref = []
+        for vid_id, v in vids:
+            for i in range(0, ids.shape[0], 2):
+                out = m.forward_inference(dict(visual_inputs=v, text_input_ids=ids[i:i + 2], text_input_mask=mask[i:i + 2]))
+                probs = torch.softmax(out["logits"].float(), 1)[:, 1].tolist()
+                sims = out["itc_scores"].float().reshape(-1).tolist()
+                ref += [dict(vid_id=vid_id, txt_id=c, score=round(p, 4), sim=round(s, 4)) for c, p, s in zip(cap_ids[i:i + 2], probs, sims)]
+    assert [(d["vid_id"], d["txt_id"]) for d in got] == [(d["vid_id"], d["txt_id"]) for d in ref]
+    assert max(abs(a["score"] - b["score"]) for a, b in zip(got, ref)) <= 2e-4
+    assert max(abs(a["sim"] - b["sim"]) for a, b in zip(got, ref)) <= 2e-4
+    metrics = eval_retrieval(got, {"t%d" % i: "v%d" % i for i in range(3)})
+    assert set(metrics) == {"text2video", "video2text"} and 0 <= metrics["text2video"]["r1"] <= 100
