@@ -113,11 +113,10 @@ class AlproBaseModel(nn.Module):
         loss_t2v = -torch.sum(F.log_softmax(sim_t2v, dim=1) * sim_targets, dim=1).mean()
         return (loss_v2t + loss_t2v) / 2, sim_v2t, sim_t2v, sim_targets
 
-    def _vtm(self, text_embeds, text_atts, video_embeds, video_atts, sim_v2t, sim_t2v):
-        """Video-text matching with in-batch hard negatives (alpro_models.py:269-344 / 800-872)."""
-        device = text_embeds.device
-        bs = text_embeds.shape[0]
-        pos = self._fusion(torch.cat([text_embeds, video_embeds], dim=1), torch.cat([text_atts, video_atts], dim=1))
+    @staticmethod
+    def _sample_negatives(sim_v2t, sim_t2v, bs):
+        """One hard negative video per text and one hard negative text per video, drawn from the softmax of the rank's own
+        similarity block with the positives masked out (alpro_models.py:287-306)."""
         local_rank = hvd.local_rank()
         b_start, b_end = bs * local_rank, bs * (local_rank + 1)
         with torch.no_grad():
@@ -129,6 +128,14 @@ class AlproBaseModel(nn.Module):
             weights_t2v = F.softmax(weights_t2v, dim=1)
             neg_video = torch.multinomial(weights_t2v, 1).view(-1)  # a negative video for each text
             neg_text = torch.multinomial(weights_v2t, 1).view(-1)   # a negative text for each video
+        return neg_video, neg_text
+
+    def _vtm(self, text_embeds, text_atts, video_embeds, video_atts, sim_v2t, sim_t2v):
+        """Video-text matching with in-batch hard negatives (alpro_models.py:269-344 / 800-872)."""
+        device = text_embeds.device
+        bs = text_embeds.shape[0]
+        pos = self._fusion(torch.cat([text_embeds, video_embeds], dim=1), torch.cat([text_atts, video_atts], dim=1))
+        neg_video, neg_text = self._sample_negatives(sim_v2t, sim_t2v, bs)
         text_embeds_all = torch.cat([text_embeds, text_embeds[neg_text]], dim=0)
         text_atts_all = torch.cat([text_atts, text_atts[neg_text]], dim=0)
         video_embeds_all = torch.cat([video_embeds[neg_video], video_embeds], dim=0)
@@ -146,6 +153,7 @@ class AlproForPretrain(AlproBaseModel):
         super().__init__(config, input_format=input_format, video_enc_cfg=video_enc_cfg)
         self.prompter = Prompter(config, video_enc_cfg)  # frozen teacher for pseudo labels
         self.use_mask_prob = 0
+        self.batch_encoder_passes = True  # one 4B fusion pass / one 2B text pass instead of the reference's 3 / 2 calls
         self.mpm_head = nn.Sequential(nn.Linear(config.hidden_size, config.hidden_size * 2), nn.ReLU(True),
                                       nn.Linear(config.hidden_size * 2, self.prompter.entity_num))
 
@@ -170,14 +178,36 @@ class AlproForPretrain(AlproBaseModel):
         video_feat = self._video_feat(video_embeds)
         video_atts = torch.ones(video_embeds.size()[:-1], dtype=torch.long, device=device)
         text_atts = batch['text_input_mask']
-        text_embeds = self._text_embeds(batch['text_input_ids'], text_atts)
-        text_feat = self._text_feat(text_embeds)
-        vtc_loss, sim_v2t, sim_t2v, _ = self._vtc(video_feat, text_feat)
-        vtm_loss, vtm_logits, vtm_labels, encoder_outputs_pos = self._vtm(text_embeds, text_atts, video_embeds, video_atts, sim_v2t, sim_t2v)
-        if 'mlm_labels' in batch:
-            mlm_loss, mlm_logits, mlm_labels = self.compute_mlm(batch['mlm_text_input_ids'], text_atts, video_embeds, video_atts, batch['mlm_labels'])
+        if 'mlm_labels' in batch and self.batch_encoder_passes:
+            # Same sequences through the same weights as the reference's three fusion calls (positive pairs :278, 2B negatives
+            # :325, MLM pairs :360) and two text-encoder calls (:99, :354), but as ONE 4B-sequence fusion batch and ONE
+            # 2B-caption text batch: every row of a BERT layer is independent of the batch it sits in, and M = 4B*237 fills
+            # the 256x256 GEMM tiles far better than 3 launches at B / 2B / B.
+            both = self._text_embeds(torch.cat([batch['text_input_ids'], batch['mlm_text_input_ids']], dim=0), torch.cat([text_atts, text_atts], dim=0))
+            text_embeds, mlm_text_embeds = both[:b], both[b:]
+            text_feat = self._text_feat(text_embeds)
+            vtc_loss, sim_v2t, sim_t2v, _ = self._vtc(video_feat, text_feat)
+            neg_video, neg_text = self._sample_negatives(sim_v2t, sim_t2v, b)
+            t_all = torch.cat([text_embeds, text_embeds, text_embeds[neg_text], mlm_text_embeds], dim=0)
+            ta_all = torch.cat([text_atts, text_atts, text_atts[neg_text], text_atts], dim=0)
+            v_all = torch.cat([video_embeds, video_embeds[neg_video], video_embeds, video_embeds], dim=0)
+            va_all = torch.cat([video_atts] * 4, dim=0)
+            fused = self._fusion(torch.cat([t_all, v_all], dim=1), torch.cat([ta_all, va_all], dim=1))
+            encoder_outputs_pos, neg, mlm_out = fused[:b], fused[b:3 * b], fused[3 * b:]
+            vtm_logits = _linear32(torch.cat([encoder_outputs_pos[:, 0, :], neg[:, 0, :]], dim=0), self.itm_head)
+            vtm_labels = torch.cat([torch.ones(b, dtype=torch.long), torch.zeros(2 * b, dtype=torch.long)], dim=0).to(device)
+            vtm_loss = F.cross_entropy(vtm_logits, vtm_labels)
+            mlm_labels = batch['mlm_labels']
+            mlm_logits, mlm_loss = self.text_encoder.cls.predictions.forward_with_loss(mlm_out[:, :text_atts.shape[1]], mlm_labels)
         else:
-            mlm_logits = mlm_loss = mlm_labels = None
+            text_embeds = self._text_embeds(batch['text_input_ids'], text_atts)
+            text_feat = self._text_feat(text_embeds)
+            vtc_loss, sim_v2t, sim_t2v, _ = self._vtc(video_feat, text_feat)
+            vtm_loss, vtm_logits, vtm_labels, encoder_outputs_pos = self._vtm(text_embeds, text_atts, video_embeds, video_atts, sim_v2t, sim_t2v)
+            if 'mlm_labels' in batch:
+                mlm_loss, mlm_logits, mlm_labels = self.compute_mlm(batch['mlm_text_input_ids'], text_atts, video_embeds, video_atts, batch['mlm_labels'])
+            else:
+                mlm_logits = mlm_loss = mlm_labels = None
         if use_mpm:
             mpm_labels, ignore_masks = self.get_pseudo_labels(batch)
             mpm_loss, mpm_logits = self.compute_mpm_with_encoder_out(encoder_outputs_pos, text_atts, mpm_labels, ignore_masks, batch['mpm_mask'])
