@@ -134,13 +134,15 @@ class AlproBaseModel(nn.Module):
         """Video-text matching with in-batch hard negatives (alpro_models.py:269-344 / 800-872)."""
         device = text_embeds.device
         bs = text_embeds.shape[0]
-        pos = self._fusion(torch.cat([text_embeds, video_embeds], dim=1), torch.cat([text_atts, video_atts], dim=1))
         neg_video, neg_text = self._sample_negatives(sim_v2t, sim_t2v, bs)
-        text_embeds_all = torch.cat([text_embeds, text_embeds[neg_text]], dim=0)
-        text_atts_all = torch.cat([text_atts, text_atts[neg_text]], dim=0)
-        video_embeds_all = torch.cat([video_embeds[neg_video], video_embeds], dim=0)
-        video_atts_all = torch.cat([video_atts, video_atts], dim=0)
-        neg = self._fusion(torch.cat([text_embeds_all, video_embeds_all], dim=1), torch.cat([text_atts_all, video_atts_all], dim=1))
+        # positives and the 2B negatives as ONE 3B-sequence fusion batch (the reference makes two calls, :278 and :325; the
+        # rows are independent, so the results are the same and the GEMM tiles are fuller)
+        text_embeds_all = torch.cat([text_embeds, text_embeds, text_embeds[neg_text]], dim=0)
+        text_atts_all = torch.cat([text_atts, text_atts, text_atts[neg_text]], dim=0)
+        video_embeds_all = torch.cat([video_embeds, video_embeds[neg_video], video_embeds], dim=0)
+        video_atts_all = torch.cat([video_atts, video_atts, video_atts], dim=0)
+        both = self._fusion(torch.cat([text_embeds_all, video_embeds_all], dim=1), torch.cat([text_atts_all, video_atts_all], dim=1))
+        pos, neg = both[:bs], both[bs:]
         vl_embeddings = torch.cat([pos[:, 0, :], neg[:, 0, :]], dim=0)
         vtm_logits = _linear32(vl_embeddings, self.itm_head)
         vtm_labels = torch.cat([torch.ones(bs, dtype=torch.long), torch.zeros(2 * bs, dtype=torch.long)], dim=0).to(device)
