@@ -290,40 +290,64 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_kernel(const T* __restrict__
 __device__ u32x4 g_bwd_zero[4];
 constexpr float LOG2E_B = 1.4426950408889634f;
 
-// wave-private transpose: accumulator pair (column = token of this lane, rows = d) -> 32 row-major 128-byte rows
-template <typename T>
+// wave-private transpose: accumulator pair (column = token of this lane, rows = d) -> 32 row-major 128-byte rows.
+// HALF: 2 KiB of staging instead of 4 -- the two 32-wide d halves go one after the other as 64-byte row pieces (used where
+// the full staging would push the workgroup over half of the CU's LDS, i.e. 8 key tiles).
+template <typename T, bool HALF = false>
 __device__ __forceinline__ void store_rows_via_lds(char* Ow, const f32x16 (&o)[2], T* dst, int64_t ld, int row_base, int rows_valid, int lane) {
   const int g = lane >> 5, ql = lane & 31;
+  if constexpr (!HALF) {
 #pragma unroll
-  for (int dt = 0; dt < 2; ++dt)
+    for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-    for (int rq = 0; rq < 4; ++rq) {
-      const uint32_t lo = pack2(o[dt][4 * rq], o[dt][4 * rq + 1], (T*)0);
-      const uint32_t hi = pack2(o[dt][4 * rq + 2], o[dt][4 * rq + 3], (T*)0);
-      *(u32x2*)(Ow + ql * 128 + (((dt * 4 + rq) ^ ((ql >> 1) & 7)) << 4) + g * 8) = mk2(lo, hi);
+      for (int rq = 0; rq < 4; ++rq) {
+        const uint32_t lo = pack2(o[dt][4 * rq], o[dt][4 * rq + 1], (T*)0);
+        const uint32_t hi = pack2(o[dt][4 * rq + 2], o[dt][4 * rq + 3], (T*)0);
+        *(u32x2*)(Ow + ql * 128 + (((dt * 4 + rq) ^ ((ql >> 1) & 7)) << 4) + g * 8) = mk2(lo, hi);
+      }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int row = p * 8 + (lane >> 3), slot = lane & 7;
+      const u32x4 v = *(const u32x4*)(Ow + row * 128 + ((slot ^ ((row >> 1) & 7)) << 4));
+      if (row_base + row < rows_valid) *(u32x4*)(dst + (int64_t)(row_base + row) * ld + slot * 8) = v;
     }
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the staging rows may be rewritten right away
+  } else {
 #pragma unroll
-  for (int p = 0; p < 4; ++p) {
-    const int row = p * 8 + (lane >> 3), slot = lane & 7;
-    const u32x4 v = *(const u32x4*)(Ow + row * 128 + ((slot ^ ((row >> 1) & 7)) << 4));
-    if (row_base + row < rows_valid) *(u32x4*)(dst + (int64_t)(row_base + row) * ld + slot * 8) = v;
+    for (int dt = 0; dt < 2; ++dt) {
+#pragma unroll
+      for (int rq = 0; rq < 4; ++rq) {
+        const uint32_t lo = pack2(o[dt][4 * rq], o[dt][4 * rq + 1], (T*)0);
+        const uint32_t hi = pack2(o[dt][4 * rq + 2], o[dt][4 * rq + 3], (T*)0);
+        *(u32x2*)(Ow + ql * 64 + ((rq ^ ((ql >> 2) & 3)) << 4) + g * 8) = mk2(lo, hi);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int p = 0; p < 2; ++p) {
+        const int row = p * 16 + (lane >> 2), slot = lane & 3;
+        const u32x4 v = *(const u32x4*)(Ow + row * 64 + ((slot ^ ((row >> 2) & 3)) << 4));
+        if (row_base + row < rows_valid) *(u32x4*)(dst + (int64_t)(row_base + row) * ld + dt * 32 + slot * 8) = v;
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
   }
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the staging rows may be rewritten right away
 }
 
 template <typename T, int NKT, bool HAS_BIAS>
-__global__ __launch_bounds__(256, NKT == 8 ? 1 : 2) void attn_bwd16_kernel(const T* __restrict__ qkv, const T* __restrict__ out,
+__global__ __launch_bounds__(256, 2) void attn_bwd16_kernel(const T* __restrict__ qkv, const T* __restrict__ out,
                                                                           const T* __restrict__ dout, const float* __restrict__ lse,
                                                                           T* __restrict__ dqkv, int L, int H, float scale,
                                                                           const float* __restrict__ key_bias, float drop_p, uint32_t drop_seed) {
   static_assert(sizeof(T) == 2, "16-bit storage only");
   constexpr int LP = NKT * 32, RB = 128;
+  constexpr bool HALF = NKT == 8;             // 8 key tiles: 2 KiB staging per wave keeps two workgroups per CU (2 x 75 KiB)
+  constexpr int OW = HALF ? 2048 : 4096;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* tA = smem;              // K, then Q
   char* tB = smem + LP * RB;    // V, then dO
   char* Os = smem + 2 * LP * RB;
-  float* Bs = (float*)(Os + 4 * 4096);  // key bias * log2(e); -inf on padded keys
+  float* Bs = (float*)(Os + 4 * OW);  // key bias * log2(e); -inf on padded keys
   float* Ls = Bs + LP;                   // -lse * log2(e); -inf on padded queries
   float* Ds = Ls + LP;                   // delta * scale
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -362,7 +386,7 @@ __global__ __launch_bounds__(256, NKT == 8 ? 1 : 2) void attn_bwd16_kernel(const
 
   const int g = lane >> 5, ql = lane & 31;
   const int ntile = (L + 31) >> 5;
-  char* Ow = Os + wave * 4096;
+  char* Ow = Os + wave * OW;
   // ---------------------------------------------------------------- phase 1: dQ (lane = query)
   auto load_q3 = [&](int qt, u32x4(&qf)[4], u32x4(&dof)[4], u32x4(&of)[4]) {
     const int qc = min(qt * 32 + ql, L - 1);
@@ -444,7 +468,7 @@ __global__ __launch_bounds__(256, NKT == 8 ? 1 : 2) void attn_bwd16_kernel(const
         __builtin_amdgcn_sched_barrier(0);
       }
     }
-    store_rows_via_lds<T>(Ow, dq, db, ldq, qt * 32, L, lane);
+    store_rows_via_lds<T, HALF>(Ow, dq, db, ldq, qt * 32, L, lane);
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       qf[ks] = qn[ks];
@@ -538,8 +562,8 @@ __global__ __launch_bounds__(256, NKT == 8 ? 1 : 2) void attn_bwd16_kernel(const
         }
       }
     }
-    store_rows_via_lds<T>(Ow, dk, db + H * HD, ldq, kt * 32, L, lane);
-    store_rows_via_lds<T>(Ow, dv, db + 2 * H * HD, ldq, kt * 32, L, lane);
+    store_rows_via_lds<T, HALF>(Ow, dk, db + H * HD, ldq, kt * 32, L, lane);
+    store_rows_via_lds<T, HALF>(Ow, dv, db + 2 * H * HD, ldq, kt * 32, L, lane);
   }
 }
 
@@ -692,7 +716,7 @@ __global__ __launch_bounds__(256, 2) void attn_temporal_bwd16_kernel(const T* __
 template <typename T, int NKT, bool HAS_BIAS>
 int launch_bwd16(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, int batch, int L, int H, float scale,
                  const float* key_bias, float dp, uint32_t ds, hipStream_t st) {
-  const size_t lds = 2 * (size_t)NKT * 32 * 128 + 4 * 4096 + 3 * (size_t)NKT * 32 * sizeof(float);
+  const size_t lds = 2 * (size_t)NKT * 32 * 128 + 4 * (NKT == 8 ? 2048 : 4096) + 3 * (size_t)NKT * 32 * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)attn_bwd16_kernel<T, NKT, HAS_BIAS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
