@@ -78,6 +78,8 @@ template <typename T, int ACT> __device__ __forceinline__ float apply_act(float 
   return x;
 }
 
+// Output / residual accesses are non-temporal: they are streamed once (150-600 MB per launch against 32 MB of L2), and
+// keeping them out of the L2 allocation path is worth 7-8 % on the bf16-output GEMMs (tools/gemm_bench.py).
 // Epilogue of 16 staged rows x 64 columns of one wave: lane l handles columns 4*(l&15)..+3 of rows p*4 + (l>>4),
 // p = 0..3, so every global access is a 16-byte (fp32) / 8-byte (16-bit) piece of a 256-/128-byte row segment.
 // FAST (wave-uniform): the whole 16x64 block is in range and every stride is vector-aligned -> no per-element
@@ -99,7 +101,10 @@ __device__ __forceinline__ void epi_rows16(const alpro_gemm_desc_t& g, const flo
     rr[p] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (g.residual && live[p] && !d.side) {
       const float* rp = g.residual + d.res * g.ldr + n;
-      if (FAST) rr[p] = *(const float4*)rp;
+      if (FAST) {
+        const f32x4 t = __builtin_nontemporal_load((const f32x4*)rp);  // streamed once
+        rr[p] = make_float4(t.x, t.y, t.z, t.w);
+      }
       else {
         rr[p].x = rp[0];
         if (n + 1 < g.N) rr[p].y = rp[1];
@@ -120,7 +125,7 @@ __device__ __forceinline__ void epi_rows16(const alpro_gemm_desc_t& g, const flo
     for (int e = 0; e < 4; ++e) v[e] = g.alpha * v[e] + bias[e];
     if ((ACT == ALPRO_ACT_GELU || ACT == ALPRO_ACT_RELU) && g.C2) {  // pre-activation copy (host guarantees vector alignment for C2)
       if constexpr (sizeof(T) == 2) {
-        *(u32x2*)((T*)g.C2 + orow[p] * g.ldc2 + n) = mk2(pack2(v[0], v[1], (T*)0), pack2(v[2], v[3], (T*)0));
+        __builtin_nontemporal_store(mk2(pack2(v[0], v[1], (T*)0), pack2(v[2], v[3], (T*)0)), (u32x2*)((T*)g.C2 + orow[p] * g.ldc2 + n));
       } else {
         *(float4*)((float*)g.C2 + orow[p] * g.ldc2 + n) = make_float4(v[0], v[1], v[2], v[3]);
       }
@@ -168,9 +173,9 @@ __device__ __forceinline__ void epi_rows16(const alpro_gemm_desc_t& g, const flo
       }
     } else if (FAST) {
       if (g.c_dtype == ALPRO_F32) {
-        *(float4*)((float*)g.C + orow[p] * g.ldc + n) = make_float4(v[0], v[1], v[2], v[3]);
+        __builtin_nontemporal_store(f32x4{v[0], v[1], v[2], v[3]}, (f32x4*)((float*)g.C + orow[p] * g.ldc + n));
       } else if constexpr (sizeof(T) == 2) {
-        *(u32x2*)((T*)g.C + orow[p] * g.ldc + n) = mk2(pack2(v[0], v[1], (T*)0), pack2(v[2], v[3], (T*)0));
+        __builtin_nontemporal_store(mk2(pack2(v[0], v[1], (T*)0), pack2(v[2], v[3], (T*)0)), (u32x2*)((T*)g.C + orow[p] * g.ldc + n));
       }
     } else {
 #pragma unroll
@@ -196,7 +201,7 @@ __device__ __forceinline__ void epi_rows16_c16(const alpro_gemm_desc_t& g, const
     const float rs = g.row_scale ? g.row_scale[m / g.row_scale_group] : 1.0f;
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] = g.alpha * v[e] + bias[e];
-    if ((ACT == ALPRO_ACT_GELU || ACT == ALPRO_ACT_RELU) && g.C2) *(u32x4*)((T*)g.C2 + m * g.ldc2 + n) = pack_chunk<T>(v);
+    if ((ACT == ALPRO_ACT_GELU || ACT == ALPRO_ACT_RELU) && g.C2) __builtin_nontemporal_store(pack_chunk<T>(v), (u32x4*)((T*)g.C2 + m * g.ldc2 + n));
     if (ACT == ALPRO_ACT_GELU_BWD) {
       float pre[8];
       unpack_chunk<T>(*(const u32x4*)((const T*)g.C2 + m * g.ldc2 + n), pre);
@@ -213,10 +218,10 @@ __device__ __forceinline__ void epi_rows16_c16(const alpro_gemm_desc_t& g, const
       for (int e = 0; e < 8; ++e) v[e] = drop_keep(g.drop_seed, i0 + e, th) ? v[e] * ks : 0.f;
     }
     if (g.residual) {
-      const float4 r0 = *(const float4*)(g.residual + m * g.ldr + n), r1 = *(const float4*)(g.residual + m * g.ldr + n + 4);
+      const f32x4 r0 = __builtin_nontemporal_load((const f32x4*)(g.residual + m * g.ldr + n)), r1 = __builtin_nontemporal_load((const f32x4*)(g.residual + m * g.ldr + n + 4));
       v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w; v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w;
     }
-    *(u32x4*)((T*)g.C + m * g.ldc + n) = pack_chunk<T>(v);
+    __builtin_nontemporal_store(pack_chunk<T>(v), (u32x4*)((T*)g.C + m * g.ldc + n));
   }
 }
 
