@@ -405,7 +405,7 @@ __global__ __launch_bounds__(256, NKT == 8 ? 1 : 2) void attn_fwd16_kernel(const
       const int row = p * 8 + (lane >> 3), slot = lane & 7;
       const u32x4 v = *(const u32x4*)(Ow + row * 128 + ((slot ^ ((row >> 1) & 7)) << 4));
       const int qq = qt * 32 + row;
-      if (qq < L) *(u32x4*)(out + ((int64_t)b * L + qq) * H * HD + h * HD + slot * 8) = v;
+      if (qq < L) __builtin_nontemporal_store(v, (u32x4*)(out + ((int64_t)b * L + qq) * H * HD + h * HD + slot * 8));
     }
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) qf[ks] = qn[ks];

@@ -310,7 +310,7 @@ __device__ __forceinline__ void store_rows_via_lds(char* Ow, const f32x16 (&o)[2
     for (int p = 0; p < 4; ++p) {
       const int row = p * 8 + (lane >> 3), slot = lane & 7;
       const u32x4 v = *(const u32x4*)(Ow + row * 128 + ((slot ^ ((row >> 1) & 7)) << 4));
-      if (row_base + row < rows_valid) *(u32x4*)(dst + (int64_t)(row_base + row) * ld + slot * 8) = v;
+      if (row_base + row < rows_valid) __builtin_nontemporal_store(v, (u32x4*)(dst + (int64_t)(row_base + row) * ld + slot * 8));
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the staging rows may be rewritten right away
   } else {
@@ -327,7 +327,7 @@ __device__ __forceinline__ void store_rows_via_lds(char* Ow, const f32x16 (&o)[2
       for (int p = 0; p < 2; ++p) {
         const int row = p * 16 + (lane >> 2), slot = lane & 3;
         const u32x4 v = *(const u32x4*)(Ow + row * 64 + ((slot ^ ((row >> 2) & 3)) << 4));
-        if (row_base + row < rows_valid) *(u32x4*)(dst + (int64_t)(row_base + row) * ld + dt * 32 + slot * 8) = v;
+        if (row_base + row < rows_valid) __builtin_nontemporal_store(v, (u32x4*)(dst + (int64_t)(row_base + row) * ld + dt * 32 + slot * 8));
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }

@@ -145,9 +145,9 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
         atomicAdd(p, r.x); atomicAdd(p + 1, r.y); atomicAdd(p + 2, r.z); atomicAdd(p + 3, r.w);
       } else if (accumulate) {
         const float4 c = *(const float4*)p;
-        *(float4*)p = make_float4(c.x + r.x, c.y + r.y, c.z + r.z, c.w + r.w);
+        __builtin_nontemporal_store(f32x4{c.x + r.x, c.y + r.y, c.z + r.z, c.w + r.w}, (f32x4*)p);
       } else {
-        *(float4*)p = r;
+        __builtin_nontemporal_store(f32x4{r.x, r.y, r.z, r.w}, (f32x4*)p);
       }
     }
   }
@@ -212,12 +212,12 @@ __global__ __launch_bounds__(NW * 64) void gather_cast_kernel(const float* __res
     for (int i = 0; i < 3; ++i) {
       T* p = out + m * LN_D + i * 256 + lane * 4;
       if constexpr (sizeof(T) == 4) {
-        *(float4*)p = make_float4(v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]);
+        __builtin_nontemporal_store(f32x4{v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]}, (f32x4*)p);
       } else {
         u32x2 u;
         u.x = pack2(v[4 * i], v[4 * i + 1], (T*)0);
         u.y = pack2(v[4 * i + 2], v[4 * i + 3], (T*)0);
-        *(u32x2*)p = u;
+        __builtin_nontemporal_store(u, (u32x2*)p);
       }
     }
   };

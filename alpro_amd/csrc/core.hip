@@ -121,13 +121,13 @@ __device__ __forceinline__ void ln_store(T* row, int lane, const float (&v)[12])
 #pragma unroll
   for (int i = 0; i < LN_V; ++i) {
     if constexpr (sizeof(T) == 4) {
-      *(float4*)(row + i * 256 + lane * 4) = make_float4(v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]);
+      __builtin_nontemporal_store(f32x4{v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]}, (f32x4*)(row + i * 256 + lane * 4));
     } else {
       T* p = row + i * 256 + lane * 4;
       u32x2 u;
       u.x = pack2(v[4 * i], v[4 * i + 1], (T*)0);
       u.y = pack2(v[4 * i + 2], v[4 * i + 3], (T*)0);
-      *(u32x2*)p = u;
+      __builtin_nontemporal_store(u, (u32x2*)p);
     }
   }
 }
