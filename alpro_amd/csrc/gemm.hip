@@ -85,7 +85,8 @@ template <typename T, int ACT> __device__ __forceinline__ float apply_act(float 
 // FAST (wave-uniform): the whole 16x64 block is in range and every stride is vector-aligned -> no per-element
 // predication at all (the predicated variant is ~4x the instructions and was costing ~11 us per 256x256 tile).
 template <typename T, int ACT, int MAP, bool FAST, int PASSES = 4>
-__device__ __forceinline__ void epi_rows16(const alpro_gemm_desc_t& g, const float* stage, int m_base, int n_base, int lane, const float (&bias)[4]) {
+__device__ __forceinline__ void epi_rows16(const alpro_gemm_desc_t& g, const float* stage, int m_base, int n_base, int lane, const float (&bias)[4],
+                                           const float4* pre_res = nullptr) {
   const int c4 = (lane & 15) * 4;
   const int n = n_base + c4;
   float4 rr[PASSES];
@@ -99,7 +100,9 @@ __device__ __forceinline__ void epi_rows16(const alpro_gemm_desc_t& g, const flo
     orow[p] = d.out;
     side[p] = d.side;
     rr[p] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (g.residual && live[p] && !d.side) {
+    if (pre_res) {
+      rr[p] = pre_res[p];  // already in flight / landed: issued two chunks ago by the caller
+    } else if (g.residual && live[p] && !d.side) {
       const float* rp = g.residual + d.res * g.ldr + n;
       if (FAST) {
         const f32x4 t = __builtin_nontemporal_load((const f32x4*)rp);  // streamed once
@@ -185,11 +188,29 @@ __device__ __forceinline__ void epi_rows16(const alpro_gemm_desc_t& g, const flo
   }
 }
 
+// Residual rows of one 8-row chunk (the two passes of epi_rows16<.., PASSES = 2>) for a FAST tile.  The persistent kernel
+// issues these one chunk ahead of their use (two would spill): loaded at the point of use, every chunk exposed a full HBM round trip
+// (16 chunks x ~1.5 us = the whole 25 us epilogue of the N=768 fp32-residual GEMMs; 16 KiB in flight per CU = ~11 B/clk).
+template <int MAP>
+__device__ __forceinline__ void epi_prefetch_res(const alpro_gemm_desc_t& g, int m_base, int n_base, int lane, float4 (&rr)[2]) {
+  const int n = n_base + (lane & 15) * 4;
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    const RowDst d = map_row<MAP>(g.map_p0, g.map_p1, m_base + p * 4 + (lane >> 4));
+    rr[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (!d.side) {
+      const f32x4 t = __builtin_nontemporal_load((const f32x4*)(g.residual + d.res * g.ldr + n));
+      rr[p] = make_float4(t.x, t.y, t.z, t.w);
+    }
+  }
+}
+
 // 16-bit outputs under the identity map (qkv / proj / fc1 / every dgrad): 8 columns per lane -> one 16-byte store per
 // lane, 8 rows per wave instruction.  The store path is ISSUE-bound per CU (~one wave-store per ~100 cycles measured),
 // so halving the number of store instructions halves the epilogue tail.  Whole block in range (FAST) only.
 template <typename T, int ACT, int PASSES = 2>
-__device__ __forceinline__ void epi_rows16_c16(const alpro_gemm_desc_t& g, const float* stage, int m_base, int n_base, int lane, const float (&bias)[8]) {
+__device__ __forceinline__ void epi_rows16_c16(const alpro_gemm_desc_t& g, const float* stage, int m_base, int n_base, int lane, const float (&bias)[8],
+                                               const u32x4* pre_c2 = nullptr) {
   const int c8 = (lane & 7) * 8;
   const int n = n_base + c8;
 #pragma unroll
@@ -204,7 +225,7 @@ __device__ __forceinline__ void epi_rows16_c16(const alpro_gemm_desc_t& g, const
     if ((ACT == ALPRO_ACT_GELU || ACT == ALPRO_ACT_RELU) && g.C2) __builtin_nontemporal_store(pack_chunk<T>(v), (u32x4*)((T*)g.C2 + m * g.ldc2 + n));
     if (ACT == ALPRO_ACT_GELU_BWD) {
       float pre[8];
-      unpack_chunk<T>(*(const u32x4*)((const T*)g.C2 + m * g.ldc2 + n), pre);
+      unpack_chunk<T>(pre_c2 ? pre_c2[p] : *(const u32x4*)((const T*)g.C2 + m * g.ldc2 + n), pre);
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] *= gelu_grad<T>(pre[e]);
     }
@@ -525,16 +546,21 @@ __global__ __launch_bounds__(NT2, 2) void gemm_nt256p_kernel(const alpro_gemm_de
       };
       auto run_epilogue = [&](auto fast_tag) {
         constexpr bool FAST = decltype(fast_tag)::value;
+        const bool pf = FAST && MAP != ALPRO_MAP_FRAME_TOKENS && g.residual != nullptr;  // (FRAME_TOKENS: its row map + the ring would spill)  // residual rows are fetched one chunk ahead (see epi_prefetch_res)
+        float4 ring[2][2];
+        if (pf) epi_prefetch_res<MAP>(g, mb, nb, lane, ring[0]);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
-            float* st = stage + ((i * 4 + q) & 1) * 512;
+            const int c = i * 4 + q;
+            if (pf && c + 1 < 16) epi_prefetch_res<MAP>(g, mb + (c + 1) * 8, nb, lane, ring[(c + 1) & 1]);
+            float* st = stage + (c & 1) * 512;
             stage_chunk(st, acc[i][0], acc[i][1], q);
-            epi_rows16<T, ACT, MAP, FAST, 2>(g, st, mb + i * 32 + q * 8, nb, lane, bias);
+            epi_rows16<T, ACT, MAP, FAST, 2>(g, st, mb + c * 8, nb, lane, bias, pf ? ring[c & 1] : nullptr);
           }
         }
-            };
+      };
       const bool fast = epi_fast_ok(g, mb, 128, nb);
       bool c16 = false;
       if constexpr (sizeof(T) == 2 && MAP == ALPRO_MAP_IDENTITY)
@@ -544,13 +570,24 @@ __global__ __launch_bounds__(NT2, 2) void gemm_nt256p_kernel(const alpro_gemm_de
           float bias8[8];
 #pragma unroll
           for (int e = 0; e < 8; ++e) bias8[e] = g.bias ? g.bias[nb + (lane & 7) * 8 + e] : 0.f;
+          // GELU_BWD: the saved pre-activation rows are fetched two chunks ahead of their use (same reason as the residual)
+          u32x4 pring[3];
+          auto load_pre = [&](int c) {
+            return __builtin_nontemporal_load((const u32x4*)((const T*)g.C2 + (int64_t)(mb + c * 8 + (lane >> 3)) * g.ldc2 + nb + (lane & 7) * 8));
+          };
+          if (ACT == ALPRO_ACT_GELU_BWD) {
+            pring[0] = load_pre(0);
+            pring[1] = load_pre(1);
+          }
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-              float* st = stage + ((i * 4 + q) & 1) * 512;
+              const int c = i * 4 + q;
+              if (ACT == ALPRO_ACT_GELU_BWD && c + 2 < 16) pring[(c + 2) % 3] = load_pre(c + 2);
+              float* st = stage + (c & 1) * 512;
               stage_chunk(st, acc[i][0], acc[i][1], q);
-              epi_rows16_c16<T, ACT, 1>(g, st, mb + i * 32 + q * 8, nb, lane, bias8);
+              epi_rows16_c16<T, ACT, 1>(g, st, mb + c * 8, nb, lane, bias8, ACT == ALPRO_ACT_GELU_BWD ? &pring[c % 3] : nullptr);
             }
           }
         }
