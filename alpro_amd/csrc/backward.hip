@@ -43,13 +43,21 @@ __device__ __forceinline__ void ld12(const float* row, int lane, float (&v)[12])
     v[4 * i] = f.x; v[4 * i + 1] = f.y; v[4 * i + 2] = f.z; v[4 * i + 3] = f.w;
   }
 }
+// streamed-once rows (x, dy, the gradient stream): non-temporal
+__device__ __forceinline__ void ld12_nt(const float* row, int lane, float (&v)[12]) {
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const f32x4 f = __builtin_nontemporal_load((const f32x4*)(row + i * 256 + lane * 4));
+    v[4 * i] = f.x; v[4 * i + 1] = f.y; v[4 * i + 2] = f.z; v[4 * i + 3] = f.w;
+  }
+}
 template <typename T> __device__ __forceinline__ void ld12_t(const T* row, int lane, float (&v)[12]) {
   if constexpr (sizeof(T) == 4) {
-    ld12((const float*)row, lane, v);
+    ld12_nt((const float*)row, lane, v);
   } else {
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-      const u32x2 u = *(const u32x2*)(row + i * 256 + lane * 4);
+      const u32x2 u = __builtin_nontemporal_load((const u32x2*)(row + i * 256 + lane * 4));
       const uint32_t w0 = u.x, w1 = u.y;
       v[4 * i] = to_f32(T{(uint16_t)(w0 & 0xffffu)}); v[4 * i + 1] = to_f32(T{(uint16_t)(w0 >> 16)});
       v[4 * i + 2] = to_f32(T{(uint16_t)(w1 & 0xffffu)}); v[4 * i + 3] = to_f32(T{(uint16_t)(w1 >> 16)});
@@ -95,11 +103,11 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
   for (int64_t m = wave; m < rows; m += nwaves) {
     const SrcRow src = ln_src_row(mode, p0, p1, m);
     float xv[12], d[12];
-    ld12(x + src.row * ldx, lane, xv);
+    ld12_nt(x + src.row * ldx, lane, xv);
     ld12_t<T>(dy + m * ld_dy, lane, d);
     if (dy2) {  // second gradient stream on the same LN output (fp32 copy consumed as a residual)
       float d2[12];
-      ld12(dy2 + m * LN_D, lane, d2);
+      ld12_nt(dy2 + m * LN_D, lane, d2);
 #pragma unroll
       for (int i = 0; i < 12; ++i) d[i] += d2[i];
     }
@@ -230,8 +238,8 @@ __global__ __launch_bounds__(NW * 64) void gather_cast_kernel(const float* __res
     const int64_t r = src_row(m, sc);
     const int64_t r2 = has2 ? src_row(m2, sc2) : r;
     float v[12], v2[12];
-    ld12(src + r * ld, lane, v);
-    ld12(src + r2 * ld, lane, v2);
+    ld12_nt(src + r * ld, lane, v);
+    ld12_nt(src + r2 * ld, lane, v2);
     emit(m, v, sc);
     if (has2) emit(m2, v2, sc2);
   }

@@ -93,6 +93,13 @@ __device__ __forceinline__ void ln_load(const float* row, int lane, float (&v)[1
     v[4 * i] = f.x; v[4 * i + 1] = f.y; v[4 * i + 2] = f.z; v[4 * i + 3] = f.w;
   }
 }
+__device__ __forceinline__ void ln_load_nt(const float* row, int lane, float (&v)[12]) {  // streamed-once token rows
+#pragma unroll
+  for (int i = 0; i < LN_V; ++i) {
+    const f32x4 f = __builtin_nontemporal_load((const f32x4*)(row + i * 256 + lane * 4));
+    v[4 * i] = f.x; v[4 * i + 1] = f.y; v[4 * i + 2] = f.z; v[4 * i + 3] = f.w;
+  }
+}
 __device__ __forceinline__ void ln_stats(const float (&v)[12], float eps, float& mean, float& rstd) {
   float s = 0.f;
 #pragma unroll
@@ -154,7 +161,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
   const int64_t nwaves = (int64_t)gridDim.x * 4;
   for (int64_t m = wave; m < rows; m += nwaves) {
     float v[12], mean, rstd;
-    ln_load(x + ln_src_row(mode, p0, p1, m) * ldx, lane, v);
+    ln_load_nt(x + ln_src_row(mode, p0, p1, m) * ldx, lane, v);
     ln_stats(v, eps, mean, rstd);
     ln_affine(v, mean, rstd, gamma, beta, lane);
     ln_store<T>(y + m * ldy, lane, v);
