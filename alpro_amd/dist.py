@@ -23,7 +23,9 @@ def init(backend=None):
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29500")
     if backend is None:
-        backend = "nccl" if torch.cuda.is_available() else "gloo"  # "nccl" IS RCCL on ROCm
+        # "nccl" IS RCCL on ROCm.  ALPRO_DIST_BACKEND=gloo lets several ranks share one GPU (functional tests of the
+        # multi-process path on a single-GPU box; RCCL refuses two ranks on one device).
+        backend = os.environ.get("ALPRO_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
     if backend == "nccl":
         torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
     td.init_process_group(backend=backend, rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))

@@ -214,7 +214,7 @@ def main():
     dist.init()
     rank, world = dist.rank(), dist.size()
     assert world == args.gpus or (args.gpus == 1 and world == 1), "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0")) % max(1, torch.cuda.device_count())  # (% only matters for gloo smoke runs)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     hip.load()
@@ -285,13 +285,16 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # per-kernel-family device time: one extra, untimed step under HIP events.  EVERY rank runs it (the training step holds
+    # collectives: a rank-0-only pass would wait forever for its peers); only rank 0 reports.
+    with (torch.enable_grad() if train else torch.no_grad()), KernelTimer(hip) as kt:
+        step()
+    ks = kt.summary()
+    dist.barrier()
     result = None
     if rank == 0:
         ms = elapsed / args.steps * 1e3
         value = world * B * args.steps / elapsed
-        with (torch.enable_grad() if train else torch.no_grad()), KernelTimer(hip) as kt:
-            step()
-        ks = kt.summary()
         gemm = dict(ks["gemm"])
         if "gemm_tn_acc" in ks:  # the wgrad GEMMs belong to the same MFMA-bound family
             for k_ in ("launches", "flops", "ms"):
@@ -321,10 +324,12 @@ def main():
                          "traffic_unit": "HBM bytes per GEMM launch (PMC)", "traffic_source": traffic_src},
             "kernel_ms_per_step": {k: round(v["ms"], 3) for k, v in ks.items()},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # reported at N=1 only (rank 0 would keep its peers waiting at N>1)
             result["cpu_baseline"] = cpu_baseline_train(T) if train else cpu_baseline(T)
-        print(json.dumps(result))
+        print(json.dumps(result), flush=True)
     dist.barrier()
+    if world > 1 and torch.distributed.is_initialized():
+        torch.distributed.destroy_process_group()
     return result
 
 

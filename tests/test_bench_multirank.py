@@ -1,0 +1,31 @@
+"""GPU: bench.py's multi-process path end to end -- two ranks sharing the one GPU of the test box over gloo
+(ALPRO_DIST_BACKEND=gloo; RCCL refuses two ranks on one device).  Exercises what the N>1 driver run exercises: rendezvous,
+parameter broadcast, the differentiable feature all-gather inside forward, the flat gradient all-reduce, the untimed
+per-kernel pass on EVERY rank (a rank-0-only extra step would hang in its collectives) and a clean exit."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_bench_two_ranks_gloo_shared_gpu():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, ALPRO_DIST_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--batch", "2", "--frames", "2", "--steps", "1", "--warmup", "1"]
+    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]          # exactly one JSON line, from rank 0
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["config"]["per_gpu_batch"] == 2
+    assert "cpu_baseline" not in d                          # reported at N=1 only
