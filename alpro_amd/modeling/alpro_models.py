@@ -303,7 +303,11 @@ class Prompter(AlproBaseModel):
         if self.training:
             self.eval()
         with torch.no_grad():
-            _, feat = self._forward_visual_embeds(batch['crop_visual_inputs'])
+            if hasattr(self.visual_encoder, "forward_cls"):  # only the CLS feature is consumed: CLS-only tail of the last block
+                cls = self.visual_encoder.forward_cls(batch['crop_visual_inputs'].transpose(1, 2))
+                feat = F.normalize(_linear32(cls, self.vision_proj), dim=-1)
+            else:
+                _, feat = self._forward_visual_embeds(batch['crop_visual_inputs'])
             prompt_feat = self.video_prompt_feat if batch['type'] == 'video' else self.image_prompt_feat
             sim_masked = feat @ prompt_feat.t() / self.temp
             return self._compute_soft_labels(sim_masked)

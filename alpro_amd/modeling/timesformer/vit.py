@@ -178,6 +178,35 @@ class Block(nn.Module):
         sv.update(h=h, qkv_t=qkv_t, a_t=a_t, lse_t=lse_t, pr=pr, xt=xt, hs=hs, qkv_s=qkv_s, a_s=a_s, lse_s=lse_s, x2=x2, h2=h2, u=u, f1=f1)
         return out, sv
 
+    def forward_cls(self, x, B, T, W):
+        """LAST block when only the CLS output is consumed (the frozen prompter: get_pseudo_labels uses feat = proj(x[:, 0])):
+        the temporal half and the spatial K/V need every token, but the spatial projection, the MLP and what follows are
+        evaluated on the CLS rows alone -- (B*T, D) / (B, D) instead of (B*S, D).  Same arithmetic as forward() for those rows
+        (vit.py:165-212); eval mode only (no drop-path).  Returns the block output's CLS rows, (B, D) fp32."""
+        dt = rt.compute_dtype()
+        S, D = x.shape[1], x.shape[2]
+        N = (S - 1) // T
+        H = self.attn.num_heads
+        xf = x.view(B * S, D)
+        ta, sa = self.temporal_attn, self.attn
+        h = hip.layernorm(x, self.temporal_norm1.weight, self.temporal_norm1.bias, VIT_EPS, dt, rows=B * N * T,
+                          map_mode=hip.MAP_SKIP_CLS, map_p0=N * T)
+        qkv = hip.gemm(h, self._w("t_qkv", ta.qkv, dt), bias=ta.qkv.bias)
+        a = hip.attn_temporal(qkv, T, H, ta.scale)
+        pr = hip.gemm(a, self._w("t_proj", ta.proj, dt), bias=ta.proj.bias)
+        hip.gemm(pr, self._w("t_fc", self.temporal_fc, dt), out=xf, bias=self.temporal_fc.bias, out_dtype=torch.float32,
+                 residual=xf, map_mode=hip.MAP_SKIP_CLS, map_p0=N * T)
+        hs = hip.layernorm(x, self.norm1.weight, self.norm1.bias, VIT_EPS, dt, rows=B * T * (N + 1),
+                           map_mode=hip.MAP_FRAME_TOKENS, map_p0=T, map_p1=N)
+        qkv = hip.gemm(hs, self._w("s_qkv", sa.qkv, dt), bias=sa.qkv.bias)
+        a = hip.attn(qkv, B * T, N + 1, H, sa.scale)
+        a_cls = a.view(B * T, N + 1, D)[:, 0].contiguous()                                  # CLS query of every frame
+        p_cls = hip.gemm(a_cls, self._w("s_proj", sa.proj, dt), bias=sa.proj.bias, out_dtype=torch.float32)
+        x_cls = x[:, 0] + p_cls.view(B, T, D).mean(1)                                        # frame mean of the CLS rows (vit.py:187)
+        h2 = hip.layernorm(x_cls.contiguous(), self.norm2.weight, self.norm2.bias, VIT_EPS, dt)
+        f1 = hip.gemm(h2, self._w("fc1", self.mlp.fc1, dt), bias=self.mlp.fc1.bias, act=hip.ACT_GELU)
+        return hip.gemm(f1, self._w("fc2", self.mlp.fc2, dt), bias=self.mlp.fc2.bias, out_dtype=torch.float32, residual=x_cls.contiguous())
+
     def _wt(self, name, lin, dt):
         return tr.transposed_operand(self._ops, name + "^T", lin.weight, dt)
 
@@ -402,6 +431,19 @@ class TimeSformer(nn.Module):
             tok = blk(tok, B, T, W)
         out32, _ = hip.vit_final_pool(tok, m.norm.weight, m.norm.bias, VIT_EPS, B, T, N, torch.float32)
         return out32
+
+    def forward_cls(self, x):
+        """x: (b, c, t, h, w) -> (b, 768): the CLS row of forward_features(x) only, inference only.  The last block's spatial
+        projection and MLP run on the CLS rows alone (Block.forward_cls); used by the frozen prompter, whose pseudo labels
+        depend on nothing else (alpro_models.py:531-551)."""
+        assert not torch.is_grad_enabled(), "forward_cls is an inference path"
+        m = self.model
+        B = x.shape[0]
+        tok, T, W, N = m._embed(x)
+        for blk in m.blocks[:-1]:
+            tok = blk(tok, B, T, W)
+        cls = m.blocks[-1].forward_cls(tok, B, T, W)
+        return hip.layernorm(cls, m.norm.weight, m.norm.bias, VIT_EPS, torch.float32)
 
     def forward(self, x):
         return self.model(x)

@@ -201,3 +201,16 @@ def test_cached_retrieval_eval_equals_forward_inference(retrieval):
     assert max(abs(a["sim"] - b["sim"]) for a, b in zip(got, ref)) <= 2e-4
     metrics = eval_retrieval(got, {"t%d" % i: "v%d" % i for i in range(3)})
     assert set(metrics) == {"text2video", "video2text"} and 0 <= metrics["text2video"]["r1"] <= 100
+
+
+@pytest.mark.parametrize("mode,tol", [("fp32", 2e-5), ("bf16", 3e-2)])
+def test_forward_cls_equals_cls_row_of_forward_features(retrieval, mode, tol):
+    """TimeSformer.forward_cls (CLS-only tail of the last block, used by the frozen prompter) == forward_features(x)[:, 0]."""
+    from alpro_amd import config as rt
+    m, batch, _ = retrieval
+    x = batch["visual_inputs"].transpose(1, 2)
+    with rt.use_compute_dtype(mode), torch.no_grad():
+        full = m.visual_encoder.forward_features(x, return_all_tokens=True)[:, 0]
+        cls = m.visual_encoder.forward_cls(x)
+    assert cls.shape == full.shape
+    assert (cls - full).abs().max().item() <= tol * max(1.0, full.abs().max().item())
