@@ -155,3 +155,43 @@ def test_retrieval_metrics_known_answer():
     out = eval_retrieval(recs, {"t0": "v0", "t1": "v1", "t2": "v2"})
     assert abs(out["text2video"]["r1"] - 200 / 3) < 1e-9 and out["text2video"]["r5"] == 100.0 and out["text2video"]["meanR"] == 4 / 3
     assert abs(out["video2text"]["r1"] - 100.0) < 1e-9
+
+
+def test_input_pipeline_ops_match_reference_semantics():
+    """alpro_amd.input_gpu (device-side batch preparation) on CPU tensors: MLM masking invariants, the
+    random-erase crop against the reference's per-sample construction for a fixed rectangle, ImageNorm."""
+    import numpy as np
+    import torch.nn.functional as F
+    from alpro_amd.input_gpu import ImageNorm, mask_batch_text_tokens, random_erase_batch, sample_erase_box
+    g = torch.Generator().manual_seed(0)
+    ids = torch.randint(1000, 30000, (64, 40), generator=g)
+    ids[:, 0] = 101
+    ids[:, 30] = 102
+    ids[:, 31:] = 0
+    masked, labels = mask_batch_text_tokens(ids, mask_token_id=103, vocab_size=30522, generator=g)
+    sel = labels != -100
+    assert not sel[:, 0].any() and not sel[:, 30:].any()                      # [CLS], [SEP], padding are never selected
+    assert torch.equal(labels[sel], ids[sel]) and torch.equal(masked[~sel], ids[~sel])
+    frac = sel.float().sum() / (64 * 29)
+    assert 0.10 < float(frac) < 0.20
+    assert 0.7 < float((masked[sel] == 103).float().mean()) < 0.9            # ~80 % [MASK]
+    # random erase: fixed boxes vs the per-sample construction of dataset_pretrain_sparse.py:277-311
+    x = torch.randn(2, 3, 3, 64, 96)
+    boxes = [(16, 32, 32, 48), (0, 0, 16, 16)]
+    out = random_erase_batch(x, patch_size=16, boxes=boxes)
+    for b, (top, left, h, w) in enumerate(boxes):
+        ctx = x[b].clone()
+        ctx[:, :, top:top + h, left:left + w] = 0
+        crop = F.pad(x[b][:, :, top:top + h, left:left + w], (left, 96 - left - w, top, 64 - top - h))
+        msk = torch.ones_like(crop)
+        msk[:, :, top:top + h, left:left + w] = 0
+        msk = F.avg_pool2d(msk, kernel_size=16, stride=16).mean((0, 1))
+        assert torch.equal(out["context_visual_inputs"][b], ctx) and torch.equal(out["crop_visual_inputs"][b], crop)
+        assert torch.allclose(out["mpm_mask"][b], msk)
+    rng = np.random.RandomState(1)
+    for _ in range(50):
+        top, left, h, w = sample_erase_box(224, 224, 16, rng=rng)
+        assert top % 16 == left % 16 == h % 16 == w % 16 == 0 and top + h <= 224 and left + w <= 224
+    img = torch.rand(1, 2, 3, 4, 4) * 255
+    ref = (img / 255 - torch.tensor([0.485, 0.456, 0.406]).view(1, 1, 3, 1, 1)) / torch.tensor([0.229, 0.224, 0.225]).view(1, 1, 3, 1, 1)
+    assert torch.allclose(ImageNorm([0.485, 0.456, 0.406], [0.229, 0.224, 0.225], device="cpu")(img.clone()), ref, atol=1e-6)
