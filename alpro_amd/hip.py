@@ -321,13 +321,14 @@ def bert_embed(ids, word, pos, type_emb, gamma, beta, eps, dtype, stats=False, d
     return y32, (y_t if y_t is not None else y32)
 
 
-def cast(src, dtype):
+def cast(src, dtype, out=None):
     """fp32 -> dtype copy on device (parameters are kept fp32; 16-bit operand copies are refreshed per step)."""
     lib = load()
     _dev(src, torch.float32)
     if dtype == torch.float32:
         return src
-    dst = torch.empty(src.shape, dtype=dtype, device=src.device)
+    dst = out if out is not None else torch.empty(src.shape, dtype=dtype, device=src.device)
+    assert dst.dtype == dtype and dst.numel() == src.numel() and dst.is_contiguous()
     _check(lib.alpro_cast_from_f32(_ptr(src), _ptr(dst), _CODE[dtype], src.numel(), _stream()), "alpro_cast_from_f32")
     return dst
 

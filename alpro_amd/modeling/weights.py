@@ -23,6 +23,42 @@ def param_epoch():
     return _PARAM_EPOCH[0]
 
 
+# One flat 16-bit copy of every parameter an optimizer with flat storage owns (alpro_amd.optim.FlatAdamW): refreshed by ONE cast
+# launch right after the update instead of ~250 per-tensor casts at first use; operands are then views into it.
+_FLAT_LP = {"base": 0, "end": 0, "lp": None, "epoch": -1, "versions": {}}
+
+
+def register_flat_lp(flat_p, flat_lp, params):
+    """flat_lp (16-bit) mirrors flat_p (fp32) element for element as of the current parameter epoch."""
+    _FLAT_LP.update(base=flat_p.data_ptr(), end=flat_p.data_ptr() + flat_p.numel() * 4, lp=flat_lp, epoch=param_epoch(),
+                    versions={id(p): p._version for p in params})
+
+
+def _flat_lp_view(plist, dtype):
+    """View of the registered flat 16-bit copy covering `plist` (parameters stored back to back), or None."""
+    f = _FLAT_LP
+    if f["lp"] is None or f["epoch"] != param_epoch() or f["lp"].dtype != dtype:
+        return None
+    off = None
+    nxt = None
+    for p in plist:
+        a = p.data_ptr()
+        if not (f["base"] <= a < f["end"]) or f["versions"].get(id(p)) != p._version or not p.is_contiguous():
+            return None
+        if nxt is not None and a != nxt:
+            return None
+        if off is None:
+            off = (a - f["base"]) // 4
+            if off % 8 != 0:  # the 16-bit view must stay 16-byte aligned for the GEMM operand loads
+                return None
+        nxt = a + p.numel() * 4
+    total = (nxt - f["base"]) // 4 - off
+    cols = plist[0].numel() // plist[0].shape[0]
+    if any(p.numel() // p.shape[0] != cols for p in plist):
+        return None
+    return f["lp"][off:off + total].view(-1, cols)
+
+
 class OperandCache:
     def __init__(self):
         self._store = {}
@@ -34,6 +70,10 @@ class OperandCache:
         if single and dtype == torch.float32:
             w = params.detach()
             return w if w.is_contiguous() else w.contiguous()
+        if dtype != torch.float32 and all(p.dim() >= 2 for p in plist):
+            v = _flat_lp_view(plist, dtype)
+            if v is not None:
+                return v
         ver = (param_epoch(),) + tuple((p.data_ptr(), p._version) for p in plist)
         hit = self._store.get(key)
         if hit is not None and hit[0] == ver and hit[1].dtype == dtype:

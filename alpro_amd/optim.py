@@ -17,7 +17,8 @@ import math
 import torch
 
 from alpro_amd import dist, hip
-from alpro_amd.modeling.weights import bump_param_epoch
+from alpro_amd import config as rt
+from alpro_amd.modeling.weights import bump_param_epoch, register_flat_lp
 
 
 class FlatAdamW:
@@ -120,6 +121,12 @@ class FlatAdamW:
         hip.adamw_step(f["p"], f["g"], f["m"], f["v"], lr, b1, b2, grp["eps"], grp["weight_decay"], step_size, norm,
                        float(self.max_grad_norm or 0.0), 1.0 / world)
         bump_param_epoch()
+        dt = rt.compute_dtype()
+        if dt != torch.float32:  # refresh the 16-bit GEMM operands of every parameter with one launch (weights.py)
+            if f.get("lp") is None or f["lp"].dtype != dt:
+                f["lp"] = torch.empty(f["n"], dtype=dt, device=f["p"].device)
+            hip.cast(f["p"], dt, out=f["lp"])
+            register_flat_lp(f["p"], f["lp"], f["live"])
 
     def state_dict(self):
         return dict(step=self.step_count, param_groups=[{k: v for k, v in g.items() if k != "params"} for g in self.param_groups],
