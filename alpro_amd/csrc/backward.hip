@@ -179,14 +179,15 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
 template <typename T, int NW>
 __global__ __launch_bounds__(NW * 64) void gather_cast_kernel(const float* __restrict__ src, int64_t ld, T* __restrict__ out, int64_t rows, int mode,
                                                           int p0, int p1, const float* __restrict__ row_scale, int group, float cls_scale,
-                                                          float drop_p, uint32_t drop_seed, float* __restrict__ colsum) {
+                                                          float drop_p, uint32_t drop_seed, float* __restrict__ colsum,
+                                                          float* __restrict__ colsum_pre) {
   __shared__ float red[NW][LN_D];
   const int lane = threadIdx.x & 63;
   const int64_t wave = (int64_t)blockIdx.x * NW + (threadIdx.x >> 6);
   const int64_t nwaves = (int64_t)gridDim.x * NW;
-  float cs[12];
+  float cs[12], cp[12];
 #pragma unroll
-  for (int i = 0; i < 12; ++i) cs[i] = 0.f;
+  for (int i = 0; i < 12; ++i) cs[i] = cp[i] = 0.f;
   auto src_row = [&](int64_t m, float& sc) -> int64_t {
     sc = row_scale ? row_scale[m / group] : 1.0f;
     if (mode == ALPRO_MAP_PATCH_EMBED) {
@@ -213,6 +214,7 @@ __global__ __launch_bounds__(NW * 64) void gather_cast_kernel(const float* __res
     }
 #pragma unroll
     for (int i = 0; i < 12; ++i) {
+      cp[i] += v[i];
       v[i] *= sc;
       cs[i] += v[i];
     }
@@ -243,20 +245,25 @@ __global__ __launch_bounds__(NW * 64) void gather_cast_kernel(const float* __res
     emit(m, v, sc);
     if (has2) emit(m2, v2, sc2);
   }
-  if (colsum) {  // bias gradient of the Linear these rows are the dY of: 4-wave LDS fold, one atomic per column per block
+  // bias gradients of the Linears these rows are the dY of (after / before the row scale): 4-wave LDS fold, one atomic per
+  // column per workgroup
+  auto flush = [&](const float (&acc)[12], float* dst) {
     const int w = threadIdx.x >> 6;
+    __syncthreads();
 #pragma unroll
     for (int i = 0; i < 3; ++i)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) red[w][i * 256 + lane * 4 + e] = cs[4 * i + e];
+      for (int e = 0; e < 4; ++e) red[w][i * 256 + lane * 4 + e] = acc[4 * i + e];
     __syncthreads();
     for (int c = threadIdx.x; c < LN_D; c += NW * 64) {
       float t = 0.f;
 #pragma unroll
       for (int k = 0; k < NW; ++k) t += red[k][c];
-      unsafeAtomicAdd(colsum + c, t);
+      unsafeAtomicAdd(dst + c, t);
     }
-  }
+  };
+  if (colsum) flush(cs, colsum);
+  if (colsum_pre) flush(cp, colsum_pre);
 }
 
 // ---- du = dh * gelu'(u) (erf GELU), elementwise over 16-byte chunks ---------------------------------------
@@ -352,17 +359,17 @@ extern "C" int alpro_layernorm_bwd(const void* dy, int dy_dtype, int64_t ld_dy, 
 
 extern "C" int alpro_gather_cast(const float* src, int64_t ld, void* out, int dtype, int rows, int D, int map_mode, int map_p0, int map_p1,
                                  const float* row_scale, int row_scale_group, float cls_scale, float drop_p, uint32_t drop_seed, float* colsum,
-                                 void* stream) {
+                                 float* colsum_pre, void* stream) {
   ALPRO_CHECK(src && out && rows > 0, "alpro_gather_cast: bad args");
   ALPRO_CHECK(D == LN_D, "alpro_gather_cast: D=%d unsupported", D);
   ALPRO_CHECK(map_mode >= 0 && map_mode <= ALPRO_MAP_PATCH_EMBED, "alpro_gather_cast: bad map_mode %d", map_mode);
   ALPRO_CHECK(!row_scale || row_scale_group > 0, "alpro_gather_cast: row_scale_group must be > 0");
   // with a colsum target: few, fat workgroups (16 waves) -- every workgroup ends with 768 same-address atomics, and those
   // serialise at the memory side (3072 workgroups cost 2x the whole cast); plain casts use many small workgroups
-  if (colsum) {
-    ALPRO_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((gather_cast_kernel<T, 16>), dim3(grid_for(rows, 32, 512)), dim3(1024), 0, (hipStream_t)stream, src, ld, (T*)out, (int64_t)rows, map_mode, map_p0, map_p1, row_scale, row_scale_group, cls_scale, drop_p, drop_seed, colsum));
+  if (colsum || colsum_pre) {
+    ALPRO_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((gather_cast_kernel<T, 16>), dim3(grid_for(rows, 32, 512)), dim3(1024), 0, (hipStream_t)stream, src, ld, (T*)out, (int64_t)rows, map_mode, map_p0, map_p1, row_scale, row_scale_group, cls_scale, drop_p, drop_seed, colsum, colsum_pre));
   } else {
-    ALPRO_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((gather_cast_kernel<T, 4>), dim3(grid_for(rows, 8, 256 * 32)), dim3(256), 0, (hipStream_t)stream, src, ld, (T*)out, (int64_t)rows, map_mode, map_p0, map_p1, row_scale, row_scale_group, cls_scale, drop_p, drop_seed, colsum));
+    ALPRO_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((gather_cast_kernel<T, 4>), dim3(grid_for(rows, 8, 256 * 32)), dim3(256), 0, (hipStream_t)stream, src, ld, (T*)out, (int64_t)rows, map_mode, map_p0, map_p1, row_scale, row_scale_group, cls_scale, drop_p, drop_seed, colsum, colsum_pre));
   }
   return check_launch("alpro_gather_cast");
 }

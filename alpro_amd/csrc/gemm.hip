@@ -164,6 +164,12 @@ __device__ __forceinline__ void epi_rows16(const alpro_gemm_desc_t& g, const flo
 #pragma unroll
       for (int e = 0; e < 4; ++e) v[e] = drop_keep(g.drop_seed, i0 + e, th) ? v[e] * ks : 0.f;
     }
+    if constexpr (MAP == ALPRO_MAP_SKIP_CLS) {
+      if (g.bias2) {  // unscaled second bias (merged temporal projection)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] += (FAST || n + e < g.N) ? g.bias2[n + e] : 0.f;
+      }
+    }
 #pragma unroll
     for (int e = 0; e < 4; ++e) v[e] += res[e];
     if (MAP == ALPRO_MAP_FRAME_TOKENS && side[p]) {
@@ -661,6 +667,7 @@ extern "C" int alpro_gemm(const alpro_gemm_desc_t* d, void* stream) {
   ALPRO_CHECK(d->c_dtype == d->dtype || d->c_dtype == ALPRO_F32, "alpro_gemm: c_dtype must be dtype or F32");
   ALPRO_CHECK(d->map_mode >= 0 && d->map_mode <= 3, "alpro_gemm: bad map_mode %d", d->map_mode);
   ALPRO_CHECK(d->act >= 0 && d->act <= ALPRO_ACT_GELU_BWD, "alpro_gemm: bad act %d", d->act);
+  ALPRO_CHECK(!d->bias2 || d->map_mode == ALPRO_MAP_SKIP_CLS, "alpro_gemm: bias2 is only defined under the SKIP_CLS map");
   ALPRO_CHECK(d->act != ALPRO_ACT_GELU_BWD || (d->C2 && d->N % 8 == 0 && d->ldc2 % 8 == 0), "alpro_gemm: GELU_BWD needs the saved pre-activation in C2 (N, ldc2 multiples of 8)");
   ALPRO_CHECK(!d->drop_seed || (d->map_mode == ALPRO_MAP_IDENTITY && d->drop_p > 0.f && d->drop_p < 1.f), "alpro_gemm: dropout needs the identity map and 0 < p < 1");
   ALPRO_CHECK(!d->C2 || (d->N % 4 == 0 && d->ldc2 % 4 == 0 && d->ldc % 4 == 0), "alpro_gemm: C2 needs N, ldc, ldc2 multiples of 4");

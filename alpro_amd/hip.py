@@ -35,7 +35,7 @@ class GemmDesc(ctypes.Structure):
                 ("map_mode", ctypes.c_int), ("map_p0", ctypes.c_int), ("map_p1", ctypes.c_int),
                 ("side", ctypes.c_void_p), ("ld_side", ctypes.c_int64),
                 ("C2", ctypes.c_void_p), ("ldc2", ctypes.c_int64),
-                ("drop_p", ctypes.c_float), ("drop_seed", ctypes.c_uint32)]
+                ("drop_p", ctypes.c_float), ("drop_seed", ctypes.c_uint32), ("bias2", ctypes.c_void_p)]
 
 
 _lib = None
@@ -68,7 +68,7 @@ def load():
     lib.alpro_gemm_tn_acc.argtypes = [vp, i64, vp, i64, vp, i64, i32, i32, i32, i32, vp, vp]
     lib.alpro_colsum_acc.argtypes = [vp, i64, vp, i32, i32, i32, vp]
     lib.alpro_adamw_step.argtypes = [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, f32, vp, f32, f32, vp]
-    lib.alpro_gather_cast.argtypes = [vp, i64, vp, i32, i32, i32, i32, i32, i32, vp, i32, f32, f32, u32, vp, vp]
+    lib.alpro_gather_cast.argtypes = [vp, i64, vp, i32, i32, i32, i32, i32, i32, vp, i32, f32, f32, u32, vp, vp, vp]
     lib.alpro_cls_mean_bwd.argtypes = [vp, i64, vp, i32, i32, i32, vp]
     lib.alpro_scatter_add_rows.argtypes = [vp, vp, vp, i32, i32, i32, vp]
     lib.alpro_attn_fwd.argtypes = [vp, vp, i32, i32, i32, i32, f32, vp, vp, f32, u32, vp]
@@ -77,7 +77,7 @@ def load():
     lib.alpro_vit_final_pool.argtypes = [vp, vp, vp, f32, vp, vp, i32, i32, i32, i32, i32, vp]
     lib.alpro_bert_embed_fwd.argtypes = [vp, vp, vp, vp, vp, vp, f32, vp, vp, i32, vp, vp, i32, i32, i32, f32, u32, vp]
     lib.alpro_cast_from_f32.argtypes = [vp, vp, i32, i64, vp]
-    if lib.alpro_hip_abi_version() != 4:
+    if lib.alpro_hip_abi_version() != 5:
         raise RuntimeError("libalpro_hip.so ABI version mismatch")
     _lib = lib
     return lib
@@ -116,8 +116,8 @@ def torch_dtype(code):
 
 # ------------------------------------------------------------------------------------------------
 def gemm(a, w, out=None, bias=None, act=ACT_NONE, out_dtype=None, alpha=1.0, row_scale=None, row_scale_group=1,
-         residual=None, map_mode=MAP_IDENTITY, map_p0=0, map_p1=0, side=None, out_rows=None, pre_act=None, drop_p=0.0, drop_seed=0):
-    """out[map(m)] = residual[map(m)] + row_scale * act(alpha * a @ w.T + bias)   (see alpro_gemm).
+         residual=None, map_mode=MAP_IDENTITY, map_p0=0, map_p1=0, side=None, out_rows=None, pre_act=None, drop_p=0.0, drop_seed=0, bias2=None):
+    """out[map(m)] = residual[map(m)] + row_scale * act(alpha * a @ w.T + bias) [+ bias2]   (see alpro_gemm).
     act=ACT_GELU_BWD: out = (alpha * a @ w.T + bias) * gelu'(pre_act) (pre_act read only)."""
     lib = load()
     _dev(a); _dev(w, a.dtype)
@@ -145,6 +145,7 @@ def gemm(a, w, out=None, bias=None, act=ACT_NONE, out_dtype=None, alpha=1.0, row
     d.C2 = _dev(pre_act, a.dtype).data_ptr() if pre_act is not None else None
     d.ldc2 = pre_act.shape[-1] if pre_act is not None else 0
     d.drop_p, d.drop_seed = drop_p, drop_seed
+    d.bias2 = _dev(bias2, torch.float32).data_ptr() if bias2 is not None else None
     _check(lib.alpro_gemm(ctypes.byref(d), _stream()), "alpro_gemm")
     return out
 
@@ -226,7 +227,7 @@ def transpose(x, out_dtype=None, pad_to=64, colsum=None):
 
 
 def gather_cast(src, dtype, rows=None, map_mode=MAP_IDENTITY, map_p0=0, map_p1=0, row_scale=None, row_scale_group=1, cls_scale=1.0,
-                drop_p=0.0, drop_seed=0, colsum=None):
+                drop_p=0.0, drop_seed=0, colsum=None, colsum_pre=None):
     """fp32 (..., 768) token-gradient rows -> (rows, 768) GEMM operand in `dtype` (see alpro_gather_cast); colsum (768,) fp32 += out.sum(0)."""
     lib = load()
     _dev(src, torch.float32)
@@ -235,7 +236,8 @@ def gather_cast(src, dtype, rows=None, map_mode=MAP_IDENTITY, map_p0=0, map_p1=0
     out = torch.empty((rows, D), dtype=dtype, device=src.device)
     _check(lib.alpro_gather_cast(_ptr(src), D, _ptr(out), _CODE[dtype], rows, D, map_mode, map_p0, map_p1,
                                  _ptr(_dev(row_scale, torch.float32)) if row_scale is not None else None, row_scale_group, cls_scale, drop_p, drop_seed,
-                                 _ptr(_dev(colsum, torch.float32)) if colsum is not None else None, _stream()),
+                                 _ptr(_dev(colsum, torch.float32)) if colsum is not None else None,
+                                 _ptr(_dev(colsum_pre, torch.float32)) if colsum_pre is not None else None, _stream()),
            "alpro_gather_cast")
     return out
 

@@ -28,7 +28,7 @@ import torch.nn as nn
 from alpro_amd import config as rt
 from alpro_amd import hip
 from alpro_amd.modeling import train as tr
-from alpro_amd.modeling.weights import OperandCache
+from alpro_amd.modeling.weights import OperandCache, param_epoch
 
 VIT_EPS = 1e-6
 
@@ -103,6 +103,29 @@ class Block(nn.Module):
     def _w(self, name, lin, dt):
         return self._ops.get(name, lin.weight, dt)
 
+    # ---- merged temporal projection ------------------------------------------------------------------------------
+    # vit.py:157-162 applies two Linears back to back with only drop_path between them:
+    #     res_temporal = drop_path(temporal_attn.proj(attn_out));  xt = x + temporal_fc(res_temporal)
+    # drop_path is a per-row scale s, so   temporal_fc(s * (a Wp^T + bp)) = s * (a (Wfc Wp)^T + Wfc bp) + bfc :
+    # ONE (768 x 768) GEMM with the merged weight We = Wfc Wp (rebuilt per optimizer step from the two fp32 parameters, a
+    # 0.9 GFLOP product), bias Wfc bp under the row scale and bfc after it (alpro_gemm bias2).  Saves one 100k x 768 x 768
+    # GEMM per block in forward and, in backward, one dgrad and one wgrad: dWe = (s*dY)^T a is taken once and pushed through
+    # the product rule (dWfc = dWe Wp^T + db1 bp^T, dWp = Wfc^T dWe, dbp = Wfc^T db1, dbfc = colsum(dY)).
+    merge_temporal_proj = True
+
+    def _merged_tproj(self, dt):
+        wp, bp, wf = self.temporal_attn.proj.weight, self.temporal_attn.proj.bias, self.temporal_fc.weight
+        ver = (param_epoch(), wp.data_ptr(), wp._version, bp._version, wf.data_ptr(), wf._version, dt)
+        hit = self._ops._store.get("t_merged")
+        if hit is not None and hit[0] == ver:
+            return hit[1]
+        with torch.no_grad():
+            we = hip.gemm(wf.detach().contiguous(), hip.transpose(wp.detach().contiguous()), out_dtype=torch.float32)   # (768, 768) fp32 = Wfc Wp
+            b1 = torch.mv(wf.detach(), bp.detach()).contiguous()
+            m = dict(w=we if dt == torch.float32 else hip.cast(we, dt), wT=hip.transpose(we, out_dtype=dt, pad_to=64), b1=b1)
+        self._ops._store["t_merged"] = (ver, m)
+        return m
+
     def _drop(self, rows, device):
         return self.drop_path.row_scale(rows, device) if isinstance(self.drop_path, DropPath) else None
 
@@ -119,9 +142,14 @@ class Block(nn.Module):
                           map_mode=hip.MAP_SKIP_CLS, map_p0=N * T)
         qkv = hip.gemm(h, self._w("t_qkv", ta.qkv, dt), bias=ta.qkv.bias)
         a = hip.attn_temporal(qkv, T, H, ta.scale)
-        pr = hip.gemm(a, self._w("t_proj", ta.proj, dt), bias=ta.proj.bias, row_scale=self._drop(B * N, x.device), row_scale_group=T)
-        hip.gemm(pr, self._w("t_fc", self.temporal_fc, dt), out=xf, bias=self.temporal_fc.bias, out_dtype=torch.float32,
-                 residual=xf, map_mode=hip.MAP_SKIP_CLS, map_p0=N * T)
+        if self.merge_temporal_proj:
+            mg = self._merged_tproj(dt)
+            hip.gemm(a, mg["w"], out=xf, bias=mg["b1"], bias2=self.temporal_fc.bias, out_dtype=torch.float32, residual=xf,
+                     row_scale=self._drop(B * N, x.device), row_scale_group=T, map_mode=hip.MAP_SKIP_CLS, map_p0=N * T)
+        else:
+            pr = hip.gemm(a, self._w("t_proj", ta.proj, dt), bias=ta.proj.bias, row_scale=self._drop(B * N, x.device), row_scale_group=T)
+            hip.gemm(pr, self._w("t_fc", self.temporal_fc, dt), out=xf, bias=self.temporal_fc.bias, out_dtype=torch.float32,
+                     residual=xf, map_mode=hip.MAP_SKIP_CLS, map_p0=N * T)
         # ---- spatial (vit.py:165-196)
         hs = hip.layernorm(x, self.norm1.weight, self.norm1.bias, VIT_EPS, dt, rows=B * T * (N + 1),
                            map_mode=hip.MAP_FRAME_TOKENS, map_p0=T, map_p1=N)
@@ -154,11 +182,18 @@ class Block(nn.Module):
                           map_mode=hip.MAP_SKIP_CLS, map_p0=N * T)
         qkv_t = hip.gemm(h, self._w("t_qkv", ta.qkv, dt), bias=ta.qkv.bias)
         a_t, lse_t = hip.attn_temporal(qkv_t, T, H, ta.scale, want_lse=True)
-        pr = hip.gemm(a_t, self._w("t_proj", ta.proj, dt), bias=ta.proj.bias, row_scale=sv["drop_t"], row_scale_group=T)
         xt = torch.empty_like(x)
         xt[:, 0] = x[:, 0]
-        hip.gemm(pr, self._w("t_fc", self.temporal_fc, dt), out=xt.view(B * S, D), bias=self.temporal_fc.bias, out_dtype=torch.float32,
-                 residual=x.view(B * S, D), map_mode=hip.MAP_SKIP_CLS, map_p0=N * T)
+        sv["merged"] = self.merge_temporal_proj
+        if self.merge_temporal_proj:
+            pr = None
+            mg = self._merged_tproj(dt)
+            hip.gemm(a_t, mg["w"], out=xt.view(B * S, D), bias=mg["b1"], bias2=self.temporal_fc.bias, out_dtype=torch.float32,
+                     residual=x.view(B * S, D), row_scale=sv["drop_t"], row_scale_group=T, map_mode=hip.MAP_SKIP_CLS, map_p0=N * T)
+        else:
+            pr = hip.gemm(a_t, self._w("t_proj", ta.proj, dt), bias=ta.proj.bias, row_scale=sv["drop_t"], row_scale_group=T)
+            hip.gemm(pr, self._w("t_fc", self.temporal_fc, dt), out=xt.view(B * S, D), bias=self.temporal_fc.bias, out_dtype=torch.float32,
+                     residual=x.view(B * S, D), map_mode=hip.MAP_SKIP_CLS, map_p0=N * T)
         hs = hip.layernorm(xt, self.norm1.weight, self.norm1.bias, VIT_EPS, dt, rows=B * T * (N + 1),
                            map_mode=hip.MAP_FRAME_TOKENS, map_p0=T, map_p1=N)
         qkv_s = hip.gemm(hs, self._w("s_qkv", sa.qkv, dt), bias=sa.qkv.bias)
@@ -193,9 +228,14 @@ class Block(nn.Module):
                           map_mode=hip.MAP_SKIP_CLS, map_p0=N * T)
         qkv = hip.gemm(h, self._w("t_qkv", ta.qkv, dt), bias=ta.qkv.bias)
         a = hip.attn_temporal(qkv, T, H, ta.scale)
-        pr = hip.gemm(a, self._w("t_proj", ta.proj, dt), bias=ta.proj.bias)
-        hip.gemm(pr, self._w("t_fc", self.temporal_fc, dt), out=xf, bias=self.temporal_fc.bias, out_dtype=torch.float32,
-                 residual=xf, map_mode=hip.MAP_SKIP_CLS, map_p0=N * T)
+        if self.merge_temporal_proj:
+            mg = self._merged_tproj(dt)
+            hip.gemm(a, mg["w"], out=xf, bias=mg["b1"], bias2=self.temporal_fc.bias, out_dtype=torch.float32, residual=xf,
+                     map_mode=hip.MAP_SKIP_CLS, map_p0=N * T)
+        else:
+            pr = hip.gemm(a, self._w("t_proj", ta.proj, dt), bias=ta.proj.bias)
+            hip.gemm(pr, self._w("t_fc", self.temporal_fc, dt), out=xf, bias=self.temporal_fc.bias, out_dtype=torch.float32,
+                     residual=xf, map_mode=hip.MAP_SKIP_CLS, map_p0=N * T)
         hs = hip.layernorm(x, self.norm1.weight, self.norm1.bias, VIT_EPS, dt, rows=B * T * (N + 1),
                            map_mode=hip.MAP_FRAME_TOKENS, map_p0=T, map_p1=N)
         qkv = hip.gemm(hs, self._w("s_qkv", sa.qkv, dt), bias=sa.qkv.bias)
@@ -209,6 +249,30 @@ class Block(nn.Module):
 
     def _wt(self, name, lin, dt):
         return tr.transposed_operand(self._ops, name + "^T", lin.weight, dt)
+
+    def _merged_tproj_backward(self, sv, dx, B, T, N, D, dt):
+        """Backward of xt[:, 1:] = x[:, 1:] + s * (a We^T + Wfc bp) + bfc (see merge_temporal_proj); returns d(a)."""
+        ta, fc = self.temporal_attn, self.temporal_fc
+        wp, bp, wf = ta.proj.weight.detach(), ta.proj.bias.detach(), fc.weight.detach()
+        mg = self._merged_tproj(dt)
+        dev = dx.device
+        # G = s * dY in the operand dtype; dbfc = colsum(dY) (unscaled) from the same pass
+        G = hip.gather_cast(dx, dt, rows=B * N * T, map_mode=hip.MAP_SKIP_CLS, map_p0=N * T, row_scale=sv["drop_t"], row_scale_group=T,
+                            colsum_pre=tr.bias_grad(fc.bias))
+        dWe = torch.zeros((D, D), dtype=torch.float32, device=dev)
+        db1 = torch.zeros(D, dtype=torch.float32, device=dev)
+        if dt != torch.float32:
+            hip.gemm_tn_acc(G, sv["a_t"], dWe, colsum=db1)                       # dWe = G^T a, db1 = colsum(G)
+        else:
+            hip.gemm(hip.transpose(G, colsum=db1), hip.transpose(sv["a_t"]), out=dWe, out_dtype=torch.float32)
+        da = tr.dgrad(G, mg["wT"])                                              # d(a) = G We
+        # product rule back onto the two real parameters (fp32, 768^3 each)
+        g_fc, g_p = tr.grad_buffer(fc.weight, zero=True)[0], tr.grad_buffer(ta.proj.weight, zero=True)[0]
+        hip.gemm(dWe, wp.contiguous(), out=g_fc, out_dtype=torch.float32, residual=g_fc)                         # += dWe Wp^T
+        g_fc.addr_(db1, bp)                                                                                       # += db1 bp^T
+        hip.gemm(hip.transpose(wf.contiguous()), hip.transpose(dWe), out=g_p, out_dtype=torch.float32, residual=g_p)  # += Wfc^T dWe
+        tr.bias_grad(ta.proj.bias).add_(torch.mv(wf.t(), db1))                                                    # += Wfc^T db1
+        return da
 
     def backward(self, sv, dx):
         """dx: gradient w.r.t. the block output, (B, S, D) fp32; overwritten with the gradient w.r.t. the block input."""
@@ -235,11 +299,14 @@ class Block(nn.Module):
         hip.layernorm_bwd(dhs, sv["xt"], self.norm1.weight, VIT_EPS, dx, g, b_, rows=B * T * (N + 1),
                           map_mode=hip.MAP_FRAME_TOKENS, map_p0=T, map_p1=N)
         # ---- temporal: xt[:, 1:] = x[:, 1:] + fc(drop_t * proj(attn(qkv(LN_t(x[:, 1:])))))
-        dfo = hip.gather_cast(dx, dt, rows=B * N * T, map_mode=hip.MAP_SKIP_CLS, map_p0=N * T)
-        tr.wgrad(dfo, sv["pr"], self.temporal_fc.weight, self.temporal_fc.bias)
-        dpp = tr.dgrad(dfo, self._wt("t_fc", self.temporal_fc, dt), row_scale=sv["drop_t"], row_scale_group=T)
-        tr.wgrad(dpp, sv["a_t"], ta.proj.weight, ta.proj.bias)
-        da = tr.dgrad(dpp, self._wt("t_proj", ta.proj, dt))
+        if sv["merged"]:
+            da = self._merged_tproj_backward(sv, dx, B, T, N, D, dt)
+        else:
+            dfo = hip.gather_cast(dx, dt, rows=B * N * T, map_mode=hip.MAP_SKIP_CLS, map_p0=N * T)
+            tr.wgrad(dfo, sv["pr"], self.temporal_fc.weight, self.temporal_fc.bias)
+            dpp = tr.dgrad(dfo, self._wt("t_fc", self.temporal_fc, dt), row_scale=sv["drop_t"], row_scale_group=T)
+            tr.wgrad(dpp, sv["a_t"], ta.proj.weight, ta.proj.bias)
+            da = tr.dgrad(dpp, self._wt("t_proj", ta.proj, dt))
         dqkv = hip.attn_temporal_bwd(sv["qkv_t"], sv["a_t"], da, sv["lse_t"], T, H, ta.scale)
         tr.wgrad(dqkv, sv["h"], ta.qkv.weight, ta.qkv.bias)
         dh = tr.dgrad(dqkv, self._wt("t_qkv", ta.qkv, dt))

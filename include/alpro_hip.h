@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define ALPRO_HIP_ABI_VERSION 4
+#define ALPRO_HIP_ABI_VERSION 5
 
 enum { ALPRO_OK = 0, ALPRO_ERR_INVALID = 1, ALPRO_ERR_LAUNCH = 2 };
 enum { ALPRO_F32 = 0, ALPRO_BF16 = 1, ALPRO_F16 = 2 };
@@ -80,6 +80,9 @@ typedef struct {
   int64_t ldc2;
   float drop_p;           /* dropout on the value BEFORE the residual add (xbert.py:358,436): keep iff hash(seed, m*N+n) */
   uint32_t drop_seed;     /* passes, kept values scaled by 1/(1-p); 0 = off.  Identity map only. */
+  const float* bias2;     /* optional (N) fp32 added AFTER the row scale: C = residual + row_scale*act(..) + bias2.  SKIP_CLS map
+                             only: the merged temporal projection W_fc*W_proj of vit.py:157-162, where drop_path scales the
+                             proj output but not temporal_fc's own bias. */
 } alpro_gemm_desc_t;
 
 int alpro_gemm(const alpro_gemm_desc_t* d, void* stream);
@@ -163,9 +166,11 @@ int alpro_transpose(const void* in, int in_dtype, int64_t ld_in, void* out, int 
  * FRAME_TOKENS the j == 0 rows read the clip's CLS row times cls_scale (= 1/T, the frame mean of vit.py:187). */
 int alpro_gather_cast(const float* src, int64_t ld, void* out, int dtype, int rows, int D, int map_mode, int map_p0,
                       int map_p1, const float* row_scale, int row_scale_group, float cls_scale, float drop_p,
-                      uint32_t drop_seed, float* colsum, void* stream);
+                      uint32_t drop_seed, float* colsum, float* colsum_pre, void* stream);
 /* drop_p > 0: additionally re-applies the GEMM-epilogue dropout mask hash(seed, m*D+n)/(1-p) (backward of alpro_gemm's drop_p).
- * colsum (optional, (D) fp32): colsum[n] += sum_m out[m, n] -- the bias gradient of the Linear these rows are the dY of. */
+ * colsum (optional, (D) fp32): colsum[n] += sum_m out[m, n] -- the bias gradient of the Linear these rows are the dY of;
+ * colsum_pre (optional): the same column sums taken BEFORE the row scale (bias gradient of a Linear that sits after the
+ * drop-path scale, e.g. temporal_fc under the merged temporal projection). */
 
 /* du = dh * gelu'(u) with the erf GELU (vit.py:61 / xbert.py:423 backward). */
 int alpro_gelu_bwd(const void* dh, const void* u, void* du, int dtype, int64_t n, void* stream);

@@ -387,3 +387,43 @@ def test_flat_adamw_behind_the_hvd_facade():
             close(q_, p.detach().cpu().double(), 1e-6, 1e-7, "facade step %d" % step)
         oa.zero_grad()
         ob.zero_grad()
+
+
+@pytest.mark.parametrize("mode,tol", [("fp32", 2e-4), ("bf16", 4e-2)])
+def test_merged_temporal_projection_equals_two_linears(mode, tol):
+    """Block with merge_temporal_proj (one GEMM with We = Wfc Wp, product rule in backward) vs the two Linears of
+    vit.py:157-162, train mode with a fixed drop-path pattern: same output, same input gradient, same parameter gradients."""
+    _hip()
+    from alpro_amd import config as rt
+    from alpro_amd.modeling.timesformer.vit import Block
+    torch.manual_seed(11)
+    blk = Block(dim=768, num_heads=12, layer_num=0, mlp_ratio=4.0, qkv_bias=True, drop_path=0.3, attention_type='divided_space_time').cuda().train()
+    with torch.no_grad():
+        for p in blk.parameters():
+            if p.dim() == 1:
+                p.normal_(0, 0.3)
+    B, T, N = 2, 4, 9
+    S = 1 + N * T
+    x = rnd(B, S, 768, seed=500).cuda()
+    dout = rnd(B, S, 768, seed=501).cuda()
+    masks = {B * N: (torch.rand(B * N, generator=torch.Generator().manual_seed(1)) > 0.3).float().cuda() / 0.7,
+             B * T: (torch.rand(B * T, generator=torch.Generator().manual_seed(2)) > 0.3).float().cuda() / 0.7,
+             B: torch.tensor([1 / 0.7, 0.0]).cuda()}
+    blk._drop = lambda rows, device: masks[rows]
+    res = {}
+    for merged in (False, True):
+        blk.merge_temporal_proj = merged
+        for p in blk.parameters():
+            p.grad = None
+        with rt.use_compute_dtype(mode), torch.no_grad():
+            out, sv = blk.forward_train(x.clone(), B, T, 3)
+            dx = blk.backward(sv, dout.clone())
+        res[merged] = (out.clone(), dx.clone(), {n: p.grad.clone() for n, p in blk.named_parameters() if p.grad is not None})
+    ref, got = res[False], res[True]
+
+    def rel(a, b):
+        return float((a - b).abs().max() / b.abs().max().clamp_min(1e-6))
+    assert rel(got[0], ref[0]) < tol and rel(got[1], ref[1]) < tol
+    assert set(got[2]) == set(ref[2])
+    for n in ref[2]:
+        assert rel(got[2][n], ref[2][n]) < 5 * tol, (n, rel(got[2][n], ref[2][n]))

@@ -37,7 +37,7 @@ def test_library_exports_every_declared_symbol():
     lib = ctypes.CDLL(hip.LIB_PATH)
     for name in declared:
         assert hasattr(lib, name), name
-    assert hip.load().alpro_hip_abi_version() == 4
+    assert hip.load().alpro_hip_abi_version() == 5
 
 
 def test_gemm_desc_matches_header_layout():
@@ -54,7 +54,7 @@ def test_gemm_desc_matches_header_layout():
         for part in decl.split(","):
             names.append(part.replace("*", " ").split()[-1])
     assert names == [f[0] for f in hip.GemmDesc._fields_]
-    assert ctypes.sizeof(hip.GemmDesc) == 176
+    assert ctypes.sizeof(hip.GemmDesc) == 184
 
 
 def test_ops_refuse_cpu_tensors():
