@@ -2,14 +2,20 @@
 // dtype, contraction over the TOKEN dimension M, fp32 accumulation, fp32 atomic accumulate into C = param.grad).
 //
 // Both operands are read in their natural layout -- no transposed copies in HBM:
-//  * 256 x 256 output tile, 8 waves (2 x 4, 128 x 64 each), contraction step = 64 tokens; LDS stage = two
-//    (64 tokens x 256 columns) images filled by global_load_lds_dwordx4, double buffered (128 KiB);
+//  * 256 x 256 output tile, 8 waves (2 x 4, 128 x 64 each); the token range is consumed in 32-token stages through a
+//    4-stage LDS ring (two (32 tokens x 256 columns) images per stage, 128 KiB) filled by global_load_lds_dwordx4 issued
+//    from inline asm, three stages in flight, tracked with exact s_waitcnt vmcnt counts (every wave issues 4 copies per
+//    step, zero-page dummies past the end); copies are placed between the MFMAs and the two waves of a SIMD use
+//    alternating slots; fragments are double buffered across a mid-step barrier;
 //  * MFMA operands need 8 consecutive tokens of ONE column per lane: ds_read_b64_tr_b16 gathers 4 tokens x 16
 //    columns per 16-lane group (semantics: tools/probe_tr.hip); the 16-byte chunk index is XOR-ed with
 //    (token & 3) << 2 on the DMA source side so the four token rows of a gather sit in different 64-byte windows;
-//  * split over M: wgrad outputs are tiny (768..3072 x 768) while M is ~10^5, so the token range is cut into
-//    `splits` slices (grid.z) sized to fill the 256 CUs; partial tiles are combined with hardware fp32 atomics,
-//    which is also what "accumulate into .grad" needs.
+//  * split over M: wgrad outputs are tiny (768..3072 x 768) while M is ~10^5, so the token range is cut into slices;
+//    slice s runs on XCD s % 8 (1-D grid decoded by hand, tools/probe_xcd.hip) so each token row is fetched from HBM
+//    once and re-used by the slice's other tiles out of that XCD's L2; the slice count is chosen against the measured
+//    fixed cost of a workgroup (~26 us, mostly the 256 KiB atomic epilogue); partial tiles are combined with hardware
+//    fp32 atomics, which is also what "accumulate into .grad" needs;
+//  * optional bias gradient: the waves of the first k-tile column sum their dY fragments on the VALU (colsum).
 // Rows >= M / columns >= N,K read a zero page, so no operand needs padding.
 #include "common.hpp"
 
