@@ -262,7 +262,7 @@ __device__ u32x4 g_attn_zero[4];
 constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
 
 template <typename T, int NKT, bool HAS_BIAS>
-__global__ __launch_bounds__(256, NKT == 8 ? 1 : 2) void attn_fwd16_kernel(const T* __restrict__ qkv, T* __restrict__ out, int L, int H, float scale,
+__global__ __launch_bounds__(256, 2) void attn_fwd16_kernel(const T* __restrict__ qkv, T* __restrict__ out, int L, int H, float scale,
                                                             const float* __restrict__ key_bias, float* __restrict__ lse, float drop_p,
                                                             uint32_t drop_seed) {
   static_assert(sizeof(T) == 2, "16-bit storage only");
@@ -271,7 +271,9 @@ __global__ __launch_bounds__(256, NKT == 8 ? 1 : 2) void attn_fwd16_kernel(const
   char* Ks = smem;
   char* Vs = smem + LP * RB;
   char* Os = smem + 2 * LP * RB;
-  float* Bs = (float*)(Os + 4 * 4096);  // additive key bias * log2(e); -inf on the padded keys
+  constexpr bool HALF = NKT == 8;         // 8 key tiles: 2 KiB of output staging per wave keeps two workgroups per CU
+  constexpr int OW = HALF ? 2048 : 4096;
+  float* Bs = (float*)(Os + 4 * OW);      // additive key bias * log2(e); -inf on the padded keys
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int b = blockIdx.x / H, h = blockIdx.x - b * H;
   for (int c = tid; c < LP; c += 256) Bs[c] = c < L ? (HAS_BIAS ? key_bias[(int64_t)b * L + c] * LOG2E : 0.f) : -INFINITY;
@@ -306,7 +308,7 @@ __global__ __launch_bounds__(256, NKT == 8 ? 1 : 2) void attn_fwd16_kernel(const
   __syncthreads();
 
   const float sl = scale * LOG2E;
-  char* Ow = Os + wave * 4096;
+  char* Ow = Os + wave * OW;
   for (int qt = wave; qt < nqt; qt += 4) {
     const int q = qt * 32 + ql;
     f32x16 s[NKT];
@@ -391,21 +393,42 @@ __global__ __launch_bounds__(256, NKT == 8 ? 1 : 2) void attn_fwd16_kernel(const
     pv_tiles<T, NKT>(o, s, Vs, lane);
 
     // ---- O^T (lane = query, 4 consecutive d per register quad) -> row-major rows through wave-private LDS
+    if constexpr (!HALF) {
 #pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
+      for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-      for (int rq = 0; rq < 4; ++rq) {
-        const uint32_t lo = pack2(o[dt][4 * rq] * inv, o[dt][4 * rq + 1] * inv, (T*)0);
-        const uint32_t hi = pack2(o[dt][4 * rq + 2] * inv, o[dt][4 * rq + 3] * inv, (T*)0);
-        *(u32x2*)(Ow + ql * 128 + (((dt * 4 + rq) ^ ((ql >> 1) & 7)) << 4) + g * 8) = mk2(lo, hi);
+        for (int rq = 0; rq < 4; ++rq) {
+          const uint32_t lo = pack2(o[dt][4 * rq] * inv, o[dt][4 * rq + 1] * inv, (T*)0);
+          const uint32_t hi = pack2(o[dt][4 * rq + 2] * inv, o[dt][4 * rq + 3] * inv, (T*)0);
+          *(u32x2*)(Ow + ql * 128 + (((dt * 4 + rq) ^ ((ql >> 1) & 7)) << 4) + g * 8) = mk2(lo, hi);
+        }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // DS ops of one wave complete in order; nothing else touches Ow
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        const int row = p * 8 + (lane >> 3), slot = lane & 7;
+        const u32x4 v = *(const u32x4*)(Ow + row * 128 + ((slot ^ ((row >> 1) & 7)) << 4));
+        const int qq = qt * 32 + row;
+        if (qq < L) __builtin_nontemporal_store(v, (u32x4*)(out + ((int64_t)b * L + qq) * H * HD + h * HD + slot * 8));
       }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // DS ops of one wave complete in order; nothing else touches Ow
+    } else {  // the two 32-wide d halves one after the other, as 64-byte row pieces
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
-      const int row = p * 8 + (lane >> 3), slot = lane & 7;
-      const u32x4 v = *(const u32x4*)(Ow + row * 128 + ((slot ^ ((row >> 1) & 7)) << 4));
-      const int qq = qt * 32 + row;
-      if (qq < L) __builtin_nontemporal_store(v, (u32x4*)(out + ((int64_t)b * L + qq) * H * HD + h * HD + slot * 8));
+      for (int dt = 0; dt < 2; ++dt) {
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq) {
+          const uint32_t lo = pack2(o[dt][4 * rq] * inv, o[dt][4 * rq + 1] * inv, (T*)0);
+          const uint32_t hi = pack2(o[dt][4 * rq + 2] * inv, o[dt][4 * rq + 3] * inv, (T*)0);
+          *(u32x2*)(Ow + ql * 64 + ((rq ^ ((ql >> 2) & 3)) << 4) + g * 8) = mk2(lo, hi);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+          const int row = p * 16 + (lane >> 2), slot = lane & 3;
+          const u32x4 v = *(const u32x4*)(Ow + row * 64 + ((slot ^ ((row >> 2) & 3)) << 4));
+          const int qq = qt * 32 + row;
+          if (qq < L) __builtin_nontemporal_store(v, (u32x4*)(out + ((int64_t)b * L + qq) * H * HD + h * HD + dt * 32 + slot * 8));
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      }
     }
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) qf[ks] = qn[ks];
@@ -487,7 +510,7 @@ int launch_attn(const void* qkv, void* out, int batch, int L, int H, float scale
 template <typename T, int NKT, bool HAS_BIAS>
 int launch_attn16(const void* qkv, void* out, int batch, int L, int H, float scale, const float* key_bias, float* lse, float drop_p,
                   uint32_t drop_seed, hipStream_t st) {
-  const size_t lds = 2 * (size_t)NKT * 32 * 128 + 4 * 4096 + (size_t)NKT * 32 * sizeof(float);
+  const size_t lds = 2 * (size_t)NKT * 32 * 128 + 4 * (NKT == 8 ? 2048 : 4096) + (size_t)NKT * 32 * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)attn_fwd16_kernel<T, NKT, HAS_BIAS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
