@@ -195,3 +195,39 @@ def test_input_pipeline_ops_match_reference_semantics():
     img = torch.rand(1, 2, 3, 4, 4) * 255
     ref = (img / 255 - torch.tensor([0.485, 0.456, 0.406]).view(1, 1, 3, 1, 1)) / torch.tensor([0.229, 0.224, 0.225]).view(1, 1, 3, 1, 1)
     assert torch.allclose(ImageNorm([0.485, 0.456, 0.406], [0.229, 0.224, 0.225], device="cpu")(img.clone()), ref, atol=1e-6)
+
+
+def test_flat_buffer_views_host_logic():
+    """Pointer arithmetic behind two flat-buffer shortcuts, on CPU tensors: (a) weights._flat_lp_view hands out views of the
+    one 16-bit copy FlatAdamW refreshes per step (adjacent matrices fuse, misaligned / stale / foreign tensors fall back);
+    (b) train.fused_grad_view turns back-to-back gradient tensors into one (rows, cols) view."""
+    from alpro_amd.modeling import train as tr
+    from alpro_amd.modeling import weights as w
+    flat = torch.arange(8 * 16 * 3 + 4 + 16 * 16, dtype=torch.float32)
+    a, b, c = (torch.nn.Parameter(flat[i * 128:(i + 1) * 128].view(8, 16)) for i in range(3))
+    vec = torch.nn.Parameter(flat[384:388])
+    odd = torch.nn.Parameter(flat[388:388 + 256].view(16, 16))            # starts at element 388: not a multiple of 8
+    lp = flat.to(torch.bfloat16)
+    w.bump_param_epoch()
+    w.register_flat_lp(flat, lp, [a, b, c, vec, odd])
+    v = w._flat_lp_view((a, b, c), torch.bfloat16)
+    assert v.shape == (24, 16) and v.data_ptr() == lp.data_ptr() and torch.equal(v, lp[:384].view(24, 16))
+    assert torch.equal(w._flat_lp_view((b,), torch.bfloat16), lp[128:256].view(8, 16))
+    assert w._flat_lp_view((a, c), torch.bfloat16) is None                 # not adjacent
+    assert w._flat_lp_view((odd,), torch.bfloat16) is None                 # 16-bit view would not be 16-byte aligned
+    assert w._flat_lp_view((a,), torch.float16) is None                    # other dtype
+    assert w._flat_lp_view((torch.nn.Parameter(torch.zeros(8, 16)),), torch.bfloat16) is None   # not in the flat buffer
+    with torch.no_grad():
+        a.add_(1.0)                                                        # in-place change after the refresh: stale copy
+    assert w._flat_lp_view((a,), torch.bfloat16) is None
+    w.bump_param_epoch()                                                   # a newer optimizer step without a refresh
+    assert w._flat_lp_view((b,), torch.bfloat16) is None
+    gflat = torch.zeros(3 * 128 + 8)
+    for i, p in enumerate((a, b, c)):
+        p.grad = gflat[i * 128:(i + 1) * 128].view(8, 16)
+    fv = tr.fused_grad_view([a, b, c])
+    assert fv.shape == (24, 16) and fv.data_ptr() == gflat.data_ptr()
+    fv[8:16] += 2.0
+    assert float(b.grad.sum()) == 2.0 * 128 and float(a.grad.abs().sum()) == 0
+    c.grad = torch.zeros(8, 16)
+    assert tr.fused_grad_view([a, b, c]) is None
