@@ -7,6 +7,7 @@ Tolerances (absolute unless noted):
   * bf16 mode (the benchmark dtype): encoder activations are rounded to bf16 at every GEMM/attention input;
     observed end-to-end drift on these fixtures is ~1e-2 on logits, asserted at 6e-2 / 5% on embeddings.
 """
+import math
 import os
 
 import numpy as np
@@ -214,3 +215,35 @@ def test_forward_cls_equals_cls_row_of_forward_features(retrieval, mode, tol):
         cls = m.visual_encoder.forward_cls(x)
     assert cls.shape == full.shape
     assert (cls - full).abs().max().item() <= tol * max(1.0, full.abs().max().item())
+
+
+def test_full_size_batch_properties(bert_cfg):
+    """BASELINE-size inputs (64 clips x 8 frames x 224^2, 40-token captions, bf16) have no golden vectors; what must hold at any
+    size is checked instead: the encoders are row-independent, so (i) permuting the batch permutes the outputs exactly,
+    (ii) one 2B-caption text pass equals two B-caption passes (the batching AlproForPretrain.forward relies on), (iii) the
+    forward is idempotent in eval mode, (iv) every output is finite and the VTC similarity rows are proper log-softmax inputs."""
+    from alpro_amd import config as rt
+    from alpro_amd.modeling.alpro_models import AlproForVideoTextRetrieval
+    torch.manual_seed(7)
+    m = AlproForVideoTextRetrieval(make_cfg(bert_cfg), dict(VENC, num_frm=8)).eval().cuda()
+    B = 64
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(B, 8, 3, 224, 224, generator=g).cuda()
+    ids = torch.randint(1000, 30000, (B, 40), generator=g).cuda()
+    ids[:, 0] = 101
+    mask = torch.ones(B, 40, dtype=torch.long).cuda()
+    mask[::3, 30:] = 0
+    perm = torch.randperm(B, generator=g).cuda()
+    with rt.use_compute_dtype("bf16"), torch.no_grad():
+        ve = m._forward_visual_embeds(x)
+        ve_p = m._forward_visual_embeds(x[perm])
+        ve_again = m._forward_visual_embeds(x)
+        te = m._text_embeds(ids, mask)
+        te_cat = m._text_embeds(torch.cat([ids, ids[perm]], 0), torch.cat([mask, mask[perm]], 0))
+        out = m(dict(visual_inputs=x, text_input_ids=ids, text_input_mask=mask))
+    assert ve.shape == (B, 197, 768) and torch.isfinite(ve).all()
+    assert torch.equal(ve_p, ve[perm])                      # (i) exact: a row's arithmetic does not depend on its position
+    assert torch.equal(ve_again, ve)                        # (iii)
+    assert torch.equal(te_cat[:B], te) and torch.equal(te_cat[B:], te[perm])   # (ii)
+    assert out["itm_scores"].shape == (3 * B, 2) and all(torch.isfinite(out[k]).all() for k in ("itm_scores", "itm_loss", "itc_loss"))
+    assert 0.0 < float(out["itc_loss"]) < 2 * math.log(B) and 0.0 < float(out["itm_loss"]) < 5.0
