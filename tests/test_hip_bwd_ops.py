@@ -427,3 +427,32 @@ def test_merged_temporal_projection_equals_two_linears(mode, tol):
     assert set(got[2]) == set(ref[2])
     for n in ref[2]:
         assert rel(got[2][n], ref[2][n]) < 5 * tol, (n, rel(got[2][n], ref[2][n]))
+
+
+def test_gemms_at_full_benchmark_size():
+    """The three GEMM kernels at the default benchmark's sizes (B=64 x 8f: M = 100416 token rows) against torch.matmul on the
+    same bf16 operands in fp32: many persistent rounds, a partial last M-tile, 27-tile XCD slices."""
+    hip = _hip()
+    dt = torch.bfloat16
+    M = 100416
+    g = torch.Generator(device="cuda").manual_seed(9)
+    a = (torch.randn(M, 768, device="cuda", generator=g) * 0.5).to(dt)
+    w = (torch.randn(2304, 768, device="cuda", generator=g) * 0.05).to(dt)
+    bias = torch.randn(2304, device="cuda", generator=g)
+    out = hip.gemm(a, w, bias=bias)                                                     # qkv: bf16 out
+    ref = a.float() @ w.float().t() + bias
+    assert float((out.float() - ref).abs().max()) < 2e-2 * float(ref.abs().max())
+    res = torch.randn(M, 768, device="cuda", generator=g)
+    a2 = (torch.randn(M, 3072, device="cuda", generator=g) * 0.3).to(dt)
+    w2 = (torch.randn(768, 3072, device="cuda", generator=g) * 0.02).to(dt)
+    rs = (torch.rand(64, device="cuda", generator=g) > 0.1).float() / 0.9
+    out2 = hip.gemm(a2, w2, out_dtype=torch.float32, residual=res, row_scale=rs, row_scale_group=M // 64)   # fc2 + residual, drop-path
+    ref2 = res + rs.repeat_interleave(M // 64)[:, None] * (a2.float() @ w2.float().t())
+    assert float((out2 - ref2).abs().max()) < 1e-3 * float(ref2.abs().max())
+    dy = (torch.randn(M, 3072, device="cuda", generator=g) * 0.1).to(dt)
+    gw = torch.zeros(3072, 768, device="cuda")
+    gb = torch.zeros(3072, device="cuda")
+    hip.gemm_tn_acc(dy, a, gw, colsum=gb)                                               # fc1 weight + bias gradient
+    refw = dy.float().t() @ a.float()
+    assert float((gw - refw).abs().max()) < 2e-3 * float(refw.abs().max())
+    assert float((gb - dy.float().sum(0)).abs().max()) < 1e-3 * float(dy.float().sum(0).abs().max()) + 1e-2
