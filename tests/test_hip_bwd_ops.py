@@ -456,3 +456,28 @@ def test_gemms_at_full_benchmark_size():
     refw = dy.float().t() @ a.float()
     assert float((gw - refw).abs().max()) < 2e-3 * float(refw.abs().max())
     assert float((gb - dy.float().sum(0)).abs().max()) < 1e-3 * float(dy.float().sum(0).abs().max()) + 1e-2
+
+
+def test_attention_properties_at_full_size():
+    """Spatial and temporal attention at the benchmark's sizes (512 sequences x 197 tokens; 100352 rows in groups of 8) through
+    a size-independent property: with V == 1 every softmax row must give exactly 1 (rows sum to one), and then dQ = dK = 0 and
+    dV[k] = sum over queries of P[q, k] * dO[q], whose total over k equals the total of dO."""
+    hip = _hip()
+    dt = torch.bfloat16
+    H = 12
+    g = torch.Generator(device="cuda").manual_seed(21)
+    for kind in ("spatial", "temporal"):
+        rows = 512 * 197 if kind == "spatial" else 64 * 196 * 8
+        qkv = (torch.randn(rows, 3 * H * 64, device="cuda", generator=g) * 0.5).to(dt)
+        qkv[:, 2 * H * 64:] = 1.0
+        do = torch.randn(rows, H * 64, device="cuda", generator=g).to(dt)
+        if kind == "spatial":
+            out, lse = hip.attn(qkv, 512, 197, H, 0.125, want_lse=True)
+            dqkv = hip.attn_bwd(qkv, out, do, lse, 512, 197, H, 0.125)
+        else:
+            out, lse = hip.attn_temporal(qkv, 8, H, 0.125, want_lse=True)
+            dqkv = hip.attn_temporal_bwd(qkv, out, do, lse, 8, H, 0.125)
+        assert float((out.float() - 1).abs().max()) < 8e-3, kind
+        assert float(dqkv[:, :2 * H * 64].float().abs().max()) < 2e-2, kind
+        dv_tot, do_tot = float(dqkv[:, 2 * H * 64:].float().sum()), float(do.float().sum())
+        assert abs(dv_tot - do_tot) < 2e-3 * float(do.float().abs().sum()), kind
