@@ -48,7 +48,7 @@ def broadcast(tensor, root_rank, name=None):
 
 
 def broadcast_optimizer_state(optimizer, root_rank=0):
-    """Every tensor of optimizer.state_dict() (moments, step counters) from root_rank; scalars ride in a tensor."""
+    """Every tensor of optimizer.state_dict() (the moments) from root_rank, then the step counter (explicitly, below)."""
     if size() == 1:
         return
     inner = getattr(optimizer, "_opt", optimizer)
@@ -64,6 +64,11 @@ def broadcast_optimizer_state(optimizer, root_rank=0):
                 walk(v)
 
     walk(inner.state_dict())
+    if hasattr(inner, "step_count"):  # FlatAdamW keeps its step counter as a Python int: broadcast it explicitly
+        dev = next((p.device for g in inner.param_groups for p in g["params"]), torch.device("cpu"))
+        t = torch.tensor([int(inner.step_count)], dtype=torch.int64, device=dev)
+        td.broadcast(t, src=root_rank)
+        inner.step_count = int(t.item())
 
 
 class _DistributedOptimizer:

@@ -498,11 +498,10 @@ template <typename T, int NKT>
 int launch_attn(const void* qkv, void* out, int batch, int L, int H, float scale, const float* key_bias, float* lse, float drop_p,
                 uint32_t drop_seed, hipStream_t st) {
   const size_t lds = 2 * (size_t)NKT * 32 * AttnCfg<T>::RB + (size_t)NKT * 32 * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
+  static DeviceOnce attr_once;
+  attr_once.run([&] {
     (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<T, NKT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
-  }
+  });
   hipLaunchKernelGGL((attn_fwd_kernel<T, NKT>), dim3(batch * H), dim3(256), lds, st, (const T*)qkv, (T*)out, L, H, scale, key_bias, lse, drop_p, drop_seed);
   return check_launch("alpro_attn_fwd");
 }
@@ -511,11 +510,10 @@ template <typename T, int NKT, bool HAS_BIAS>
 int launch_attn16(const void* qkv, void* out, int batch, int L, int H, float scale, const float* key_bias, float* lse, float drop_p,
                   uint32_t drop_seed, hipStream_t st) {
   const size_t lds = 2 * (size_t)NKT * 32 * 128 + 4 * (NKT == 8 ? 2048 : 4096) + (size_t)NKT * 32 * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
+  static DeviceOnce attr_once;
+  attr_once.run([&] {
     (void)hipFuncSetAttribute((const void*)attn_fwd16_kernel<T, NKT, HAS_BIAS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
-  }
+  });
   hipLaunchKernelGGL((attn_fwd16_kernel<T, NKT, HAS_BIAS>), dim3(batch * H), dim3(256), lds, st, (const T*)qkv, (T*)out, L, H, scale, key_bias, lse, drop_p, drop_seed);
   return check_launch("alpro_attn_fwd");
 }

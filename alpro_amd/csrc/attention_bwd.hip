@@ -717,11 +717,10 @@ template <typename T, int NKT, bool HAS_BIAS>
 int launch_bwd16(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, int batch, int L, int H, float scale,
                  const float* key_bias, float dp, uint32_t ds, hipStream_t st) {
   const size_t lds = 2 * (size_t)NKT * 32 * 128 + 4 * (NKT == 8 ? 2048 : 4096) + 3 * (size_t)NKT * 32 * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
+  static DeviceOnce attr_once;
+  attr_once.run([&] {
     (void)hipFuncSetAttribute((const void*)attn_bwd16_kernel<T, NKT, HAS_BIAS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
-  }
+  });
   hipLaunchKernelGGL((attn_bwd16_kernel<T, NKT, HAS_BIAS>), dim3((unsigned)(batch * H)), dim3(256), lds, st, (const T*)qkv, (const T*)out, (const T*)dout,
                      lse, (T*)dqkv, L, H, scale, key_bias, dp, ds);
   return check_launch("alpro_attn_bwd");
@@ -731,11 +730,10 @@ template <typename T, int NKT, int NW, bool GROUPED>
 int launch_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, int64_t nblocks_b, int L, int H, float scale,
                const float* key_bias, int Tn, int64_t total_rows, float dp, uint32_t ds, hipStream_t st) {
   const size_t lds = 2 * (size_t)NKT * 32 * BCfg<T>::RB + 3 * (size_t)NKT * 32 * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
+  static DeviceOnce attr_once;
+  attr_once.run([&] {
     (void)hipFuncSetAttribute((const void*)attn_bwd_kernel<T, NKT, NW, GROUPED>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
-  }
+  });
   hipLaunchKernelGGL((attn_bwd_kernel<T, NKT, NW, GROUPED>), dim3((unsigned)(nblocks_b * H)), dim3(NW * 64), lds, st, (const T*)qkv, (const T*)out,
                      (const T*)dout, lse, (T*)dqkv, L, H, scale, key_bias, Tn, total_rows, dp, ds);
   return check_launch("alpro_attn_bwd");
@@ -785,12 +783,11 @@ extern "C" int alpro_attn_temporal_bwd(const void* qkv, const void* out, const v
     int64_t grid = (units + 3) / 4;
     if (grid > 512) grid = 512;
     const size_t lds = 4 * (4 * 4096 + 256);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static DeviceOnce attr_once;
+    attr_once.run([&] {
       (void)hipFuncSetAttribute((const void*)attn_temporal_bwd16_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       (void)hipFuncSetAttribute((const void*)attn_temporal_bwd16_kernel<f16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      attr_set = true;
-    }
+    });
     if (dtype == ALPRO_BF16) {
       hipLaunchKernelGGL(attn_temporal_bwd16_kernel<bf16_t>, dim3((unsigned)grid), dim3(256), lds, (hipStream_t)stream, (const bf16_t*)qkv, (const bf16_t*)dout, lse,
                          (bf16_t*)dqkv, rows, T, H, scale, units);

@@ -178,6 +178,27 @@ __device__ __forceinline__ uint32_t lds_addr_of(const void* p) { return (uint32_
 
 // ---- host side -----------------------------------------------------------------------------
 void set_error(const char* fmt, ...);
+
+// Tuning knobs (measurement aids, not part of the arithmetic): initialised ONCE from the environment when the library is
+// loaded (ALPRO_GEMM_TILE / ALPRO_GEMM_GRID / ALPRO_GEMM_TUNE / ALPRO_TN_SPLITS), changed at run time only through
+// alpro_hip_set_option -- no getenv() on the launch path.  0 = "not set" for every knob except GEMM_TUNE.
+enum { OPT_GEMM_TILE = 0, OPT_GEMM_GRID = 1, OPT_GEMM_TUNE = 2, OPT_TN_SPLITS = 3, OPT_GEMM_KIND = 4, OPT_COUNT = 5 };
+int get_option(int which);
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) must be applied once per (kernel, device): a per-instantiation bit mask
+// over device ordinals, safe under concurrent first launches (setting the attribute twice is harmless).
+struct DeviceOnce {
+  unsigned long long mask = 0;
+  template <typename F> void run(F&& f) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (!(__atomic_load_n(&mask, __ATOMIC_ACQUIRE) & bit)) {
+      f();
+      __atomic_fetch_or(&mask, bit, __ATOMIC_RELEASE);
+    }
+  }
+};
 #define ALPRO_CHECK(cond, ...)            \
   do {                                    \
     if (!(cond)) {                        \

@@ -2,6 +2,8 @@
 // final-norm temporal pooling).  All are HBM-bound: one wave per 768-wide row, 16-byte accesses.
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
 
 #include "common.hpp"
 
@@ -15,6 +17,22 @@ void set_error(const char* fmt, ...) {
   vsnprintf(g_err, sizeof(g_err), fmt, ap);
   va_end(ap);
 }
+
+namespace {
+const char* const kOptNames[OPT_COUNT] = {"gemm_tile", "gemm_grid", "gemm_tune", "tn_splits", "gemm_kind"};
+const char* const kOptEnv[OPT_COUNT] = {"ALPRO_GEMM_TILE", "ALPRO_GEMM_GRID", "ALPRO_GEMM_TUNE", "ALPRO_TN_SPLITS", "ALPRO_GEMM_KIND"};
+int g_opts[OPT_COUNT];
+struct OptInit {
+  OptInit() {
+    for (int i = 0; i < OPT_COUNT; ++i) {
+      const char* e = getenv(kOptEnv[i]);
+      g_opts[i] = e ? atoi(e) : (i == OPT_GEMM_TUNE ? 1 : 0);
+    }
+  }
+} g_opt_init;
+}  // namespace
+
+int get_option(int which) { return __atomic_load_n(&g_opts[which], __ATOMIC_RELAXED); }
 
 int check_launch(const char* what) {
   hipError_t e = hipGetLastError();
@@ -257,6 +275,16 @@ using namespace alpro;
 
 extern "C" const char* alpro_hip_last_error(void) { return g_err; }
 extern "C" int alpro_hip_abi_version(void) { return ALPRO_HIP_ABI_VERSION; }
+extern "C" int alpro_hip_set_option(const char* name, int value) {
+  using namespace alpro;
+  for (int i = 0; name && i < OPT_COUNT; ++i)
+    if (!strcmp(name, kOptNames[i])) {
+      __atomic_store_n(&g_opts[i], value, __ATOMIC_RELAXED);
+      return ALPRO_OK;
+    }
+  set_error("alpro_hip_set_option: unknown option '%s'", name ? name : "(null)");
+  return ALPRO_ERR_INVALID;
+}
 
 extern "C" int alpro_cast_from_f32(const float* src, void* dst, int dtype, int64_t n, void* stream) {
   ALPRO_CHECK(src && dst && n >= 0, "alpro_cast_from_f32: bad args");

@@ -411,7 +411,20 @@ constexpr int TILE2_BYTES = BM2 * ROWB;  // 32 KiB per operand per stage
 // Fragment reads are register double-buffered (the reads of K-chunk s+1 are in flight under the MFMAs of s).
 constexpr int EPI_BYTES = 8 * 16 * 64 * 4;  // 32 KiB: 8 waves x (16 rows x 64 cols) fp32
 
-template <typename T, int ACT, int MAP>
+// TUNE: where the 8 DMA pieces of the next K-tile are issued among the 32 MFMAs of a K-step (experiment knob, ALPRO_GEMM_TUNE):
+//   0  copy c after MFMA 4c+1 (waves 0-3) / 4c+3 (waves 4-7): spread over the whole step -- the last piece is issued ~100 cycles
+//      before the step ends, so its full L2 / MALL latency is exposed at the next step's vmcnt(0)
+//   1  copy c after MFMA 2c+1 / 2c+2: all pieces out in the first half of the step (default: +3-5 % on every shape,
+//      tools/gemm_tune_bench.py, gpurun_out/r2b_tune.txt)
+//   2  copy c after MFMA 3c+1 / 3c+2: first three quarters
+__device__ __forceinline__ constexpr int copy_slot(int tune, int q, int pos) {
+  if (tune == 0) return ((q & 1) && ((q >> 1) & 1) == pos) ? (q >> 2) : -1;
+  if (tune == 1) { const int r = q - 1 - pos; return (r >= 0 && r < 16 && (r & 1) == 0) ? (r >> 1) : -1; }
+  const int r = q - 1 - pos;
+  return (r >= 0 && r < 24 && r % 3 == 0) ? r / 3 : -1;
+}
+
+template <typename T, int ACT, int MAP, int TUNE = 1>
 __global__ __launch_bounds__(NT2, 2) void gemm_nt256p_kernel(const alpro_gemm_desc_t g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -523,8 +536,11 @@ __global__ __launch_bounds__(NT2, 2) void gemm_nt256p_kernel(const alpro_gemm_de
 #pragma unroll
           for (int j = 0; j < 2; ++j) {
             mma_chunk<T>(acc[i][j], fa[s & 1][i], fb[s & 1][j]);
-            const int q = s * 8 + i * 2 + j;  // 0..31; copy c = q >> 2 goes after MFMA 4c+1 (waves 0-3) / 4c+3 (waves 4-7)
-            if ((q & 1) && do_copy && ((q >> 1) & 1) == pos) copy_piece(q >> 2, ckt, cur ^ 1);
+            const int q = s * 8 + i * 2 + j;  // 0..31; see copy_slot
+            if (do_copy) {
+              if (copy_slot(TUNE, q, 0) >= 0 && pos == 0) copy_piece(copy_slot(TUNE, q, 0), ckt, cur ^ 1);
+              if (copy_slot(TUNE, q, 1) >= 0 && pos == 1) copy_piece(copy_slot(TUNE, q, 1), ckt, cur ^ 1);
+            }
           }
       }
     }
@@ -611,20 +627,28 @@ __global__ __launch_bounds__(NT2, 2) void gemm_nt256p_kernel(const alpro_gemm_de
 
 template <typename T, int ACT, int MAP>
 int launch_gemm_inst(const alpro_gemm_desc_t& g, hipStream_t st) {
-  static bool attr_set = false;
-  if (!attr_set) {
+  static DeviceOnce attr_once;
+  attr_once.run([&] {
     (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<T, ACT, MAP>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE_BYTES);
     (void)hipFuncSetAttribute((const void*)gemm_nt256p_kernel<T, ACT, MAP>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE2_BYTES + EPI_BYTES);
-    attr_set = true;
-  }
+    if constexpr (std::is_same<T, bf16_t>::value && ACT == ALPRO_ACT_NONE && MAP == ALPRO_MAP_IDENTITY) {
+      (void)hipFuncSetAttribute((const void*)gemm_nt256p_kernel<T, ACT, MAP, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE2_BYTES + EPI_BYTES);
+      (void)hipFuncSetAttribute((const void*)gemm_nt256p_kernel<T, ACT, MAP, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE2_BYTES + EPI_BYTES);
+    }
+  });
   const int big_tiles = ((g.N + BN2 - 1) / BN2) * ((g.M + BM2 - 1) / BM2);
-  const char* force = getenv("ALPRO_GEMM_TILE");
+  const int force = get_option(OPT_GEMM_TILE);
   const int nk = (g.K * (int)sizeof(T)) / ROWB;
   // the persistent 256^2 kernel wins from ~160 tiles up (measured, tools/gemm_bert_bench.py: M=15168 N=768 = 180 tiles is 15-25 % faster than on the 128^2 kernel; M=2560 N=3072 = 120 tiles is not); its pipeline needs >= 2 K-tiles
-  const bool use256 = nk >= 2 && (force ? atoi(force) == 256 : big_tiles >= 160);
+  const bool use256 = nk >= 2 && (force ? force == 256 : big_tiles >= 160);
   if (use256) {
     int grid = big_tiles < 256 ? (big_tiles + 7) / 8 * 8 : 256;  // multiple of 8: the XCD-contiguous slot map must be a bijection
-    if (const char* e = getenv("ALPRO_GEMM_GRID")) grid = atoi(e) < grid ? (atoi(e) + 7) / 8 * 8 : grid;  // tuning aid: cap the persistent grid
+    if (const int cap = get_option(OPT_GEMM_GRID)) grid = cap < grid ? (cap + 7) / 8 * 8 : grid;  // tuning aid: cap the persistent grid
+    const int tune = get_option(OPT_GEMM_TUNE);
+    if constexpr (std::is_same<T, bf16_t>::value && ACT == ALPRO_ACT_NONE && MAP == ALPRO_MAP_IDENTITY) {
+      if (tune == 0) { hipLaunchKernelGGL((gemm_nt256p_kernel<T, ACT, MAP, 0>), dim3(grid), dim3(NT2), 4 * TILE2_BYTES + EPI_BYTES, st, g); return check_launch("alpro_gemm"); }
+      if (tune == 2) { hipLaunchKernelGGL((gemm_nt256p_kernel<T, ACT, MAP, 2>), dim3(grid), dim3(NT2), 4 * TILE2_BYTES + EPI_BYTES, st, g); return check_launch("alpro_gemm"); }
+    }
     hipLaunchKernelGGL((gemm_nt256p_kernel<T, ACT, MAP>), dim3(grid), dim3(NT2), 4 * TILE2_BYTES + EPI_BYTES, st, g);
   } else {
     const int ntn = (g.N + BN - 1) / BN, ntm = (g.M + BM - 1) / BM;

@@ -292,7 +292,7 @@ extern "C" int alpro_gemm_tn_acc(const void* A, int64_t lda, const void* B, int6
     if (t < best_t * 0.98) { best_t = t; best = s8; }
   }
   int splits = 8 * best;
-  if (const char* e = getenv("ALPRO_TN_SPLITS")) splits = atoi(e);
+  if (const int forced = get_option(OPT_TN_SPLITS)) splits = forced;
   const int per = (total_steps + splits - 1) / splits;
   splits = (total_steps + per - 1) / per;
   const int slices8 = (splits + 7) / 8 * 8;  // grid covers a multiple of 8 slices (one per XCD per pass); empty ones exit
@@ -300,12 +300,12 @@ extern "C" int alpro_gemm_tn_acc(const void* A, int64_t lda, const void* B, int6
   const size_t lds = (size_t)NSTAGE * 2 * IMG_BYTES;
   hipStream_t st = (hipStream_t)stream;
   if (dtype == ALPRO_BF16) {
-    static bool set = false;
-    if (!set) { (void)hipFuncSetAttribute((const void*)gemm_tn_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); set = true; }
+    static DeviceOnce once;
+    once.run([&] { (void)hipFuncSetAttribute((const void*)gemm_tn_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); });
     hipLaunchKernelGGL(gemm_tn_kernel<bf16_t>, dim3(grid), dim3(NT3), lds, st, (const bf16_t*)A, lda, (const bf16_t*)B, ldb, C, ldc, M, N, K, per, tn, tk, colsum);
   } else {
-    static bool set = false;
-    if (!set) { (void)hipFuncSetAttribute((const void*)gemm_tn_kernel<f16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); set = true; }
+    static DeviceOnce once;
+    once.run([&] { (void)hipFuncSetAttribute((const void*)gemm_tn_kernel<f16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); });
     hipLaunchKernelGGL(gemm_tn_kernel<f16_t>, dim3(grid), dim3(NT3), lds, st, (const f16_t*)A, lda, (const f16_t*)B, ldb, C, ldc, M, N, K, per, tn, tk, colsum);
   }
   return check_launch("alpro_gemm_tn_acc");

@@ -18,7 +18,7 @@ MAP_IDENTITY, MAP_SKIP_CLS, MAP_FRAME_TOKENS, MAP_PATCH_EMBED = 0, 1, 2, 3
 _TORCH_DTYPE = {F32: torch.float32, BF16: torch.bfloat16, F16: torch.float16}
 _CODE = {v: k for k, v in _TORCH_DTYPE.items()}
 
-EXPORTS = ["alpro_hip_last_error", "alpro_hip_abi_version", "alpro_gemm", "alpro_layernorm_fwd",
+EXPORTS = ["alpro_hip_last_error", "alpro_hip_abi_version", "alpro_hip_set_option", "alpro_gemm", "alpro_layernorm_fwd",
            "alpro_attn_temporal_fwd", "alpro_attn_fwd", "alpro_patchify", "alpro_cls_mean_residual",
            "alpro_vit_final_pool", "alpro_bert_embed_fwd", "alpro_cast_from_f32", "alpro_attn_bwd", "alpro_attn_temporal_bwd",
            "alpro_layernorm_bwd", "alpro_transpose", "alpro_gelu_bwd", "alpro_cls_mean_bwd", "alpro_scatter_add_rows", "alpro_gather_cast", "alpro_sumsq", "alpro_adamw_step", "alpro_gemm_tn_acc", "alpro_colsum_acc", "alpro_softmax_xent"]
@@ -38,6 +38,7 @@ class GemmDesc(ctypes.Structure):
                 ("drop_p", ctypes.c_float), ("drop_seed", ctypes.c_uint32), ("bias2", ctypes.c_void_p)]
 
 
+ABI_VERSION = 6
 _lib = None
 
 
@@ -77,10 +78,29 @@ def load():
     lib.alpro_vit_final_pool.argtypes = [vp, vp, vp, f32, vp, vp, i32, i32, i32, i32, i32, vp]
     lib.alpro_bert_embed_fwd.argtypes = [vp, vp, vp, vp, vp, vp, f32, vp, vp, i32, vp, vp, i32, i32, i32, f32, u32, vp]
     lib.alpro_cast_from_f32.argtypes = [vp, vp, i32, i64, vp]
-    if lib.alpro_hip_abi_version() != 5:
+    lib.alpro_hip_set_option.argtypes = [ctypes.c_char_p, i32]
+    if lib.alpro_hip_abi_version() != ABI_VERSION:
         raise RuntimeError("libalpro_hip.so ABI version mismatch")
     _lib = lib
     return lib
+
+
+def set_option(name, value):
+    """Measurement knob of the library (alpro_hip_set_option): 'gemm_tile', 'gemm_grid', 'gemm_tune', 'gemm_kind', 'tn_splits'."""
+    _check(load().alpro_hip_set_option(name.encode(), int(value)), "alpro_hip_set_option")
+
+
+class option:
+    """`with hip.option('gemm_tile', 256): ...` -- set a knob for a block, reset to its default (0; gemm_tune 1) after."""
+
+    def __init__(self, name, value):
+        self.name, self.value = name, value
+
+    def __enter__(self):
+        set_option(self.name, self.value)
+
+    def __exit__(self, *a):
+        set_option(self.name, 1 if self.name == "gemm_tune" else 0)
 
 
 def _check(rc, what):

@@ -516,9 +516,11 @@ class TimeSformer(nn.Module):
         return self.model(x)
 
     def load_state_dict(self, state_dict, strict=True, **kw):
+        """A string is a pre-trained checkpoint source exactly as in the reference (vit.py:515-533: 'vit_base_patch16_224', a CLIP
+        ViT file, or a Kinetics TimeSformer checkpoint path; remapped by timesformer/helpers.py); a mapping is a plain state_dict."""
         if isinstance(state_dict, str):
-            raise RuntimeError("checkpoint download/remap helpers (helpers.py:262-375) are outside the hot path; "
-                               "load a converted state_dict instead of %r" % state_dict)
+            from alpro_amd.modeling.timesformer.helpers import load_visual_checkpoint
+            return load_visual_checkpoint(self, state_dict)
         return super().load_state_dict(state_dict, strict=strict, **kw)
 
 

@@ -204,6 +204,40 @@ class BertEncoder(nn.Module):
         return 0, self.config.num_hidden_layers  # 'multi_modal' (xbert.py:557-559)
 
 
+def _resolve_pretrained(name_or_path):
+    """Local file holding the weights `name_or_path` stands for, or None (see BertPreTrainedModel.from_pretrained)."""
+    import os
+    names = ("pytorch_model.bin", "model.safetensors")
+
+    def pick(p):
+        if not isinstance(p, str) or not p:
+            return None
+        if os.path.isfile(p):
+            return p
+        if os.path.isdir(p):
+            for n in names:
+                if os.path.isfile(os.path.join(p, n)):
+                    return os.path.join(p, n)
+        return None
+
+    cands = [name_or_path, os.environ.get("ALPRO_BERT_WEIGHTS")]
+    if os.environ.get("ALPRO_PRETRAINED_DIR") and isinstance(name_or_path, str):
+        cands.append(os.path.join(os.environ["ALPRO_PRETRAINED_DIR"], name_or_path))
+    for c in cands:
+        hit = pick(c)
+        if hit:
+            return hit
+    try:
+        from huggingface_hub import try_to_load_from_cache
+        for n in names:
+            hit = try_to_load_from_cache(name_or_path, n)
+            if isinstance(hit, str) and os.path.isfile(hit):
+                return hit
+    except Exception:  # no hub package / malformed repo id: the cache is simply not a source
+        pass
+    return None
+
+
 class BertPreTrainedModel(nn.Module):
     """Weight init of xbert.py:728-738 (normal(0, initializer_range), LN ones/zeros, zero biases)."""
 
@@ -225,19 +259,45 @@ class BertPreTrainedModel(nn.Module):
 
     @classmethod
     def from_pretrained(cls, name_or_path, config=None, **kwargs):
-        """Reference call sites (alpro_models.py:30,637) pass 'bert-base-uncased'.  There is no network on the
-        GPU box: a local directory / file with a HF-format `pytorch_model.bin` (or .pt state_dict) is loaded if
-        given, otherwise the model is randomly initialised exactly like xbert.py:728-738."""
+        """Reference call sites (alpro_models.py:30,637) pass 'bert-base-uncased' and get the HF weights.  There is no network
+        on the GPU boxes, so the name is resolved LOCALLY, in this order: (1) `name_or_path` itself if it is a file / directory,
+        (2) $ALPRO_BERT_WEIGHTS (file or directory), (3) $ALPRO_PRETRAINED_DIR/<name>/, (4) the Hugging Face cache
+        (huggingface_hub.try_to_load_from_cache).  Files: `pytorch_model.bin`, `model.safetensors`, or a torch-saved state_dict.
+        If nothing is found the model keeps the random init of xbert.py:728-738 and says so LOUDLY (warning; RuntimeError when
+        ALPRO_REQUIRE_PRETRAINED=1) -- a pretrain / finetune run that silently starts from random BERT weights does not reproduce
+        the reference.  Missing and unexpected keys are reported, never swallowed."""
+        import logging
         import os
+        import warnings
+        log = logging.getLogger(__name__)
         model = cls(config, **kwargs)
-        path = name_or_path
-        if isinstance(path, str) and os.path.isdir(path):
-            path = os.path.join(path, "pytorch_model.bin")
-        if isinstance(path, str) and os.path.isfile(path):
+        path = _resolve_pretrained(name_or_path)
+        if path is None:
+            msg = ("%s.from_pretrained(%r): no local weights found (looked at the path itself, $ALPRO_BERT_WEIGHTS, $ALPRO_PRETRAINED_DIR and "
+                   "the Hugging Face cache); the text encoder starts from RANDOM initialisation" % (cls.__name__, name_or_path))
+            if os.environ.get("ALPRO_REQUIRE_PRETRAINED", "0") == "1":
+                raise RuntimeError(msg)
+            warnings.warn(msg)
+            log.warning(msg)
+            return model
+        if path.endswith(".safetensors"):
+            from safetensors.torch import load_file
+            sd = load_file(path)
+        else:
             sd = torch.load(path, map_location="cpu")
-            sd = {k.replace("gamma", "weight").replace("beta", "bias"): v for k, v in sd.items()}
-            model.load_state_dict(sd, strict=False)
-            model.tie_weights()
+        sd = {k.replace("gamma", "weight").replace("beta", "bias"): v for k, v in sd.items()}
+        own = model.state_dict()
+        if not any(k in own for k in sd) and any(k.startswith("bert.") for k in sd):
+            # a BertForMaskedLM-style checkpoint ('bert.encoder...') loaded into the bare BertModel (alpro_models.py:637)
+            sd = {k[len("bert."):]: v for k, v in sd.items() if k.startswith("bert.")}
+        res = model.load_state_dict(sd, strict=False)
+        model.tie_weights()
+        model.pretrained_report = dict(path=path, missing=list(res.missing_keys), unexpected=list(res.unexpected_keys))
+        loaded = len(own) - len(res.missing_keys)
+        log.info("%s.from_pretrained: %s -> %d / %d tensors loaded; missing %d %s; unexpected %d %s", cls.__name__, path, loaded, len(own),
+                 len(res.missing_keys), res.missing_keys[:6], len(res.unexpected_keys), res.unexpected_keys[:6])
+        if loaded == 0:
+            raise RuntimeError("%s.from_pretrained: %s shares no key with the model (first keys: %s)" % (cls.__name__, path, list(sd)[:4]))
         return model
 
     def tie_weights(self):

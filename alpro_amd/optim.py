@@ -30,6 +30,7 @@ class FlatAdamW:
         self.allreduce = allreduce
         self.bucket_elems = bucket_elems
         self.step_count = 0
+        self._pending_state = None  # load_state_dict() before the flat buffers exist: applied by _build()
         self.flat = None  # built at the first step(), when we know which parameters actually receive gradients
         self.last_grad_norm = None
         self._pre_synced = None  # "sum" / "avg": synchronize() already ran for this step (hvd-style drivers call it themselves)
@@ -42,7 +43,7 @@ class FlatAdamW:
                 seen.add(id(p))
                 live.append(p)
         if not live:
-            raise RuntimeError("FlatAdamW.step() called before any backward pass")
+            return False
         # matrices first (original order), vectors after: BERT's query/key/value weights (and their biases) then sit back
         # to back in the flat gradient buffer, so the fused-QKV weight gradient is ONE N=2304 GEMM into a (2304, 768) view
         live.sort(key=lambda p: p.dim() < 2)
@@ -63,6 +64,23 @@ class FlatAdamW:
         self.flat = dict(p=fp, g=fg, m=torch.zeros_like(fp), v=torch.zeros_like(fp), n=n, live=live, offs=offs,
                          norm=torch.zeros(1, dtype=torch.float32, device=dev))
         bump_param_epoch()
+        if self._pending_state is not None:
+            pend, self._pending_state = self._pending_state, None
+            self._restore_moments(pend)
+        return True
+
+    def _layout(self):
+        """[(index of the parameter in the constructor's list, flat offset, numel)]: what the m / v buffers mean."""
+        pos = {id(p): i for i, p in enumerate(self.params)}
+        return [(pos[id(p)], o, p.numel()) for p, o in zip(self.flat["live"], self.flat["offs"])]
+
+    def _restore_moments(self, sd):
+        lay = [tuple(int(x) for x in e) for e in sd["layout"]]
+        if lay != self._layout():
+            raise RuntimeError("FlatAdamW.load_state_dict: the checkpoint's flat layout (%d tensors) does not match this model's (%d): "
+                               "different set of trained parameters" % (len(lay), len(self.flat["live"])))
+        for k in ("m", "v"):
+            self.flat[k].copy_(sd[k].to(self.flat[k].device, torch.float32).reshape(-1))
 
     @property
     def n_params(self):
@@ -94,10 +112,12 @@ class FlatAdamW:
         self._pre_synced = "avg" if average else "sum"
         return n * 4
 
-    def step(self):
+    def step(self, closure=None):
         pre, self._pre_synced = self._pre_synced, None
-        if self.flat is None:
-            self._build()
+        if self.flat is None and not self._build():
+            # no parameter has a gradient yet: a no-op like torch.optim (the reference calls optimizer.step() once before the
+            # first backward, run_pretrain_sparse.py:508-511)
+            return None
         f, grp = self.flat, self.param_groups[0]
         late = [p for p in self.params if p.grad is not None and p.grad.data_ptr() < f["g"].data_ptr()
                 or (p.grad is not None and p.grad.data_ptr() >= f["g"].data_ptr() + f["n"] * 4)]
@@ -129,5 +149,31 @@ class FlatAdamW:
             register_flat_lp(f["p"], f["lp"], f["live"])
 
     def state_dict(self):
-        return dict(step=self.step_count, param_groups=[{k: v for k, v in g.items() if k != "params"} for g in self.param_groups],
-                    m=None if self.flat is None else self.flat["m"], v=None if self.flat is None else self.flat["v"])
+        """{'step', 'param_groups', 'layout', 'm', 'v'}: the Adam moments as the two flat buffers plus the layout that gives them
+        meaning (parameter index in the constructor's list, offset, numel).  Savers may move / narrow the tensors
+        (E2E_TrainingRestorer stores fp16 on the CPU, load_save.py:181-196); load_state_dict widens them again."""
+        groups = [{k: v for k, v in g.items() if k != "params"} for g in self.param_groups]
+        if self.flat is None:
+            if self._pending_state is not None:
+                return dict(self._pending_state, step=self.step_count, param_groups=groups)
+            return dict(step=self.step_count, param_groups=groups, layout=[], m=None, v=None)
+        return dict(step=self.step_count, param_groups=groups, layout=self._layout(), m=self.flat["m"], v=self.flat["v"])
+
+    def load_state_dict(self, sd):
+        """Restore the step counter, hyper-parameters and moments written by state_dict().  The flat buffers only exist after the
+        first backward + step(): before that the moments are parked and applied by the first step(), which checks that the same set
+        of parameters is being trained (the layout is a pure function of which parameters receive gradients)."""
+        self.step_count = int(sd["step"])
+        for g, saved in zip(self.param_groups, sd.get("param_groups", [])):
+            for k, v in saved.items():
+                g[k] = tuple(v) if k == "betas" else v
+        if sd.get("m") is None:
+            self._pending_state = None
+            if self.flat is not None:
+                self.flat["m"].zero_()
+                self.flat["v"].zero_()
+            return
+        if self.flat is None:
+            self._pending_state = dict(layout=[tuple(e) for e in sd["layout"]], m=sd["m"], v=sd["v"])
+        else:
+            self._restore_moments(sd)

@@ -69,3 +69,163 @@ def load_state_dict_with_pos_embed_resizing(model, loaded_state_dict_or_path, nu
     LOGGER.info("Keys in model and loaded, but shape mismatched: %s", sorted(mismatched))
     model.load_state_dict(toload, strict=strict)
     return mismatched
+
+
+# ---- savers / restorers the reference's drivers construct (src/utils/load_save.py:45-70, 202-347) --------------------------------
+# Same constructor arguments, file names (`{prefix}_step_{step}.pt`, `{prefix}_step_{step}_train_state.pt`, `restore.pt`,
+# `restore_backup.pt`) and dictionary keys, so checkpoints are interchangeable with the reference's in both directions.  Optimizer
+# state goes through `optimizer.state_dict()` / `load_state_dict()` -- alpro_amd.optim.FlatAdamW implements both on its flat buffers.
+def _map_tensors(state, fn):
+    if torch.is_tensor(state):
+        return fn(state)
+    if isinstance(state, dict):
+        return {k: _map_tensors(v, fn) for k, v in state.items()}
+    if isinstance(state, (list, tuple)):
+        return type(state)(_map_tensors(v, fn) for v in state)
+    return state
+
+
+def _to_cpu(state, narrow=True):
+    """Host copy for a checkpoint.  Model tensors are narrowed fp32 -> fp16 like the reference's restorer files
+    (load_save.py:181-196).  Optimizer state is NOT (narrow=False): Adam's second moments sit around 1e-10..1e-6, below fp16's
+    range, and come back as zeros -- the reference narrows them too (a restore there restarts with v == 0); the files stay
+    loadable by either side because both widen whatever they find."""
+    return _map_tensors(state, lambda t: t.detach().cpu().half() if (narrow and t.dtype == torch.float32) else t.detach().cpu())
+
+
+def _to_device(state, device=None):
+    """Back onto the current device; fp16 tensors widen to fp32 (load_save.py:162-178)."""
+    if device is None:
+        device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
+    return _map_tensors(state, lambda t: t.to(device).float() if t.dtype == torch.float16 else t.to(device))
+
+
+def _with_retries(what, fn, trials):
+    """Blob stores fail now and then: the reference retries every save / restore up to 10 times and moves on; so do we,
+    but the last error is logged instead of being dropped."""
+    err = None
+    for n in range(trials):
+        try:
+            return fn()
+        except Exception as e:  # noqa: BLE001 -- any failure is retried, like the reference
+            err = e
+            LOGGER.warning("%s: trial %d failed: %r", what, n, e)
+    LOGGER.error("%s: giving up after %d trials: %r", what, trials, err)
+    return None
+
+
+class ModelSaver:
+    """`{output_dir}/{prefix}_step_{step}.pt` = model.state_dict() on the CPU; with an optimizer also
+    `..._train_state.pt` = {'step', 'optimizer'} (load_save.py:45-70)."""
+
+    def __init__(self, output_dir):
+        self.output_dir = output_dir
+        self.max_save_load_trial = 10
+
+    def save(self, step, model, optimizer=None, prefix="model"):
+        import os
+
+        def once():
+            sd = {k: v.cpu() if torch.is_tensor(v) else v for k, v in model.state_dict().items()}
+            torch.save(sd, os.path.join(self.output_dir, "%s_step_%s.pt" % (prefix, step)))
+            if optimizer is not None:
+                osd = _map_tensors(optimizer.state_dict(), lambda t: t.detach().cpu())
+                torch.save({"step": step, "optimizer": osd}, os.path.join(self.output_dir, "%s_step_%s_train_state.pt" % (prefix, step)))
+            return True
+        return _with_retries("ModelSaver.save", once, self.max_save_load_trial)
+
+
+class _RestorerBase:
+    def _init_paths(self, opts):
+        self.save_path = "%s/restore.pt" % opts.output_dir
+        self.backup_path = "%s/restore_backup.pt" % opts.output_dir
+        self.amp = getattr(opts, "fp16", 0)
+        self.max_save_load_trial = 10
+
+    def _resume_or_start(self):
+        import os
+        if os.path.exists(self.save_path) or os.path.exists(self.backup_path):
+            LOGGER.info("found previous checkpoint. try to resume...")
+            self.global_step = None
+            _with_retries(type(self).__name__ + ".restore", self.restore, self.max_save_load_trial)
+            if self.global_step is None:
+                raise RuntimeError("%s: restore.pt exists but could not be restored (see the log)" % type(self).__name__)
+        else:
+            self.global_step = 0
+
+    def _read(self):
+        try:
+            return torch.load(self.save_path, map_location="cpu")
+        except Exception:  # noqa: BLE001 -- a torn restore.pt falls back to the previous one
+            return torch.load(self.backup_path, map_location="cpu")
+
+    def _write(self, checkpoint):
+        import os
+        if self.amp:
+            from apex import amp
+            checkpoint["amp_state_dict"] = amp.state_dict()
+        if os.path.exists(self.save_path):
+            os.rename(self.save_path, self.backup_path)   # keep two generations in case a save is interrupted
+        torch.save(checkpoint, self.save_path)
+
+    def step(self):
+        self.global_step += 1
+        if self.global_step % self.save_steps == 0:
+            _with_retries(type(self).__name__ + ".save", self.save, self.max_save_load_trial)
+
+
+class TrainingRestorer(_RestorerBase):
+    """Generic restorer over named state holders (load_save.py:202-277): restore.pt = {'global_step', <name>: state_dict, ...}."""
+
+    def __init__(self, opts, **ckpt_dict):
+        self._init_paths(opts)
+        self.ckpt_dict = ckpt_dict
+        self.save_steps = opts.save_steps
+        self._resume_or_start()
+
+    def save(self):
+        ck = {"global_step": self.global_step}
+        for k, holder in self.ckpt_dict.items():
+            ck[k] = _to_cpu(holder.state_dict(), narrow=not hasattr(holder, "param_groups"))
+        self._write(ck)
+
+    def restore(self):
+        ck = self._read()
+        for k, holder in self.ckpt_dict.items():
+            holder.load_state_dict(_to_device(ck[k]))
+        if self.amp:
+            from apex import amp
+            amp.load_state_dict(ck["amp_state_dict"])
+        self.global_step = ck["global_step"]
+        LOGGER.info("resume training from step %d", self.global_step)
+
+
+class E2E_TrainingRestorer(_RestorerBase):
+    """The pretraining / finetuning drivers' restorer (load_save.py:280-347): restore.pt = {'global_step', 'model_state_dict',
+    'optim_state_dict'[, 'amp_state_dict']}, written every save_steps_ratio * num_train_steps steps."""
+
+    def __init__(self, opts, model, optimizer):
+        import json
+        import os
+        args_json = "%s/log/args.json" % opts.output_dir
+        if os.path.exists(args_json):
+            with open(os.path.join(opts.output_dir, "log", "restore_args.json"), "w") as w:
+                json.dump(dict(vars(opts)) if not isinstance(opts, dict) else dict(opts), w, indent=4, default=str)
+        self._init_paths(opts)
+        self.model, self.optimizer = model, optimizer
+        self.save_steps = max(1, int(opts.save_steps_ratio * opts.num_train_steps))
+        self._resume_or_start()
+
+    def save(self):
+        self._write({"global_step": self.global_step, "model_state_dict": _to_cpu(self.model.state_dict()),
+                     "optim_state_dict": _to_cpu(self.optimizer.state_dict(), narrow=False)})
+
+    def restore(self, opts=None):
+        ck = self._read()
+        self.model.load_state_dict(_to_device(ck["model_state_dict"]))
+        self.optimizer.load_state_dict(_to_device(ck["optim_state_dict"]))
+        if self.amp:
+            from apex import amp
+            amp.load_state_dict(ck["amp_state_dict"])
+        self.global_step = ck["global_step"]
+        LOGGER.info("resume training from step %d", self.global_step)

@@ -354,6 +354,18 @@ class AlproOracle:
         out = self.fusion(torch.cat([te, ve], 1), torch.cat([batch["text_input_mask"], video_atts], 1))
         return dict(logits=linear(out[:, 0, :], self.p, self.pre + "itm_head"), itc_scores=itc_scores)
 
+    def build_text_prompts(self, ids, mask, entity_num, step_size=10000):
+        """One prompt set of Prompter.build_text_prompts (alpro_models.py:430-507): text-encode the E x n_templates prompt
+        sentences in chunks of step_size, project + normalise the CLS rows, average over the templates (the encoded list is
+        template-major: chunk(n_templates) yields one (E, 256) block per template, :470-472)."""
+        feats = []
+        with torch.no_grad():
+            for s in range(0, ids.shape[0], step_size):
+                feats.append(self.text_feat(self.text_embeds(ids[s:s + step_size], mask[s:s + step_size])))
+            feat = torch.cat(feats, 0)
+            n_templates = int(feat.shape[0] / entity_num)
+            return torch.stack(feat.chunk(n_templates), dim=1).mean(dim=1)
+
     def forward_prompter(self, batch, world=None):
         """Prompter.forward (alpro_models.py:553-594)."""
         vf = self.video_feat(self.visual_embeds(batch["visual_inputs"]))

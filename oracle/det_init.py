@@ -117,3 +117,26 @@ def det_batch(B, T, Lt=40, img=224, vocab=30522, seed_name="batch", with_mlm=Tru
         batch["context_visual_inputs"] = batch["visual_inputs"] * pix
         batch["type"] = "video"
     return batch
+
+
+class PromptEncoding:
+    """Stand-in for the tokenizer's BatchEncoding that Prompter.build_text_prompts reads (.input_ids / .attention_mask,
+    alpro_models.py:450-456)."""
+
+    def __init__(self, input_ids, attention_mask):
+        self.input_ids, self.attention_mask = input_ids, attention_mask
+
+
+def det_prompts(E, n_templates, Lp, seed_name):
+    """E entities x n_templates prompt sentences of <= Lp tokens, template-major like the reference's prompt list
+    (alpro_models.py:470-472 chunks the encoded prompts into n_templates groups of E rows)."""
+    n = E * n_templates
+    x = (unit_uniform(seed_name + "/ids", n * Lp) + 1.0) * 0.5
+    ids = torch.from_numpy((1000 + np.floor(x * 29000)).astype(np.int64).reshape(n, Lp))
+    ids[:, 0] = 101
+    mask = torch.ones(n, Lp, dtype=torch.long)
+    for r in range(n):
+        nv = Lp - (5 * r + 1) % (Lp - 4)
+        mask[r, nv:] = 0
+        ids[r, nv:] = 0
+    return PromptEncoding(ids, mask)

@@ -19,7 +19,7 @@ import torch
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 
-from oracle.det_init import det_batch, fill_state_dict_, unit_uniform  # noqa: E402
+from oracle.det_init import det_batch, det_prompts, fill_state_dict_, unit_uniform  # noqa: E402
 from tests.golden import ref_harness as rh  # noqa: E402
 
 MLM_COL_STRIDE = 61
@@ -169,14 +169,130 @@ def case_block_droppath(fname, T=2, B=4, layer=11):
     np.savez_compressed(os.path.join(HERE, fname), **g)
 
 
+def case_prompter(am, T, B, E, fname, n_templates=12, Lp=15):
+    """Prompter (alpro_models.py:389-632): build_text_prompts on E entities x n_templates templates, forward (VTC of the
+    teacher, single rank and as rank 1 of a simulated 2-rank job), get_pseudo_labels with the built prompts."""
+    cfg, venc = rh.make_configs(num_frm=T, num_entities=E)
+    m = am.Prompter(cfg, venc)
+    fill_state_dict_(m)
+    m.eval()
+    prompts = dict(batch_enc_video_prompts=det_prompts(E, n_templates, Lp, "prompts/video"),
+                   batch_enc_image_prompts=det_prompts(E, n_templates - 2, Lp, "prompts/image"))
+    g = {}
+    cuda = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self  # build_text_prompts hard-codes .cuda() (alpro_models.py:453)
+    try:
+        m.build_text_prompts(prompts)
+    finally:
+        torch.Tensor.cuda = cuda
+    g["video_prompt_feat"], g["image_prompt_feat"] = npf(m.video_prompt_feat), npf(m.image_prompt_feat)
+    batch = det_batch(B, T, seed_name="prompter_T%d" % T, with_mlm=False, with_mpm=True)
+    with torch.no_grad():
+        out = m(batch)
+        for k in ("itc_loss", "itc_labels", "i2t_scores", "t2i_scores"):
+            g[k] = npf(out[k])
+        other_v = torch.nn.functional.normalize(torch.from_numpy(unit_uniform("w2/video", B * 256).astype(np.float32)).view(B, 256), dim=-1)
+        other_t = torch.nn.functional.normalize(torch.from_numpy(unit_uniform("w2/text", B * 256).astype(np.float32)).view(B, 256), dim=-1)
+        rh.set_sim_ranks(1, [other_v, None], [other_t, None])
+        try:
+            out2 = m(batch)
+        finally:
+            rh.clear_sim_ranks()
+        for k in ("itc_loss", "itc_labels", "i2t_scores", "t2i_scores"):
+            g["w2_" + k] = npf(out2[k])
+        for ty in ("video", "img"):
+            soft, ign = m.get_pseudo_labels(dict(batch, type=ty))
+            g["pseudo_labels_" + ty] = npf(soft)
+            g["pseudo_ignore_" + ty] = npf(ign.to(torch.float32))
+    np.savez_compressed(os.path.join(HERE, fname), **g)
+
+
+RET_GRAD_FULL = ["vision_proj.weight", "text_proj.bias", "itm_head.weight", "itm_head.bias", "temp",
+                 "visual_encoder.model.blocks.11.attn.proj.bias", "visual_encoder.model.blocks.0.temporal_attn.proj.bias",
+                 "visual_encoder.model.time_embed", "visual_encoder.model.blocks.6.norm2.weight",
+                 "text_encoder.bert.encoder.layer.5.attention.self.value.bias",
+                 "text_encoder.bert.encoder.layer.6.attention.output.LayerNorm.weight",
+                 "text_encoder.bert.embeddings.LayerNorm.weight"]
+
+
+def case_retrieval_grads(am, T, B, fname):
+    """Retrieval finetune step (BASELINE configs[4]): loss = itm_loss + itc_loss (run_video_retrieval.py:432-434) backward
+    through AlproForVideoTextRetrieval.forward (alpro_models.py:733-798); eval-mode layers so the graph is deterministic."""
+    cfg, venc = rh.make_configs(num_frm=T)
+    m = am.AlproForVideoTextRetrieval(cfg, venc)
+    fill_state_dict_(m)
+    m.eval()
+    batch = det_batch(B, T, seed_name="retrieval_T%d" % T, with_mlm=False, with_mpm=False)
+    orig = torch.multinomial
+    torch.multinomial = argmax_multinomial
+    try:
+        out = m(batch)
+    finally:
+        torch.multinomial = orig
+    g = {k: npf(out[k]) for k in ("itc_loss", "itm_loss", "itm_scores")}
+    (out["itm_loss"] + out["itc_loss"]).backward()
+    names, norms = [], []
+    for n_, p_ in m.named_parameters():
+        if p_.grad is not None:
+            names.append(n_)
+            norms.append(float(p_.grad.norm()))
+    g["grad_norm_names"] = np.array(names)
+    g["grad_norms"] = np.array(norms, dtype=np.float64)
+    pd = dict(m.named_parameters())
+    for n_ in RET_GRAD_FULL:
+        assert pd[n_].grad is not None, n_
+        g["grad/" + n_] = npf(pd[n_].grad)
+    np.savez_compressed(os.path.join(HERE, fname), **g)
+
+
+def case_retrieval_frames(am, T, B, fname):
+    """Model-level forward with a T-slot time_embed (BASELINE configs[4] quotes 16 frames; config_release/msrvtt_ret.json
+    itself sets num_frm 8): forward, visual embeddings and 1-video-x-n-captions inference."""
+    cfg, venc = rh.make_configs(num_frm=T)
+    m = am.AlproForVideoTextRetrieval(cfg, venc)
+    fill_state_dict_(m)
+    m.eval()
+    batch = det_batch(B, T, seed_name="retrieval_T%d" % T, with_mlm=False, with_mpm=False)
+    g = {}
+    orig = torch.multinomial
+    torch.multinomial = argmax_multinomial
+    try:
+        with torch.no_grad():
+            out = m(batch)
+            ve = m.visual_encoder.forward_features(batch["visual_inputs"].transpose(1, 2))
+            inf = m.forward_inference(dict(visual_inputs=batch["visual_inputs"][:1], text_input_ids=batch["text_input_ids"],
+                                           text_input_mask=batch["text_input_mask"]))
+    finally:
+        torch.multinomial = orig
+    for k in ("itc_loss", "itm_loss", "itm_scores", "itm_labels"):
+        g[k] = npf(out[k])
+    summarize_embeds("video_embeds", ve, [0, 1, 100, 196], g)
+    g["inf_logits"], g["inf_itc_scores"] = npf(inf["logits"]), npf(inf["itc_scores"])
+    np.savez_compressed(os.path.join(HERE, fname), **g)
+
+
 def main():
     am, _ = rh.import_reference()
     torch.set_num_threads(8)
+    only = set(sys.argv[1:])  # e.g. `python -m tests.golden.make_golden prompter retrieval_grads` regenerates just those
+
+    def want(name):
+        return not only or name in only
     keys = {}
-    keys["retrieval_T2"] = case_retrieval(am, 2, 3, "retrieval_T2_B3.npz")
-    keys["pretrain_T8"] = case_pretrain(am, 8, 2, "pretrain_T8_B2.npz", with_grads=True)
-    case_block_droppath("block11_droppath_T2_B4.npz")
-    json.dump(keys, open(os.path.join(HERE, "state_keys.json"), "w"), indent=0, sort_keys=True)
+    if want("retrieval"):
+        keys["retrieval_T2"] = case_retrieval(am, 2, 3, "retrieval_T2_B3.npz")
+    if want("pretrain"):
+        keys["pretrain_T8"] = case_pretrain(am, 8, 2, "pretrain_T8_B2.npz", with_grads=True)
+    if want("block"):
+        case_block_droppath("block11_droppath_T2_B4.npz")
+    if want("prompter"):
+        case_prompter(am, 2, 3, 8, "prompter_T2_B3_E8.npz")
+    if want("retrieval_grads"):
+        case_retrieval_grads(am, 2, 3, "retrieval_grads_T2_B3.npz")
+    if want("retrieval_T16"):
+        case_retrieval_frames(am, 16, 2, "retrieval_T16_B2.npz")
+    if len(keys) == 2:
+        json.dump(keys, open(os.path.join(HERE, "state_keys.json"), "w"), indent=0, sort_keys=True)
     for f in sorted(os.listdir(HERE)):
         if f.endswith((".npz", ".json")):
             print(f, os.path.getsize(os.path.join(HERE, f)))

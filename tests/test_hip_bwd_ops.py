@@ -292,14 +292,14 @@ def test_softmax_xent(dt):
 
 @pytest.mark.parametrize("dt", DTYPES)
 @pytest.mark.parametrize("M,N,K,tile", [(300, 3072, 768, "128"), (70000, 768, 768, "256"), (1000, 256, 768, "256")])
-def test_gemm_gelu_bwd_epilogue(dt, M, N, K, tile, monkeypatch):
+def test_gemm_gelu_bwd_epilogue(dt, M, N, K, tile):
     """alpro_gemm with ACT_GELU_BWD (dX *= gelu'(saved pre-activation)) on both tile kernels incl. partial edge tiles."""
     hip = _hip()
-    monkeypatch.setenv("ALPRO_GEMM_TILE", tile)
     dy = rnd(M, K, seed=300, scale=0.5).to(dt)
     w = rnd(N, K, seed=301, scale=0.05).to(dt)
     pre = rnd(M, N, seed=302).to(dt)
-    out = hip.gemm(dy.cuda(), w.cuda(), act=hip.ACT_GELU_BWD, pre_act=pre.cuda())
+    with hip.option("gemm_tile", int(tile)):
+        out = hip.gemm(dy.cuda(), w.cuda(), act=hip.ACT_GELU_BWD, pre_act=pre.cuda())
     p64 = pre.double().requires_grad_(True)
     torch.nn.functional.gelu(p64).sum().backward()
     ref = (dy.double() @ w.double().T) * p64.grad

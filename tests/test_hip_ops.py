@@ -232,13 +232,13 @@ def test_attn_temporal(dt, T, groups):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("M,N,K", [(15168, 768, 768), (45 * 256 + 17, 1024, 128), (2560, 3072, 768)])
-def test_gemm_persistent_partial_grid(M, N, K, monkeypatch):
+def test_gemm_persistent_partial_grid(M, N, K):
     """Persistent 256x256 kernel with fewer tiles than CUs (grid not a multiple of 8 before rounding): every tile is visited."""
     hip = _hip()
-    monkeypatch.setenv("ALPRO_GEMM_TILE", "256")
     dt = torch.bfloat16
     a, w = rnd(M, K, seed=40).to(dt), rnd(N, K, seed=41, scale=0.05).to(dt)
-    out = hip.gemm(a.cuda(), w.cuda())
+    with hip.option("gemm_tile", 256):
+        out = hip.gemm(a.cuda(), w.cuda())
     ref = (a.cuda().float() @ w.cuda().float().T)
     err = (out.float() - ref).abs().max().item()
     assert err < 2e-2 * max(1.0, ref.abs().max().item()), err

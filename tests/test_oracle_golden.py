@@ -110,3 +110,78 @@ def test_pretrain_forward_backward(bert_cfg):
     for k in g.files:
         if k.startswith("grad/"):
             close(p[k[5:]].grad, g[k], rtol=2e-3, atol=2e-6, what=k)
+
+
+def _other_rank_feats(B):
+    ov = torch.nn.functional.normalize(torch.from_numpy(unit_uniform("w2/video", B * 256).astype(np.float32)).view(B, 256), dim=-1)
+    ot = torch.nn.functional.normalize(torch.from_numpy(unit_uniform("w2/text", B * 256).astype(np.float32)).view(B, 256), dim=-1)
+    return ov, ot
+
+
+def test_prompter_build_prompts_forward_and_pseudo_labels(bert_cfg):
+    """Prompter (alpro_models.py:389-632) against the reference run on 8 entities x 12 / 10 templates: build_text_prompts
+    buffers, forward (VTC of the teacher, single rank and as rank 1 of 2), get_pseudo_labels on both prompt sets."""
+    from oracle.det_init import det_prompts
+    T, B, E = 2, 3, 8
+    g = np.load(os.path.join(GOLDEN, "prompter_T2_B3_E8.npz"))
+    p = ao.det_state("prompter", bert_cfg, T, num_entities=E)
+    orc = ao.AlproOracle(p, bert_cfg, T)
+    pv, pi = det_prompts(E, 12, 15, "prompts/video"), det_prompts(E, 10, 15, "prompts/image")
+    vfeat = orc.build_text_prompts(pv.input_ids, pv.attention_mask, E)
+    ifeat = orc.build_text_prompts(pi.input_ids, pi.attention_mask, E, step_size=32)   # chunking must not matter
+    close(vfeat, g["video_prompt_feat"], what="video_prompt_feat")
+    close(ifeat, g["image_prompt_feat"], what="image_prompt_feat")
+    assert vfeat.shape == (E, 256) and float(vfeat.norm(dim=-1).max()) < 1.0   # mean of unit vectors
+    batch = det_batch(B, T, seed_name="prompter_T2", with_mlm=False, with_mpm=True)
+    with torch.no_grad():
+        out = orc.forward_prompter(batch)
+        ov, ot = _other_rank_feats(B)
+        out2 = orc.forward_prompter(batch, world=(1, [ov, None], [ot, None]))
+    for k in ("itc_loss", "i2t_scores", "t2i_scores"):
+        close(out[k], g[k], what=k)
+        close(out2[k], g["w2_" + k], what="w2_" + k)
+    assert np.array_equal(out["itc_labels"].numpy(), g["itc_labels"].astype(np.int64))
+    assert np.array_equal(out2["itc_labels"].numpy(), g["w2_itc_labels"].astype(np.int64)) and out2["itc_labels"].min() == B
+    orc.p["video_prompt_feat"], orc.p["image_prompt_feat"] = vfeat, ifeat
+    for ty in ("video", "img"):
+        soft, ign = orc.pseudo_labels(batch["crop_visual_inputs"], ty)
+        close(soft, g["pseudo_labels_" + ty], what="pseudo labels " + ty)
+        assert np.array_equal(ign.numpy().astype(np.float32), g["pseudo_ignore_" + ty])
+
+
+def test_retrieval_finetune_gradients(bert_cfg):
+    """loss = itm_loss + itc_loss (run_video_retrieval.py:432-434) backward through AlproForVideoTextRetrieval.forward:
+    per-parameter gradient norms of every trained tensor + 12 full gradients vs the reference's autograd."""
+    T, B = 2, 3
+    g = np.load(os.path.join(GOLDEN, "retrieval_grads_T2_B3.npz"))
+    p = ao.det_state("retrieval", bert_cfg, T)
+    names = [str(n) for n in g["grad_norm_names"]]
+    for n in names:
+        p[n].requires_grad_(True)
+    orc = ao.AlproOracle(p, bert_cfg, T)
+    out = orc.forward_retrieval(det_batch(B, T, seed_name="retrieval_T2", with_mlm=False, with_mpm=False))
+    for k in ("itc_loss", "itm_loss", "itm_scores"):
+        close(out[k], g[k], what=k)
+    (out["itm_loss"] + out["itc_loss"]).backward()
+    got = np.array([0.0 if p[n].grad is None else float(p[n].grad.norm()) for n in names])
+    np.testing.assert_allclose(got, g["grad_norms"], rtol=2e-3, atol=1e-7)
+    for k in g.files:
+        if k.startswith("grad/"):
+            close(p[k[5:]].grad, g[k], rtol=2e-3, atol=2e-6, what=k)
+
+
+def test_retrieval_16_frames(bert_cfg):
+    """Model-level forward with a 16-slot time_embed (BASELINE configs[4] quotes 16 frames)."""
+    T, B = 16, 2
+    g = np.load(os.path.join(GOLDEN, "retrieval_T16_B2.npz"))
+    orc = ao.AlproOracle(ao.det_state("retrieval", bert_cfg, T), bert_cfg, T)
+    batch = det_batch(B, T, seed_name="retrieval_T16", with_mlm=False, with_mpm=False)
+    with torch.no_grad():
+        out = orc.forward_retrieval(batch)
+        ve = orc.visual_embeds(batch["visual_inputs"])
+        inf = orc.forward_inference(dict(visual_inputs=batch["visual_inputs"][:1], text_input_ids=batch["text_input_ids"],
+                                         text_input_mask=batch["text_input_mask"]))
+    for k in ("itc_loss", "itm_loss", "itm_scores", "itm_labels"):
+        close(out[k], g[k], what=k)
+    close(ve[:, [0, 1, 100, 196]], g["video_embeds_rows"]); close(ve.norm(dim=-1), g["video_embeds_rownorm"])
+    close(inf["logits"], g["inf_logits"]); close(inf["itc_scores"], g["inf_itc_scores"])

@@ -19,7 +19,7 @@ for name, m, n, k, opt in shapes:
     out = torch.empty(m, n, device="cuda", dtype=torch.float32 if res is not None else dt)
     line = "%-14s M=%d N=%d K=%d " % (name, m, n, k)
     for tile in tiles:
-        os.environ["ALPRO_GEMM_TILE"] = tile
+        hip.set_option("gemm_tile", int(tile))
         kw = dict(out=out, bias=bias, act=opt.get("act", 0), out_dtype=out.dtype, residual=res)
         for _ in range(3):
             hip.gemm(a, w, **kw)

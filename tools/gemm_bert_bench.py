@@ -12,7 +12,7 @@ for M in (2560, 15168, 30336):
         out = torch.empty(M, N, device="cuda", dtype=torch.float32 if res else dt)
         line = "M=%5d N=%4d K=%4d res=%d " % (M, N, K, res)
         for tile in ("128", "256"):
-            os.environ["ALPRO_GEMM_TILE"] = tile
+            hip.set_option("gemm_tile", int(tile))
             for _ in range(3): hip.gemm(a, w, out=out, out_dtype=out.dtype, residual=r)
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

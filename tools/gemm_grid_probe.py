@@ -5,14 +5,14 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from alpro_amd import hip
 hip.load()
-os.environ["ALPRO_GEMM_TILE"] = "256"
+hip.set_option("gemm_tile", int("256"))
 dt = torch.bfloat16
 for (M, N, K) in [(204800, 768, 768), (204800, 768, 3072), (204800, 768, 128)]:
     a = torch.randn(M, K, device="cuda").to(dt); w = (torch.randn(N, K, device="cuda") * 0.05).to(dt)
     out = torch.empty(M, N, device="cuda", dtype=dt)
     tiles = (M // 256) * (N // 256)
     for G in (256, 128, 64, 32, 8):
-        os.environ["ALPRO_GEMM_GRID"] = str(G)
+        hip.set_option("gemm_grid", G)
         for _ in range(2): hip.gemm(a, w, out=out)
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

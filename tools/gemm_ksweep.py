@@ -3,7 +3,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from alpro_amd import hip
 hip.load()
-os.environ["ALPRO_GEMM_TILE"] = sys.argv[1] if len(sys.argv) > 1 else "256"
+hip.set_option("gemm_tile", int(sys.argv[1] if len(sys.argv) > 1 else "256"))
 M, N = 50176, 2304
 for out_f32 in (False, True):
     for K in (64, 128, 256, 768, 1536, 3072):

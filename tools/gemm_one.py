@@ -6,7 +6,7 @@ from alpro_amd import hip
 hip.load()
 M, N, K = (int(x) for x in sys.argv[1:4])
 if len(sys.argv) > 4:
-    os.environ["ALPRO_GEMM_TILE"] = sys.argv[4]
+    hip.set_option("gemm_tile", int(sys.argv[4]))
 iters = int(sys.argv[5]) if len(sys.argv) > 5 else 5
 a = torch.randn(M, K, device="cuda").to(torch.bfloat16)
 w = (torch.randn(N, K, device="cuda") * 0.05).to(torch.bfloat16)
