@@ -37,7 +37,11 @@ class use_compute_dtype:
 
 # ---- dropout seeds: the HIP kernels draw masks from hash(seed, element index); every dropout site of every forward
 # gets a fresh 31-bit seed from this counter-based stream (deterministic given seed_dropout()).
-_drop_state = [0x1234567, 0]
+#
+# Seeding: unless seed_dropout() was called explicitly, the stream is keyed on first use by torch.initial_seed() (what the
+# reference's set_random_seed -> torch.manual_seed controls, src/utils/misc.py:20-24) plus the data-parallel rank, so a different run
+# seed gives different masks and the ranks of one job do not drop the same element indices.
+_drop_state = [None, 0]
 
 
 def seed_dropout(seed):
@@ -45,7 +49,15 @@ def seed_dropout(seed):
     _drop_state[1] = 0
 
 
+def _auto_seed():
+    import torch.distributed as td
+    rank = td.get_rank() if (td.is_available() and td.is_initialized()) else 0
+    seed_dropout((torch.initial_seed() * 0x9E3779B1 + rank * 0x85EBCA77 + 0x1234567) & 0x7FFFFFFF)
+
+
 def next_dropout_seed():
+    if _drop_state[0] is None:
+        _auto_seed()
     _drop_state[1] += 1
     x = (_drop_state[0] * 0x9E3779B1 + _drop_state[1] * 0x85EBCA77) & 0xFFFFFFFF
     x ^= x >> 15

@@ -46,9 +46,27 @@ def local_rank():
     return 0
 
 
+# Gradient of the differentiable all-gather.  Horovod 0.19.4 (the reference's pin, env/requirements.txt) implements
+# HorovodAllgather.backward as `allreduce(grad_output, average=True)` followed by narrowing to this rank's rows
+# (horovod/torch/mpi_ops.py; not vendored under /root/reference -- restated from the published source): the cross-rank VTC key
+# gradient is the MEAN over ranks of d loss_r / d feat.  The mathematically exact full-batch gradient is the SUM (what a
+# reduce-scatter gives).  Default "average" reproduces the reference's training dynamics; "sum" makes N ranks x B pairs identical to
+# one rank x N*B pairs (tests/test_dist_cpu.py checks both).  Select with ALPRO_ALLGATHER_GRAD or set_allgather_grad_mode().
+_GATHER_GRAD = [os.environ.get("ALPRO_ALLGATHER_GRAD", "average")]
+
+
+def set_allgather_grad_mode(mode):
+    assert mode in ("average", "sum"), mode
+    _GATHER_GRAD[0] = mode
+
+
+def allgather_grad_mode():
+    return _GATHER_GRAD[0]
+
+
 class _AllGather(torch.autograd.Function):
-    """Differentiable all-gather along dim 0 (Horovod's torch allgather semantics): backward is a
-    sum-reduce of the gathered gradient followed by taking this rank's rows (one reduce-scatter)."""
+    """Differentiable all-gather along dim 0: backward reduces the gathered gradient across ranks (mean or sum, see above)
+    and keeps this rank's rows -- ONE reduce-scatter on RCCL."""
 
     @staticmethod
     def forward(ctx, x):
@@ -67,6 +85,8 @@ class _AllGather(torch.autograd.Function):
             out.copy_(g[rank() * ctx.n:(rank() + 1) * ctx.n])
         else:
             td.reduce_scatter_tensor(out, g)
+        if _GATHER_GRAD[0] == "average":
+            out.div_(size())
         return out
 
 

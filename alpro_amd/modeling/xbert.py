@@ -500,7 +500,7 @@ class _LMHeadRun:
         if self.labels is not None:
             dl = self.dl                       # (softmax - onehot) / n_valid, already in the operand dtype
             if dloss is not None:
-                dl = dl * dloss.to(dl.dtype)   # upstream scale of the loss (1 in the reference's sum of losses)
+                dl = dl * dloss.reshape(()).float()   # upstream scale of the loss (1 in the reference's sum of losses): fp32 scalar, fp32 multiply, one rounding
             if dlogits is not None:            # someone also differentiated through mlm_scores
                 dl = dl.clone()
                 dl[:, :V] += dlogits.reshape(M, V).to(dt)

@@ -1,7 +1,7 @@
 """CPU, world_size 2 over gloo: the data-parallel pieces of the path (alpro_amd/dist.py) -- differentiable
-all-gather (forward order = rank order, backward = sum-reduce + own slice, i.e. Horovod's allgather semantics used at
-alpro_models.py:110-111), bucketed gradient all-reduce, parameter broadcast, and the VTC loss identity
-"2 ranks x B pairs == 1 rank x 2B pairs" that makes data parallelism exact for the contrastive term."""
+all-gather (forward order = rank order; backward = reduce across ranks + own slice, "average" = Horovod 0.19's
+HorovodAllgather.backward used at alpro_models.py:110-111, "sum" = the exact full-batch gradient), bucketed gradient all-reduce,
+parameter broadcast, and the VTC loss identity "2 ranks x B pairs == 1 rank x 2B pairs" that holds in "sum" mode."""
 import os
 import socket
 
@@ -43,7 +43,9 @@ def _worker(rank, world, port, out):
     # forward: gathered rows in rank order
     g = dist.allgather(v)
     assert torch.allclose(g, full_v)
-    # loss averaged over ranks == single-process loss on the concatenated batch; same for the gradients
+    # loss averaged over ranks == single-process loss on the concatenated batch; in "sum" mode the same holds for the gradients
+    assert dist.allgather_grad_mode() == "average"          # the default follows the reference's Horovod
+    dist.set_allgather_grad_mode("sum")
     loss = _vtc(v, t, 0.07, rank, dist.allgather)
     loss.backward()
     fv, ft = full_v.clone().requires_grad_(True), full_t.clone().requires_grad_(True)
@@ -55,6 +57,26 @@ def _worker(rank, world, port, out):
     # d(mean over ranks of loss_r)/dv = fv.grad rows: each rank's backward already sums the other ranks' contributions
     assert torch.allclose(v.grad / world, fv.grad[rank * B:(rank + 1) * B], atol=1e-6)
     assert torch.allclose(t.grad / world, ft.grad[rank * B:(rank + 1) * B], atol=1e-6)
+    # "average" (Horovod 0.19 HorovodAllgather.backward = allreduce(grad, average=True).narrow(own rows)): the gradient that reaches
+    # a rank's features through the GATHERED copies is the mean over ranks; the direct path (features as queries) is untouched.
+    # Restated per rank with the gathered tensors as independent leaves.
+    dist.set_allgather_grad_mode("average")
+    v.grad = t.grad = None
+    _vtc(v, t, 0.07, rank, dist.allgather).backward()
+    direct_v = direct_t = None
+    via_gv, via_gt = torch.zeros_like(full_v), torch.zeros_like(full_t)
+    for q in range(world):
+        vq = full_v[q * B:(q + 1) * B].clone().requires_grad_(True)
+        tq = full_t[q * B:(q + 1) * B].clone().requires_grad_(True)
+        gv, gt = full_v.clone().requires_grad_(True), full_t.clone().requires_grad_(True)
+        leaves = iter([gv, gt])                               # allgather order: video, then text (alpro_models.py:110-111)
+        _vtc(vq, tq, 0.07, q, lambda x: next(leaves)).backward()
+        via_gv += gv.grad
+        via_gt += gt.grad
+        if q == rank:
+            direct_v, direct_t = vq.grad, tq.grad
+    assert torch.allclose(v.grad, direct_v + via_gv[rank * B:(rank + 1) * B] / world, atol=1e-6)
+    assert torch.allclose(t.grad, direct_t + via_gt[rank * B:(rank + 1) * B] / world, atol=1e-6)
     # bucketed gradient all-reduce (average), skipping parameters without gradients
     ps = [torch.nn.Parameter(torch.zeros(5, 7)), torch.nn.Parameter(torch.zeros(11)), torch.nn.Parameter(torch.zeros(3))]
     ps[0].grad = torch.full((5, 7), float(rank + 1))

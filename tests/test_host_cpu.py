@@ -231,3 +231,178 @@ def test_flat_buffer_views_host_logic():
     assert float(b.grad.sum()) == 2.0 * 128 and float(a.grad.abs().sum()) == 0
     c.grad = torch.zeros(8, 16)
     assert tr.fused_grad_view([a, b, c]) is None
+
+
+# ---- N1: checkpoint / restore / launcher plumbing (host logic, no GPU) -------------------------------------------------------------
+def _tiny_timesformer(num_frm=4):
+    from alpro_amd.modeling.timesformer.vit import TimeSformer
+    torch.manual_seed(3)
+    return TimeSformer(dict(VENC, num_frm=num_frm), input_format="RGB")
+
+
+def test_timesformer_load_state_dict_from_checkpoint_paths(tmp_path, monkeypatch):
+    """TimeSformer.load_state_dict(<str>) as load_separate_ckpt calls it (vit.py:515-533 -> helpers.py:207-375): a Kinetics checkpoint
+    ('model_state' wrapper, 'model.' prefixes, 8-frame time table, other classifier) is strict-loaded with the tables resampled; a
+    CLIP / ImageNet image checkpoint (no temporal branch) seeds temporal_attn / temporal_norm1 from the spatial branch."""
+    from alpro_amd.utils.load_save import nearest_index
+    src = _tiny_timesformer(num_frm=8)
+    with torch.no_grad():
+        for p in src.parameters():
+            p.uniform_(-1, 1)
+    sd = src.model.state_dict()
+    kin = {"model." + k: v.clone() for k, v in sd.items()}
+    kin["model.head.weight"], kin["model.head.bias"] = torch.zeros(600, 768), torch.zeros(600)   # K600 classifier: ignored
+    path = str(tmp_path / "TimeSformer_divST_8x32_224_K600.pyth")
+    torch.save({"model_state": kin}, path)
+    dst = _tiny_timesformer(num_frm=4)
+    head0 = dst.model.head.weight.detach().clone()
+    dst.load_state_dict(path)
+    got = dst.model.state_dict()
+    assert torch.equal(got["blocks.7.temporal_attn.qkv.weight"], sd["blocks.7.temporal_attn.qkv.weight"])
+    assert torch.equal(got["time_embed"], sd["time_embed"].index_select(1, nearest_index(8, 4)))
+    assert torch.equal(got["head.weight"], head0) and got["head.weight"].shape == (400, 768)
+    # image checkpoint: spatial keys only
+    img = {k: v.clone() for k, v in sd.items() if "temporal" not in k and k not in ("time_embed", "head.weight", "head.bias")}
+    clip = str(tmp_path / "CLIP_ViT_B16.pt")
+    torch.save(img, clip)
+    dst2 = _tiny_timesformer(num_frm=4)
+    time0 = dst2.model.time_embed.detach().clone()
+    missing, unexpected, mismatched = dst2.load_state_dict(clip)
+    got2 = dst2.model.state_dict()
+    assert torch.equal(got2["blocks.3.temporal_attn.proj.weight"], sd["blocks.3.attn.proj.weight"])
+    assert torch.equal(got2["blocks.3.temporal_norm1.bias"], sd["blocks.3.norm1.bias"])
+    assert torch.equal(got2["blocks.3.attn.qkv.weight"], sd["blocks.3.attn.qkv.weight"])
+    assert torch.equal(got2["time_embed"], time0) and "time_embed" in missing and "blocks.0.temporal_fc.weight" in missing
+    assert not unexpected and not mismatched
+    # ImageNet source: a local file named by the environment (no timm / network here), loud failure otherwise
+    dst3 = _tiny_timesformer(num_frm=4)
+    monkeypatch.delenv("ALPRO_VIT_IMAGENET_CKPT", raising=False)
+    with pytest.raises(FileNotFoundError, match="ALPRO_VIT_IMAGENET_CKPT"):
+        dst3.load_state_dict("vit_base_patch16_224")
+    monkeypatch.setenv("ALPRO_VIT_IMAGENET_CKPT", clip)
+    dst3.load_state_dict("vit_base_patch16_224")
+    assert torch.equal(dst3.model.state_dict()["blocks.11.temporal_attn.qkv.bias"], sd["blocks.11.attn.qkv.bias"])
+    with pytest.raises(FileNotFoundError):
+        dst3.load_state_dict(str(tmp_path / "does_not_exist.pyth"))
+
+
+def test_bert_from_pretrained_resolves_local_weights_and_is_loud(tmp_path, monkeypatch, bert_cfg):
+    from alpro_amd.modeling.xbert import BertForMaskedLM, BertModel
+    cfg = make_cfg(dict(bert_cfg, num_hidden_layers=2, vocab_size=64, max_position_embeddings=16))
+    monkeypatch.delenv("ALPRO_BERT_WEIGHTS", raising=False)
+    monkeypatch.delenv("ALPRO_PRETRAINED_DIR", raising=False)
+    with pytest.warns(UserWarning, match="RANDOM initialisation"):
+        m = BertForMaskedLM.from_pretrained("bert-base-uncased", config=cfg)
+    monkeypatch.setenv("ALPRO_REQUIRE_PRETRAINED", "1")
+    with pytest.raises(RuntimeError, match="no local weights"):
+        BertForMaskedLM.from_pretrained("bert-base-uncased", config=cfg)
+    monkeypatch.delenv("ALPRO_REQUIRE_PRETRAINED")
+    d = tmp_path / "bert-base-uncased"
+    d.mkdir()
+    hf = {k.replace("LayerNorm.weight", "LayerNorm.gamma").replace("LayerNorm.bias", "LayerNorm.beta"): v for k, v in m.state_dict().items()}
+    torch.save(hf, str(d / "pytorch_model.bin"))
+    monkeypatch.setenv("ALPRO_PRETRAINED_DIR", str(tmp_path))
+    m2 = BertForMaskedLM.from_pretrained("bert-base-uncased", config=cfg)
+    assert m2.pretrained_report["missing"] == [] and m2.pretrained_report["unexpected"] == []
+    assert all(torch.equal(a, b) for a, b in zip(m.state_dict().values(), m2.state_dict().values()))
+    b = BertModel.from_pretrained("bert-base-uncased", config=cfg, add_pooling_layer=False)   # 'bert.'-prefixed file into the bare model
+    assert b.pretrained_report["missing"] == []
+    assert torch.equal(b.state_dict()["encoder.layer.1.output.dense.weight"], m.state_dict()["bert.encoder.layer.1.output.dense.weight"])
+    torch.save({"something.else": torch.zeros(1)}, str(d / "pytorch_model.bin"))
+    with pytest.raises(RuntimeError, match="shares no key"):
+        BertForMaskedLM.from_pretrained("bert-base-uncased", config=cfg)
+
+
+def test_model_saver_and_restorers_file_layout(tmp_path):
+    """Same file names / dictionary keys as src/utils/load_save.py:45-70,202-347; restore picks up where save left off."""
+    from alpro_amd.utils.load_save import E2E_TrainingRestorer, ModelSaver, TrainingRestorer
+    torch.manual_seed(0)
+    model = torch.nn.Linear(4, 3)
+    opt = torch.optim.Adam(model.parameters(), lr=0.1)
+    model(torch.randn(2, 4)).sum().backward()
+    opt.step()
+    out = tmp_path / "run"
+    (out / "log").mkdir(parents=True)
+    (out / "log" / "args.json").write_text("{}")
+    ModelSaver(str(out)).save(step=7, model=model, optimizer=opt)
+    assert set(torch.load(str(out / "model_step_7.pt"))) == {"weight", "bias"}
+    ts = torch.load(str(out / "model_step_7_train_state.pt"))
+    assert ts["step"] == 7 and set(ts["optimizer"]) == {"state", "param_groups"}
+    opts = Cfg(dict(output_dir=str(out), save_steps_ratio=0.5, num_train_steps=4, fp16=0, save_steps=2))
+    r = E2E_TrainingRestorer(opts, model, opt)
+    assert r.global_step == 0 and r.save_steps == 2 and (out / "log" / "restore_args.json").exists()
+    r.step()
+    assert not (out / "restore.pt").exists()
+    r.step()
+    ck = torch.load(str(out / "restore.pt"))
+    assert set(ck) == {"global_step", "model_state_dict", "optim_state_dict"} and ck["global_step"] == 2
+    assert ck["model_state_dict"]["weight"].dtype == torch.float16               # narrowed like the reference's files
+    assert ck["optim_state_dict"]["state"][0]["exp_avg_sq"].dtype == torch.float32  # moments are not (see _to_cpu)
+    r.step(); r.step()
+    assert (out / "restore_backup.pt").exists() and torch.load(str(out / "restore.pt"))["global_step"] == 4
+    model2 = torch.nn.Linear(4, 3)
+    opt2 = torch.optim.Adam(model2.parameters(), lr=0.1)
+    r2 = E2E_TrainingRestorer(opts, model2, opt2)
+    assert r2.global_step == 4
+    assert torch.allclose(model2.weight, model.weight, atol=2e-3)                # through fp16
+    assert torch.equal(opt2.state_dict()["state"][0]["exp_avg_sq"], opt.state_dict()["state"][0]["exp_avg_sq"])
+    (out / "restore.pt").write_bytes(b"torn")                                    # torn file -> falls back to the backup
+    assert E2E_TrainingRestorer(opts, torch.nn.Linear(4, 3), torch.optim.Adam(model2.parameters())).global_step == 2
+    out2 = tmp_path / "run2"
+    out2.mkdir()
+    opts2 = Cfg(dict(output_dir=str(out2), save_steps=1, fp16=0))
+    g = TrainingRestorer(opts2, model=model, optim=opt)
+    g.step()
+    assert set(torch.load(str(out2 / "restore.pt"))) == {"global_step", "model", "optim"}
+    assert TrainingRestorer(opts2, model=model2, optim=opt2).global_step == 1
+
+
+def test_flat_adamw_state_and_first_step_host_logic():
+    """What the reference's loop does around the optimizer before any kernel runs (run_pretrain_sparse.py:508-511, load_save.py:
+    280-347): step() with no gradient anywhere is a no-op; a state restored before the first backward is parked, reported by
+    state_dict(), and hvd.broadcast_optimizer_state / DistributedOptimizer.load_state_dict reach the flat optimizer."""
+    import sys
+    import alpro_amd.compat
+    sys.path.insert(0, alpro_amd.compat.PATH)
+    try:
+        from horovod import torch as hvd
+    finally:
+        sys.path.remove(alpro_amd.compat.PATH)
+    from alpro_amd.optim import FlatAdamW
+    ps = [torch.nn.Parameter(torch.randn(4, 8)), torch.nn.Parameter(torch.randn(8))]
+    opt = hvd.DistributedOptimizer(FlatAdamW(ps, lr=1e-3, betas=(0.9, 0.98)), named_parameters=None)
+    with opt.skip_synchronize():
+        opt.zero_grad()
+        assert opt.step() is None                       # nothing has a gradient: no-op, no error
+    sd0 = opt.state_dict()
+    assert sd0["step"] == 0 and sd0["m"] is None and sd0["layout"] == []
+    saved = dict(step=5, param_groups=[dict(lr=3e-4, betas=[0.9, 0.98], eps=1e-6, weight_decay=0.0, correct_bias=True)],
+                 layout=[(0, 0, 32), (1, 32, 8)], m=torch.arange(40.0).half(), v=torch.ones(40).half())
+    opt.load_state_dict(saved)
+    inner = opt._opt
+    assert inner.step_count == 5 and inner.param_groups[0]["lr"] == 3e-4 and inner.param_groups[0]["betas"] == (0.9, 0.98)
+    sd1 = opt.state_dict()
+    assert sd1["step"] == 5 and sd1["layout"] == [(0, 0, 32), (1, 32, 8)] and torch.equal(sd1["m"], saved["m"])
+    hvd.broadcast_optimizer_state(opt, root_rank=0)     # size() == 1: identity
+    assert inner.step_count == 5
+
+
+def test_src_package_extends_the_reference_and_launcher_command():
+    import subprocess
+    import sys
+    from alpro_amd import launch
+    cmd, env, cwd = launch.build_command(8, "/opt/ALPRO", "src/pretrain/run_pretrain_sparse.py", ["--config", "c.json"], port=29999, dtype="bf16", env={})
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node" in cmd and cmd[-3:] == ["src/pretrain/run_pretrain_sparse.py", "--config", "c.json"]
+    pp = env["PYTHONPATH"].split(os.pathsep)
+    assert pp[0] == ROOT and pp[1] == os.path.join(ROOT, "alpro_amd", "compat") and pp[2] == "/opt/ALPRO" and cwd == "/opt/ALPRO"
+    assert env["MASTER_ADDR"] == "127.0.0.1" and env["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    ref = os.environ.get("ALPRO_REFERENCE", "/root/reference")
+    if not os.path.isdir(os.path.join(ref, "src")):
+        pytest.skip("reference checkout not present on this box")
+    code = ("import src.modeling.alpro_models as a, src.utils.load_save as l, src.optimization.sched as s, src.modeling.timesformer.vit as v;"
+            "print(a.__file__); print(l.__file__); print(s.__file__); print(v.__file__)")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd="/tmp",
+                       env=dict(os.environ, PYTHONPATH=os.pathsep.join([ROOT, os.path.join(ROOT, "alpro_amd", "compat"), ref])))
+    assert r.returncode == 0, r.stderr[-2000:]
+    a, l, s, v = r.stdout.split()
+    assert a.startswith(ROOT) and l.startswith(ROOT) and v.startswith(ROOT) and s.startswith(ref)
