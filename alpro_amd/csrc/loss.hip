@@ -64,10 +64,127 @@ __global__ __launch_bounds__(256) void xent_kernel(const float* __restrict__ log
     }
   }
 }
+
+// ---- video-text contrastive loss (alpro_models.py:103-128 / 570-587 / 750-779) ----------------------------------------------------
+// sim_v2t = v gt^T / temp, sim_t2v = t gv^T / temp over the GATHERED features (G = world * B rows), soft-target cross entropy with
+// the positives at columns col0 + i, both directions averaged: loss = (mean_i ce_v[i] + mean_i ce_t[i]) / 2.  B x G x 256 is tiny
+// (33 MFLOP at B = 64, G = 512): the point of the kernel is ONE launch instead of ~25 ATen launches, not throughput.
+// Block (dir, i): query row in LDS, thread j owns key columns j, j + 256, ...
+constexpr int VTC_MAX_E = 1024;
+
+__global__ __launch_bounds__(256) void vtc_fwd_kernel(const float* __restrict__ v, const float* __restrict__ t, const float* __restrict__ gv,
+                                                      const float* __restrict__ gt, const float* __restrict__ temp, int B, int G, int E, int col0,
+                                                      float* __restrict__ sim_v2t, float* __restrict__ sim_t2v, float* __restrict__ lse,
+                                                      float* __restrict__ loss) {
+  __shared__ float q[VTC_MAX_E];
+  __shared__ float sh[4];
+  __shared__ float pos;
+  const int dir = blockIdx.x / B, i = blockIdx.x - dir * B;
+  const float* qrow = (dir == 0 ? v : t) + (int64_t)i * E;
+  const float* keys = dir == 0 ? gt : gv;
+  float* sim = (dir == 0 ? sim_v2t : sim_t2v) + (int64_t)i * G;
+  const float inv_temp = 1.0f / fminf(fmaxf(*temp, 0.001f), 0.5f);  // temp.clamp_(0.001, 0.5), alpro_models.py:80-81
+  for (int e = threadIdx.x; e < E; e += 256) q[e] = qrow[e];
+  __syncthreads();
+  float mx = -INFINITY;
+  for (int j = threadIdx.x; j < G; j += 256) {
+    const float4* k4 = (const float4*)(keys + (int64_t)j * E);
+    float acc = 0.f;
+    for (int e = 0; e < E / 4; ++e) {
+      const float4 k = k4[e];
+      acc = fmaf(k.x, q[4 * e], fmaf(k.y, q[4 * e + 1], fmaf(k.z, q[4 * e + 2], fmaf(k.w, q[4 * e + 3], acc))));
+    }
+    acc *= inv_temp;
+    sim[j] = acc;
+    if (j == col0 + i) pos = acc;  // the positive pair's logit, handed to thread 0 through LDS
+    mx = fmaxf(mx, acc);
+  }
+  mx = block_reduce(mx, sh, true);
+  float s = 0.f;
+  for (int j = threadIdx.x; j < G; j += 256) s += expf(sim[j] - mx);  // own writes: visible to the writing thread
+  s = block_reduce(s, sh, false);
+  if (threadIdx.x == 0) {
+    const float l = mx + logf(s);
+    lse[blockIdx.x] = l;
+    atomicAdd(loss, (l - pos) * (0.5f / B));
+  }
+}
+
+// Backward, rows: ds[i][j] = (softmax(sim[i])[j] - [j == col0 + i]) * dloss / (2B); d(query i) = sum_j ds[i][j] key[j] / temp;
+// d(temp) -= sum_j ds[i][j] sim[i][j] / temp.  ds is kept (B x G per direction) for the column pass.
+__global__ __launch_bounds__(256) void vtc_bwd_rows_kernel(const float* __restrict__ gv, const float* __restrict__ gt, const float* __restrict__ temp,
+                                                           int B, int G, int E, int col0, const float* __restrict__ sim_v2t,
+                                                           const float* __restrict__ sim_t2v, const float* __restrict__ lse,
+                                                           const float* __restrict__ dloss, float* __restrict__ ds_v2t, float* __restrict__ ds_t2v,
+                                                           float* __restrict__ dv, float* __restrict__ dt, float* __restrict__ dtemp) {
+  extern __shared__ float dsrow[];  // G floats
+  __shared__ float sh[4];
+  const int dir = blockIdx.x / B, i = blockIdx.x - dir * B;
+  const float* keys = dir == 0 ? gt : gv;
+  const float* sim = (dir == 0 ? sim_v2t : sim_t2v) + (int64_t)i * G;
+  float* ds = (dir == 0 ? ds_v2t : ds_t2v) + (int64_t)i * G;
+  const float tc = fminf(fmaxf(*temp, 0.001f), 0.5f);
+  const float inv_temp = 1.0f / tc;
+  const float scale = *dloss * (0.5f / B), l = lse[blockIdx.x];
+  float tacc = 0.f;
+  for (int j = threadIdx.x; j < G; j += 256) {
+    const float sj = sim[j];
+    const float d = (expf(sj - l) - (j == col0 + i ? 1.f : 0.f)) * scale;
+    dsrow[j] = d;
+    ds[j] = d;
+    tacc += d * sj;
+  }
+  tacc = block_reduce(tacc, sh, false);  // (also the barrier that publishes dsrow)
+  if (threadIdx.x == 0 && dtemp) atomicAdd(dtemp, -tacc * inv_temp);
+  float* dq = (dir == 0 ? dv : dt) + (int64_t)i * E;
+  for (int e = threadIdx.x; e < E; e += 256) {
+    float acc = 0.f;
+    for (int j = 0; j < G; ++j) acc = fmaf(dsrow[j], keys[(int64_t)j * E + e], acc);
+    dq[e] = acc * inv_temp;
+  }
+}
+
+// Backward, columns: d(key j of direction dir) = sum_i ds_dir[i][j] query_dir[i] / temp  (v2t: keys = gathered text, queries = v).
+__global__ __launch_bounds__(256) void vtc_bwd_cols_kernel(const float* __restrict__ v, const float* __restrict__ t, const float* __restrict__ temp, int B,
+                                                           int G, int E, const float* __restrict__ ds_v2t, const float* __restrict__ ds_t2v,
+                                                           float* __restrict__ dgv, float* __restrict__ dgt) {
+  const int dir = blockIdx.x / G, j = blockIdx.x - dir * G;
+  const float* qs = dir == 0 ? v : t;
+  const float* ds = dir == 0 ? ds_v2t : ds_t2v;
+  float* dk = (dir == 0 ? dgt : dgv) + (int64_t)j * E;
+  const float inv_temp = 1.0f / fminf(fmaxf(*temp, 0.001f), 0.5f);
+  for (int e = threadIdx.x; e < E; e += 256) {
+    float acc = 0.f;
+    for (int i = 0; i < B; ++i) acc = fmaf(ds[(int64_t)i * G + j], qs[(int64_t)i * E + e], acc);
+    dk[e] = acc * inv_temp;
+  }
+}
 }  // namespace
 }  // namespace alpro
 
 using namespace alpro;
+
+extern "C" int alpro_vtc_loss_fwd(const float* v, const float* t, const float* gv, const float* gt, const float* temp, int B, int G, int E,
+                                  int col0, float* sim_v2t, float* sim_t2v, float* lse, float* loss, void* stream) {
+  ALPRO_CHECK(v && t && gv && gt && temp && sim_v2t && sim_t2v && lse && loss, "alpro_vtc_loss_fwd: null argument");
+  ALPRO_CHECK(B > 0 && G >= B && E > 0 && E % 4 == 0 && E <= VTC_MAX_E && col0 >= 0 && col0 + B <= G, "alpro_vtc_loss_fwd: bad shape B=%d G=%d E=%d col0=%d", B, G, E, col0);
+  (void)hipMemsetAsync(loss, 0, sizeof(float), (hipStream_t)stream);
+  hipLaunchKernelGGL(vtc_fwd_kernel, dim3(2 * B), dim3(256), 0, (hipStream_t)stream, v, t, gv, gt, temp, B, G, E, col0, sim_v2t, sim_t2v, lse, loss);
+  return check_launch("alpro_vtc_loss_fwd");
+}
+
+extern "C" int alpro_vtc_loss_bwd(const float* v, const float* t, const float* gv, const float* gt, const float* temp, int B, int G, int E,
+                                  int col0, const float* sim_v2t, const float* sim_t2v, const float* lse, const float* dloss, float* ds_v2t,
+                                  float* ds_t2v, float* dv, float* dt, float* dgv, float* dgt, float* dtemp, void* stream) {
+  ALPRO_CHECK(v && t && gv && gt && temp && sim_v2t && sim_t2v && lse && dloss && ds_v2t && ds_t2v && dv && dt && dgv && dgt, "alpro_vtc_loss_bwd: null argument");
+  ALPRO_CHECK(B > 0 && G >= B && E > 0 && E % 4 == 0 && E <= VTC_MAX_E && G <= 8192, "alpro_vtc_loss_bwd: bad shape B=%d G=%d E=%d", B, G, E);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtemp) (void)hipMemsetAsync(dtemp, 0, sizeof(float), st);
+  hipLaunchKernelGGL(vtc_bwd_rows_kernel, dim3(2 * B), dim3(256), G * sizeof(float), st, gv, gt, temp, B, G, E, col0, sim_v2t, sim_t2v, lse, dloss, ds_v2t,
+                     ds_t2v, dv, dt, dtemp);
+  hipLaunchKernelGGL(vtc_bwd_cols_kernel, dim3(2 * G), dim3(256), 0, st, v, t, temp, B, G, E, ds_v2t, ds_t2v, dgv, dgt);
+  return check_launch("alpro_vtc_loss_bwd");
+}
 
 extern "C" int alpro_softmax_xent(const float* logits, int64_t ld, const int64_t* labels, int ignore_index, float* loss_rows, void* dlogits,
                                   int dtype, int64_t ldd, const float* grad_scale, int M, int V, int Vpad, void* stream) {

@@ -21,7 +21,7 @@ _CODE = {v: k for k, v in _TORCH_DTYPE.items()}
 EXPORTS = ["alpro_hip_last_error", "alpro_hip_abi_version", "alpro_hip_set_option", "alpro_gemm", "alpro_layernorm_fwd",
            "alpro_attn_temporal_fwd", "alpro_attn_fwd", "alpro_patchify", "alpro_cls_mean_residual",
            "alpro_vit_final_pool", "alpro_bert_embed_fwd", "alpro_cast_from_f32", "alpro_attn_bwd", "alpro_attn_temporal_bwd",
-           "alpro_layernorm_bwd", "alpro_transpose", "alpro_gelu_bwd", "alpro_cls_mean_bwd", "alpro_scatter_add_rows", "alpro_gather_cast", "alpro_sumsq", "alpro_adamw_step", "alpro_gemm_tn_acc", "alpro_colsum_acc", "alpro_softmax_xent"]
+           "alpro_layernorm_bwd", "alpro_transpose", "alpro_gelu_bwd", "alpro_cls_mean_bwd", "alpro_scatter_add_rows", "alpro_gather_cast", "alpro_sumsq", "alpro_adamw_step", "alpro_gemm_tn_acc", "alpro_colsum_acc", "alpro_softmax_xent", "alpro_vtc_loss_fwd", "alpro_vtc_loss_bwd"]
 
 
 class GemmDesc(ctypes.Structure):
@@ -38,7 +38,7 @@ class GemmDesc(ctypes.Structure):
                 ("drop_p", ctypes.c_float), ("drop_seed", ctypes.c_uint32), ("bias2", ctypes.c_void_p)]
 
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 _lib = None
 
 
@@ -79,6 +79,8 @@ def load():
     lib.alpro_bert_embed_fwd.argtypes = [vp, vp, vp, vp, vp, vp, f32, vp, vp, i32, vp, vp, i32, i32, i32, f32, u32, vp]
     lib.alpro_cast_from_f32.argtypes = [vp, vp, i32, i64, vp]
     lib.alpro_hip_set_option.argtypes = [ctypes.c_char_p, i32]
+    lib.alpro_vtc_loss_fwd.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp]
+    lib.alpro_vtc_loss_bwd.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     if lib.alpro_hip_abi_version() != ABI_VERSION:
         raise RuntimeError("libalpro_hip.so ABI version mismatch")
     _lib = lib
@@ -406,3 +408,38 @@ def softmax_xent(logits, labels, grad_dtype=None, grad_scale=None, ignore_index=
                                   _CODE[grad_dtype] if grad_dtype is not None else 0, Vp, _ptr(grad_scale), M, V, Vp, _stream()),
            "alpro_softmax_xent")
     return (loss_rows, dl) if dl is not None else loss_rows
+
+
+def vtc_loss_fwd(v, t, gv, gt, temp, col0):
+    """alpro_vtc_loss_fwd: returns (loss (), sim_v2t (B, G), sim_t2v (B, G), lse (2B,))."""
+    lib = load()
+    for x in (v, t, gv, gt):
+        _dev(x, torch.float32)
+        assert x.is_contiguous()
+    _dev(temp, torch.float32)
+    B, E = v.shape
+    G = gv.shape[0]
+    sim_v2t = torch.empty((B, G), dtype=torch.float32, device=v.device)
+    sim_t2v = torch.empty_like(sim_v2t)
+    lse = torch.empty(2 * B, dtype=torch.float32, device=v.device)
+    loss = torch.empty((), dtype=torch.float32, device=v.device)
+    _check(lib.alpro_vtc_loss_fwd(_ptr(v), _ptr(t), _ptr(gv), _ptr(gt), _ptr(temp), B, G, E, int(col0), _ptr(sim_v2t), _ptr(sim_t2v), _ptr(lse),
+                                  _ptr(loss), _stream()), "alpro_vtc_loss_fwd")
+    return loss, sim_v2t, sim_t2v, lse
+
+
+def vtc_loss_bwd(v, t, gv, gt, temp, col0, sim_v2t, sim_t2v, lse, dloss, want_dtemp=True):
+    """alpro_vtc_loss_bwd: returns (dv, dt, dgv, dgt, dtemp or None)."""
+    lib = load()
+    B, E = v.shape
+    G = gv.shape[0]
+    dev = v.device
+    ds = torch.empty((2, B, G), dtype=torch.float32, device=dev)
+    dv, dt = torch.empty_like(v), torch.empty_like(t)
+    dgv, dgt = torch.empty_like(gv), torch.empty_like(gt)
+    dtemp = torch.empty((), dtype=torch.float32, device=dev) if want_dtemp else None
+    dloss = dloss.reshape(()).to(torch.float32).contiguous()
+    _check(lib.alpro_vtc_loss_bwd(_ptr(v), _ptr(t), _ptr(gv), _ptr(gt), _ptr(temp), B, G, E, int(col0), _ptr(sim_v2t), _ptr(sim_t2v), _ptr(lse),
+                                  _ptr(dloss), _ptr(ds[0]), _ptr(ds[1]), _ptr(dv), _ptr(dt), _ptr(dgv), _ptr(dgt), _ptr(dtemp), _stream()),
+           "alpro_vtc_loss_bwd")
+    return dv, dt, dgv, dgt, dtemp

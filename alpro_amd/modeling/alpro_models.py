@@ -60,6 +60,31 @@ def _pad_k(t):
     return t if r == 0 else F.pad(t, (0, r))
 
 
+class _VtcLoss(torch.autograd.Function):
+    """alpro_vtc_loss as an autograd node: (v, t, gathered v, gathered t, temp) -> (loss, sim_v2t, sim_t2v); the similarity
+    matrices are outputs for the hard-negative mining and the Prompter's score dict, gradients flow through the loss only (the
+    reference differentiates nothing else through them: alpro_models.py:287-306 runs under no_grad)."""
+
+    @staticmethod
+    def forward(ctx, v, t, gv, gt, temp, col0):
+        v, t, gv, gt = (x.contiguous().float() for x in (v, t, gv, gt))
+        temp32 = temp.detach().reshape(1).float().contiguous()
+        loss, sim_v2t, sim_t2v, lse = hip.vtc_loss_fwd(v, t, gv, gt, temp32, col0)
+        ctx.save_for_backward(v, t, gv, gt, temp32, sim_v2t, sim_t2v, lse)
+        ctx.col0 = col0
+        ctx.mark_non_differentiable(sim_v2t, sim_t2v)
+        ctx.set_materialize_grads(False)
+        return loss, sim_v2t, sim_t2v
+
+    @staticmethod
+    def backward(ctx, dloss, _d1, _d2):
+        if dloss is None:
+            return (None,) * 6
+        v, t, gv, gt, temp32, sim_v2t, sim_t2v, lse = ctx.saved_tensors
+        dv, dt, dgv, dgt, dtemp = hip.vtc_loss_bwd(v, t, gv, gt, temp32, ctx.col0, sim_v2t, sim_t2v, lse, dloss, want_dtemp=ctx.needs_input_grad[4])
+        return dv, dt, dgv, dgt, dtemp, None
+
+
 class AlproBaseModel(nn.Module):
     def __init__(self, config=None, input_format='RGB', video_enc_cfg=None, temp=0.07):
         super().__init__()
@@ -103,15 +128,9 @@ class AlproBaseModel(nn.Module):
         b = video_feat.shape[0]
         gathered_video_feats = hvd.allgather(video_feat)
         gathered_text_feats = hvd.allgather(text_feat)
-        sim_v2t = video_feat @ gathered_text_feats.t() / self.temp
-        sim_t2v = text_feat @ gathered_video_feats.t() / self.temp
-        sim_targets = torch.zeros_like(sim_v2t)
-        local_rank = hvd.local_rank()
-        b_start, b_end = b * local_rank, b * (local_rank + 1)
-        sim_targets[:, b_start:b_end] = torch.eye(b, device=sim_v2t.device)
-        loss_v2t = -torch.sum(F.log_softmax(sim_v2t, dim=1) * sim_targets, dim=1).mean()
-        loss_t2v = -torch.sum(F.log_softmax(sim_t2v, dim=1) * sim_targets, dim=1).mean()
-        return (loss_v2t + loss_t2v) / 2, sim_v2t, sim_t2v, sim_targets
+        b_start = b * hvd.local_rank()   # targets: eye(b) at columns [b_start, b_start + b) of the gathered similarity (:121-123)
+        loss, sim_v2t, sim_t2v = _VtcLoss.apply(video_feat, text_feat, gathered_video_feats, gathered_text_feats, self.temp, b_start)
+        return loss, sim_v2t, sim_t2v, b_start
 
     @staticmethod
     def _sample_negatives(sim_v2t, sim_t2v, bs):
@@ -321,8 +340,9 @@ class Prompter(AlproBaseModel):
 
     def forward(self, batch):
         _, video_feat, _, text_feat = self.forward_feats(batch)
-        vtc_loss, sim_v2t, sim_t2v, sim_targets = self._vtc(video_feat, text_feat)
-        return dict(itc_loss=vtc_loss, itc_labels=torch.max(sim_targets, dim=1)[1],
+        vtc_loss, sim_v2t, sim_t2v, b_start = self._vtc(video_feat, text_feat)
+        itc_labels = b_start + torch.arange(video_feat.shape[0], device=sim_v2t.device)   # == max(sim_targets, 1)[1] (:589)
+        return dict(itc_loss=vtc_loss, itc_labels=itc_labels,
                     i2t_scores=F.log_softmax(sim_v2t, dim=1), t2i_scores=F.log_softmax(sim_t2v, dim=1))
 
 

@@ -28,7 +28,7 @@ import torch.nn as nn
 from alpro_amd import config as rt
 from alpro_amd import hip
 from alpro_amd.modeling import train as tr
-from alpro_amd.modeling.weights import OperandCache, param_epoch
+from alpro_amd.modeling.weights import OperandCache, param_version
 
 VIT_EPS = 1e-6
 
@@ -115,7 +115,7 @@ class Block(nn.Module):
 
     def _merged_tproj(self, dt):
         wp, bp, wf = self.temporal_attn.proj.weight, self.temporal_attn.proj.bias, self.temporal_fc.weight
-        ver = (param_epoch(), wp.data_ptr(), wp._version, bp._version, wf.data_ptr(), wf._version, dt)
+        ver = (param_version(wp), param_version(bp), param_version(wf), dt)
         hit = self._ops._store.get("t_merged")
         if hit is not None and hit[0] == ver:
             return hit[1]
@@ -127,7 +127,12 @@ class Block(nn.Module):
         return m
 
     def _drop(self, rows, device):
-        return self.drop_path.row_scale(rows, device) if isinstance(self.drop_path, DropPath) else None
+        if not isinstance(self.drop_path, DropPath):
+            return None
+        pre = getattr(self, "_presampled", None)
+        if pre is not None and rows in pre:      # sampled for all 12 blocks at once by sample_drop_paths (4 launches, not 132)
+            return pre.pop(rows)
+        return self.drop_path.row_scale(rows, device)
 
     def forward(self, x, B, T, W):
         """x: (B, 1 + N*T, D) fp32 contiguous token tensor; updated IN PLACE and returned (inference path)."""
@@ -259,8 +264,10 @@ class Block(nn.Module):
         # G = s * dY in the operand dtype; dbfc = colsum(dY) (unscaled) from the same pass
         G = hip.gather_cast(dx, dt, rows=B * N * T, map_mode=hip.MAP_SKIP_CLS, map_p0=N * T, row_scale=sv["drop_t"], row_scale_group=T,
                             colsum_pre=tr.bias_grad(fc.bias))
-        dWe = torch.zeros((D, D), dtype=torch.float32, device=dev)
-        db1 = torch.zeros(D, dtype=torch.float32, device=dev)
+        ws = sv.get("ws")  # zeroed slice of the per-backward workspace (one fill for all 12 blocks), else allocate
+        if ws is None:
+            ws = torch.zeros(D * D + D, dtype=torch.float32, device=dev)
+        dWe, db1 = ws[:D * D].view(D, D), ws[D * D:]
         if dt != torch.float32:
             hip.gemm_tn_acc(G, sv["a_t"], dWe, colsum=db1)                       # dWe = G^T a, db1 = colsum(G)
         else:
@@ -314,6 +321,33 @@ class Block(nn.Module):
         hip.layernorm_bwd(dh, sv["x"], self.temporal_norm1.weight, VIT_EPS, dx, g, b_, rows=B * N * T,
                           map_mode=hip.MAP_SKIP_CLS, map_p0=N * T)
         return dx
+
+
+_KEEP_CACHE = {}
+
+
+def sample_drop_paths(blocks, B, T, N, device):
+    """All stochastic-depth row masks of one training forward in ONE draw: per block three Bernoulli(keep_i) vectors of
+    B*N (temporal), B*T (spatial) and B (MLP) rows, scaled by 1/keep_i (vit_utils.py:137-151, rates vit.py:272).  The reference
+    draws them one by one (36 x {rand, add, floor, div}); the distribution is the same, the launch count is 4."""
+    sizes = (B * N, B * T, B)
+    live = [blk for blk in blocks if isinstance(blk.drop_path, DropPath) and blk.drop_path.drop_prob and blk.training]
+    if not live:
+        return
+    per = sum(sizes)
+    key = (per, str(device), tuple(blk.drop_path.drop_prob for blk in live))
+    keep = _KEEP_CACHE.get(key)
+    if keep is None:  # per-row keep probability, built once per (batch geometry, rates)
+        keep = torch.tensor([1.0 - blk.drop_path.drop_prob for blk in live], dtype=torch.float32).repeat_interleave(per).to(device)
+        _KEEP_CACHE.clear()
+        _KEEP_CACHE[key] = keep
+    scale = torch.floor(keep + torch.rand(per * len(live), dtype=torch.float32, device=device)) / keep
+    off = 0
+    for blk in live:
+        blk._presampled = {}
+        for n in sizes:
+            blk._presampled[n] = scale[off:off + n]
+            off += n
 
 
 class PatchEmbed(nn.Module):
@@ -536,8 +570,11 @@ class _VisualRun:
         tok, T, W, N = m._embed(x)
         self.rows, self.dims, self.Wg = m._last_rows, (B, T, N), W
         self.saved = []
+        if B * N != B * T and B * T != B:  # (the table is keyed by row count: the three counts must differ, else draw per call)
+            sample_drop_paths(m.blocks, B, T, N, tok.device)
         for blk in m.blocks:
             tok, sv = blk.forward_train(tok, B, T, W)
+            blk._presampled = None
             self.saved.append(sv)
         self.tok = tok
         out32, _ = hip.vit_final_pool(tok, m.norm.weight, m.norm.bias, VIT_EPS, B, T, N, torch.float32)
@@ -555,7 +592,9 @@ class _VisualRun:
         g, b_ = tr.grad_buffer(m.norm.weight, zero=True)[0], tr.grad_buffer(m.norm.bias, zero=True)[0]
         hip.layernorm_bwd(dy.view(-1, D), self.tok, m.norm.weight, VIT_EPS, dtok, g, b_, accumulate=False)
         del dy
-        for blk, sv in zip(reversed(m.blocks), reversed(self.saved)):
+        ws = torch.zeros((len(m.blocks), D * D + D), dtype=torch.float32, device=dout.device)
+        for i, (blk, sv) in enumerate(zip(reversed(m.blocks), reversed(self.saved))):
+            sv["ws"] = ws[i]
             dtok = blk.backward(sv, dtok)
             sv.clear()
         m._embed_backward(self.rows, dtok, B, T, N, self.Wg)

@@ -11,7 +11,7 @@ behind in the reference (run_pretrain_sparse.py:599), ready for the all-reduce a
 import torch
 
 from alpro_amd import hip
-from alpro_amd.modeling.weights import param_epoch
+from alpro_amd.modeling.weights import param_version
 
 
 def grad_buffer(p, zero=False):
@@ -31,7 +31,7 @@ def add_grad(p, g):
 
 def transposed_operand(cache, key, weight, dt):
     """(N, K) fp32 parameter -> cached (K, N64) operand in `dt` for dgrad (dX = dY @ W), refreshed on version change."""
-    ver = (param_epoch(), weight.data_ptr(), weight._version)
+    ver = param_version(weight)
     hit = cache._store.get(key)
     if hit is not None and hit[0] == ver and hit[1].dtype == dt:
         return hit[1]

@@ -23,6 +23,15 @@ def param_epoch():
     return _PARAM_EPOCH[0]
 
 
+def param_version(p):
+    """Cache key of a parameter's VALUE: (data_ptr, torch version counter) plus the optimizer epoch -- but only for parameters that
+    live in a flat optimizer buffer, the only ones updated behind torch's back.  Parameters no optimizer touches (the frozen
+    prompter: 231 M values, 12 merged temporal projections) keep their operand copies across steps instead of being re-cast."""
+    a = p.data_ptr()
+    in_flat = _FLAT_LP["base"] <= a < _FLAT_LP["end"]
+    return (param_epoch() if in_flat else -1, a, p._version)
+
+
 # One flat 16-bit copy of every parameter an optimizer with flat storage owns (alpro_amd.optim.FlatAdamW): refreshed by ONE cast
 # launch right after the update instead of ~250 per-tensor casts at first use; operands are then views into it.
 _FLAT_LP = {"base": 0, "end": 0, "lp": None, "epoch": -1, "versions": {}}
@@ -74,7 +83,7 @@ class OperandCache:
             v = _flat_lp_view(plist, dtype)
             if v is not None:
                 return v
-        ver = (param_epoch(),) + tuple((p.data_ptr(), p._version) for p in plist)
+        ver = tuple(param_version(p) for p in plist)
         hit = self._store.get(key)
         if hit is not None and hit[0] == ver and hit[1].dtype == dtype:
             return hit[1]

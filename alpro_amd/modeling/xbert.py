@@ -181,7 +181,7 @@ class BertLayer(nn.Module):
             for i, lin in enumerate(lins):
                 tr.wgrad(dqkv[:, i * Hd:(i + 1) * Hd], sv["h_t"], lin.weight, lin.bias)
         wT = self._ops._store.get("qkv_w^T")
-        ver = (tr.param_epoch(),) + tuple((p.data_ptr(), p._version) for p in (sa.query.weight, sa.key.weight, sa.value.weight))
+        ver = tuple(tr.param_version(p) for p in (sa.query.weight, sa.key.weight, sa.value.weight))
         if wT is None or wT[0] != ver or wT[1].dtype != dt:
             wcat = torch.cat([sa.query.weight.detach(), sa.key.weight.detach(), sa.value.weight.detach()], 0).contiguous()
             wT = (ver, hip.transpose(wcat, out_dtype=dt, pad_to=64))

@@ -64,6 +64,7 @@ class FlatAdamW:
         self.flat = dict(p=fp, g=fg, m=torch.zeros_like(fp), v=torch.zeros_like(fp), n=n, live=live, offs=offs,
                          norm=torch.zeros(1, dtype=torch.float32, device=dev))
         bump_param_epoch()
+        register_flat_lp(fp, None, live)  # announces the flat range (weights.param_version); the 16-bit mirror follows in step()
         if self._pending_state is not None:
             pend, self._pending_state = self._pending_state, None
             self._restore_moments(pend)

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define ALPRO_HIP_ABI_VERSION 6
+#define ALPRO_HIP_ABI_VERSION 7
 
 enum { ALPRO_OK = 0, ALPRO_ERR_INVALID = 1, ALPRO_ERR_LAUNCH = 2 };
 enum { ALPRO_F32 = 0, ALPRO_BF16 = 1, ALPRO_F16 = 2 };
@@ -203,6 +203,18 @@ int alpro_colsum_acc(const void* A, int64_t lda, float* out, int dtype, int M, i
 int alpro_softmax_xent(const float* logits, int64_t ld, const int64_t* labels, int ignore_index, float* loss_rows,
                        void* dlogits, int dtype, int64_t ldd, const float* grad_scale, int M, int V, int Vpad,
                        void* stream);
+
+/* Video-text contrastive loss over gathered features (alpro_models.py:103-128 Pretrain, :570-587 Prompter, :750-779 Retrieval; the
+ * normalised (B, E) projections v / t are this rank's rows, gv / gt the (G = world * B, E) all-gathered ones, positives at columns
+ * col0 + i (col0 = local_rank * B, :121-123), temp the learnable temperature (clamped to [0.001, 0.5] like :80-81):
+ *   sim_v2t = v gt^T / temp, sim_t2v = t gv^T / temp   (B, G) fp32, written out (hard-negative mining :287-306 reads them)
+ *   *loss   = (mean_i CE(sim_v2t[i], col0 + i) + mean_i CE(sim_t2v[i], col0 + i)) / 2;  lse (2B): row log-sum-exps for the backward.
+ * _bwd: gradients w.r.t. v, t (B, E), gv, gt (G, E) and temp (*dtemp, optional) for upstream *dloss; ds_* are (B, G) scratch. */
+int alpro_vtc_loss_fwd(const float* v, const float* t, const float* gv, const float* gt, const float* temp, int B, int G, int E, int col0,
+                       float* sim_v2t, float* sim_t2v, float* lse, float* loss, void* stream);
+int alpro_vtc_loss_bwd(const float* v, const float* t, const float* gv, const float* gt, const float* temp, int B, int G, int E, int col0,
+                       const float* sim_v2t, const float* sim_t2v, const float* lse, const float* dloss, float* ds_v2t, float* ds_t2v,
+                       float* dv, float* dt, float* dgv, float* dgt, float* dtemp, void* stream);
 
 /* ---- step epilogue on flat fp32 buffers (run_pretrain_sparse.py:633-648, src/optimization/adamw.py:40-103) ---- */
 

@@ -481,3 +481,36 @@ def test_attention_properties_at_full_size():
         assert float(dqkv[:, :2 * H * 64].float().abs().max()) < 2e-2, kind
         dv_tot, do_tot = float(dqkv[:, 2 * H * 64:].float().sum()), float(do.float().sum())
         assert abs(dv_tot - do_tot) < 2e-3 * float(do.float().abs().sum()), kind
+
+
+@pytest.mark.parametrize("B,world,rank,temp", [(3, 1, 0, 0.07), (64, 1, 0, 0.07), (5, 2, 1, 0.05), (64, 8, 3, 0.9), (7, 3, 2, 0.0001)])
+def test_vtc_loss_fwd_bwd(B, world, rank, temp):
+    """alpro_vtc_loss (forward + backward through the autograd node the models use) against the reference's arithmetic
+    (alpro_models.py:113-128) in fp64: loss, both similarity matrices, gradients w.r.t. the local rows, the gathered rows and
+    the temperature; positives at columns rank*B + i; temp outside [0.001, 0.5] is clamped like :80-81."""
+    _hip()
+    import torch.nn.functional as F
+    from alpro_amd.modeling.alpro_models import _VtcLoss
+    E, G = 256, B * world
+    nrm = lambda x: F.normalize(x, dim=-1)  # noqa: E731
+    v, t = nrm(rnd(B, E, seed=900 + B)), nrm(rnd(B, E, seed=901 + B))
+    gv, gt = nrm(rnd(G, E, seed=902 + B)), nrm(rnd(G, E, seed=903 + B))
+    gv[rank * B:(rank + 1) * B], gt[rank * B:(rank + 1) * B] = v, t
+    tp = torch.tensor(temp)
+    leaves = [x.clone().cuda().requires_grad_(True) for x in (v, t, gv, gt, tp)]
+    loss, s_v2t, s_t2v = _VtcLoss.apply(*leaves, rank * B)
+    (loss * 1.7).backward()
+    r = [x.double().requires_grad_(True) for x in (v, t, gv, gt, tp)]
+    tc = r[4].clamp(0.001, 0.5)
+    rv2t, rt2v = r[0] @ r[3].t() / tc, r[1] @ r[2].t() / tc
+    tgt = torch.zeros(B, G, dtype=torch.float64)
+    tgt[:, rank * B:(rank + 1) * B] = torch.eye(B, dtype=torch.float64)
+    rl = (-(F.log_softmax(rv2t, 1) * tgt).sum(1).mean() - (F.log_softmax(rt2v, 1) * tgt).sum(1).mean()) / 2
+    (rl * 1.7).backward()
+    close(loss.reshape(1), rl.detach().reshape(1), 2e-5, 2e-5, "vtc loss")
+    close(s_v2t, rv2t.detach(), 2e-5, 2e-4, "sim_v2t")
+    close(s_t2v, rt2v.detach(), 2e-5, 2e-4, "sim_t2v")
+    for got, ref, name in zip(leaves[:4], r[:4], ("dv", "dt", "dgv", "dgt")):
+        close(got.grad, ref.grad, 2e-4, 2e-5 * float(ref.grad.abs().max().clamp_min(1.0)), name)
+    if 0.001 < temp < 0.5:   # (a clamped temperature has zero gradient in the restatement, the in-place clamp_ of the model does not)
+        close(leaves[4].grad.reshape(1), r[4].grad.reshape(1), 2e-4, 1e-4 * float(r[4].grad.abs()), "dtemp")
