@@ -97,6 +97,32 @@ def allgather(x, name=None):
     return _AllGather.apply(x)
 
 
+# ---- "these gradients are final" notifications: the hand-written backward passes tell whoever owns the gradient exchange (FlatAdamW)
+# which parameter gradients will not change any more in this step, so their slice of the flat buffer can go onto the wire while the
+# rest of backward still runs (Horovod overlaps the same way from its background thread, run_pretrain_sparse.py:432-439).
+_GRAD_FINAL_HOOKS = []
+
+
+def register_grads_final_hook(fn):
+    """fn(params=None, all_but=None); kept by weak reference when `fn` is a bound method."""
+    import weakref
+    ref = weakref.WeakMethod(fn) if hasattr(fn, "__self__") else (lambda f=fn: f)
+    _GRAD_FINAL_HOOKS.append(ref)
+
+
+def grads_final(params=None, all_but=None):
+    """Called from backward code: the gradients of `params` (or of every parameter EXCEPT `all_but`) are complete for this step."""
+    if size() == 1 or not _GRAD_FINAL_HOOKS:
+        return
+    live = []
+    for ref in _GRAD_FINAL_HOOKS:
+        fn = ref()
+        if fn is not None:
+            fn(params=params, all_but=all_but)
+            live.append(ref)
+    _GRAD_FINAL_HOOKS[:] = live
+
+
 def allreduce_grads_(params, bucket_bytes=64 << 20, average=True):
     """Average gradients across ranks in a few large flat buckets (a ring all-reduce over xGMI is per-link
     bound, so fewer / larger messages win).  Skips parameters without a gradient instead of materialising

@@ -593,9 +593,19 @@ class _VisualRun:
         hip.layernorm_bwd(dy.view(-1, D), self.tok, m.norm.weight, VIT_EPS, dtok, g, b_, accumulate=False)
         del dy
         ws = torch.zeros((len(m.blocks), D * D + D), dtype=torch.float32, device=dout.device)
+        # Data parallel: this node is the LAST one autograd runs (it was created first and its input needs no gradient), so every
+        # gradient outside the visual encoder is final now and can be exchanged while the ViT backward (half of the backward pass)
+        # runs; the blocks' own gradients follow four blocks at a time (alpro_amd.dist.grads_final -> FlatAdamW).
+        from alpro_amd import dist
+        overlap = dist.size() > 1
+        if overlap:
+            dist.grads_final(all_but=list(self.enc.parameters()))
+        nb = len(m.blocks)
         for i, (blk, sv) in enumerate(zip(reversed(m.blocks), reversed(self.saved))):
             sv["ws"] = ws[i]
             dtok = blk.backward(sv, dtok)
+            if overlap and (i + 1) % 4 == 0 and i + 1 < nb:
+                dist.grads_final(params=[p for b in m.blocks[nb - 1 - i:nb - 1 - i + 4] for p in b.parameters()] + (list(m.norm.parameters()) if i == 3 else []))
             sv.clear()
         m._embed_backward(self.rows, dtok, B, T, N, self.Wg)
         self.saved = self.rows = self.tok = None

@@ -23,12 +23,19 @@ from alpro_amd.modeling.weights import bump_param_epoch, register_flat_lp
 
 class FlatAdamW:
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-6, weight_decay=0.0, correct_bias=True, max_grad_norm=None,
-                 allreduce=True, bucket_elems=64 << 20):
+                 allreduce=True, bucket_elems=64 << 20, overlap_backward=True, wire_dtype=None):
         self.params = [p for p in params if p.requires_grad]
         self.param_groups = [dict(params=self.params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, correct_bias=correct_bias)]
         self.max_grad_norm = max_grad_norm
         self.allreduce = allreduce
         self.bucket_elems = bucket_elems
+        # overlap_backward: slices of the flat gradient buffer are all-reduced (async, RCCL's own stream) as soon as the backward
+        # code reports them final (dist.grads_final): BERT + heads before the ViT backward starts, ViT blocks four at a time.
+        # Needs ONE backward per step (gradient accumulation over several backward passes: pass overlap_backward=False).
+        # wire_dtype=torch.bfloat16 halves the bytes on xGMI (cast -> all-reduce -> cast back; sums of <= 8 ranks in bf16).
+        self.overlap_backward = overlap_backward
+        self.wire_dtype = wire_dtype
+        self._inflight, self._reduced = [], []     # async handles (+ staging tensors) and element ranges already on the wire
         self.step_count = 0
         self._pending_state = None  # load_state_dict() before the flat buffers exist: applied by _build()
         self.flat = None  # built at the first step(), when we know which parameters actually receive gradients
@@ -65,6 +72,9 @@ class FlatAdamW:
                          norm=torch.zeros(1, dtype=torch.float32, device=dev))
         bump_param_epoch()
         register_flat_lp(fp, None, live)  # announces the flat range (weights.param_version); the 16-bit mirror follows in step()
+        self._span = {id(p): (o, o + (p.numel() + 3) // 4 * 4) for p, o in zip(live, offs)}
+        if self.allreduce and self.overlap_backward and dist.size() > 1:
+            dist.register_grads_final_hook(self._on_grads_final)
         if self._pending_state is not None:
             pend, self._pending_state = self._pending_state, None
             self._restore_moments(pend)
@@ -88,11 +98,69 @@ class FlatAdamW:
         return 0 if self.flat is None else sum(p.numel() for p in self.flat["live"])
 
     def zero_grad(self, set_to_none=False):
+        for h, _, _ in self._inflight:  # a driver that skips step() (e.g. on a NaN loss) must not zero under a running all-reduce
+            h.wait()
+        self._inflight, self._reduced = [], []
         if self.flat is None:
             for p in self.params:
                 p.grad = None
         else:
             self.flat["g"].zero_()
+
+    # ---- overlapped exchange -----------------------------------------------------------------------------
+    @staticmethod
+    def _merge(ranges):
+        out = []
+        for s, e in sorted(ranges):
+            if out and s <= out[-1][1]:
+                out[-1][1] = max(out[-1][1], e)
+            else:
+                out.append([s, e])
+        return [(s, e) for s, e in out]
+
+    def _ranges_of(self, params=None, all_but=None):
+        if params is not None:
+            spans = [self._span[id(p)] for p in params if id(p) in self._span]
+        else:
+            skip = {id(p) for p in all_but}
+            spans = [v for k, v in self._span.items() if k not in skip]
+        return self._merge(spans)
+
+    def _launch(self, s, e):
+        g = self.flat["g"][s:e]
+        if self.wire_dtype is not None and self.wire_dtype != torch.float32:
+            w = g.to(self.wire_dtype)
+            h = torch.distributed.all_reduce(w, async_op=True)
+            self._inflight.append((h, w, g))
+        else:
+            h = torch.distributed.all_reduce(g, async_op=True)
+            self._inflight.append((h, None, g))
+        self._reduced.append((s, e))
+
+    def _on_grads_final(self, params=None, all_but=None):
+        if self.flat is None or not self.allreduce or dist.size() == 1:
+            return
+        done = self._merge(self._reduced)
+        for s, e in self._ranges_of(params, all_but):
+            if any(s < de and ds < e for ds, de in done):
+                raise RuntimeError("FlatAdamW: a gradient range was reported final twice in one step (several backward passes per step?); "
+                                   "construct the optimizer with overlap_backward=False for gradient accumulation")
+            for c in range(s, e, self.bucket_elems):
+                self._launch(c, min(e, c + self.bucket_elems))
+
+    def _finish_exchange(self):
+        """All-reduce whatever is not on the wire yet, then make the compute stream wait for every handle."""
+        n = self.flat["n"]
+        pos = 0
+        for s, e in self._merge(self._reduced) + [(n, n)]:
+            for c in range(pos, s, self.bucket_elems):
+                self._launch(c, min(s, c + self.bucket_elems))
+            pos = max(pos, e)
+        for h, w, g in self._inflight:
+            h.wait()
+            if w is not None:
+                g.copy_(w)
+        self._inflight, self._reduced = [], []
 
     def synchronize(self, average=False):
         """Sum gradients across ranks; step() folds the 1/world averaging into the AdamW kernel's grad_scale.
@@ -106,8 +174,7 @@ class FlatAdamW:
             self._pre_synced = "avg" if average else "sum"
             return 0
         g, n = self.flat["g"], self.flat["n"]
-        for s in range(0, n, self.bucket_elems):
-            torch.distributed.all_reduce(g[s:min(n, s + self.bucket_elems)])
+        self._finish_exchange()
         if average:
             g.div_(dist.size())
         self._pre_synced = "avg" if average else "sum"

@@ -316,6 +316,7 @@ def main():
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype, "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2**30, 2), "data": "synthetic (randn clips, random token ids; random-init weights)",
             "config": {"workload": wl, "per_gpu_batch": B, "frames": T, "parallelism": ("dp%d (RCCL: feature all-gather + flat gradient all-reduce)" % world) if train else ("dp%d (independent clips, no data-path collective)" % world)},
+            "world_size": world, "dist_backend": (torch.distributed.get_backend() if torch.distributed.is_initialized() else "none (single process)"),
             "model_tflops_per_gpu": round(value / world * flops_per_unit / 1e12, 2),
             "roofline": {"bound": "mfma", "kernel": "gemm_nt*/gemm_tn kernels<%s> (all %d GEMM launches of one step)" % (args.dtype, gemm["launches"]),
                          "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),

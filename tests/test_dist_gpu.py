@@ -1,0 +1,54 @@
+"""GPU: data parallelism of the HIP path.  Two ranks share the one GPU of the test box over gloo
+(RCCL refuses two ranks on one device): 2 ranks x B pairs must give the same VTC loss AND the same averaged gradients as 1 rank x 2B
+pairs (run_pretrain_sparse.py:595-648 semantics; all-gather gradient in its exact "sum" mode), with the gradient exchange of the
+second step overlapped with backward (FlatAdamW.overlap_backward: BERT + heads go on the wire before the ViT backward starts)."""
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+WORKER = os.path.join(ROOT, "tests", "dist_gpu_worker.py")
+
+
+def _run(world, out_base, B, wire):
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, ALPRO_DIST_BACKEND="gloo", RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, WORKER, "%s.%d.pt" % (out_base, r), str(B), wire], cwd=ROOT, env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=900)[0] for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o[-3000:]
+    return [torch.load("%s.%d.pt" % (out_base, r)) for r in range(world)]
+
+
+@pytest.mark.parametrize("wire,tol", [("fp32", 2e-4), ("bf16", 4e-2)])  # bf16 wire: each rank's value and the sum are rounded to 8 bits
+def test_two_ranks_equal_one_rank_with_twice_the_batch(tmp_path, wire, tol):
+    B = 2
+    two = _run(2, str(tmp_path / "w2"), B, wire)
+    one = _run(1, str(tmp_path / "w1"), B, "fp32")[0]
+    assert two[0]["names"] == one["names"] == two[1]["names"]
+    assert abs(two[0]["loss"] - one["loss"]) < 1e-5 * max(1.0, abs(one["loss"])), (two[0]["loss"], one["loss"])
+    for r in two:
+        assert r["on_wire_early"] >= 2, "the exchange did not start before backward returned (%d ranges)" % r["on_wire_early"]
+        rel = (r["norms"] - one["norms"]).abs() / one["norms"].clamp_min(1e-6)
+        for i, n in enumerate(one["names"]):   # key.bias gradients are exactly 0 in exact arithmetic (softmax shift invariance): fp32 noise only
+            if n.endswith("attention.self.key.bias"):
+                assert float(r["norms"][i]) < 1e-5
+                rel[i] = 0.0
+        worst = int(rel.argmax())
+        assert float(rel.max()) < tol, (one["names"][worst], float(r["norms"][worst]), float(one["norms"][worst]))
+        for n, g in one["grads"].items():
+            err = float((r["grads"][n] - g).abs().max())
+            assert err <= tol * max(float(g.abs().max()), 1e-6), (n, err, float(g.abs().max()))
+    for n in one["grads"]:   # both ranks hold the same averaged gradient
+        assert torch.equal(two[0]["grads"][n], two[1]["grads"][n]), n
