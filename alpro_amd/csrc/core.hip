@@ -294,6 +294,77 @@ extern "C" int alpro_cast_from_f32(const float* src, void* dst, int dtype, int64
   return check_launch("alpro_cast_from_f32");
 }
 
+namespace alpro {
+namespace {
+// ---- clip preparation: ImageNorm + the MPM random-erase crop in ONE pass (data_utils.py:437-457, dataset_pretrain_sparse.py:277-311,
+// dataloader.py:104-115).  raw (B, T, 3, H, W) pixels (uint8 or float) are read once; per element
+//   n(x) = (x * scale - mean[c]) / std[c]        (torch's img.div_(255.) is a multiply by 1/255 on the device; sub_/div_ by the tensors are exact)
+//   visual = n(x);  crop = n(inside ? x : 0);  context = n(inside ? 0 : x)     inside = the sample's patch-aligned rectangle
+// The erase happens on RAW pixels, so erased regions hold n(0) = -mean/std, not 0 -- exactly what the reference feeds the encoders.
+template <typename In>
+__global__ __launch_bounds__(256) void prepare_clips_kernel(const In* __restrict__ raw, const int* __restrict__ boxes, float scale, float m0, float m1,
+                                                            float m2, float s0, float s1, float s2, float* __restrict__ vis, float* __restrict__ crop,
+                                                            float* __restrict__ ctx, int T, int H, int W, int64_t nvec) {
+  const int W4 = W >> 2;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * 256) {
+    const int w = (int)(i % W4) * 4;
+    int64_t r = i / W4;
+    const int h = (int)(r % H);
+    r /= H;
+    const int c = (int)(r % 3);
+    const int b = (int)(r / 3 / T);
+    const float mean = c == 0 ? m0 : (c == 1 ? m1 : m2), sd = c == 0 ? s0 : (c == 1 ? s1 : s2);
+    float x[4];
+    if constexpr (sizeof(In) == 1) {
+      const uint32_t u = *(const uint32_t*)(raw + i * 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) x[e] = (float)((u >> (8 * e)) & 0xffu);
+    } else {
+      const f32x4 v = __builtin_nontemporal_load((const f32x4*)(raw + i * 4));
+      x[0] = v.x; x[1] = v.y; x[2] = v.z; x[3] = v.w;
+    }
+    float nv[4], nc[4], nx[4];
+    const float zero_n = (0.f * scale - mean) / sd;
+    bool row_in = false;
+    int left = 0, right = 0;
+    if (boxes) {
+      const int top = boxes[4 * b], lf = boxes[4 * b + 1], bh = boxes[4 * b + 2], bw = boxes[4 * b + 3];
+      row_in = h >= top && h < top + bh;
+      left = lf;
+      right = lf + bw;
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      nv[e] = (x[e] * scale - mean) / sd;
+      const bool inside = row_in && (w + e) >= left && (w + e) < right;
+      nc[e] = inside ? nv[e] : zero_n;
+      nx[e] = inside ? zero_n : nv[e];
+    }
+    __builtin_nontemporal_store(f32x4{nv[0], nv[1], nv[2], nv[3]}, (f32x4*)(vis + i * 4));
+    if (crop) __builtin_nontemporal_store(f32x4{nc[0], nc[1], nc[2], nc[3]}, (f32x4*)(crop + i * 4));
+    if (ctx) __builtin_nontemporal_store(f32x4{nx[0], nx[1], nx[2], nx[3]}, (f32x4*)(ctx + i * 4));
+  }
+}
+}  // namespace
+}  // namespace alpro
+
+extern "C" int alpro_prepare_clips(const void* raw, int raw_is_u8, const int* boxes, float scale, const float* mean3, const float* std3, float* visual,
+                                   float* crop, float* context, int B, int T, int H, int W, void* stream) {
+  using namespace alpro;
+  ALPRO_CHECK(raw && mean3 && std3 && visual && B > 0 && T > 0 && H > 0 && W > 0, "alpro_prepare_clips: bad args");
+  ALPRO_CHECK(W % 4 == 0, "alpro_prepare_clips: width %d must be a multiple of 4", W);
+  ALPRO_CHECK((crop == nullptr && context == nullptr) || boxes, "alpro_prepare_clips: crop / context outputs need the erase boxes");
+  const int64_t nvec = (int64_t)B * T * 3 * H * (W / 4);
+  const unsigned grid = (unsigned)((nvec + 255) / 256 < 256 * 16 ? (nvec + 255) / 256 : 256 * 16);
+  if (raw_is_u8)
+    hipLaunchKernelGGL(prepare_clips_kernel<uint8_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const uint8_t*)raw, boxes, scale, mean3[0], mean3[1], mean3[2],
+                       std3[0], std3[1], std3[2], visual, crop, context, T, H, W, nvec);
+  else
+    hipLaunchKernelGGL(prepare_clips_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float*)raw, boxes, scale, mean3[0], mean3[1], mean3[2],
+                       std3[0], std3[1], std3[2], visual, crop, context, T, H, W, nvec);
+  return check_launch("alpro_prepare_clips");
+}
+
 extern "C" int alpro_patchify(const float* img, void* out, int dtype, int BT, int C, int Himg, int Wimg, void* stream) {
   ALPRO_CHECK(img && out && BT > 0 && C > 0, "alpro_patchify: bad args");
   ALPRO_CHECK(Himg % 16 == 0 && Wimg % 16 == 0, "alpro_patchify: image %dx%d not a multiple of the 16x16 patch", Himg, Wimg);

@@ -21,7 +21,7 @@ _CODE = {v: k for k, v in _TORCH_DTYPE.items()}
 EXPORTS = ["alpro_hip_last_error", "alpro_hip_abi_version", "alpro_hip_set_option", "alpro_gemm", "alpro_layernorm_fwd",
            "alpro_attn_temporal_fwd", "alpro_attn_fwd", "alpro_patchify", "alpro_cls_mean_residual",
            "alpro_vit_final_pool", "alpro_bert_embed_fwd", "alpro_cast_from_f32", "alpro_attn_bwd", "alpro_attn_temporal_bwd",
-           "alpro_layernorm_bwd", "alpro_transpose", "alpro_gelu_bwd", "alpro_cls_mean_bwd", "alpro_scatter_add_rows", "alpro_gather_cast", "alpro_sumsq", "alpro_adamw_step", "alpro_gemm_tn_acc", "alpro_colsum_acc", "alpro_softmax_xent", "alpro_vtc_loss_fwd", "alpro_vtc_loss_bwd"]
+           "alpro_layernorm_bwd", "alpro_transpose", "alpro_gelu_bwd", "alpro_cls_mean_bwd", "alpro_scatter_add_rows", "alpro_gather_cast", "alpro_sumsq", "alpro_adamw_step", "alpro_gemm_tn_acc", "alpro_colsum_acc", "alpro_softmax_xent", "alpro_vtc_loss_fwd", "alpro_vtc_loss_bwd", "alpro_prepare_clips"]
 
 
 class GemmDesc(ctypes.Structure):
@@ -38,7 +38,7 @@ class GemmDesc(ctypes.Structure):
                 ("drop_p", ctypes.c_float), ("drop_seed", ctypes.c_uint32), ("bias2", ctypes.c_void_p)]
 
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 _lib = None
 
 
@@ -79,6 +79,7 @@ def load():
     lib.alpro_bert_embed_fwd.argtypes = [vp, vp, vp, vp, vp, vp, f32, vp, vp, i32, vp, vp, i32, i32, i32, f32, u32, vp]
     lib.alpro_cast_from_f32.argtypes = [vp, vp, i32, i64, vp]
     lib.alpro_hip_set_option.argtypes = [ctypes.c_char_p, i32]
+    lib.alpro_prepare_clips.argtypes = [vp, i32, vp, f32, ctypes.POINTER(f32), ctypes.POINTER(f32), vp, vp, vp, i32, i32, i32, i32, vp]
     lib.alpro_vtc_loss_fwd.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp]
     lib.alpro_vtc_loss_bwd.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     if lib.alpro_hip_abi_version() != ABI_VERSION:
@@ -443,3 +444,22 @@ def vtc_loss_bwd(v, t, gv, gt, temp, col0, sim_v2t, sim_t2v, lse, dloss, want_dt
                                   _ptr(dloss), _ptr(ds[0]), _ptr(ds[1]), _ptr(dv), _ptr(dt), _ptr(dgv), _ptr(dgt), _ptr(dtemp), _stream()),
            "alpro_vtc_loss_bwd")
     return dv, dt, dgv, dgt, dtemp
+
+
+def prepare_clips(raw, mean, std, scale, boxes=None, want_crop=True):
+    """alpro_prepare_clips: raw (B, T, 3, H, W) uint8 / fp32 device tensor -> (visual, crop, context) fp32 (crop / context None
+    without boxes).  boxes: (B, 4) int32 device tensor {top, left, h, w}."""
+    lib = load()
+    if not raw.is_cuda or not raw.is_contiguous() or raw.dtype not in (torch.uint8, torch.float32):
+        raise RuntimeError("prepare_clips needs a contiguous uint8 / fp32 device tensor (no CPU fallback)")
+    B, T, C, H, W = raw.shape
+    assert C == 3
+    vis = torch.empty(raw.shape, dtype=torch.float32, device=raw.device)
+    crop = ctx = None
+    if boxes is not None and want_crop:
+        _dev(boxes, torch.int32)
+        crop, ctx = torch.empty_like(vis), torch.empty_like(vis)
+    m3, s3 = (ctypes.c_float * 3)(*[float(x) for x in mean]), (ctypes.c_float * 3)(*[float(x) for x in std])
+    _check(lib.alpro_prepare_clips(_ptr(raw), int(raw.dtype == torch.uint8), _ptr(boxes) if crop is not None else None, float(scale), m3, s3,
+                                   _ptr(vis), _ptr(crop), _ptr(ctx), B, T, H, W, _stream()), "alpro_prepare_clips")
+    return vis, crop, ctx

@@ -86,3 +86,28 @@ def random_erase_batch(visual_inputs, patch_size=16, boxes=None, rng=np.random, 
     context = visual_inputs * (1 - m)
     mpm_mask = 1.0 - torch.nn.functional.avg_pool2d(inside.float()[:, None], kernel_size=patch_size, stride=patch_size)[:, 0]
     return dict(crop_visual_inputs=crop, context_visual_inputs=context, mpm_mask=mpm_mask, boxes=boxes)
+
+
+def prepare_pretrain_clips(raw, mean, std, patch_size=16, boxes=None, rng=np.random, assume_255=None, **box_kw):
+    """The whole visual side of a pretraining batch in ONE kernel (alpro_prepare_clips): raw (B, T, 3, H, W) uint8 / float pixels on
+    the device -> dict(visual_inputs, crop_visual_inputs, context_visual_inputs, mpm_mask, boxes), identical to what the reference
+    assembles from PretrainCollator's random_erase on raw pixels (dataset_pretrain_sparse.py:277-311) followed by ImageNorm on each of
+    the three tensors (dataloader.py:104-115): 1 read + 3 writes instead of ~15 elementwise passes.
+    assume_255: True / False fixes ImageNorm's data-dependent `torch.max(img) > 1` test (data_utils.py:455) without a device sync;
+    None evaluates it (uint8 input is always 0..255)."""
+    from alpro_amd import hip
+    B, T, C, H, W = raw.shape
+    if boxes is None:
+        boxes = [sample_erase_box(H, W, patch_size, rng=rng, **box_kw) for _ in range(B)]
+    if assume_255 is None:
+        assume_255 = True if raw.dtype == torch.uint8 else bool(torch.max(raw) > 1)
+    scale = (1.0 / 255.0) if (assume_255 and max(mean) <= 1) else 1.0
+    bx = torch.tensor(boxes, dtype=torch.int32, device=raw.device)
+    vis, crop, ctx = hip.prepare_clips(raw.contiguous(), mean, std, scale, boxes=bx)
+    gh, gw = H // patch_size, W // patch_size
+    ys = torch.arange(gh, device=raw.device)[None, :, None] * patch_size
+    xs = torch.arange(gw, device=raw.device)[None, None, :] * patch_size
+    b64 = bx.long()
+    inside = ((ys >= b64[:, 0, None, None]) & (ys < (b64[:, 0] + b64[:, 2])[:, None, None]) &
+              (xs >= b64[:, 1, None, None]) & (xs < (b64[:, 1] + b64[:, 3])[:, None, None]))
+    return dict(visual_inputs=vis, crop_visual_inputs=crop, context_visual_inputs=ctx, mpm_mask=1.0 - inside.float(), boxes=boxes)

@@ -41,6 +41,68 @@ def inference_retrieval_cached(model, videos, text_input_ids, text_input_mask, c
     return res
 
 
+@torch.no_grad()
+def score_all_pairs(model, videos, text_input_ids, text_input_mask, pair_bsz=512, text_bsz=1024):
+    """Every caption against every video with nothing leaving the device: videos (V, T, C, H, W) or an iterable of (1, T, C, H, W)
+    clips, captions (C, Lt).  Each video / caption is encoded ONCE; the V*C fusion passes run in flat mini-batches of `pair_bsz`
+    (video, caption) pairs gathered from the two caches -- the GEMMs see M = pair_bsz * 237 rows whatever V and C are, where the
+    reference loop (run_video_retrieval.py:642-690) runs one video x eval_bsz captions at a time.
+    Returns (score (V, C) = softmax(itm_logits)[:, 1], sim (V, C) = ITC similarity), fp32 device tensors (unrounded)."""
+    model.eval()
+    ve, vf = [], []
+    clips = videos if torch.is_tensor(videos) else torch.cat(list(videos), 0)
+    for i in range(0, clips.shape[0], 8):
+        e, f = model.encode_video(clips[i:i + 8])
+        ve.append(e)
+        vf.append(f)
+    ve, vf = torch.cat(ve, 0), torch.cat(vf, 0)                                     # (V, 1+N, D), (V, 256)
+    te, tf = [], []
+    for i in range(0, text_input_ids.shape[0], text_bsz):
+        e, f = model.encode_text(text_input_ids[i:i + text_bsz], text_input_mask[i:i + text_bsz])
+        te.append(e)
+        tf.append(f)
+    te, tf = torch.cat(te, 0), torch.cat(tf, 0)                                     # (C, Lt, D), (C, 256)
+    V, C = ve.shape[0], te.shape[0]
+    sim = vf @ tf.t() / model.temp
+    score = torch.empty(V * C, dtype=torch.float32, device=ve.device)
+    ones = torch.ones(ve.shape[:2], dtype=text_input_mask.dtype, device=ve.device)
+    for s in range(0, V * C, pair_bsz):
+        idx = torch.arange(s, min(V * C, s + pair_bsz), device=ve.device)
+        vi, ci = idx // C, idx % C
+        out = model._fusion(torch.cat([te[ci], ve[vi]], dim=1), torch.cat([text_input_mask[ci], ones[vi]], dim=1))
+        from alpro_amd.modeling.alpro_models import _linear32
+        score[s:s + idx.numel()] = torch.softmax(_linear32(out[:, 0, :], model.itm_head).float(), dim=1)[:, 1]
+    return score.view(V, C), sim
+
+
+def records_from_matrices(score, sim, vid_ids, txt_ids):
+    """(V, C) matrices -> the reference's result records (vid_id, txt_id, score, sim rounded to 4 decimals, :683-689), video-major."""
+    sc, sm = score.detach().float().cpu().tolist(), sim.detach().float().cpu().tolist()
+    return [dict(vid_id=v, txt_id=t, score=round(sc[i][j], 4), sim=round(sm[i][j], 4)) for i, v in enumerate(vid_ids) for j, t in enumerate(txt_ids)]
+
+
+@torch.no_grad()
+def retrieval_metrics_on_device(score, gt_col):
+    """R@1/5/10, median and mean rank of a (rows, cols) device score matrix with ground-truth column gt_col[row], without sorting
+    and without leaving the device until the five numbers are read: rank = 1 + #(columns scoring higher) + #(equal-scoring columns
+    with a smaller index), i.e. the position a STABLE descending sort gives the ground truth (the reference sorts on the host,
+    :541-555; on tie-free scores the two agree exactly)."""
+    gt_col = gt_col.to(score.device).view(-1, 1)
+    gt = score.gather(1, gt_col)
+    cols = torch.arange(score.shape[1], device=score.device)[None, :]
+    rank = 1 + (score > gt).sum(1) + ((score == gt) & (cols < gt_col)).sum(1)
+    r = rank.double()
+    out = torch.stack([(rank <= 1).double().mean() * 100, (rank <= 5).double().mean() * 100, (rank <= 10).double().mean() * 100, r.median() if r.numel() % 2 else
+                       (r.sort()[0][r.numel() // 2 - 1] + r.sort()[0][r.numel() // 2]) / 2, r.mean()]).tolist()
+    return dict(r1=out[0], r5=out[1], r10=out[2], medianR=out[3], meanR=out[4])
+
+
+@torch.no_grad()
+def topk_on_device(score, k):
+    """Top-k columns of every row (values, indices) on the device -- e.g. the k best videos per caption of score.t()."""
+    return torch.topk(score, min(k, score.shape[1]), dim=1)
+
+
 def get_retrieval_metric_from_bool_matrix(bool_matrix):
     """R@1/5/10, median and mean rank from a (#rows, #cols) matrix sorted by decreasing score with exactly one ground-truth
     1 per row (run_video_retrieval.py:515-538)."""

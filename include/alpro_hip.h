@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define ALPRO_HIP_ABI_VERSION 7
+#define ALPRO_HIP_ABI_VERSION 8
 
 enum { ALPRO_OK = 0, ALPRO_ERR_INVALID = 1, ALPRO_ERR_LAUNCH = 2 };
 enum { ALPRO_F32 = 0, ALPRO_BF16 = 1, ALPRO_F16 = 2 };
@@ -118,6 +118,15 @@ int alpro_attn_fwd(const void* qkv, void* out, int dtype, int batch, int L, int 
 /* out[(b*T+t)*N + n, c*256 + i*16 + j] = img[b, t, c, ph*16 + i, pw*16 + j], n = ph*(W/16) + pw:
  * the im2col rows of the stride-16 Conv2d (vit.py:230-238), cast to `dtype`. */
 int alpro_patchify(const float* img, void* out, int dtype, int BT, int C, int Himg, int Wimg, void* stream);
+
+/* Clip preparation in one pass over the raw pixels: ImageNorm (src/datasets/data_utils.py:437-457, applied to the three clip tensors at
+ * dataloader.py:104-115) fused with the MPM random-erase crop (dataset_pretrain_sparse.py:277-311).  raw (B, T, 3, H, W) uint8 or fp32;
+ * boxes (B, 4) int32 {top, left, h, w} on the DEVICE (NULL: no crop / context); mean3 / std3 are HOST arrays; scale = 1/255 when the
+ * pixels are 0..255 and the mean is <= 1 (the reference's test), else 1.
+ *   visual = (x*scale - mean)/std;  crop = the same of (x inside the box, 0 outside);  context = of (0 inside, x outside).
+ * crop / context may be NULL. */
+int alpro_prepare_clips(const void* raw, int raw_is_u8, const int* boxes, float scale, const float* mean3, const float* std3, float* visual,
+                        float* crop, float* context, int B, int T, int H, int W, void* stream);
 
 /* x_out[b, 0, :] = x_in[b, 0, :] + mean_t side[b*T + t, :]   (vit.py:184-187,195-196) */
 int alpro_cls_mean_residual(const float* x_in, int64_t ld_batch_in, const float* side, float* x_out,

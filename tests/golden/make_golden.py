@@ -271,6 +271,66 @@ def case_retrieval_frames(am, T, B, fname):
     np.savez_compressed(os.path.join(HERE, fname), **g)
 
 
+def reference_eval_functions():
+    """get_retrieval_metric_from_bool_matrix / get_retrieval_scores / eval_retrieval of the reference driver, EXECUTED from its
+    source without importing the module (src/tasks/run_video_retrieval.py pulls in lmdb / decord / cv2 datasets that this image
+    lacks): the three function definitions are cut out with `ast` and compiled as they stand."""
+    import ast
+    from collections import defaultdict
+    path = os.path.join(rh.REF, "src/tasks/run_video_retrieval.py")
+    tree = ast.parse(open(path).read())
+    want = {"get_retrieval_metric_from_bool_matrix", "get_retrieval_scores", "eval_retrieval"}
+    mod = ast.Module(body=[n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name in want], type_ignores=[])
+    ns = {"np": np, "torch": torch, "defaultdict": defaultdict}
+    exec(compile(mod, path, "exec"), ns)
+    return ns
+
+
+def case_retrieval_eval(am, T, V, fname, eval_bsz=3):
+    """The reference's retrieval evaluation on V videos x V captions (caption i belongs to video i): records built exactly like
+    inference_retrieval (run_video_retrieval.py:642-690: one video, caption mini-batches of eval_bsz, forward_inference, softmax
+    of the ITM logits, rounding to 4 decimals) and the metrics its own eval_retrieval computes from them (:558-628)."""
+    import torch.nn.functional as F
+    cfg, venc = rh.make_configs(num_frm=T)
+    m = am.AlproForVideoTextRetrieval(cfg, venc)
+    fill_state_dict_(m)
+    m.eval()
+    batch = det_batch(V, T, seed_name="retrieval_eval_T%d" % T, with_mlm=False, with_mpm=False)
+    recs = []
+    with torch.no_grad():
+        for v in range(V):
+            for i in range(0, V, eval_bsz):
+                out = m.forward_inference(dict(visual_inputs=batch["visual_inputs"][v:v + 1], text_input_ids=batch["text_input_ids"][i:i + eval_bsz],
+                                               text_input_mask=batch["text_input_mask"][i:i + eval_bsz]))
+                logits = torch.stack([out["logits"].cpu()]).squeeze().float()
+                sims = torch.stack([out["itc_scores"].cpu()]).squeeze().float().tolist()
+                if not isinstance(sims, list):
+                    sims = [sims]
+                if logits.dim() == 1:
+                    logits = logits[None]
+                probs = F.softmax(logits, dim=1)[:, 1].tolist()
+                for j, (p, s) in enumerate(zip(probs, sims)):
+                    recs.append(dict(vid_id="v%d" % v, txt_id="t%d" % (i + j), score=round(p, 4), sim=round(s, 4)))
+    ns = reference_eval_functions()
+    gt = {"t%d" % i: "v%d" % i for i in range(V)}
+    metrics = ns["eval_retrieval"](recs, gt, None)
+    g = {"score": np.array([r["score"] for r in recs]).reshape(V, V), "sim": np.array([r["sim"] for r in recs]).reshape(V, V)}
+    for d in ("text2video", "video2text"):
+        for k, val in metrics[d].items():
+            g["%s/%s" % (d, k)] = np.float64(val)
+    # known-answer check of the metric code itself on a synthetic score table with ties (rounded scores tie often)
+    rng = np.random.RandomState(0)
+    n = 12
+    table = np.round(rng.rand(n, n), 1)
+    srecs = [dict(vid_id="v%d" % v, txt_id="t%d" % t, score=float(table[v, t]), sim=0.0) for v in range(n) for t in range(n)]
+    sm = ns["eval_retrieval"](srecs, {"t%d" % i: "v%d" % i for i in range(n)}, None)
+    g["synthetic_table"] = table
+    for d in ("text2video", "video2text"):
+        for k, val in sm[d].items():
+            g["synthetic/%s/%s" % (d, k)] = np.float64(val)
+    np.savez_compressed(os.path.join(HERE, fname), **g)
+
+
 def main():
     am, _ = rh.import_reference()
     torch.set_num_threads(8)
@@ -289,6 +349,8 @@ def main():
         case_prompter(am, 2, 3, 8, "prompter_T2_B3_E8.npz")
     if want("retrieval_grads"):
         case_retrieval_grads(am, 2, 3, "retrieval_grads_T2_B3.npz")
+    if want("retrieval_eval"):
+        case_retrieval_eval(am, 2, 5, "retrieval_eval_T2_V5.npz")
     if want("retrieval_T16"):
         case_retrieval_frames(am, 16, 2, "retrieval_T16_B2.npz")
     if len(keys) == 2:

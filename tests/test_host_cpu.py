@@ -37,7 +37,7 @@ def test_library_exports_every_declared_symbol():
     lib = ctypes.CDLL(hip.LIB_PATH)
     for name in declared:
         assert hasattr(lib, name), name
-    assert hip.load().alpro_hip_abi_version() == hip.ABI_VERSION == 7
+    assert hip.load().alpro_hip_abi_version() == hip.ABI_VERSION == 8
 
 
 def test_gemm_desc_matches_header_layout():
@@ -406,3 +406,29 @@ def test_src_package_extends_the_reference_and_launcher_command():
     assert r.returncode == 0, r.stderr[-2000:]
     a, l, s, v = r.stdout.split()
     assert a.startswith(ROOT) and l.startswith(ROOT) and v.startswith(ROOT) and s.startswith(ref)
+
+
+def test_retrieval_eval_known_answers_from_the_reference():
+    """eval_retrieval on records rebuilt from score tables the REFERENCE produced, against the metrics the reference's own
+    eval_retrieval computed from them (tests/golden/retrieval_eval_T2_V5.npz: a 5 x 5 model table and a 12 x 12 synthetic table
+    full of ties), plus the sort-free device formula on tie-free scores."""
+    import numpy as np
+    from alpro_amd.retrieval_eval import eval_retrieval, records_from_matrices, retrieval_metrics_on_device, topk_on_device
+    g = np.load(os.path.join(GOLDEN, "retrieval_eval_T2_V5.npz"))
+    for prefix, table, sim in (("", g["score"], g["sim"]), ("synthetic/", g["synthetic_table"], np.zeros_like(g["synthetic_table"]))):
+        n = table.shape[0]
+        recs = records_from_matrices(torch.from_numpy(table), torch.from_numpy(sim), ["v%d" % i for i in range(n)], ["t%d" % i for i in range(n)])
+        m = eval_retrieval(recs, {"t%d" % i: "v%d" % i for i in range(n)})
+        for d in ("text2video", "video2text"):
+            for k in ("r1", "r5", "r10", "medianR", "meanR"):
+                assert abs(float(m[d][k]) - float(g["%s%s/%s" % (prefix, d, k)])) < 1e-9, (prefix, d, k, m[d][k])
+    torch.manual_seed(0)
+    s = torch.rand(37, 37)
+    recs = records_from_matrices(s * 1e4, s, ["v%d" % i for i in range(37)], ["t%d" % i for i in range(37)])   # 4 decimals keep these tie-free
+    ref = eval_retrieval(recs, {"t%d" % i: "v%d" % i for i in range(37)})
+    dev_v2t = retrieval_metrics_on_device(s, torch.arange(37))
+    dev_t2v = retrieval_metrics_on_device(s.t().contiguous(), torch.arange(37))
+    for k in ("r1", "r5", "r10", "medianR", "meanR"):
+        assert abs(dev_v2t[k] - float(ref["video2text"][k])) < 1e-9 and abs(dev_t2v[k] - float(ref["text2video"][k])) < 1e-9, k
+    vals, idx = topk_on_device(s, 5)
+    assert torch.equal(idx[:, 0], s.argmax(1)) and vals.shape == (37, 5)

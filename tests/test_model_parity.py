@@ -433,3 +433,33 @@ def test_retrieval_16_frames_vs_reference(bert_cfg, monkeypatch, mode, tol):
     close(ve[:, [0, 1, 100, 196]], g["video_embeds_rows"], tol * (1 if mode == "fp32" else 3), what="video_embeds rows (16 frames)")
     close(inf["itc_scores"], g["inf_itc_scores"], tol, what="VTC logits (16 frames)")
     close(inf["logits"], g["inf_logits"], tol, what="inference ITM logits (16 frames)")
+
+
+@pytest.mark.parametrize("mode,tol", [("fp32", 2e-4), ("bf16", 2e-2)])
+def test_batched_retrieval_scoring_vs_reference_records(bert_cfg, mode, tol):
+    """N3: every caption against every cached video in flat fusion mini-batches (score_all_pairs) reproduces the records the
+    REFERENCE's evaluation loop produced for 5 videos x 5 captions (tests/golden/retrieval_eval_T2_V5.npz: forward_inference per
+    (video, 3-caption mini-batch), softmax of the ITM logits, ITC similarity, both rounded to 4 decimals), and the cached loop
+    (inference_retrieval_cached) gives the same numbers."""
+    from oracle.det_init import det_batch, fill_state_dict_
+    from alpro_amd import config as rt
+    from alpro_amd.modeling.alpro_models import AlproForVideoTextRetrieval
+    from alpro_amd.retrieval_eval import inference_retrieval_cached, records_from_matrices, retrieval_metrics_on_device, score_all_pairs
+    g = np.load(os.path.join(GOLDEN, "retrieval_eval_T2_V5.npz"))
+    V = 5
+    m = AlproForVideoTextRetrieval(make_cfg(bert_cfg), dict(VENC, num_frm=2))
+    fill_state_dict_(m)
+    m.eval().cuda()
+    batch = to_dev(det_batch(V, 2, seed_name="retrieval_eval_T2", with_mlm=False, with_mpm=False))
+    with rt.use_compute_dtype(mode):
+        score, sim = score_all_pairs(m, batch["visual_inputs"], batch["text_input_ids"], batch["text_input_mask"], pair_bsz=7)
+        recs = inference_retrieval_cached(m, [("v%d" % i, batch["visual_inputs"][i:i + 1]) for i in range(V)], batch["text_input_ids"],
+                                          batch["text_input_mask"], ["t%d" % i for i in range(V)], eval_bsz=3)
+    assert score.is_cuda and score.shape == (V, V)
+    close(score, g["score"], tol + 5e-5, what="ITM match probability (V x C)")       # the fixture is rounded to 4 decimals
+    close(sim, g["sim"], tol * 5 + 5e-5, what="ITC similarity (V x C)")
+    mine = records_from_matrices(score, sim, ["v%d" % i for i in range(V)], ["t%d" % i for i in range(V)])
+    assert [(r["vid_id"], r["txt_id"]) for r in mine] == [(r["vid_id"], r["txt_id"]) for r in recs]
+    assert max(abs(a["score"] - b["score"]) for a, b in zip(mine, recs)) <= 2e-4 + tol
+    dm = retrieval_metrics_on_device(score, torch.arange(V))
+    assert 0 <= dm["r1"] <= 100 and 1 <= dm["medianR"] <= V
