@@ -214,7 +214,7 @@ __device__ __forceinline__ void epi_prefetch_res(const alpro_gemm_desc_t& g, int
 // 16-bit outputs under the identity map (qkv / proj / fc1 / every dgrad): 8 columns per lane -> one 16-byte store per
 // lane, 8 rows per wave instruction.  The store path is ISSUE-bound per CU (~one wave-store per ~100 cycles measured),
 // so halving the number of store instructions halves the epilogue tail.  Whole block in range (FAST) only.
-template <typename T, int ACT, int PASSES = 2>
+template <typename T, int ACT, int PASSES = 2, int ABL = 0>
 __device__ __forceinline__ void epi_rows16_c16(const alpro_gemm_desc_t& g, const float* stage, int m_base, int n_base, int lane, const float (&bias)[8],
                                                const u32x4* pre_c2 = nullptr) {
   const int c8 = (lane & 7) * 8;
@@ -248,7 +248,12 @@ __device__ __forceinline__ void epi_rows16_c16(const alpro_gemm_desc_t& g, const
       const f32x4 r0 = __builtin_nontemporal_load((const f32x4*)(g.residual + m * g.ldr + n)), r1 = __builtin_nontemporal_load((const f32x4*)(g.residual + m * g.ldr + n + 4));
       v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w; v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w;
     }
-    __builtin_nontemporal_store(pack_chunk<T>(v), (u32x4*)((T*)g.C + m * g.ldc + n));
+    if (ABL == 1) {  // ablation (gemm_tune 3): everything but the global store
+      u32x4 keep = pack_chunk<T>(v);
+      asm volatile("" ::"v"(keep));
+    } else {
+      __builtin_nontemporal_store(pack_chunk<T>(v), (u32x4*)((T*)g.C + m * g.ldc + n));
+    }
   }
 }
 
@@ -417,9 +422,11 @@ constexpr int EPI_BYTES = 8 * 16 * 64 * 4;  // 32 KiB: 8 waves x (16 rows x 64 c
 //   1  copy c after MFMA 2c+1 / 2c+2: all pieces out in the first half of the step (default: +3-5 % on every shape,
 //      tools/gemm_tune_bench.py, gpurun_out/r2b_tune.txt)
 //   2  copy c after MFMA 3c+1 / 3c+2: first three quarters
+//   3, 4  ablations of the 16-bit-output epilogue (no global stores / no epilogue at all; wrong results by construction) -- the
+//      measurements and the three epilogue rewrites they led to are in profiles/r2_gemm_epilogue_experiments.txt
 __device__ __forceinline__ constexpr int copy_slot(int tune, int q, int pos) {
   if (tune == 0) return ((q & 1) && ((q >> 1) & 1) == pos) ? (q >> 2) : -1;
-  if (tune == 1) { const int r = q - 1 - pos; return (r >= 0 && r < 16 && (r & 1) == 0) ? (r >> 1) : -1; }
+  if (tune == 1 || tune >= 3) { const int r = q - 1 - pos; return (r >= 0 && r < 16 && (r & 1) == 0) ? (r >> 1) : -1; }
   const int r = q - 1 - pos;
   return (r >= 0 && r < 24 && r % 3 == 0) ? r / 3 : -1;
 }
@@ -601,15 +608,20 @@ __global__ __launch_bounds__(NT2, 2) void gemm_nt256p_kernel(const alpro_gemm_de
             pring[0] = load_pre(0);
             pring[1] = load_pre(1);
           }
+          if constexpr (TUNE == 4) {  // ablation: no epilogue at all (accumulators kept live)
 #pragma unroll
-          for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < 4; ++i) asm volatile("" ::"v"(acc[i][0]), "v"(acc[i][1]));
+          } else {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              const int c = i * 4 + q;
-              if (ACT == ALPRO_ACT_GELU_BWD && c + 2 < 16) pring[(c + 2) % 3] = load_pre(c + 2);
-              float* st = stage + (c & 1) * 512;
-              stage_chunk(st, acc[i][0], acc[i][1], q);
-              epi_rows16_c16<T, ACT, 1>(g, st, mb + c * 8, nb, lane, bias8, ACT == ALPRO_ACT_GELU_BWD ? &pring[c % 3] : nullptr);
+            for (int i = 0; i < 4; ++i) {
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {
+                const int c = i * 4 + q;
+                if (ACT == ALPRO_ACT_GELU_BWD && c + 2 < 16) pring[(c + 2) % 3] = load_pre(c + 2);
+                float* st = stage + (c & 1) * 512;
+                stage_chunk(st, acc[i][0], acc[i][1], q);
+                epi_rows16_c16<T, ACT, 1, (TUNE == 3 ? 1 : 0)>(g, st, mb + c * 8, nb, lane, bias8, ACT == ALPRO_ACT_GELU_BWD ? &pring[c % 3] : nullptr);
+              }
             }
           }
         }
@@ -634,6 +646,8 @@ int launch_gemm_inst(const alpro_gemm_desc_t& g, hipStream_t st) {
     if constexpr (std::is_same<T, bf16_t>::value && ACT == ALPRO_ACT_NONE && MAP == ALPRO_MAP_IDENTITY) {
       (void)hipFuncSetAttribute((const void*)gemm_nt256p_kernel<T, ACT, MAP, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE2_BYTES + EPI_BYTES);
       (void)hipFuncSetAttribute((const void*)gemm_nt256p_kernel<T, ACT, MAP, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE2_BYTES + EPI_BYTES);
+      (void)hipFuncSetAttribute((const void*)gemm_nt256p_kernel<T, ACT, MAP, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE2_BYTES + EPI_BYTES);
+      (void)hipFuncSetAttribute((const void*)gemm_nt256p_kernel<T, ACT, MAP, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE2_BYTES + EPI_BYTES);
     }
   });
   const int big_tiles = ((g.N + BN2 - 1) / BN2) * ((g.M + BM2 - 1) / BM2);
@@ -648,6 +662,8 @@ int launch_gemm_inst(const alpro_gemm_desc_t& g, hipStream_t st) {
     if constexpr (std::is_same<T, bf16_t>::value && ACT == ALPRO_ACT_NONE && MAP == ALPRO_MAP_IDENTITY) {
       if (tune == 0) { hipLaunchKernelGGL((gemm_nt256p_kernel<T, ACT, MAP, 0>), dim3(grid), dim3(NT2), 4 * TILE2_BYTES + EPI_BYTES, st, g); return check_launch("alpro_gemm"); }
       if (tune == 2) { hipLaunchKernelGGL((gemm_nt256p_kernel<T, ACT, MAP, 2>), dim3(grid), dim3(NT2), 4 * TILE2_BYTES + EPI_BYTES, st, g); return check_launch("alpro_gemm"); }
+      if (tune == 3) { hipLaunchKernelGGL((gemm_nt256p_kernel<T, ACT, MAP, 3>), dim3(grid), dim3(NT2), 4 * TILE2_BYTES + EPI_BYTES, st, g); return check_launch("alpro_gemm"); }
+      if (tune == 4) { hipLaunchKernelGGL((gemm_nt256p_kernel<T, ACT, MAP, 4>), dim3(grid), dim3(NT2), 4 * TILE2_BYTES + EPI_BYTES, st, g); return check_launch("alpro_gemm"); }
     }
     hipLaunchKernelGGL((gemm_nt256p_kernel<T, ACT, MAP>), dim3(grid), dim3(NT2), 4 * TILE2_BYTES + EPI_BYTES, st, g);
   } else {
