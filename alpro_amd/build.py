@@ -50,12 +50,17 @@ def _compile(src, force):
     return obj, True
 
 
-def build(force=False, verbose=True):
+def build(force=False, verbose=True, force_files=()):
+    """force: recompile everything; force_files: basenames (e.g. 'optim.hip') recompiled even when their digest stamp is current --
+    the driver's "does it build" check uses this to exercise hipcc on every run without paying for all nine translation units."""
     os.makedirs(OBJDIR, exist_ok=True)
     srcs = _sources()
     with concurrent.futures.ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
-        res = list(ex.map(lambda s: _compile(s, force), srcs))
+        res = list(ex.map(lambda s: _compile(s, force or os.path.basename(s) in force_files), srcs))
     objs = [o for o, _ in res]
+    if verbose:
+        for s, (_, compiled) in zip(srcs, res):
+            print("  %-20s %s" % (os.path.basename(s), "compiled (hipcc --offload-arch=gfx950)" if compiled else "up to date (source digest matches its stamp)"))
     if any(c for _, c in res) or not os.path.exists(LIB):
         r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs, capture_output=True, text=True)
         if r.returncode != 0:
