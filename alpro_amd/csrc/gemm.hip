@@ -510,8 +510,16 @@ __global__ __launch_bounds__(NT2, 2) void gemm_nt256p_kernel(const alpro_gemm_de
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     for (int kt = 0; kt < nk; ++kt) {
       const int cur = s0 ^ (kt & 1);
+      if constexpr (TUNE == 10) {          // ablation: NO synchronisation in the K loop (races by construction): what any re-ordering of
+        if (kt == nk) block_sync();        // waits / barriers could gain at most; TUNE == 11: barrier only, TUNE == 12: DMA wait only
+      } else if constexpr (TUNE == 11) {
+        block_sync();
+      } else if constexpr (TUNE == 12) {
+        if (kt >= 2) wait_vm0();
+      } else {
       if (kt >= 2) wait_vm0();  // own pieces of K-tile kt (issued one step ago); at kt == 2 also the previous tile's stores
       block_sync();             // K-tile kt visible to everyone; everyone is done with K-tile kt-1
+      }
       // The buffer of K-tile kt-1 is free from here on: its 8 copies (K-tile kt+1, or K-tile 0 of the NEXT tile on the
       // last step) are issued BETWEEN this step's 32 MFMAs, and the two waves that share a SIMD (w, w+4) use alternating
       // slots -- a copy stalls its wave ~60-150 cycles at issue, which the partner's MFMAs cover; issued back to back by
@@ -648,6 +656,9 @@ int launch_gemm_inst(const alpro_gemm_desc_t& g, hipStream_t st) {
       (void)hipFuncSetAttribute((const void*)gemm_nt256p_kernel<T, ACT, MAP, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE2_BYTES + EPI_BYTES);
       (void)hipFuncSetAttribute((const void*)gemm_nt256p_kernel<T, ACT, MAP, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE2_BYTES + EPI_BYTES);
       (void)hipFuncSetAttribute((const void*)gemm_nt256p_kernel<T, ACT, MAP, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE2_BYTES + EPI_BYTES);
+      (void)hipFuncSetAttribute((const void*)gemm_nt256p_kernel<T, ACT, MAP, 12>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE2_BYTES + EPI_BYTES);
+      (void)hipFuncSetAttribute((const void*)gemm_nt256p_kernel<T, ACT, MAP, 11>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE2_BYTES + EPI_BYTES);
+      (void)hipFuncSetAttribute((const void*)gemm_nt256p_kernel<T, ACT, MAP, 10>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE2_BYTES + EPI_BYTES);
     }
   });
   const int big_tiles = ((g.N + BN2 - 1) / BN2) * ((g.M + BM2 - 1) / BM2);
@@ -664,6 +675,9 @@ int launch_gemm_inst(const alpro_gemm_desc_t& g, hipStream_t st) {
       if (tune == 2) { hipLaunchKernelGGL((gemm_nt256p_kernel<T, ACT, MAP, 2>), dim3(grid), dim3(NT2), 4 * TILE2_BYTES + EPI_BYTES, st, g); return check_launch("alpro_gemm"); }
       if (tune == 3) { hipLaunchKernelGGL((gemm_nt256p_kernel<T, ACT, MAP, 3>), dim3(grid), dim3(NT2), 4 * TILE2_BYTES + EPI_BYTES, st, g); return check_launch("alpro_gemm"); }
       if (tune == 4) { hipLaunchKernelGGL((gemm_nt256p_kernel<T, ACT, MAP, 4>), dim3(grid), dim3(NT2), 4 * TILE2_BYTES + EPI_BYTES, st, g); return check_launch("alpro_gemm"); }
+      if (tune == 12) { hipLaunchKernelGGL((gemm_nt256p_kernel<T, ACT, MAP, 12>), dim3(grid), dim3(NT2), 4 * TILE2_BYTES + EPI_BYTES, st, g); return check_launch("alpro_gemm"); }
+      if (tune == 11) { hipLaunchKernelGGL((gemm_nt256p_kernel<T, ACT, MAP, 11>), dim3(grid), dim3(NT2), 4 * TILE2_BYTES + EPI_BYTES, st, g); return check_launch("alpro_gemm"); }
+      if (tune == 10) { hipLaunchKernelGGL((gemm_nt256p_kernel<T, ACT, MAP, 10>), dim3(grid), dim3(NT2), 4 * TILE2_BYTES + EPI_BYTES, st, g); return check_launch("alpro_gemm"); }
     }
     hipLaunchKernelGGL((gemm_nt256p_kernel<T, ACT, MAP>), dim3(grid), dim3(NT2), 4 * TILE2_BYTES + EPI_BYTES, st, g);
   } else {
