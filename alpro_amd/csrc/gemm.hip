@@ -584,17 +584,22 @@ __global__ __launch_bounds__(NT2, 2) void gemm_nt256p_kernel(const alpro_gemm_de
       auto run_epilogue = [&](auto fast_tag) {
         constexpr bool FAST = decltype(fast_tag)::value;
         const bool pf = FAST && MAP != ALPRO_MAP_FRAME_TOKENS && g.residual != nullptr;  // (FRAME_TOKENS: its row map + the ring would spill)  // residual rows are fetched one chunk ahead (see epi_prefetch_res)
-        float4 ring[2][2];
-        if (pf) epi_prefetch_res<MAP>(g, mb, nb, lane, ring[0]);
+        // Residual ring: RD - 1 chunks (2 KiB per wave each) are in flight ahead of the one being finished.
+        constexpr int RD = 2;  // deeper (4: no change, 6: spills) -- profiles/r2_gemm_epilogue_experiments.txt item 5
+        float4 ring[RD][2];
+        if (pf) {
+#pragma unroll
+          for (int c0 = 0; c0 < RD - 1; ++c0) epi_prefetch_res<MAP>(g, mb + c0 * 8, nb, lane, ring[c0]);
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             const int c = i * 4 + q;
-            if (pf && c + 1 < 16) epi_prefetch_res<MAP>(g, mb + (c + 1) * 8, nb, lane, ring[(c + 1) & 1]);
+            if (pf && c + RD - 1 < 16) epi_prefetch_res<MAP>(g, mb + (c + RD - 1) * 8, nb, lane, ring[(c + RD - 1) % RD]);
             float* st = stage + (c & 1) * 512;
             stage_chunk(st, acc[i][0], acc[i][1], q);
-            epi_rows16<T, ACT, MAP, FAST, 2>(g, st, mb + c * 8, nb, lane, bias, pf ? ring[c & 1] : nullptr);
+            epi_rows16<T, ACT, MAP, FAST, 2>(g, st, mb + c * 8, nb, lane, bias, pf ? ring[c % RD] : nullptr);
           }
         }
       };
