@@ -494,6 +494,98 @@ __global__ __launch_bounds__(256) void attn_temporal_fwd_kernel(const T* __restr
   }
 }
 
+// ================================================================================================
+// 16-bit temporal attention, throughput form (round 2): one WAVE per (32 consecutive tokens, head) unit, everything wave-private
+// like attn_temporal_bwd16.  The three 4 KiB tiles K, V, Q of the unit go global -> LDS by DMA in 128-byte row pieces (12 copies per
+// unit, bank swizzle on the source side) instead of fragment-shaped 16-byte-per-row register loads (32 cache lines per instruction),
+// log2-domain softmax with the 1/sum applied to the 32x64 output tile, and the output leaves through the dead K tile as 16-byte row
+// stores.  No workgroup barrier: 4 independent waves per workgroup, units handed out grid-stride.
+template <typename T>
+__global__ __launch_bounds__(256, 2) void attn_temporal_fwd16_kernel(const T* __restrict__ qkv, T* __restrict__ out, int64_t rows, int Tn, int H,
+                                                                    float scale, int64_t units, float* __restrict__ lse) {
+  static_assert(sizeof(T) == 2, "16-bit storage only");
+  constexpr int WB = 3 * 4096;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  char* tK = smem + wave * WB;
+  char* tV = tK + 4096;
+  char* tQ = tK + 8192;
+  const uint32_t lds0 = lds_addr_of(tK);
+  const char* zero = (const char*)g_attn_zero;
+  const int64_t ldq = 3 * (int64_t)H * HD, ldo = (int64_t)H * HD;
+  const int g = lane >> 5, ql = lane & 31;
+  const float sl = scale * LOG2E;
+  const int qgrp = ql / Tn;
+  for (int64_t unit = (int64_t)blockIdx.x * 4 + wave; unit < units; unit += (int64_t)gridDim.x * 4) {
+    const int64_t chunk = unit / H;
+    const int h = (int)(unit - chunk * H);
+    const int64_t r0 = chunk * 32;
+    const int Le = (int)((rows - r0) < 32 ? (rows - r0) : 32);
+    const T* qb = qkv + r0 * ldq + h * HD;
+    // (the previous unit's LDS reads fed MFMAs / global stores that were issued before this point, so they have completed)
+#pragma unroll
+    for (int piece = 0; piece < 4; ++piece) {
+      const int row = piece * 8 + (lane >> 3), slot = lane & 7;
+      const bool ok = row < Le;
+      const T* src = qb + (int64_t)row * ldq;
+      const int ck = (slot ^ ((row >> 1) & 7)) << 3, cv = (slot ^ (((row >> 1) & 1) << 2)) << 3;
+      dma16(ok ? (const char*)(src + H * HD + ck) : zero, __builtin_amdgcn_readfirstlane(lds0 + piece * 1024));
+      dma16(ok ? (const char*)(src + 2 * H * HD + cv) : zero, __builtin_amdgcn_readfirstlane(lds0 + 4096 + piece * 1024));
+      dma16(ok ? (const char*)(src + ck) : zero, __builtin_amdgcn_readfirstlane(lds0 + 8192 + piece * 1024));
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    f32x16 s[1];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s[0][r] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int off = ql * 128 + (((2 * ks + g) ^ ((ql >> 1) & 7)) << 4);
+      mma_chunk<T>(s[0], *(const u32x4*)(tK + off), *(const u32x4*)(tQ + off));
+    }
+    // block-diagonal mask: a query attends to the Tn frames of its own patch (vit.py:146-157)
+    float m = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const bool mine = ((r & 3) + 8 * (r >> 2) + 4 * g) / Tn == qgrp;
+      s[0][r] = mine ? s[0][r] * sl : -INFINITY;
+      m = fmaxf(m, s[0][r]);
+    }
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float pr = __builtin_amdgcn_exp2f(s[0][r] - m);  // exp2(-inf) == 0 off the diagonal block
+      s[0][r] = pr;
+      sum += pr;
+    }
+    sum += __shfl_xor(sum, 32, 64);
+    const float inv = 1.0f / sum;
+    if (lse && g == 0 && ql < Le) lse[unit * 32 + ql] = (m + __builtin_amdgcn_logf(sum)) * LN2;  // (chunk*H + h)*32 + token
+    f32x16 o[2];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
+    pv_tiles<T, 1>(o, s, tV, lane);
+    // O^T (lane = query, 4 consecutive d per register quad) -> row-major rows through the dead K tile
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int rq = 0; rq < 4; ++rq) {
+        const uint32_t lo = pack2(o[dt][4 * rq] * inv, o[dt][4 * rq + 1] * inv, (T*)0);
+        const uint32_t hi = pack2(o[dt][4 * rq + 2] * inv, o[dt][4 * rq + 3] * inv, (T*)0);
+        *(u32x2*)(tK + ql * 128 + (((dt * 4 + rq) ^ ((ql >> 1) & 7)) << 4) + g * 8) = mk2(lo, hi);
+      }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // DS ops of one wave complete in order; nothing else touches this tile
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int row = p * 8 + (lane >> 3), slot = lane & 7;
+      const u32x4 v = *(const u32x4*)(tK + row * 128 + ((slot ^ ((row >> 1) & 7)) << 4));
+      if (row < Le) __builtin_nontemporal_store(v, (u32x4*)(out + (r0 + row) * ldo + h * HD + slot * 8));
+    }
+  }
+}
+
 template <typename T, int NKT>
 int launch_attn(const void* qkv, void* out, int batch, int L, int H, float scale, const float* key_bias, float* lse, float drop_p,
                 uint32_t drop_seed, hipStream_t st) {
@@ -561,6 +653,20 @@ extern "C" int alpro_attn_temporal_fwd(const void* qkv, void* out, int dtype, in
   const int64_t units = ((rows + 31) / 32) * H;
   int64_t grid = (units + 3) / 4;
   if (grid > 256 * 8) grid = 256 * 8;
+  if (dtype != ALPRO_F32) {  // 16-bit storage: DMA-staged wave-private tiles
+    const size_t lds16 = 4 * 3 * 4096;
+    static DeviceOnce attr_once;
+    attr_once.run([&] {
+      (void)hipFuncSetAttribute((const void*)attn_temporal_fwd16_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds16);
+      (void)hipFuncSetAttribute((const void*)attn_temporal_fwd16_kernel<f16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds16);
+    });
+    if (grid > 512) grid = 512;  // 2 workgroups per CU, units handed out grid-stride
+    if (dtype == ALPRO_BF16)
+      hipLaunchKernelGGL(attn_temporal_fwd16_kernel<bf16_t>, dim3((unsigned)grid), dim3(256), lds16, (hipStream_t)stream, (const bf16_t*)qkv, (bf16_t*)out, rows, T, H, scale, units, lse);
+    else
+      hipLaunchKernelGGL(attn_temporal_fwd16_kernel<f16_t>, dim3((unsigned)grid), dim3(256), lds16, (hipStream_t)stream, (const f16_t*)qkv, (f16_t*)out, rows, T, H, scale, units, lse);
+    return check_launch("alpro_attn_temporal_fwd");
+  }
   const int esz = dtype == ALPRO_F32 ? 4 : 2;
   const size_t lds = 4 * 32 * 64 * (size_t)esz;
   ALPRO_DISPATCH_DTYPE(dtype, T_, hipLaunchKernelGGL(attn_temporal_fwd_kernel<T_>, dim3((unsigned)grid), dim3(256), lds, (hipStream_t)stream, (const T_*)qkv, (T_*)out, rows, T, H, scale, units, lse));

@@ -273,11 +273,17 @@ class Block(nn.Module):
         else:
             hip.gemm(hip.transpose(G, colsum=db1), hip.transpose(sv["a_t"]), out=dWe, out_dtype=torch.float32)
         da = tr.dgrad(G, mg["wT"])                                              # d(a) = G We
-        # product rule back onto the two real parameters (fp32, 768^3 each)
+        # product rule back onto the two real parameters (768^3 each).  Exact mode: fp32 MFMA.  16-bit modes: 16-bit operands with fp32
+        # accumulation into the fp32 gradient, like every other weight gradient on this path (dWe itself came from 16-bit operands) --
+        # the two fp32 768^3 GEMMs were 57 us each on 36 workgroups, 2 x 12 of them per step.
         g_fc, g_p = tr.grad_buffer(fc.weight, zero=True)[0], tr.grad_buffer(ta.proj.weight, zero=True)[0]
-        hip.gemm(dWe, wp.contiguous(), out=g_fc, out_dtype=torch.float32, residual=g_fc)                         # += dWe Wp^T
+        if dt != torch.float32:
+            hip.gemm(hip.cast(dWe, dt), self._w("t_proj", ta.proj, dt), out=g_fc, out_dtype=torch.float32, residual=g_fc)   # += dWe Wp^T
+            hip.gemm(self._wt("t_fc", fc, dt)[:, :D], hip.transpose(dWe, out_dtype=dt), out=g_p, out_dtype=torch.float32, residual=g_p)  # += Wfc^T dWe
+        else:
+            hip.gemm(dWe, wp.contiguous(), out=g_fc, out_dtype=torch.float32, residual=g_fc)                     # += dWe Wp^T
+            hip.gemm(hip.transpose(wf.contiguous()), hip.transpose(dWe), out=g_p, out_dtype=torch.float32, residual=g_p)  # += Wfc^T dWe
         g_fc.addr_(db1, bp)                                                                                       # += db1 bp^T
-        hip.gemm(hip.transpose(wf.contiguous()), hip.transpose(dWe), out=g_p, out_dtype=torch.float32, residual=g_p)  # += Wfc^T dWe
         tr.bias_grad(ta.proj.bias).add_(torch.mv(wf.t(), db1))                                                    # += Wfc^T db1
         return da
 
