@@ -89,7 +89,7 @@ def load():
 
 
 def set_option(name, value):
-    """Measurement knob of the library (alpro_hip_set_option): 'gemm_tile', 'gemm_grid', 'gemm_tune', 'gemm_kind', 'tn_splits'."""
+    """Measurement knob of the library (alpro_hip_set_option): 'gemm_tile', 'gemm_grid', 'gemm_tune', 'tn_splits'."""
     _check(load().alpro_hip_set_option(name.encode(), int(value)), "alpro_hip_set_option")
 
 
