@@ -593,7 +593,7 @@ class _VisualRun:
         # final norm + temporal mean pool (vit.py:372,484-492): every frame token receives dout / T, the CLS token dout
         dy = torch.empty((B, 1 + N * T, D), dtype=torch.float32, device=dout.device)
         dy[:, 0] = dout[:, 0]
-        dy[:, 1:] = (dout[:, 1:] * (1.0 / T)).repeat_interleave(T, dim=1)
+        torch.mul(dout[:, 1:].unsqueeze(2).expand(B, N, T, D), 1.0 / T, out=dy[:, 1:].view(B, N, T, D))  # one broadcast pass (was mul + repeat_interleave + copy)
         dtok = torch.empty_like(dy)
         g, b_ = tr.grad_buffer(m.norm.weight, zero=True)[0], tr.grad_buffer(m.norm.bias, zero=True)[0]
         hip.layernorm_bwd(dy.view(-1, D), self.tok, m.norm.weight, VIT_EPS, dtok, g, b_, accumulate=False)
