@@ -88,22 +88,29 @@ def load():
     return lib
 
 
+_OPTION_DEFAULTS = {"gemm_tile": 0, "gemm_grid": 0, "gemm_tune": 1, "tn_splits": 0}
+_option_values = {}
+
+
 def set_option(name, value):
     """Measurement knob of the library (alpro_hip_set_option): 'gemm_tile', 'gemm_grid', 'gemm_tune', 'tn_splits'."""
     _check(load().alpro_hip_set_option(name.encode(), int(value)), "alpro_hip_set_option")
+    _option_values[name] = int(value)
 
 
 class option:
-    """`with hip.option('gemm_tile', 256): ...` -- set a knob for a block, reset to its default (0; gemm_tune 1) after."""
+    """`with hip.option('gemm_tile', 256): ...` -- set a knob for a block and put back what was set before (the value of the last
+    set_option call, else the built-in default; an initial value taken from the environment is not visible here)."""
 
     def __init__(self, name, value):
         self.name, self.value = name, value
 
     def __enter__(self):
+        self.prev = _option_values.get(self.name, _OPTION_DEFAULTS[self.name])
         set_option(self.name, self.value)
 
     def __exit__(self, *a):
-        set_option(self.name, 1 if self.name == "gemm_tune" else 0)
+        set_option(self.name, self.prev)
 
 
 def _check(rc, what):

@@ -33,7 +33,11 @@ def read_checkpoint(path, use_ema=False):
     `model_state` (strip 'model.'), a top-level 'model' entry, or the dict itself."""
     if not (path and os.path.isfile(path)):
         raise FileNotFoundError("No checkpoint found at %r" % (path,))
-    ckpt = torch.load(path, map_location="cpu")
+    try:
+        ckpt = torch.load(path, map_location="cpu")                       # tensors-only unpickling (torch >= 2.6 default)
+    except Exception as e:  # noqa: BLE001 -- released TimeSformer .pyth files also pickle their config objects
+        LOGGER.warning("%s is not a tensors-only checkpoint (%s); loading it with full unpickling -- only do this for files you trust", path, type(e).__name__)
+        ckpt = torch.load(path, map_location="cpu", weights_only=False)
     if isinstance(ckpt, dict):
         key = "state_dict_ema" if (use_ema and "state_dict_ema" in ckpt) else "state_dict"
         if key in ckpt:

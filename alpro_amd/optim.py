@@ -140,6 +140,8 @@ class FlatAdamW:
     def _on_grads_final(self, params=None, all_but=None):
         if self.flat is None or not self.allreduce or dist.size() == 1:
             return
+        if all_but is not None and not any(id(p) in self._span for p in all_but):
+            return  # "everything but <module>" from a module this optimizer does not train (another model in the same process)
         done = self._merge(self._reduced)
         for s, e in self._ranges_of(params, all_but):
             if any(s < de and ds < e for ds, de in done):
