@@ -19,8 +19,8 @@ void set_error(const char* fmt, ...) {
 }
 
 namespace {
-const char* const kOptNames[OPT_COUNT] = {"gemm_tile", "gemm_grid", "gemm_tune", "tn_splits"};
-const char* const kOptEnv[OPT_COUNT] = {"ALPRO_GEMM_TILE", "ALPRO_GEMM_GRID", "ALPRO_GEMM_TUNE", "ALPRO_TN_SPLITS"};
+const char* const kOptNames[OPT_COUNT] = {"gemm_tile", "gemm_grid", "gemm_tune", "tn_splits", "tn_kind"};
+const char* const kOptEnv[OPT_COUNT] = {"ALPRO_GEMM_TILE", "ALPRO_GEMM_GRID", "ALPRO_GEMM_TUNE", "ALPRO_TN_SPLITS", "ALPRO_TN_KIND"};
 int g_opts[OPT_COUNT];
 struct OptInit {
   OptInit() {

@@ -55,22 +55,25 @@ __device__ __forceinline__ u32x4 frag8(const char* img, int ks, int col0, int la
 
 template <typename T>
 __global__ __launch_bounds__(NT3, 1) void gemm_tn_kernel(const T* __restrict__ A, int64_t lda, const T* __restrict__ B, int64_t ldb,
-                                                         float* __restrict__ C, int64_t ldc, int M, int N, int K, int steps_per_split,
-                                                         int tn_cnt, int tk_cnt, float* __restrict__ colsum) {
+                                                         float* __restrict__ C, int64_t ldc, int M, int N, int K, int per,
+                                                         int tiles, int units, int tn_cnt, float* __restrict__ colsum, float* __restrict__ part,
+                                                         float* __restrict__ part_cs, int ablate) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 2, wc = wave & 3;
-  // XCD-aware decode of the 1-D grid: all (n-tile, k-tile) workgroups of one token slice run on ONE XCD (blockIdx % 8)
-  // back to back, so each token row of dY and X is fetched from HBM once and re-used out of that XCD's L2 by the
-  // other tiles of the slice (without this the operands are re-read N/256 resp. K/256 times).
-  const int tiles = tn_cnt * tk_cnt;
-  const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
-  const int slice = (idx / tiles) * 8 + xcd;
-  const int tile = idx - (idx / tiles) * tiles;
-  const int n0 = (tile % tn_cnt) * TW, k0 = (tile / tn_cnt) * TW;
+  // Work units: (token range, tile), range-major; a unit is `per` 32-token stages of one 256 x 256 tile.  The 1-D grid is decoded
+  // so that XCD x (= blockIdx % 8; workgroups are dealt to the XCDs round-robin, tools/probe_xcd.hip) owns a CONTIGUOUS run of
+  // units: the workgroups that share an L2 then work on the same token range and on tiles with a common dY / X column panel.  The
+  // re-use across XCDs (every token row is wanted by all tiles of its range at about the same time) is served by the Infinity
+  // Cache -- binding a range to one XCD, as earlier versions did, buys nothing measurable and costs the freedom to pick the
+  // number of ranges that fills the 256 CUs in one round (profiles/r2_gemm_epilogue_experiments.txt, experiment 8).
+  const int upx = (units + 7) >> 3;
+  const int unit = (blockIdx.x & 7) * upx + (blockIdx.x >> 3);
+  if (unit >= units) return;
+  const int range = unit / tiles, tile = unit - range * tiles;
   const int total_steps = (M + TM - 1) / TM;
-  const int s0 = slice * steps_per_split;
-  const int s1 = min(s0 + steps_per_split, total_steps);
+  const int s0 = range * per, s1 = min(s0 + per, total_steps);
+  const int n0 = (tile % tn_cnt) * TW, k0 = (tile / tn_cnt) * TW;
   if (s0 >= s1) return;
 
   // DMA pieces: 1 KiB = 2 token rows x 512 B; wave w moves pieces w and w+8 of each image per stage.
@@ -199,10 +202,27 @@ __global__ __launch_bounds__(NT3, 1) void gemm_tn_kernel(const T* __restrict__ A
     for (int i = 0; i < 4; ++i) {
       const float t = cs[i] + __shfl_xor(cs[i], 32, 64);  // the two token halves of the fragment
       const int n = n0 + wr * 128 + i * 32 + (lane & 31);
-      if (lane < 32 && n < N) unsafeAtomicAdd(colsum + n, t);
+      if (lane < 32 && part_cs) part_cs[(int64_t)range * (tn_cnt * TW) + n] = t;  // workspace mode: summed by tn_reduce_kernel
+      else if (lane < 32 && n < N) unsafeAtomicAdd(colsum + n, t);
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the tail copies (zero page) before the wave exits
+  if (ablate == 1 && acc[0][0][0] != 12345.f) return;  // measurement only (tn_kind 1): no atomic epilogue
+  if (part) {
+    // Workspace mode: the partial tile goes out in accumulator order -- 16 bytes per lane, 1 KiB per wave instruction, 32 plain
+    // stores per lane instead of 128 fabric atomics -- and tn_reduce_kernel adds the partials of a tile to C in a fixed order.
+    float* dst = part + (int64_t)unit * (TW * TW) + wave * 8192 + lane * 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          f32x4 v = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+          __builtin_nontemporal_store(v, (f32x4*)(dst + ((i * 2 + j) * 4 + q) * 256));
+        }
+    return;
+  }
   // C[n, k] += acc: lane owns column k = k0 + wc*64 + j*32 + (lane & 31); hardware fp32 atomics
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
@@ -216,6 +236,42 @@ __global__ __launch_bounds__(NT3, 1) void gemm_tn_kernel(const T* __restrict__ A
           if (n < N) unsafeAtomicAdd(C + (int64_t)n * ldc + k, acc[i][j][r]);
         }
     }
+  }
+}
+
+// Second half of the workspace mode: C[n, k] += sum over token ranges of the partial tiles (fixed order: bit-reproducible), and the
+// same for the bias-gradient partials.  One thread per 16-byte piece of a tile in accumulator order (see the store above): piece f
+// of wave w = f >> 11 is rows wr*128 + i*32 + 8q + 4*(lane >> 5) + {0..3}, column wc*64 + j*32 + (lane & 31).
+__global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict__ part, const float* __restrict__ part_cs, float* __restrict__ C,
+                                                        int64_t ldc, float* __restrict__ colsum, int N, int K, int tiles, int ranges, int tn_cnt) {
+  const int tile_blocks = tiles * 64;
+  if ((int)blockIdx.x >= tile_blocks) {  // bias gradient: one thread per column
+    const int n = (blockIdx.x - tile_blocks) * 256 + threadIdx.x;
+    if (n < N) {
+      float t = 0.f;
+      for (int r = 0; r < ranges; ++r) t += part_cs[(int64_t)r * (tn_cnt * TW) + n];
+      colsum[n] += t;
+    }
+    return;
+  }
+  const int tile = blockIdx.x >> 6, f = ((blockIdx.x & 63) << 8) + threadIdx.x;
+  const int lane = f & 63, q = (f >> 6) & 3, j = (f >> 8) & 1, i = (f >> 9) & 3, wave = f >> 11;
+  const int n = (tile % tn_cnt) * TW + (wave >> 2) * 128 + i * 32 + 8 * q + 4 * (lane >> 5);
+  const int k = (tile / tn_cnt) * TW + (wave & 3) * 64 + j * 32 + (lane & 31);
+  const float* src = part + (int64_t)tile * (TW * TW) + f * 4;
+  const int64_t stride = (int64_t)tiles * (TW * TW);
+  f32x4 t = {0.f, 0.f, 0.f, 0.f};
+  int r = 0;
+  for (; r + 4 <= ranges; r += 4) {
+    const f32x4 a = __builtin_nontemporal_load((const f32x4*)(src + (r + 0) * stride)), b = __builtin_nontemporal_load((const f32x4*)(src + (r + 1) * stride));
+    const f32x4 c = __builtin_nontemporal_load((const f32x4*)(src + (r + 2) * stride)), d = __builtin_nontemporal_load((const f32x4*)(src + (r + 3) * stride));
+    t = (((t + a) + b) + c) + d;
+  }
+  for (; r < ranges; ++r) t = t + __builtin_nontemporal_load((const f32x4*)(src + r * stride));
+  if (k < K) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+      if (n + c < N) C[(int64_t)(n + c) * ldc + k] += t[c];
   }
 }
 
@@ -269,46 +325,88 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ A, in
 
 using namespace alpro;
 
-extern "C" int alpro_gemm_tn_acc(const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc, int dtype, int M, int N,
-                                 int K, float* colsum, void* stream) {
+namespace {
+struct TnPlan {
+  int tn, tiles, total_steps, ranges, per, units;
+  size_t part_floats, cs_floats;
+};
+// Token ranges (see the kernel): R ranges x tiles workgroups, one workgroup per CU.  R is picked against a measured cost model --
+// rounds over the 256 CUs x (fixed ~26 us per workgroup: pipeline fill + epilogue issue, + ~1.15 us per stage) plus what the R sets
+// of partial tiles cost on the way to C: through fp32 fabric atomics ~2 TB/s (1.14 us per MB) when every workgroup finishes at
+// once, through the workspace (plain stores + tn_reduce_kernel) about a third of that.  36 tiles -> 7 ranges = 252 workgroups
+// in ONE round; 9 tiles -> 28 ranges; a 30522-row vocabulary projection (360 tiles) at 2560 tokens -> no split.
+TnPlan tn_plan(int M, int N, int K, bool ws) {
+  TnPlan p;
+  p.tn = (N + TW - 1) / TW;
+  p.tiles = p.tn * ((K + TW - 1) / TW);
+  p.total_steps = (M + TM - 1) / TM;
+  p.ranges = 1;
+  const int forced = get_option(OPT_TN_SPLITS);
+  if (forced > 0) {
+    p.ranges = forced;
+  } else {
+    const double set_us = (ws ? 0.4e-6 : 1.14e-6) * 4.0 * (double)N * (double)K;
+    double best_t = 1e30;
+    for (int r = 1; r <= 256; ++r) {
+      const int per_try = (p.total_steps + r - 1) / r;
+      if (per_try < 4 && r > 1) break;
+      const double t = (double)(((long)p.tiles * r + 255) / 256) * (26.0 + 1.15 * per_try) + set_us * r + (ws && r > 1 ? 6.0 : 0.0);
+      if (t < best_t * 0.98) { best_t = t; p.ranges = r; }
+    }
+  }
+  p.per = (p.total_steps + p.ranges - 1) / p.ranges;
+  p.ranges = (p.total_steps + p.per - 1) / p.per;
+  p.units = p.ranges * p.tiles;
+  p.part_floats = p.ranges > 1 ? (size_t)p.units * TW * TW : 0;
+  p.cs_floats = p.ranges > 1 ? (size_t)p.ranges * p.tn * TW : 0;
+  return p;
+}
+}  // namespace
+
+extern "C" size_t alpro_gemm_tn_workspace_bytes(int M, int N, int K) {
+  if (M <= 0 || N <= 0 || K <= 0) return 0;
+  const TnPlan p = tn_plan(M, N, K, true);
+  return (p.part_floats + p.cs_floats) * sizeof(float);
+}
+
+extern "C" int alpro_gemm_tn_acc_ws(const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc, int dtype, int M, int N,
+                                    int K, float* colsum, void* workspace, size_t workspace_bytes, void* stream) {
   ALPRO_CHECK(A && B && C && M > 0 && N > 0 && K > 0, "alpro_gemm_tn_acc: bad args");
   ALPRO_CHECK(dtype == ALPRO_BF16 || dtype == ALPRO_F16, "alpro_gemm_tn_acc: 16-bit operands only (fp32 mode uses alpro_transpose + alpro_gemm)");
   ALPRO_CHECK(lda % 8 == 0 && ldb % 8 == 0 && lda >= (N + 7) / 8 * 8 && ldb >= (K + 7) / 8 * 8,
               "alpro_gemm_tn_acc: lda/ldb must be multiples of 8 covering N/K rounded up to 8 (16-byte chunks are read whole)");
   ALPRO_CHECK(((uintptr_t)A % 16) == 0 && ((uintptr_t)B % 16) == 0, "alpro_gemm_tn_acc: operands must be 16-byte aligned");
-  const int tn = (N + TW - 1) / TW, tk = (K + TW - 1) / TW;
-  const int tiles = tn * tk;
-  const int total_steps = (M + TM - 1) / TM;
-  // Token slices: a multiple of 8 (slice s runs on XCD s % 8 -- see the kernel), s8 per XCD.  Pick the s8 whose
-  // workgroups (tiles * s8 per XCD, 32 CUs, one workgroup per CU) quantise best against the fixed per-workgroup cost
-  // (pipeline fill + the 256 KiB atomic epilogue, ~26 us measured, vs ~1.15 us per 32-token stage).
-  int best = 1;
-  double best_t = 1e30;
-  for (int s8 = 1; s8 <= 32; ++s8) {
-    const int per_try = (total_steps + 8 * s8 - 1) / (8 * s8);
-    if (per_try < 8 && s8 > 1) break;
-    const int units = tiles * s8;
-    const double t = (double)((units + 31) / 32) * (26.0 + 1.15 * per_try);
-    if (t < best_t * 0.98) { best_t = t; best = s8; }
+  const bool ws = workspace != nullptr;
+  const TnPlan p = tn_plan(M, N, K, ws);
+  float* part = nullptr;
+  float* part_cs = nullptr;
+  if (ws && p.ranges > 1) {
+    ALPRO_CHECK(((uintptr_t)workspace % 16) == 0 && workspace_bytes >= (p.part_floats + p.cs_floats) * sizeof(float),
+                "alpro_gemm_tn_acc_ws: workspace must be 16-byte aligned and hold alpro_gemm_tn_workspace_bytes(M, N, K) bytes");
+    part = (float*)workspace;
+    part_cs = colsum ? part + p.part_floats : nullptr;
   }
-  int splits = 8 * best;
-  if (const int forced = get_option(OPT_TN_SPLITS)) splits = forced;
-  const int per = (total_steps + splits - 1) / splits;
-  splits = (total_steps + per - 1) / per;
-  const int slices8 = (splits + 7) / 8 * 8;  // grid covers a multiple of 8 slices (one per XCD per pass); empty ones exit
-  const unsigned grid = (unsigned)(slices8 * tiles);
+  const int kind = get_option(OPT_TN_KIND);
+  const unsigned grid = (unsigned)((p.units + 7) / 8 * 8);
   const size_t lds = (size_t)NSTAGE * 2 * IMG_BYTES;
   hipStream_t st = (hipStream_t)stream;
   if (dtype == ALPRO_BF16) {
     static DeviceOnce once;
     once.run([&] { (void)hipFuncSetAttribute((const void*)gemm_tn_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); });
-    hipLaunchKernelGGL(gemm_tn_kernel<bf16_t>, dim3(grid), dim3(NT3), lds, st, (const bf16_t*)A, lda, (const bf16_t*)B, ldb, C, ldc, M, N, K, per, tn, tk, colsum);
+    hipLaunchKernelGGL(gemm_tn_kernel<bf16_t>, dim3(grid), dim3(NT3), lds, st, (const bf16_t*)A, lda, (const bf16_t*)B, ldb, C, ldc, M, N, K, p.per, p.tiles, p.units, p.tn, colsum, part, part_cs, kind);
   } else {
     static DeviceOnce once;
     once.run([&] { (void)hipFuncSetAttribute((const void*)gemm_tn_kernel<f16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); });
-    hipLaunchKernelGGL(gemm_tn_kernel<f16_t>, dim3(grid), dim3(NT3), lds, st, (const f16_t*)A, lda, (const f16_t*)B, ldb, C, ldc, M, N, K, per, tn, tk, colsum);
+    hipLaunchKernelGGL(gemm_tn_kernel<f16_t>, dim3(grid), dim3(NT3), lds, st, (const f16_t*)A, lda, (const f16_t*)B, ldb, C, ldc, M, N, K, p.per, p.tiles, p.units, p.tn, colsum, part, part_cs, kind);
   }
+  if (part && kind != 1)
+    hipLaunchKernelGGL(tn_reduce_kernel, dim3(p.tiles * 64 + (part_cs ? p.tn : 0)), dim3(256), 0, st, part, part_cs, C, ldc, colsum, N, K, p.tiles, p.ranges, p.tn);
   return check_launch("alpro_gemm_tn_acc");
+}
+
+extern "C" int alpro_gemm_tn_acc(const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc, int dtype, int M, int N,
+                                 int K, float* colsum, void* stream) {
+  return alpro_gemm_tn_acc_ws(A, lda, B, ldb, C, ldc, dtype, M, N, K, colsum, nullptr, 0, stream);
 }
 
 extern "C" int alpro_colsum_acc(const void* A, int64_t lda, float* out, int dtype, int M, int N, void* stream) {

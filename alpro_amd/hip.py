@@ -21,7 +21,7 @@ _CODE = {v: k for k, v in _TORCH_DTYPE.items()}
 EXPORTS = ["alpro_hip_last_error", "alpro_hip_abi_version", "alpro_hip_set_option", "alpro_gemm", "alpro_layernorm_fwd",
            "alpro_attn_temporal_fwd", "alpro_attn_fwd", "alpro_patchify", "alpro_cls_mean_residual",
            "alpro_vit_final_pool", "alpro_bert_embed_fwd", "alpro_cast_from_f32", "alpro_attn_bwd", "alpro_attn_temporal_bwd",
-           "alpro_layernorm_bwd", "alpro_transpose", "alpro_gelu_bwd", "alpro_cls_mean_bwd", "alpro_scatter_add_rows", "alpro_gather_cast", "alpro_sumsq", "alpro_adamw_step", "alpro_gemm_tn_acc", "alpro_colsum_acc", "alpro_softmax_xent", "alpro_vtc_loss_fwd", "alpro_vtc_loss_bwd", "alpro_prepare_clips"]
+           "alpro_layernorm_bwd", "alpro_transpose", "alpro_gelu_bwd", "alpro_cls_mean_bwd", "alpro_scatter_add_rows", "alpro_gather_cast", "alpro_sumsq", "alpro_adamw_step", "alpro_gemm_tn_acc", "alpro_gemm_tn_acc_ws", "alpro_gemm_tn_workspace_bytes", "alpro_colsum_acc", "alpro_softmax_xent", "alpro_vtc_loss_fwd", "alpro_vtc_loss_bwd", "alpro_prepare_clips"]
 
 
 class GemmDesc(ctypes.Structure):
@@ -38,7 +38,7 @@ class GemmDesc(ctypes.Structure):
                 ("drop_p", ctypes.c_float), ("drop_seed", ctypes.c_uint32), ("bias2", ctypes.c_void_p)]
 
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 _lib = None
 
 
@@ -67,6 +67,9 @@ def load():
     lib.alpro_sumsq.argtypes = [vp, i64, vp, vp]
     lib.alpro_softmax_xent.argtypes = [vp, i64, vp, i32, vp, vp, i32, i64, vp, i32, i32, i32, vp]
     lib.alpro_gemm_tn_acc.argtypes = [vp, i64, vp, i64, vp, i64, i32, i32, i32, i32, vp, vp]
+    lib.alpro_gemm_tn_acc_ws.argtypes = [vp, i64, vp, i64, vp, i64, i32, i32, i32, i32, vp, vp, ctypes.c_size_t, vp]
+    lib.alpro_gemm_tn_workspace_bytes.argtypes = [i32, i32, i32]
+    lib.alpro_gemm_tn_workspace_bytes.restype = ctypes.c_size_t
     lib.alpro_colsum_acc.argtypes = [vp, i64, vp, i32, i32, i32, vp]
     lib.alpro_adamw_step.argtypes = [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, f32, vp, f32, f32, vp]
     lib.alpro_gather_cast.argtypes = [vp, i64, vp, i32, i32, i32, i32, i32, i32, vp, i32, f32, f32, u32, vp, vp, vp]
@@ -88,7 +91,7 @@ def load():
     return lib
 
 
-_OPTION_DEFAULTS = {"gemm_tile": 0, "gemm_grid": 0, "gemm_tune": 1, "tn_splits": 0}
+_OPTION_DEFAULTS = {"gemm_tile": 0, "gemm_grid": 0, "gemm_tune": 1, "tn_splits": 0, "tn_kind": 0}
 _option_values = {}
 
 
@@ -381,17 +384,51 @@ def adamw_step(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step_size, gnorm
                                 _ptr(gnorm_sq), max_norm, grad_scale, _stream()), "alpro_adamw_step")
 
 
-def gemm_tn_acc(a, b, c, colsum=None):
-    """c (N, K) fp32 += a(M, N)^T @ b(M, K) with 16-bit a, b in their natural row-major layout (alpro_gemm_tn_acc);
-    colsum (N,) fp32 += a.sum(0) (the bias gradient) from the same pass."""
+_TN_WORKSPACE = {}  # device index -> grow-only byte buffer for the partial tiles of the weight-gradient GEMM
+
+
+def _tn_workspace(device, nbytes):
+    ws = _TN_WORKSPACE.get(device.index)
+    if ws is None or ws.numel() < nbytes:
+        ws = _TN_WORKSPACE[device.index] = torch.empty(max(nbytes, 64 << 20), dtype=torch.uint8, device=device)
+    return ws
+
+
+_DETERMINISTIC_WGRAD = [False]
+
+
+def set_deterministic_wgrad(on=True):
+    """True: every weight gradient takes the workspace path (bit-reproducible parameter gradients run to run, ~0.3 % of the step);
+    False (default): the faster of the two per shape -- see gemm_tn_acc."""
+    _DETERMINISTIC_WGRAD[0] = bool(on)
+
+
+def gemm_tn_acc(a, b, c, colsum=None, atomic=None):
+    """c (N, K) fp32 += a(M, N)^T @ b(M, K) with 16-bit a, b in their natural row-major layout; colsum (N,) fp32 += a.sum(0) (the
+    bias gradient) from the same pass.
+    atomic=False: alpro_gemm_tn_acc_ws -- the token ranges' partial tiles go through a workspace (one grow-only buffer per device,
+    used in stream order) and are added in a fixed order: bit-reproducible.  atomic=True: alpro_gemm_tn_acc, partials combined by
+    fp32 atomics (no workspace; run-to-run differences in the last bits, tests/test_hip_bwd_ops.py pins 2e-6 of scale).
+    atomic=None: the measured faster one (tools/gemm_tn_shapes.py) -- the workspace up to 65536 tokens or <= 9 tiles (the
+    workgroups finish together there and the atomics queue up: -10..-25 %), atomics above (the ranges finish spread out and the
+    atomics hide under the stragglers' MFMAs; the extra reduce launch would cost +3..7 %) -- unless set_deterministic_wgrad(True)."""
     lib = load()
     _dev(a); _dev(b, a.dtype); _dev(c, torch.float32)
     assert a.shape[0] == b.shape[0] and tuple(c.shape) == (a.shape[1], b.shape[1])
     if colsum is not None:
         _dev(colsum, torch.float32)
         assert colsum.numel() >= a.shape[1]
-    _check(lib.alpro_gemm_tn_acc(_ptr(a), a.stride(0), _ptr(b), b.stride(0), _ptr(c), c.stride(0), _CODE[a.dtype], a.shape[0], a.shape[1],
-                                 b.shape[1], _ptr(colsum), _stream()), "alpro_gemm_tn_acc")
+    M, N, K = a.shape[0], a.shape[1], b.shape[1]
+    if atomic is None:
+        atomic = not _DETERMINISTIC_WGRAD[0] and M > 65536 and ((N + 255) // 256) * ((K + 255) // 256) > 9
+    nbytes = 0 if atomic else lib.alpro_gemm_tn_workspace_bytes(M, N, K)
+    if nbytes == 0:
+        _check(lib.alpro_gemm_tn_acc(_ptr(a), a.stride(0), _ptr(b), b.stride(0), _ptr(c), c.stride(0), _CODE[a.dtype], M, N, K, _ptr(colsum), _stream()),
+               "alpro_gemm_tn_acc")
+        return c
+    ws = _tn_workspace(a.device, nbytes)
+    _check(lib.alpro_gemm_tn_acc_ws(_ptr(a), a.stride(0), _ptr(b), b.stride(0), _ptr(c), c.stride(0), _CODE[a.dtype], M, N, K, _ptr(colsum),
+                                    _ptr(ws), ws.numel(), _stream()), "alpro_gemm_tn_acc_ws")
     return c
 
 

@@ -180,10 +180,12 @@ def test_flat_adamw_matches_reference_update():
         assert all(float(p.grad.abs().sum()) == 0 for p in params)
 
 
+@pytest.mark.parametrize("atomic", [False, True])
 @pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("M,N,K", [(3138, 768, 768), (1000, 2304, 768), (6400, 768, 3072), (130, 30522, 768), (64, 8, 8)])
-def test_gemm_tn_acc(dt, M, N, K):
-    """Weight-gradient GEMM on natural layouts (tr-read operands, split over tokens, atomic accumulate)."""
+@pytest.mark.parametrize("M,N,K", [(3138, 768, 768), (1000, 2304, 768), (6400, 768, 3072), (130, 30522, 768), (64, 8, 8), (4001, 520, 264)])
+def test_gemm_tn_acc(dt, M, N, K, atomic):
+    """Weight-gradient GEMM on natural layouts (tr-read operands, split over token ranges; partial tiles combined through the
+    workspace + fixed-order reduce, or by fp32 atomics)."""
     hip = _hip()
     ldn = (N + 7) // 8 * 8
     a = torch.zeros(M, ldn)
@@ -192,7 +194,7 @@ def test_gemm_tn_acc(dt, M, N, K):
     c0 = rnd(N, K, seed=122)
     c = c0.clone().cuda()
     bg = torch.full((ldn,), 2.0).cuda()
-    hip.gemm_tn_acc(a.to(dt).cuda()[:, :N], b.to(dt).cuda(), c, colsum=bg)
+    hip.gemm_tn_acc(a.to(dt).cuda()[:, :N], b.to(dt).cuda(), c, colsum=bg, atomic=atomic)
     ref = c0.double() + a[:, :N].to(dt).double().T @ b.to(dt).double()
     close(c, ref, 2e-5, 2e-3 * math.sqrt(M / 1000.0), "gemm_tn_acc")
     close(bg[:N], 2 + a[:, :N].to(dt).double().sum(0), 1e-5, 1e-3, "gemm_tn_acc fused bias gradient")
@@ -516,22 +518,28 @@ def test_vtc_loss_fwd_bwd(B, world, rank, temp):
         close(leaves[4].grad.reshape(1), r[4].grad.reshape(1), 2e-4, 1e-4 * float(r[4].grad.abs()), "dtemp")
 
 
-def test_wgrad_atomic_accumulation_run_to_run_tolerance():
-    """alpro_gemm_tn_acc combines its token slices with fp32 hardware atomics, so the summation ORDER (not the set of summands) can
-    differ between two launches: parameter gradients are reproducible only up to fp32 re-association.  This pins that tolerance: two
-    runs of the fc1 weight gradient at the benchmark size agree to 2e-6 of the gradient's scale (observed ~3e-7), far below the bf16
-    operand rounding (4e-3) -- and a launch that keeps one slice per tile (tn_splits = 1) is bit-reproducible."""
+def test_wgrad_run_to_run_reproducibility():
+    """Two ways of combining the token ranges of a weight gradient.  Workspace mode (alpro_gemm_tn_acc_ws: partial tiles stored, then
+    added in a fixed order) is BIT-reproducible at every size, bias gradient included.  Atomic mode (alpro_gemm_tn_acc) adds the same
+    summands in an order that can differ between launches: reproducible only up to fp32 re-association -- two runs of a weight
+    gradient at the benchmark size agree to 2e-6 of the gradient's scale (observed ~3e-7), far below the bf16 operand rounding
+    (4e-3) -- and bit-reproducible when the tokens are not split (tn_splits = 1)."""
     hip = _hip()
     dt = torch.bfloat16
     M = 100416
     g = torch.Generator(device="cuda").manual_seed(77)
     dy = (torch.randn(M, 768, device="cuda", generator=g) * 0.1).to(dt)
     x = (torch.randn(M, 768, device="cuda", generator=g) * 0.5).to(dt)
-    runs = []
-    for _ in range(3):
-        gw = torch.zeros(768, 768, device="cuda")
-        hip.gemm_tn_acc(dy, x, gw)
-        runs.append(gw)
+
+    def run(atomic, rows=M):
+        gw, gb = torch.zeros(768, 768, device="cuda"), torch.zeros(768, device="cuda")
+        hip.gemm_tn_acc(dy[:rows], x[:rows], gw, colsum=gb, atomic=atomic)
+        return gw, gb
+    assert hip.load().alpro_gemm_tn_workspace_bytes(M, 768, 768) > 0          # the tokens ARE split at this size
+    ws = [run(False) for _ in range(3)]
+    for gw, gb in ws[1:]:
+        assert torch.equal(gw, ws[0][0]) and torch.equal(gb, ws[0][1])
+    runs = [run(True)[0] for _ in range(3)] + [ws[0][0]]
     scale = float(runs[0].abs().max())
     worst = max(float((runs[0] - r).abs().max()) for r in runs[1:])
     assert worst <= 2e-6 * scale, (worst, scale)
@@ -539,8 +547,6 @@ def test_wgrad_atomic_accumulation_run_to_run_tolerance():
     one = []
     with hip.option("tn_splits", 1):
         for _ in range(2):
-            gw = torch.zeros(768, 768, device="cuda")
-            hip.gemm_tn_acc(dy[:20000], x[:20000], gw)
-            one.append(gw)
+            one.append(run(True, 20000)[0])
     assert torch.equal(one[0], one[1])
     assert float((one[0] - ref).abs().max()) < 2e-3 * float(ref.abs().max())
