@@ -9,10 +9,9 @@ namespace {
 // ---- out[c, r] = (Tout) in[r, c] for r < R, zero for R <= r < Rpad; optional fp32 column sums (bias gradient) --
 // 64x64 tile through LDS (fp32, +1 padding).  wgrad needs both operands with the token dimension contiguous.
 template <typename Tin, typename Tout>
-__global__ __launch_bounds__(256) void transpose_kernel(const Tin* __restrict__ in, int64_t ld_in, Tout* __restrict__ out, int64_t ld_out,
-                                                        int R, int C, int Rpad, float* __restrict__ colsum) {
-  __shared__ float tile[64][65];
-  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+__device__ __forceinline__ void transpose_tile(float (&tile)[64][65], const Tin* __restrict__ in, int64_t ld_in, Tout* __restrict__ out,
+                                               int64_t ld_out, int R, int C, int Rpad, float* __restrict__ colsum, int bx, int by) {
+  const int r0 = by * 64, c0 = bx * 64;
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;  // 4 row-groups of 64 lanes
 #pragma unroll 4
   for (int i = ty; i < 64; i += 4) {
@@ -31,6 +30,30 @@ __global__ __launch_bounds__(256) void transpose_kernel(const Tin* __restrict__ 
     const int c = c0 + i, r = r0 + tx;
     if (c < C && r < Rpad) out[(int64_t)c * ld_out + r] = from_f32<Tout>(tile[tx][i]);
   }
+}
+
+template <typename Tin, typename Tout>
+__global__ __launch_bounds__(256) void transpose_kernel(const Tin* __restrict__ in, int64_t ld_in, Tout* __restrict__ out, int64_t ld_out,
+                                                        int R, int C, int Rpad, float* __restrict__ colsum) {
+  __shared__ float tile[64][65];
+  transpose_tile<Tin, Tout>(tile, in, ld_in, out, ld_out, R, C, Rpad, colsum, blockIdx.x, blockIdx.y);
+}
+
+// Many independent transposes in ONE launch: the dgrad operands W^T of every Linear are refreshed after each optimizer step, ~130
+// matrices of 0.6-2.4 M elements -- each far too small to cover its own launch (10 us apiece, 2 ms per step as separate launches).
+// Workgroup -> job by binary search over the jobs' first-tile prefix (uniform, a handful of scalar loads).
+template <typename Tout>
+__global__ __launch_bounds__(256) void transpose_batch_kernel(const alpro_transpose_job_t* __restrict__ jobs, int njobs) {
+  __shared__ float tile[64][65];
+  int lo = 0, hi = njobs - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (jobs[mid].tile0 <= (int)blockIdx.x) lo = mid;
+    else hi = mid - 1;
+  }
+  const alpro_transpose_job_t jb = jobs[lo];
+  const int t = blockIdx.x - jb.tile0, tcx = (jb.C + 63) / 64;
+  transpose_tile<float, Tout>(tile, jb.in, jb.ld_in, (Tout*)jb.out, jb.ld_out, jb.R, jb.C, jb.Rpad, nullptr, t % tcx, t / tcx);
 }
 
 // ---- LayerNorm backward, D = 768, one wave per row ------------------------------------------------------
@@ -344,6 +367,12 @@ extern "C" int alpro_transpose(const void* in, int in_dtype, int64_t ld_in, void
     ALPRO_DISPATCH_DTYPE(out_dtype, T, return (launch_transpose<T, T>(in, ld_in, out, ld_out, R, C, Rpad, colsum, st)));
   }
   return ALPRO_OK;
+}
+
+extern "C" int alpro_transpose_batch(const alpro_transpose_job_t* jobs, int njobs, int total_tiles, int out_dtype, void* stream) {
+  ALPRO_CHECK(jobs && njobs > 0 && total_tiles > 0, "alpro_transpose_batch: bad args");
+  ALPRO_DISPATCH_DTYPE(out_dtype, T, hipLaunchKernelGGL(transpose_batch_kernel<T>, dim3((unsigned)total_tiles), dim3(256), 0, (hipStream_t)stream, jobs, njobs));
+  return check_launch("alpro_transpose_batch");
 }
 
 extern "C" int alpro_layernorm_bwd(const void* dy, int dy_dtype, int64_t ld_dy, const float* dy2, const float* x, int64_t ldx,

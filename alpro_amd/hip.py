@@ -21,7 +21,7 @@ _CODE = {v: k for k, v in _TORCH_DTYPE.items()}
 EXPORTS = ["alpro_hip_last_error", "alpro_hip_abi_version", "alpro_hip_set_option", "alpro_gemm", "alpro_layernorm_fwd",
            "alpro_attn_temporal_fwd", "alpro_attn_fwd", "alpro_patchify", "alpro_cls_mean_residual",
            "alpro_vit_final_pool", "alpro_bert_embed_fwd", "alpro_cast_from_f32", "alpro_attn_bwd", "alpro_attn_temporal_bwd",
-           "alpro_layernorm_bwd", "alpro_transpose", "alpro_gelu_bwd", "alpro_cls_mean_bwd", "alpro_scatter_add_rows", "alpro_gather_cast", "alpro_sumsq", "alpro_adamw_step", "alpro_gemm_tn_acc", "alpro_gemm_tn_acc_ws", "alpro_gemm_tn_workspace_bytes", "alpro_colsum_acc", "alpro_softmax_xent", "alpro_vtc_loss_fwd", "alpro_vtc_loss_bwd", "alpro_prepare_clips"]
+           "alpro_layernorm_bwd", "alpro_transpose", "alpro_transpose_batch", "alpro_gelu_bwd", "alpro_cls_mean_bwd", "alpro_scatter_add_rows", "alpro_gather_cast", "alpro_sumsq", "alpro_adamw_step", "alpro_gemm_tn_acc", "alpro_gemm_tn_acc_ws", "alpro_gemm_tn_workspace_bytes", "alpro_colsum_acc", "alpro_softmax_xent", "alpro_vtc_loss_fwd", "alpro_vtc_loss_bwd", "alpro_prepare_clips"]
 
 
 class GemmDesc(ctypes.Structure):
@@ -36,6 +36,11 @@ class GemmDesc(ctypes.Structure):
                 ("side", ctypes.c_void_p), ("ld_side", ctypes.c_int64),
                 ("C2", ctypes.c_void_p), ("ldc2", ctypes.c_int64),
                 ("drop_p", ctypes.c_float), ("drop_seed", ctypes.c_uint32), ("bias2", ctypes.c_void_p)]
+
+
+class TransposeJob(ctypes.Structure):
+    _fields_ = [("in_", ctypes.c_void_p), ("out", ctypes.c_void_p), ("ld_in", ctypes.c_int64), ("ld_out", ctypes.c_int64),
+                ("R", ctypes.c_int32), ("C", ctypes.c_int32), ("Rpad", ctypes.c_int32), ("tile0", ctypes.c_int32)]   # 48 bytes
 
 
 ABI_VERSION = 9
@@ -71,6 +76,7 @@ def load():
     lib.alpro_gemm_tn_workspace_bytes.argtypes = [i32, i32, i32]
     lib.alpro_gemm_tn_workspace_bytes.restype = ctypes.c_size_t
     lib.alpro_colsum_acc.argtypes = [vp, i64, vp, i32, i32, i32, vp]
+    lib.alpro_transpose_batch.argtypes = [vp, i32, i32, i32, vp]
     lib.alpro_adamw_step.argtypes = [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, f32, vp, f32, f32, vp]
     lib.alpro_gather_cast.argtypes = [vp, i64, vp, i32, i32, i32, i32, i32, i32, vp, i32, f32, f32, u32, vp, vp, vp]
     lib.alpro_cls_mean_bwd.argtypes = [vp, i64, vp, i32, i32, i32, vp]
@@ -430,6 +436,25 @@ def gemm_tn_acc(a, b, c, colsum=None, atomic=None):
     _check(lib.alpro_gemm_tn_acc_ws(_ptr(a), a.stride(0), _ptr(b), b.stride(0), _ptr(c), c.stride(0), _CODE[a.dtype], M, N, K, _ptr(colsum),
                                     _ptr(ws), ws.numel(), _stream()), "alpro_gemm_tn_acc_ws")
     return c
+
+
+def transpose_jobs(pairs):
+    """[(src (R, C) fp32 contiguous-row device tensor, out (C, Rpad) tensor)] -> (device job table, njobs, total_tiles) for
+    transpose_batch; build once, launch every step."""
+    jobs = (TransposeJob * len(pairs))()
+    t0 = 0
+    for j, (src, out) in zip(jobs, pairs):
+        _dev(src, torch.float32); _dev(out)
+        assert src.dim() == 2 and out.dim() == 2 and src.stride(1) == 1 and out.stride(1) == 1 and out.shape[0] == src.shape[1] and out.shape[1] >= src.shape[0]
+        j.in_, j.out, j.ld_in, j.ld_out = src.data_ptr(), out.data_ptr(), src.stride(0), out.stride(0)
+        j.R, j.C, j.Rpad, j.tile0 = src.shape[0], src.shape[1], out.shape[1], t0
+        t0 += ((src.shape[1] + 63) // 64) * ((out.shape[1] + 63) // 64)
+    table = torch.frombuffer(bytearray(bytes(jobs)), dtype=torch.uint8).to(pairs[0][0].device)
+    return table, len(pairs), t0
+
+
+def transpose_batch(table, njobs, total_tiles, out_dtype):
+    _check(load().alpro_transpose_batch(_ptr(table), njobs, total_tiles, _CODE[out_dtype], _stream()), "alpro_transpose_batch")
 
 
 def colsum_acc(a, out):

@@ -8,6 +8,9 @@ alpro_layernorm_bwd, alpro_gemm, alpro_transpose, ...).  Parameter gradients are
 into `param.grad` (fp32) by the wgrad GEMM's residual input, which is what `loss.backward()` leaves
 behind in the reference (run_pretrain_sparse.py:599), ready for the all-reduce and the optimizer.
 """
+import os
+import weakref
+
 import torch
 
 from alpro_amd import hip
@@ -29,18 +32,85 @@ def add_grad(p, g):
         p.grad.add_(g.reshape(p.shape))
 
 
+def fused_param_view(params):
+    """If `params` (equal trailing shape, contiguous) lie back to back in one storage (FlatAdamW's flat parameter buffer), return a
+    single (sum of rows, cols) view over their values, else None."""
+    ps = [p.detach() for p in params]
+    if any(not p.is_contiguous() for p in ps):
+        return None
+    base = ps[0]
+    off = base.data_ptr()
+    for p in ps:
+        if p.untyped_storage().data_ptr() != base.untyped_storage().data_ptr() or p.data_ptr() != off or p.shape[1:] != base.shape[1:]:
+            return None
+        off += p.numel() * 4
+    rows = sum(p.shape[0] for p in ps)
+    return torch.as_strided(base, (rows, base.numel() // base.shape[0]), (base.numel() // base.shape[0], 1))
+
+
+# W^T operands that live across steps: (cache, key) -> entry.  After an optimizer step ALL of them are stale at once, so
+# refresh_transposed_operands() rewrites them with ONE alpro_transpose_batch launch instead of ~130 launches at first use.
+_WT_REGISTRY = {}
+_WT_TABLE = {}  # out dtype -> dict(sig, table, njobs, tiles): the device job table, rebuilt only when the set of operands changes
+
+
 def transposed_operand(cache, key, weight, dt):
-    """(N, K) fp32 parameter -> cached (K, N64) operand in `dt` for dgrad (dX = dY @ W), refreshed on version change."""
-    ver = param_version(weight)
+    """(N, K) fp32 parameter -- or a tuple of parameters concatenated along dim 0 -- -> cached (K, N64) operand in `dt` for dgrad
+    (dX = dY @ W), refreshed when the parameter value changes (weights.param_version)."""
+    plist = (weight,) if torch.is_tensor(weight) else tuple(weight)
+    ver = tuple(param_version(p) for p in plist)
     hit = cache._store.get(key)
     if hit is not None and hit[0] == ver and hit[1].dtype == dt:
         return hit[1]
     with torch.no_grad():
-        w = weight.detach()
-        w = w.reshape(w.shape[0], -1).contiguous()
-        out = hip.transpose(w, out_dtype=dt, pad_to=64)
+        src = fused_param_view(plist) if len(plist) > 1 else plist[0].detach().reshape(plist[0].shape[0], -1)
+        if src is None:
+            src = torch.cat([p.detach().reshape(p.shape[0], -1) for p in plist], 0)
+        src = src.contiguous()
+        out = hip.transpose(src, out_dtype=dt, pad_to=64)
     cache._store[key] = (ver, out)
+    # a view of the parameter storage itself, of parameters an optimizer with flat storage updates (the only ones that go stale
+    # every step; frozen ones never do): re-read by the batched refresh
+    stable = src.data_ptr() == plist[0].data_ptr() and all(v[0] != -1 for v in ver)
+    if stable and src.dtype == torch.float32 and src.is_cuda:
+        _WT_REGISTRY[(id(cache), key)] = dict(cache=weakref.ref(cache), key=key, params=[weakref.ref(p) for p in plist], src=src, out=out)
+    else:
+        _WT_REGISTRY.pop((id(cache), key), None)
     return out
+
+
+def refresh_transposed_operands():
+    """Called by the optimizer right after it updated the parameters: rewrite every registered W^T operand in place with one
+    batched launch and stamp it with the new parameter versions.  Entries whose module is gone, whose parameters moved, or whose
+    operand was replaced meanwhile are dropped (they fall back to the lazy path above)."""
+    if os.environ.get("ALPRO_WT_REFRESH", "1") == "0":  # measurement knob: back to one transpose launch per Linear at first use
+        return 0
+    live = []
+    for k, e in list(_WT_REGISTRY.items()):
+        cache, ps = e["cache"](), [r() for r in e["params"]]
+        hit = cache._store.get(e["key"]) if cache is not None else None
+        if hit is None or hit[1] is not e["out"] or any(p is None for p in ps) or ps[0].data_ptr() != e["src"].data_ptr():
+            del _WT_REGISTRY[k]
+            continue
+        live.append((e, cache, ps))
+    if not live:
+        return 0
+    t = _WT_TABLE
+    by_dtype = {}
+    for item in live:
+        by_dtype.setdefault(item[0]["out"].dtype, []).append(item)
+    n = 0
+    for dt, items in by_dtype.items():
+        sig = tuple((e["src"].data_ptr(), e["out"].data_ptr()) for e, _, _ in items)
+        slot = t.setdefault(dt, {})
+        if slot.get("sig") != sig:
+            slot["table"], slot["njobs"], slot["tiles"] = hip.transpose_jobs([(e["src"], e["out"]) for e, _, _ in items])
+            slot["sig"] = sig
+        hip.transpose_batch(slot["table"], slot["njobs"], slot["tiles"], dt)
+        for e, cache, ps in items:
+            cache._store[e["key"]] = (tuple(param_version(p) for p in ps), e["out"])
+        n += len(items)
+    return n
 
 
 def bias_grad(bias):

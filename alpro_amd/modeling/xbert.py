@@ -180,12 +180,7 @@ class BertLayer(nn.Module):
         else:
             for i, lin in enumerate(lins):
                 tr.wgrad(dqkv[:, i * Hd:(i + 1) * Hd], sv["h_t"], lin.weight, lin.bias)
-        wT = self._ops._store.get("qkv_w^T")
-        ver = tuple(tr.param_version(p) for p in (sa.query.weight, sa.key.weight, sa.value.weight))
-        if wT is None or wT[0] != ver or wT[1].dtype != dt:
-            wcat = torch.cat([sa.query.weight.detach(), sa.key.weight.detach(), sa.value.weight.detach()], 0).contiguous()
-            wT = (ver, hip.transpose(wcat, out_dtype=dt, pad_to=64))
-            self._ops._store["qkv_w^T"] = wT
+        wT = (None, tr.transposed_operand(self._ops, "qkv_w^T", (sa.query.weight, sa.key.weight, sa.value.weight), dt))
         dh_t = tr.dgrad(dqkv, wT[1])
         return ds1, dh_t
 

@@ -217,6 +217,8 @@ class FlatAdamW:
                 f["lp"] = torch.empty(f["n"], dtype=dt, device=f["p"].device)
             hip.cast(f["p"], dt, out=f["lp"])
             register_flat_lp(f["p"], f["lp"], f["live"])
+        from alpro_amd.modeling.train import refresh_transposed_operands
+        refresh_transposed_operands()  # the dgrad operands W^T of every Linear, one launch (modeling/train.py)
 
     def state_dict(self):
         """{'step', 'param_groups', 'layout', 'm', 'v'}: the Adam moments as the two flat buffers plus the layout that gives them

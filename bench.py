@@ -359,15 +359,19 @@ def main():
                 gemm[k_] += ks["gemm_tn_acc"][k_]
         ach = gemm["flops"] / (gemm["ms"] * 1e-3) / 1e12
         traffic, traffic_src = None, None
-        prof = os.path.join(ROOT, "profiles", "r1e_pretrain_step_B64_pmc_traffic.json")
-        if train and B == 64 and T == 8 and args.dtype == "bf16" and os.path.exists(prof):
+        import glob
+        import re
+        profs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pretrain_step_B64_pmc_traffic.json")),
+                       key=lambda f: (int(re.match(r"r(\d+)", os.path.basename(f)).group(1)), os.path.basename(f)))
+        prof = profs[-1] if profs else ""  # the latest round's PMC passes
+        if train and B == 64 and T == 8 and args.dtype == "bf16" and prof:
             # HBM bytes per GEMM launch from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command
             # (tools/pmc_summary.py; FETCH_SIZE doubled per MI355X_MICROARCH.md): launch-weighted mean over the GEMM kernels
             pm = json.load(open(prof))
             gk = {k: v for k, v in pm.items() if k.startswith("gemm_")}
             n = sum(v["launches"] for v in gk.values())
             traffic = round(sum(v["launches"] * (v["read_bytes_corrected_per_launch"] + v["write_bytes_per_launch"]) for v in gk.values()) / n)
-            traffic_src = "profiles/r1e_pretrain_step_B64_pmc_traffic.json"
+            traffic_src = "profiles/" + os.path.basename(prof)
         peak = MFMA_PEAK_TFLOPS[args.dtype]
         result = {
             "metric": "video-text pairs/sec (8f x 224^2, 40-tok)", "value": round(value, 3), "unit": unit, "n_gpus": world,

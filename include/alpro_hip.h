@@ -175,6 +175,17 @@ int alpro_layernorm_bwd(const void* dy, int dy_dtype, int64_t ld_dy, const float
 int alpro_transpose(const void* in, int in_dtype, int64_t ld_in, void* out, int out_dtype, int64_t ld_out, int R, int C,
                     int Rpad, float* colsum, void* stream);
 
+/* njobs independent fp32 -> out_dtype transposes (same semantics as alpro_transpose without colsum) in one launch: the W^T operands of
+ * all Linear layers after an optimizer step.  `jobs` is DEVICE memory; tile0 = number of 64 x 64 tiles of the jobs before this one
+ * (a tile grid of ceil(C / 64) x ceil(Rpad / 64) per job), total_tiles = their sum over all jobs. */
+typedef struct alpro_transpose_job {
+  const float* in;
+  void* out;
+  int64_t ld_in, ld_out;
+  int32_t R, C, Rpad, tile0;
+} alpro_transpose_job_t; /* 48 bytes */
+int alpro_transpose_batch(const alpro_transpose_job_t* jobs, int njobs, int total_tiles, int out_dtype, void* stream);
+
 /* out[m, :] = (dtype)(row_scale[m / group] * src[map(m), :]) over D == 768: turns the fp32 token-gradient tensor into
  * the operand rows of the backward GEMMs (inverse of the forward scatter maps, drop-path scale re-applied).  Under
  * FRAME_TOKENS the j == 0 rows read the clip's CLS row times cls_scale (= 1/T, the frame mean of vit.py:187). */

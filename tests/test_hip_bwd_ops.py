@@ -550,3 +550,38 @@ def test_wgrad_run_to_run_reproducibility():
             one.append(run(True, 20000)[0])
     assert torch.equal(one[0], one[1])
     assert float((one[0] - ref).abs().max()) < 2e-3 * float(ref.abs().max())
+
+
+def test_transpose_batch_and_operand_refresh():
+    """alpro_transpose_batch == the per-matrix alpro_transpose on ragged shapes, and the optimizer-side refresh of the registered W^T
+    operands (modeling/train.py) hands the next backward exactly what the lazy per-Linear path would have produced."""
+    hip = _hip()
+    from alpro_amd.modeling import train as tr
+    from alpro_amd.modeling.weights import OperandCache
+    from alpro_amd.optim import FlatAdamW
+    g = torch.Generator(device="cuda").manual_seed(5)
+    for dt in (torch.bfloat16, torch.float32):
+        srcs = [torch.randn(r, c, device="cuda", generator=g) for r, c in ((768, 768), (2304, 768), (100, 70), (1, 64), (3072, 768), (65, 129))]
+        outs = [torch.full((s.shape[1], (s.shape[0] + 63) // 64 * 64), 7.0, device="cuda", dtype=dt) for s in srcs]
+        table, n, tiles = hip.transpose_jobs(list(zip(srcs, outs)))
+        hip.transpose_batch(table, n, tiles, dt)
+        for s, o in zip(srcs, outs):
+            assert torch.equal(o, hip.transpose(s, out_dtype=dt, pad_to=64))
+    lins = [torch.nn.Linear(768, 768).cuda() for _ in range(3)] + [torch.nn.Linear(768, 3072).cuda()]
+    params = [p for l in lins for p in l.parameters()]
+    opt = FlatAdamW(params, lr=1e-2, allreduce=False)
+    cache = OperandCache()
+
+    def operands():
+        return [tr.transposed_operand(cache, "qkv^T", tuple(l.weight for l in lins[:3]), torch.bfloat16), tr.transposed_operand(cache, "fc^T", lins[3].weight, torch.bfloat16)]
+    for step in range(3):
+        for p in params:
+            p.grad = torch.randn_like(p) if p.grad is None else p.grad.copy_(torch.randn_like(p))
+        before = [o.clone() for o in operands()]
+        opt.step()
+        got = operands()
+        want = [hip.transpose(torch.cat([l.weight.detach() for l in lins[:3]], 0), out_dtype=torch.bfloat16, pad_to=64),
+                hip.transpose(lins[3].weight.detach(), out_dtype=torch.bfloat16, pad_to=64)]
+        for a, b, c in zip(got, want, before):
+            assert torch.equal(a, b) and not torch.equal(a, c)
+    assert len(tr._WT_REGISTRY) >= 2 and tr.refresh_transposed_operands() >= 2
