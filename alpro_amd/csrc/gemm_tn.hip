@@ -150,17 +150,25 @@ __global__ __launch_bounds__(NT3, 1) void gemm_tn_kernel(const T* __restrict__ A
     for (int i = 0; i < 4; ++i) fa[i] = frag8(cA, ks, wr * 128 + i * 32, lane);
   };
   // Bias gradient for free: colsum[n] += sum over tokens of A[m, n].  The A fragments already sit in registers (lane = one
-  // column, 8 tokens per fragment), so the waves of the first k-tile column (k0 == 0, wc == 0) add them up on the VALU
-  // while the MFMA pipe runs -- the separate pass over dY that torch / alpro_colsum_acc would make never happens.
-  const bool do_cs = colsum != nullptr && k0 == 0 && wc == 0;
-  float cs[4] = {0.f, 0.f, 0.f, 0.f};
+  // column, 8 tokens per fragment), so the waves add them up on the VALU while the MFMA pipe
+  // runs -- the separate pass over dY that torch / alpro_colsum_acc would make never happens.  The four waves of a wave row hold
+  // the SAME four A fragments: wave (wr, wc) sums fragment wc only, so the extra VALU work (16 converts + adds per 16 tokens) is
+  // spread evenly -- with the wc == 0 waves doing all four, they arrived late at every barrier and the whole kernel ran 12 % slower.
+  // ... and the k-tiles that share a dY column panel take turns: k-tile tk sums the stages with stage % (number of k-tiles) == tk,
+  // so every wave of every workgroup carries the same small share and the lock-step of the waves is not disturbed (with the k0 == 0
+  // workgroups doing all of it, a third of the workgroups of a K = 768 gradient finished 9 % late).
+  const int tk_cnt = tiles / tn_cnt, tk = tile / tn_cnt;
+  const bool do_cs = colsum != nullptr;
+  int cs_turn = s0 % tk_cnt;
+  float cs = 0.f;
   auto add_cols = [&](const u32x4* fa) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      float f[8];
-      unpack_chunk<T>(fa[i], f);
-      cs[i] += ((f[0] + f[1]) + (f[2] + f[3])) + ((f[4] + f[5]) + (f[6] + f[7]));
-    }
+    for (int i = 0; i < 4; ++i)
+      if (i == wc) {  // wave-uniform
+        float f[8];
+        unpack_chunk<T>(fa[i], f);
+        cs += ((f[0] + f[1]) + (f[2] + f[3])) + ((f[4] + f[5]) + (f[6] + f[7]));
+      }
   };
   u32x4 fa0[4], fb0[2], fa1[4], fb1[2];
   asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
@@ -179,7 +187,9 @@ __global__ __launch_bounds__(NT3, 1) void gemm_tn_kernel(const T* __restrict__ A
         mma_chunk<T>(acc[i][j], fa0[i], fb0[j]);
         if (j == 1 && (i & 1) == pos) copy(2 + (i >> 1), b3);  // piece 1 (A, B) of stage st+3
       }
-    if (do_cs) add_cols(fa0);
+    const bool cs_now = do_cs && cs_turn == tk;
+    cs_turn = cs_turn + 1 == tk_cnt ? 0 : cs_turn + 1;
+    if (cs_now) add_cols(fa0);
     advance(1);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
@@ -194,17 +204,14 @@ __global__ __launch_bounds__(NT3, 1) void gemm_tn_kernel(const T* __restrict__ A
         mma_chunk<T>(acc[i][j], fa1[i], fb1[j]);
         if (j == 1 && (i & 1) == pos) copy(i >> 1, cur);  // piece 0 (A, B) of stage st+4
       }
-    if (do_cs) add_cols(fa1);
+    if (cs_now) add_cols(fa1);
     advance(0);
   }
   if (do_cs) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const float t = cs[i] + __shfl_xor(cs[i], 32, 64);  // the two token halves of the fragment
-      const int n = n0 + wr * 128 + i * 32 + (lane & 31);
-      if (lane < 32 && part_cs) part_cs[(int64_t)range * (tn_cnt * TW) + n] = t;  // workspace mode: summed by tn_reduce_kernel
-      else if (lane < 32 && n < N) unsafeAtomicAdd(colsum + n, t);
-    }
+    const float t = cs + __shfl_xor(cs, 32, 64);  // the two token halves of the fragment
+    const int n = n0 + wr * 128 + wc * 32 + (lane & 31);
+    if (lane < 32 && part_cs) part_cs[((int64_t)range * tk_cnt + tk) * (tn_cnt * TW) + n] = t;  // workspace mode: summed by tn_reduce_kernel
+    else if (lane < 32 && n < N) unsafeAtomicAdd(colsum + n, t);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the tail copies (zero page) before the wave exits
   if (ablate == 1 && acc[0][0][0] != 12345.f) return;  // measurement only (tn_kind 1): no atomic epilogue
@@ -245,13 +252,16 @@ __global__ __launch_bounds__(NT3, 1) void gemm_tn_kernel(const T* __restrict__ A
 __global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict__ part, const float* __restrict__ part_cs, float* __restrict__ C,
                                                         int64_t ldc, float* __restrict__ colsum, int N, int K, int tiles, int ranges, int tn_cnt) {
   const int tile_blocks = tiles * 64;
-  if ((int)blockIdx.x >= tile_blocks) {  // bias gradient: one thread per column
-    const int n = (blockIdx.x - tile_blocks) * 256 + threadIdx.x;
-    if (n < N) {
-      float t = 0.f;
-      for (int r = 0; r < ranges; ++r) t += part_cs[(int64_t)r * (tn_cnt * TW) + n];
-      colsum[n] += t;
-    }
+  if ((int)blockIdx.x >= tile_blocks) {  // bias gradient: 32 columns per block, the partial sets dealt to 8 thread groups
+    __shared__ float red[8][32];
+    const int c = threadIdx.x & 31, p = threadIdx.x >> 5;
+    const int n = (blockIdx.x - tile_blocks) * 32 + c;
+    const int sets = ranges * (tiles / tn_cnt);  // one partial per (token range, k-tile)
+    float t = 0.f;
+    for (int r = p; r < sets; r += 8) t += part_cs[(int64_t)r * (tn_cnt * TW) + n];
+    red[p][c] = t;
+    __syncthreads();
+    if (p == 0 && n < N) colsum[n] += ((red[0][c] + red[1][c]) + (red[2][c] + red[3][c])) + ((red[4][c] + red[5][c]) + (red[6][c] + red[7][c]));
     return;
   }
   const int tile = blockIdx.x >> 6, f = ((blockIdx.x & 63) << 8) + threadIdx.x;
@@ -358,7 +368,7 @@ TnPlan tn_plan(int M, int N, int K, bool ws) {
   p.ranges = (p.total_steps + p.per - 1) / p.per;
   p.units = p.ranges * p.tiles;
   p.part_floats = p.ranges > 1 ? (size_t)p.units * TW * TW : 0;
-  p.cs_floats = p.ranges > 1 ? (size_t)p.ranges * p.tn * TW : 0;
+  p.cs_floats = p.ranges > 1 ? (size_t)p.ranges * (p.tiles / p.tn) * p.tn * TW : 0;
   return p;
 }
 }  // namespace
@@ -400,7 +410,7 @@ extern "C" int alpro_gemm_tn_acc_ws(const void* A, int64_t lda, const void* B, i
     hipLaunchKernelGGL(gemm_tn_kernel<f16_t>, dim3(grid), dim3(NT3), lds, st, (const f16_t*)A, lda, (const f16_t*)B, ldb, C, ldc, M, N, K, p.per, p.tiles, p.units, p.tn, colsum, part, part_cs, kind);
   }
   if (part && kind != 1)
-    hipLaunchKernelGGL(tn_reduce_kernel, dim3(p.tiles * 64 + (part_cs ? p.tn : 0)), dim3(256), 0, st, part, part_cs, C, ldc, colsum, N, K, p.tiles, p.ranges, p.tn);
+    hipLaunchKernelGGL(tn_reduce_kernel, dim3(p.tiles * 64 + (part_cs ? p.tn * (TW / 32) : 0)), dim3(256), 0, st, part, part_cs, C, ldc, colsum, N, K, p.tiles, p.ranges, p.tn);
   return check_launch("alpro_gemm_tn_acc");
 }
 
