@@ -10,12 +10,12 @@
 //  * MFMA operands need 8 consecutive tokens of ONE column per lane: ds_read_b64_tr_b16 gathers 4 tokens x 16
 //    columns per 16-lane group (semantics: tools/probe_tr.hip); the 16-byte chunk index is XOR-ed with
 //    (token & 3) << 2 on the DMA source side so the four token rows of a gather sit in different 64-byte windows;
-//  * split over M: wgrad outputs are tiny (768..3072 x 768) while M is ~10^5, so the token range is cut into slices;
-//    slice s runs on XCD s % 8 (1-D grid decoded by hand, tools/probe_xcd.hip) so each token row is fetched from HBM
-//    once and re-used by the slice's other tiles out of that XCD's L2; the slice count is chosen against the measured
-//    fixed cost of a workgroup (~26 us, mostly the 256 KiB atomic epilogue); partial tiles are combined with hardware
-//    fp32 atomics, which is also what "accumulate into .grad" needs;
-//  * optional bias gradient: the waves of the first k-tile column sum their dY fragments on the VALU (colsum).
+//  * split over M: wgrad outputs are tiny (768..3072 x 768) while M is ~10^5, so the token dimension is cut into R ranges and a
+//    workgroup takes one (range, tile) unit; R is chosen so that R x tiles fills the 256 CUs in one round (36 tiles -> 7 ranges);
+//    the 1-D grid is decoded so that an XCD owns a contiguous run of units (tools/probe_xcd.hip) and the cross-XCD re-use of token
+//    rows is left to the Infinity Cache; partial tiles are combined with hardware fp32 atomics (which is also what "accumulate
+//    into .grad" needs) or, bit-reproducibly, through a workspace + tn_reduce_kernel (alpro_gemm_tn_acc_ws);
+//  * optional bias gradient: the waves sum their dY fragments on the VALU (colsum), every wave an equal share.
 // Rows >= M / columns >= N,K read a zero page, so no operand needs padding.
 #include "common.hpp"
 

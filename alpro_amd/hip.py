@@ -102,7 +102,8 @@ _option_values = {}
 
 
 def set_option(name, value):
-    """Measurement knob of the library (alpro_hip_set_option): 'gemm_tile', 'gemm_grid', 'gemm_tune', 'tn_splits'."""
+    """Measurement knob of the library (alpro_hip_set_option): 'gemm_tile', 'gemm_grid', 'gemm_tune', 'tn_splits' (token ranges of the
+    weight-gradient GEMM), 'tn_kind' (1 = no wgrad epilogue, timing only)."""
     _check(load().alpro_hip_set_option(name.encode(), int(value)), "alpro_hip_set_option")
     _option_values[name] = int(value)
 

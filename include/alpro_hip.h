@@ -48,7 +48,8 @@ enum { ALPRO_MAP_IDENTITY = 0, ALPRO_MAP_SKIP_CLS = 1, ALPRO_MAP_FRAME_TOKENS = 
 const char* alpro_hip_last_error(void);
 int alpro_hip_abi_version(void);
 /* Measurement knobs (never change results): "gemm_tile" (128 / 256 forces a tile kernel, 0 = heuristic), "gemm_grid" (cap of the
- * persistent grid), "gemm_tune" (DMA issue placement variant / ablations), "tn_splits" (wgrad slice count).  Defaults come from the
+ * persistent grid), "gemm_tune" (DMA issue placement variant / ablations), "tn_splits" (number of token ranges of the weight-gradient GEMM), "tn_kind" (1: weight-gradient workgroups return before their
+ * epilogue -- timing only, results are garbage).  Defaults come from the
  * environment (ALPRO_GEMM_TILE, ...) once at load time; there is no reference counterpart (tools/ and bench.py use it). */
 int alpro_hip_set_option(const char* name, int value);
 
