@@ -250,7 +250,7 @@ __global__ __launch_bounds__(NW * 64) void gather_cast_kernel(const float* __res
         u32x2 u;
         u.x = pack2(v[4 * i], v[4 * i + 1], (T*)0);
         u.y = pack2(v[4 * i + 2], v[4 * i + 3], (T*)0);
-        __builtin_nontemporal_store(u, (u32x2*)p);
+        *(u32x2*)p = u;  // plain store: the wgrad / dgrad GEMMs read it next out of the Infinity Cache (see ln_store in core.hip)
       }
     }
   };

@@ -152,7 +152,8 @@ __device__ __forceinline__ void ln_store(T* row, int lane, const float (&v)[12])
       u32x2 u;
       u.x = pack2(v[4 * i], v[4 * i + 1], (T*)0);
       u.y = pack2(v[4 * i + 2], v[4 * i + 3], (T*)0);
-      __builtin_nontemporal_store(u, (u32x2*)p);
+      *(u32x2*)p = u;  // plain, not non-temporal: 154 MB at the benchmark size stay in the Infinity Cache for the GEMM that reads them next
+                       // (step 174.1 -> 171.4 ms together with gather_cast; the same change on GEMM / attention outputs LOSES 5 ms)
     }
   }
 }
