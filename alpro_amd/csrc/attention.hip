@@ -408,7 +408,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd16_kernel(const T* __restrict_
         const int row = p * 8 + (lane >> 3), slot = lane & 7;
         const u32x4 v = *(const u32x4*)(Ow + row * 128 + ((slot ^ ((row >> 1) & 7)) << 4));
         const int qq = qt * 32 + row;
-        if (qq < L) __builtin_nontemporal_store(v, (u32x4*)(out + ((int64_t)b * L + qq) * H * HD + h * HD + slot * 8));
+        if (qq < L) store16_sc1(out + ((int64_t)b * L + qq) * H * HD + h * HD + slot * 8, v);
       }
     } else {  // the two 32-wide d halves one after the other, as 64-byte row pieces
 #pragma unroll
@@ -425,7 +425,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd16_kernel(const T* __restrict_
           const int row = p * 16 + (lane >> 2), slot = lane & 3;
           const u32x4 v = *(const u32x4*)(Ow + row * 64 + ((slot ^ ((row >> 2) & 3)) << 4));
           const int qq = qt * 32 + row;
-          if (qq < L) __builtin_nontemporal_store(v, (u32x4*)(out + ((int64_t)b * L + qq) * H * HD + h * HD + dt * 32 + slot * 8));
+          if (qq < L) store16_sc1(out + ((int64_t)b * L + qq) * H * HD + h * HD + dt * 32 + slot * 8, v);
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       }
@@ -581,7 +581,7 @@ __global__ __launch_bounds__(256, 2) void attn_temporal_fwd16_kernel(const T* __
     for (int p = 0; p < 4; ++p) {
       const int row = p * 8 + (lane >> 3), slot = lane & 7;
       const u32x4 v = *(const u32x4*)(tK + row * 128 + ((slot ^ ((row >> 1) & 7)) << 4));
-      if (row < Le) __builtin_nontemporal_store(v, (u32x4*)(out + (r0 + row) * ldo + h * HD + slot * 8));
+      if (row < Le) store16_sc1(out + (r0 + row) * ldo + h * HD + slot * 8, v);
     }
   }
 }

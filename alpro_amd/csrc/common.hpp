@@ -174,6 +174,12 @@ __host__ __device__ inline uint32_t drop_thresh24(float p) { return (uint32_t)(p
 __device__ __forceinline__ void dma16(const void* src, uint32_t lds_addr) {
   asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(lds_addr) : "memory", "m0");
 }
+// 16-byte write-through store (sc1): the line leaves the XCD's L2 and lands memory-side.  Used for the attention outputs (read next by
+// the projection GEMM / the weight gradient): same speed as a non-temporal store for the attention kernel, ~0.3 % of the step for its
+// consumers (profiles/r2_gemm_epilogue_experiments.txt, experiment 10d); on the GEMM's own 16-bit outputs it LOSES 1.8 ms.
+__device__ __forceinline__ void store16_sc1(void* p, const u32x4& v) {
+  asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+}
 __device__ __forceinline__ uint32_t lds_addr_of(const void* p) { return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)p; }
 
 // ---- host side -----------------------------------------------------------------------------
