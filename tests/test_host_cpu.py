@@ -57,6 +57,31 @@ def test_gemm_desc_matches_header_layout():
     assert ctypes.sizeof(hip.GemmDesc) == 184
 
 
+def test_transpose_job_layout_and_wgrad_workspace_plan():
+    """Host-side pieces of two entry points: the job record of alpro_transpose_batch mirrors the header, and
+    alpro_gemm_tn_workspace_bytes (pure host arithmetic: the token-range plan of the weight-gradient GEMM) gives the documented
+    splits -- 36 tiles x 7 ranges and 9 tiles x 28 ranges fill the 256 CUs in one round, tiny problems are not split."""
+    from alpro_amd import hip
+    hdr = open(os.path.join(ROOT, "include", "alpro_hip.h")).read()
+    body = hdr[hdr.index("typedef struct alpro_transpose_job {"):hdr.index("} alpro_transpose_job_t;")]
+    names = re.findall(r"(\w+)\s*[,;]", re.sub(r"/\*.*?\*/", "", body.split("{", 1)[1], flags=re.S))
+    assert names == [f[0].rstrip("_") for f in hip.TransposeJob._fields_], names
+    assert ctypes.sizeof(hip.TransposeJob) == 48
+    lib = hip.load()
+    tile, M = 256 * 256 * 4, 100416
+
+    def ranges(m, n, k):
+        tn, tk = (n + 255) // 256, (k + 255) // 256
+        nbytes = lib.alpro_gemm_tn_workspace_bytes(m, n, k)
+        per_range = tn * tk * tile + tk * tn * 256 * 4      # partial tiles + one bias-gradient partial per (range, k-tile)
+        assert nbytes % per_range == 0, (nbytes, per_range)
+        return nbytes // per_range
+    assert ranges(M, 3072, 768) == 7 and ranges(M, 768, 3072) == 7      # 36 tiles -> 252 workgroups
+    assert ranges(M, 2304, 768) == 9 and ranges(M, 768, 768) == 28      # 27 -> 243, 9 -> 252
+    assert lib.alpro_gemm_tn_workspace_bytes(64, 8, 8) == 0              # one range: nothing to combine
+    assert lib.alpro_gemm_tn_workspace_bytes(0, 8, 8) == 0
+
+
 def test_ops_refuse_cpu_tensors():
     from alpro_amd import hip
     with pytest.raises(RuntimeError, match="no CPU fallback"):
