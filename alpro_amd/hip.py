@@ -428,12 +428,13 @@ def gemm_tn_acc(a, b, c, colsum=None, atomic=None):
     M, N, K = a.shape[0], a.shape[1], b.shape[1]
     if atomic is None:
         atomic = not _DETERMINISTIC_WGRAD[0] and M > 65536 and ((N + 255) // 256) * ((K + 255) // 256) > 9
-    nbytes = 0 if atomic else lib.alpro_gemm_tn_workspace_bytes(M, N, K)
-    if nbytes == 0:
+    if atomic:
         _check(lib.alpro_gemm_tn_acc(_ptr(a), a.stride(0), _ptr(b), b.stride(0), _ptr(c), c.stride(0), _CODE[a.dtype], M, N, K, _ptr(colsum), _stream()),
                "alpro_gemm_tn_acc")
         return c
-    ws = _tn_workspace(a.device, nbytes)
+    # always hand over the buffer, even when this shape needs none (0 bytes = the workspace plan keeps ONE token range): a NULL workspace
+    # would select the atomic plan, which may split where the workspace plan does not
+    ws = _tn_workspace(a.device, lib.alpro_gemm_tn_workspace_bytes(M, N, K))
     _check(lib.alpro_gemm_tn_acc_ws(_ptr(a), a.stride(0), _ptr(b), b.stride(0), _ptr(c), c.stride(0), _CODE[a.dtype], M, N, K, _ptr(colsum),
                                     _ptr(ws), ws.numel(), _stream()), "alpro_gemm_tn_acc_ws")
     return c
