@@ -265,6 +265,68 @@ def _tiny_timesformer(num_frm=4):
     return TimeSformer(dict(VENC, num_frm=num_frm), input_format="RGB")
 
 
+def test_transposed_operand_registry_host_logic(monkeypatch):
+    """modeling/train.py keeps the dgrad operands W^T of all Linear layers in a registry and rewrites them with ONE batched launch
+    after each optimizer step.  The bookkeeping on CPU tensors (the three hip entry points replaced by torch stand-ins): only
+    parameters inside the flat optimizer buffer are registered (frozen ones never go stale), q / k / v stored back to back become one
+    fused job, a refresh re-reads the CURRENT parameter values and stamps the operand valid, operands replaced or dropped meanwhile
+    leave the registry, and a value changed behind the registry's back still falls through to the lazy path."""
+    from alpro_amd import hip
+    from alpro_amd.modeling import train as tr
+    from alpro_amd.modeling import weights as w
+    launches = []
+
+    def fake_transpose(x, out_dtype=None, pad_to=1, colsum=None):
+        rp = (x.shape[0] + pad_to - 1) // pad_to * pad_to
+        out = torch.zeros(x.shape[1], rp, dtype=out_dtype or x.dtype)
+        out[:, :x.shape[0]] = x.t().to(out.dtype)
+        return out
+
+    def fake_jobs(pairs):
+        return list(pairs), len(pairs), sum(((s.shape[1] + 63) // 64) * ((o.shape[1] + 63) // 64) for s, o in pairs)
+
+    def fake_batch(table, njobs, tiles, dt):
+        launches.append(njobs)
+        for src, out in table:
+            out[:, :src.shape[0]] = src.t().to(dt)
+    monkeypatch.setattr(hip, "transpose", fake_transpose)
+    monkeypatch.setattr(hip, "transpose_jobs", fake_jobs)
+    monkeypatch.setattr(hip, "transpose_batch", fake_batch)
+    monkeypatch.setattr(torch.Tensor, "is_cuda", property(lambda self: True))      # the registry only tracks device tensors
+    tr._WT_REGISTRY.clear()
+    tr._WT_TABLE.clear()
+    flat = torch.randn(3 * 64 * 32 + 48 * 32)
+    q, k, v = (torch.nn.Parameter(flat[i * 2048:(i + 1) * 2048].view(64, 32)) for i in range(3))
+    fc = torch.nn.Parameter(flat[6144:6144 + 1536].view(48, 32))
+    frozen = torch.nn.Parameter(torch.randn(16, 32))
+    w.bump_param_epoch()
+    w.register_flat_lp(flat, None, [q, k, v, fc])
+    cache = w.OperandCache()
+    ops = dict(qkv=tr.transposed_operand(cache, "qkv^T", (q, k, v), torch.bfloat16), fc=tr.transposed_operand(cache, "fc^T", fc, torch.bfloat16),
+               fr=tr.transposed_operand(cache, "frozen^T", frozen, torch.bfloat16))
+    assert ops["qkv"].shape == (32, 192) and ops["fc"].shape == (32, 64)            # (K, N padded to 64)
+    assert set(k_[1] for k_ in tr._WT_REGISTRY) == {"qkv^T", "fc^T"}               # the frozen parameter is not tracked
+    assert tr.transposed_operand(cache, "fc^T", fc, torch.bfloat16) is ops["fc"]    # cache hit while the version stands
+    with torch.no_grad():
+        flat.mul_(2.0)                      # what FlatAdamW's kernel does: the values change behind torch's version counters
+    w.bump_param_epoch()
+    w.register_flat_lp(flat, None, [q, k, v, fc])
+    assert tr.refresh_transposed_operands() == 2 and launches == [2]
+    assert torch.equal(ops["qkv"], torch.cat([q, k, v], 0).detach().t().to(torch.bfloat16))
+    assert torch.equal(ops["fc"][:, :48], fc.detach().t().to(torch.bfloat16))
+    assert tr.transposed_operand(cache, "qkv^T", (q, k, v), torch.bfloat16) is ops["qkv"]   # stamped valid: no lazy transpose
+    cache._store.pop("fc^T")                                                                 # operand dropped meanwhile
+    w.bump_param_epoch()
+    w.register_flat_lp(flat, None, [q, k, v, fc])
+    assert tr.refresh_transposed_operands() == 1 and launches == [2, 1]
+    with torch.no_grad():
+        q.add_(1.0)                         # an in-place edit torch DOES see (checkpoint load, manual init)
+    again = tr.transposed_operand(cache, "qkv^T", (q, k, v), torch.bfloat16)
+    assert again is not ops["qkv"] and torch.equal(again, torch.cat([q, k, v], 0).detach().t().to(torch.bfloat16))
+    tr._WT_REGISTRY.clear()
+    tr._WT_TABLE.clear()
+
+
 def test_timesformer_load_state_dict_from_checkpoint_paths(tmp_path, monkeypatch):
     """TimeSformer.load_state_dict(<str>) as load_separate_ckpt calls it (vit.py:515-533 -> helpers.py:207-375): a Kinetics checkpoint
     ('model_state' wrapper, 'model.' prefixes, 8-frame time table, other classifier) is strict-loaded with the tables resampled; a
