@@ -1,6 +1,9 @@
 """Build libalpro_hip.so for gfx950 with hipcc (cross-compiles without a GPU).
 
-    python -m alpro_amd.build [--force]
+    python -m alpro_amd.build [--force] [--ablations]
+
+--ablations (or ALPRO_ABLATIONS=1) builds the MEASUREMENT variant lib/libalpro_hip_ablate.so with -DALPRO_ABLATIONS: the
+result-corrupting knobs of tools/ (gemm_tune 3/4/10/11/12, tn_kind 1) exist only there; load it with ALPRO_HIP_LIB=<path>.
 
 One object per .hip file (parallel), linked into alpro_amd/lib/libalpro_hip.so.  The .so is
 git-ignored but travels to the GPU box with the repo snapshot.
@@ -15,9 +18,12 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 OBJDIR = os.path.join(LIBDIR, "obj")
-LIB = os.path.join(LIBDIR, "libalpro_hip.so")
+ABLATIONS = os.environ.get("ALPRO_ABLATIONS", "0") == "1" or "--ablations" in sys.argv
+if ABLATIONS:
+    OBJDIR = os.path.join(LIBDIR, "obj_ablate")
+LIB = os.path.join(LIBDIR, "libalpro_hip_ablate.so" if ABLATIONS else "libalpro_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"] + (["-DALPRO_ABLATIONS"] if ABLATIONS else [])
 
 
 def _sources():

@@ -108,7 +108,11 @@ class _DistributedOptimizer:
         if not self._synced and not self._skip:
             self.synchronize()
         self._synced = False
-        return self._opt.step() if closure is None else self._opt.step(closure)
+        out = self._opt.step() if closure is None else self._opt.step(closure)
+        if not hasattr(self._opt, "flat"):   # any optimizer but FlatAdamW updated the parameters in place: 16-bit operand copies are stale
+            from alpro_amd.modeling.weights import notify_params_updated
+            notify_params_updated()
+        return out
 
     def zero_grad(self, *a, **k):
         return self._opt.zero_grad(*a, **k)

@@ -22,11 +22,29 @@ namespace {
 const char* const kOptNames[OPT_COUNT] = {"gemm_tile", "gemm_grid", "gemm_tune", "tn_splits", "tn_kind"};
 const char* const kOptEnv[OPT_COUNT] = {"ALPRO_GEMM_TILE", "ALPRO_GEMM_GRID", "ALPRO_GEMM_TUNE", "ALPRO_TN_SPLITS", "ALPRO_TN_KIND"};
 int g_opts[OPT_COUNT];
+// Values that change RESULTS (gemm_tune 3 / 4 / 10 / 11 / 12: epilogue / synchronisation ablations; tn_kind 1: weight gradient without
+// its epilogue) exist only in the measurement build (-DALPRO_ABLATIONS, `python -m alpro_amd.build --ablations`, used by tools/); the
+// product library refuses them, from alpro_hip_set_option and from the environment alike.
+bool option_allowed(int which, int value) {
+#ifdef ALPRO_ABLATIONS
+  (void)which; (void)value;
+  return true;
+#else
+  if (which == OPT_GEMM_TUNE) return value >= 0 && value <= 2;
+  if (which == OPT_TN_KIND) return value == 0;
+  return value >= 0;
+#endif
+}
 struct OptInit {
   OptInit() {
     for (int i = 0; i < OPT_COUNT; ++i) {
       const char* e = getenv(kOptEnv[i]);
-      g_opts[i] = e ? atoi(e) : (i == OPT_GEMM_TUNE ? 1 : 0);
+      const int dflt = i == OPT_GEMM_TUNE ? 1 : 0;
+      g_opts[i] = e ? atoi(e) : dflt;
+      if (!option_allowed(i, g_opts[i])) {
+        fprintf(stderr, "libalpro_hip: %s=%d is a result-corrupting ablation and is not part of this build (ignored)\n", kOptEnv[i], g_opts[i]);
+        g_opts[i] = dflt;
+      }
     }
   }
 } g_opt_init;
@@ -280,6 +298,10 @@ extern "C" int alpro_hip_set_option(const char* name, int value) {
   using namespace alpro;
   for (int i = 0; name && i < OPT_COUNT; ++i)
     if (!strcmp(name, kOptNames[i])) {
+      if (!option_allowed(i, value)) {
+        set_error("alpro_hip_set_option: %s=%d is a result-corrupting ablation, only available in the measurement build (-DALPRO_ABLATIONS)", name, value);
+        return ALPRO_ERR_INVALID;
+      }
       __atomic_store_n(&g_opts[i], value, __ATOMIC_RELAXED);
       return ALPRO_OK;
     }

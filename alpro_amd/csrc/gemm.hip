@@ -659,11 +659,13 @@ int launch_gemm_inst(const alpro_gemm_desc_t& g, hipStream_t st) {
     if constexpr (std::is_same<T, bf16_t>::value && ACT == ALPRO_ACT_NONE && MAP == ALPRO_MAP_IDENTITY) {
       (void)hipFuncSetAttribute((const void*)gemm_nt256p_kernel<T, ACT, MAP, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE2_BYTES + EPI_BYTES);
       (void)hipFuncSetAttribute((const void*)gemm_nt256p_kernel<T, ACT, MAP, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE2_BYTES + EPI_BYTES);
+#ifdef ALPRO_ABLATIONS  // result-corrupting measurement variants: only in the tools/ build (python -m alpro_amd.build --ablations)
       (void)hipFuncSetAttribute((const void*)gemm_nt256p_kernel<T, ACT, MAP, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE2_BYTES + EPI_BYTES);
       (void)hipFuncSetAttribute((const void*)gemm_nt256p_kernel<T, ACT, MAP, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE2_BYTES + EPI_BYTES);
       (void)hipFuncSetAttribute((const void*)gemm_nt256p_kernel<T, ACT, MAP, 12>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE2_BYTES + EPI_BYTES);
       (void)hipFuncSetAttribute((const void*)gemm_nt256p_kernel<T, ACT, MAP, 11>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE2_BYTES + EPI_BYTES);
       (void)hipFuncSetAttribute((const void*)gemm_nt256p_kernel<T, ACT, MAP, 10>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE2_BYTES + EPI_BYTES);
+#endif
     }
   });
   const int big_tiles = ((g.N + BN2 - 1) / BN2) * ((g.M + BM2 - 1) / BM2);
@@ -678,11 +680,13 @@ int launch_gemm_inst(const alpro_gemm_desc_t& g, hipStream_t st) {
     if constexpr (std::is_same<T, bf16_t>::value && ACT == ALPRO_ACT_NONE && MAP == ALPRO_MAP_IDENTITY) {
       if (tune == 0) { hipLaunchKernelGGL((gemm_nt256p_kernel<T, ACT, MAP, 0>), dim3(grid), dim3(NT2), 4 * TILE2_BYTES + EPI_BYTES, st, g); return check_launch("alpro_gemm"); }
       if (tune == 2) { hipLaunchKernelGGL((gemm_nt256p_kernel<T, ACT, MAP, 2>), dim3(grid), dim3(NT2), 4 * TILE2_BYTES + EPI_BYTES, st, g); return check_launch("alpro_gemm"); }
+#ifdef ALPRO_ABLATIONS
       if (tune == 3) { hipLaunchKernelGGL((gemm_nt256p_kernel<T, ACT, MAP, 3>), dim3(grid), dim3(NT2), 4 * TILE2_BYTES + EPI_BYTES, st, g); return check_launch("alpro_gemm"); }
       if (tune == 4) { hipLaunchKernelGGL((gemm_nt256p_kernel<T, ACT, MAP, 4>), dim3(grid), dim3(NT2), 4 * TILE2_BYTES + EPI_BYTES, st, g); return check_launch("alpro_gemm"); }
       if (tune == 12) { hipLaunchKernelGGL((gemm_nt256p_kernel<T, ACT, MAP, 12>), dim3(grid), dim3(NT2), 4 * TILE2_BYTES + EPI_BYTES, st, g); return check_launch("alpro_gemm"); }
       if (tune == 11) { hipLaunchKernelGGL((gemm_nt256p_kernel<T, ACT, MAP, 11>), dim3(grid), dim3(NT2), 4 * TILE2_BYTES + EPI_BYTES, st, g); return check_launch("alpro_gemm"); }
       if (tune == 10) { hipLaunchKernelGGL((gemm_nt256p_kernel<T, ACT, MAP, 10>), dim3(grid), dim3(NT2), 4 * TILE2_BYTES + EPI_BYTES, st, g); return check_launch("alpro_gemm"); }
+#endif
     }
     hipLaunchKernelGGL((gemm_nt256p_kernel<T, ACT, MAP>), dim3(grid), dim3(NT2), 4 * TILE2_BYTES + EPI_BYTES, st, g);
   } else {

@@ -214,7 +214,9 @@ __global__ __launch_bounds__(NT3, 1) void gemm_tn_kernel(const T* __restrict__ A
     else if (lane < 32 && n < N) unsafeAtomicAdd(colsum + n, t);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the tail copies (zero page) before the wave exits
-  if (ablate == 1 && acc[0][0][0] != 12345.f) return;  // measurement only (tn_kind 1): no atomic epilogue
+#ifdef ALPRO_ABLATIONS
+  if (ablate == 1 && acc[0][0][0] != 12345.f) return;  // measurement only (tn_kind 1, tools/ build): no epilogue, results are garbage
+#endif
   if (part) {
     // Workspace mode: the partial tile goes out in accumulator order -- 16 bytes per lane, 1 KiB per wave instruction, 32 plain
     // stores per lane instead of 128 fabric atomics -- and tn_reduce_kernel adds the partials of a tile to C in a fixed order.
@@ -251,7 +253,7 @@ __global__ __launch_bounds__(NT3, 1) void gemm_tn_kernel(const T* __restrict__ A
 // of wave w = f >> 11 is rows wr*128 + i*32 + 8q + 4*(lane >> 5) + {0..3}, column wc*64 + j*32 + (lane & 31).
 __global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict__ part, const float* __restrict__ part_cs, float* __restrict__ C,
                                                         int64_t ldc, float* __restrict__ colsum, int N, int K, int tiles, int ranges, int tn_cnt) {
-  const int tile_blocks = tiles * 64;
+  const int tile_blocks = part ? tiles * 64 : 0;  // part == NULL: one token range, the tile went straight to C; only the bias partials are summed
   if ((int)blockIdx.x >= tile_blocks) {  // bias gradient: 32 columns per block, the partial sets dealt to 8 thread groups
     __shared__ float red[8][32];
     const int c = threadIdx.x & 31, p = threadIdx.x >> 5;
@@ -368,7 +370,10 @@ TnPlan tn_plan(int M, int N, int K, bool ws) {
   p.ranges = (p.total_steps + p.per - 1) / p.per;
   p.units = p.ranges * p.tiles;
   p.part_floats = p.ranges > 1 ? (size_t)p.units * TW * TW : 0;
-  p.cs_floats = p.ranges > 1 ? (size_t)p.ranges * (p.tiles / p.tn) * p.tn * TW : 0;
+  // bias-gradient partials: one per (token range, k-tile).  The workspace plan routes them through tn_reduce_kernel even for ONE range
+  // (K = 3072 has 12 k-tiles): atomics from the k-tiles of a column panel would arrive in arbitrary order and the "bit-reproducible"
+  // promise of the workspace path would not cover the bias gradient.
+  p.cs_floats = (ws || p.ranges > 1) ? (size_t)p.ranges * (p.tiles / p.tn) * p.tn * TW : 0;
   return p;
 }
 }  // namespace
@@ -390,13 +395,17 @@ extern "C" int alpro_gemm_tn_acc_ws(const void* A, int64_t lda, const void* B, i
   const TnPlan p = tn_plan(M, N, K, ws);
   float* part = nullptr;
   float* part_cs = nullptr;
-  if (ws && p.ranges > 1) {
+  if (ws) {
     ALPRO_CHECK(((uintptr_t)workspace % 16) == 0 && workspace_bytes >= (p.part_floats + p.cs_floats) * sizeof(float),
                 "alpro_gemm_tn_acc_ws: workspace must be 16-byte aligned and hold alpro_gemm_tn_workspace_bytes(M, N, K) bytes");
-    part = (float*)workspace;
-    part_cs = colsum ? part + p.part_floats : nullptr;
+    part = p.ranges > 1 ? (float*)workspace : nullptr;
+    part_cs = colsum ? (float*)workspace + p.part_floats : nullptr;
   }
+#ifdef ALPRO_ABLATIONS
   const int kind = get_option(OPT_TN_KIND);
+#else
+  const int kind = 0;
+#endif
   const unsigned grid = (unsigned)((p.units + 7) / 8 * 8);
   const size_t lds = (size_t)NSTAGE * 2 * IMG_BYTES;
   hipStream_t st = (hipStream_t)stream;
@@ -409,8 +418,8 @@ extern "C" int alpro_gemm_tn_acc_ws(const void* A, int64_t lda, const void* B, i
     once.run([&] { (void)hipFuncSetAttribute((const void*)gemm_tn_kernel<f16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); });
     hipLaunchKernelGGL(gemm_tn_kernel<f16_t>, dim3(grid), dim3(NT3), lds, st, (const f16_t*)A, lda, (const f16_t*)B, ldb, C, ldc, M, N, K, p.per, p.tiles, p.units, p.tn, colsum, part, part_cs, kind);
   }
-  if (part && kind != 1)
-    hipLaunchKernelGGL(tn_reduce_kernel, dim3(p.tiles * 64 + (part_cs ? p.tn * (TW / 32) : 0)), dim3(256), 0, st, part, part_cs, C, ldc, colsum, N, K, p.tiles, p.ranges, p.tn);
+  if ((part || part_cs) && kind != 1)
+    hipLaunchKernelGGL(tn_reduce_kernel, dim3((part ? p.tiles * 64 : 0) + (part_cs ? p.tn * (TW / 32) : 0)), dim3(256), 0, st, part, part_cs, C, ldc, colsum, N, K, p.tiles, p.ranges, p.tn);
   return check_launch("alpro_gemm_tn_acc");
 }
 

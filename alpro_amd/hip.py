@@ -9,7 +9,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libalpro_hip.so")
+LIB_PATH = os.environ.get("ALPRO_HIP_LIB") or os.path.join(_HERE, "lib", "libalpro_hip.so")  # ALPRO_HIP_LIB: tools/ load the ablation build
 
 F32, BF16, F16 = 0, 1, 2
 ACT_NONE, ACT_GELU, ACT_RELU, ACT_GELU_BWD = 0, 1, 2, 3
@@ -401,12 +401,13 @@ def _tn_workspace(device, nbytes):
     return ws
 
 
-_DETERMINISTIC_WGRAD = [False]
+_DETERMINISTIC_WGRAD = [os.environ.get("ALPRO_ATOMIC_WGRAD", "0") != "1"]
 
 
 def set_deterministic_wgrad(on=True):
-    """True: every weight gradient takes the workspace path (bit-reproducible parameter gradients run to run, ~0.3 % of the step);
-    False (default): the faster of the two per shape -- see gemm_tn_acc."""
+    """True (the default since round 3): every weight gradient takes the workspace path -- parameter gradients, bias gradients included,
+    are bit-reproducible run to run; costs ~0.3 % of the training step.  False (opt-in, also ALPRO_ATOMIC_WGRAD=1): the faster of the
+    two plans per shape, fp32 atomics above 65536 tokens -- see gemm_tn_acc."""
     _DETERMINISTIC_WGRAD[0] = bool(on)
 
 
@@ -416,9 +417,10 @@ def gemm_tn_acc(a, b, c, colsum=None, atomic=None):
     atomic=False: alpro_gemm_tn_acc_ws -- the token ranges' partial tiles go through a workspace (one grow-only buffer per device,
     used in stream order) and are added in a fixed order: bit-reproducible.  atomic=True: alpro_gemm_tn_acc, partials combined by
     fp32 atomics (no workspace; run-to-run differences in the last bits, tests/test_hip_bwd_ops.py pins 2e-6 of scale).
-    atomic=None: the measured faster one (tools/gemm_tn_shapes.py) -- the workspace up to 65536 tokens or <= 9 tiles (the
-    workgroups finish together there and the atomics queue up: -10..-25 %), atomics above (the ranges finish spread out and the
-    atomics hide under the stragglers' MFMAs; the extra reduce launch would cost +3..7 %) -- unless set_deterministic_wgrad(True)."""
+    atomic=None: the workspace (deterministic) plan, unless set_deterministic_wgrad(False) opted into the measured faster one per shape
+    (tools/gemm_tn_shapes.py) -- the workspace up to 65536 tokens or <= 9 tiles (the workgroups finish together there and the atomics
+    queue up: -10..-25 %), atomics above (the ranges finish spread out and the atomics hide under the stragglers' MFMAs; the extra
+    reduce launch costs +3..7 % of the kernel)."""
     lib = load()
     _dev(a); _dev(b, a.dtype); _dev(c, torch.float32)
     assert a.shape[0] == b.shape[0] and tuple(c.shape) == (a.shape[1], b.shape[1])

@@ -599,11 +599,13 @@ class _VisualRun:
         hip.layernorm_bwd(dy.view(-1, D), self.tok, m.norm.weight, VIT_EPS, dtok, g, b_, accumulate=False)
         del dy
         ws = torch.zeros((len(m.blocks), D * D + D), dtype=torch.float32, device=dout.device)
-        # Data parallel: this node is the LAST one autograd runs (it was created first and its input needs no gradient), so every
-        # gradient outside the visual encoder is final now and can be exchanged while the ViT backward (half of the backward pass)
-        # runs; the blocks' own gradients follow four blocks at a time (alpro_amd.dist.grads_final -> FlatAdamW).
+        # Data parallel: in the pretraining / retrieval models this node is the LAST one autograd runs (created first, its input needs
+        # no gradient), so every gradient outside the visual encoder is final now and can be exchanged while the ViT backward (half of
+        # the backward pass) runs; the blocks' own gradients follow four blocks at a time (alpro_amd.dist.grads_final -> FlatAdamW).
+        # That is only true when no other anchored backward is still pending (tr.Anchor sets others_pending; a model that anchors the
+        # text encoder first runs this node BEFORE it): then nothing is declared final here and everything goes at synchronize().
         from alpro_amd import dist
-        overlap = dist.size() > 1
+        overlap = dist.size() > 1 and not getattr(self, "others_pending", False)
         if overlap:
             dist.grads_final(all_but=list(self.enc.parameters()))
         nb = len(m.blocks)

@@ -71,7 +71,7 @@ def transposed_operand(cache, key, weight, dt):
     cache._store[key] = (ver, out)
     # a view of the parameter storage itself, of parameters an optimizer with flat storage updates (the only ones that go stale
     # every step; frozen ones never do): re-read by the batched refresh
-    stable = src.data_ptr() == plist[0].data_ptr() and all(v[0] != -1 for v in ver)
+    stable = src.data_ptr() == plist[0].data_ptr() and all(v[0] >= 0 for v in ver)
     if stable and src.dtype == torch.float32 and src.is_cuda:
         _WT_REGISTRY[(id(cache), key)] = dict(cache=weakref.ref(cache), key=key, params=[weakref.ref(p) for p in plist], src=src, out=out)
     else:
@@ -168,6 +168,13 @@ def dgrad(dy_t, wT, out_dtype=None, row_scale=None, row_scale_group=1, gelu_pre=
                     act=hip.ACT_GELU_BWD if gelu_pre is not None else hip.ACT_NONE, pre_act=gelu_pre)
 
 
+# Anchored runs whose backward has not executed yet (weak: an abandoned graph drops out when it is freed).  A run may only declare
+# gradients OUTSIDE itself final -- FlatAdamW then puts them on the wire -- when no other anchored backward is still to come:
+# autograd's node order is not a promise (AlproForSequenceClassification anchors the text encoder BEFORE the visual encoder, so the
+# visual node runs first), and a gradient range that is all-reduced before its backward wrote it makes the replicas diverge silently.
+_LIVE_ANCHORS = weakref.WeakSet()
+
+
 class Anchor(torch.autograd.Function):
     """Ties a hand-written encoder backward into torch.autograd.
 
@@ -183,6 +190,7 @@ class Anchor(torch.autograd.Function):
         ctx.n_act = n_act
         ctx.n_in = len(inputs)
         ctx.set_materialize_grads(False)  # an unused output (mlm_scores: 312 MB at B = 64) arrives as None, not as a zero tensor
+        _LIVE_ANCHORS.add(ctx)
         with torch.no_grad():
             outs = run.forward(*inputs[:n_act])
         ctx.single = torch.is_tensor(outs)
@@ -190,8 +198,13 @@ class Anchor(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, *grads):
-        with torch.no_grad():
-            g = ctx.run.backward(*[None if x is None else x.contiguous() for x in grads])
+        # what the run may assume about the rest of the backward pass: True = some other anchored backward has not run yet
+        ctx.run.others_pending = any(c is not ctx for c in _LIVE_ANCHORS)
+        try:
+            with torch.no_grad():
+                g = ctx.run.backward(*[None if x is None else x.contiguous() for x in grads])
+        finally:
+            _LIVE_ANCHORS.discard(ctx)
         g = (g,) if (torch.is_tensor(g) or g is None) else tuple(g)
         g = g + (None,) * (ctx.n_act - len(g))
         ctx.run = None

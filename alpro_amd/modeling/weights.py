@@ -23,13 +23,40 @@ def param_epoch():
     return _PARAM_EPOCH[0]
 
 
+# Parameters updated by anything ELSE than FlatAdamW.  The reference's own optimizer (src/optimization/adamw.py:88,101) writes through
+# `p.data.addcdiv_` / `p.data.add_`: `.data` carries its own version counter, so p._version does not move and a cache keyed on it
+# alone would hand the forward the INITIAL weights forever.  Every torch.optim.Optimizer.step() (any subclass, the reference's AdamW
+# included) therefore bumps this second epoch through a global post-step hook; the hvd.DistributedOptimizer facade and drivers with
+# hand-rolled updates call notify_params_updated() themselves.
+_EXT_EPOCH = [0]
+
+
+def notify_params_updated():
+    """Parameters outside FlatAdamW's flat buffer may have changed in place: their operand copies are re-cast at next use."""
+    _EXT_EPOCH[0] += 1
+
+
+def _install_optimizer_hook():
+    try:
+        from torch.optim.optimizer import register_optimizer_step_post_hook
+        register_optimizer_step_post_hook(lambda opt, args, kwargs: notify_params_updated())
+    except Exception:  # noqa: BLE001 -- very old torch: the facade / the driver must call notify_params_updated()
+        pass
+
+
+_install_optimizer_hook()
+
+
 def param_version(p):
-    """Cache key of a parameter's VALUE: (data_ptr, torch version counter) plus the optimizer epoch -- but only for parameters that
-    live in a flat optimizer buffer, the only ones updated behind torch's back.  Parameters no optimizer touches (the frozen
-    prompter: 231 M values, 12 merged temporal projections) keep their operand copies across steps instead of being re-cast."""
+    """Cache key of a parameter's VALUE: (epoch tag, data_ptr, torch version counter).  Parameters inside FlatAdamW's flat buffer are
+    updated through raw pointers: tag = the flat optimizer epoch (>= 0).  All others: tag = -1 - (external epoch), which only moves when
+    some torch optimizer stepped (see above) -- so under FlatAdamW the parameters no optimizer touches (the frozen prompter: 231 M
+    values, 12 merged temporal projections) keep their operand copies across steps, and under the reference's AdamW every copy is
+    refreshed after every step.  Parameters that do not require gradients never go stale through an optimizer: tag -1."""
     a = p.data_ptr()
-    in_flat = _FLAT_LP["base"] <= a < _FLAT_LP["end"]
-    return (param_epoch() if in_flat else -1, a, p._version)
+    if _FLAT_LP["base"] <= a < _FLAT_LP["end"]:
+        return (param_epoch(), a, p._version)
+    return (-1 - _EXT_EPOCH[0] if p.requires_grad else -1, a, p._version)
 
 
 # One flat 16-bit copy of every parameter an optimizer with flat storage owns (alpro_amd.optim.FlatAdamW): refreshed by ONE cast

@@ -114,6 +114,60 @@ def _with_retries(what, fn, trials):
     return None
 
 
+def save_training_meta(args):
+    """What every driver calls once on rank 0 before training (load_save.py:19-42; run_pretrain_sparse.py:443, run_video_retrieval.py:
+    363): `{output_dir}/log` and `/ckpt` exist afterwards, `log/args.json` holds the run arguments, `log/model_config.json` a copy of
+    the model config file, and `code.zip` a snapshot of the code base (directories named __pycache__ / output / data / ext or containing
+    'results', and *.pyc / *.ipynb / *.swap / *.pt files, are left out).  `args` is an EasyDict or any mapping / attribute bag with
+    `output_dir` and `model_config`."""
+    import json
+    import os
+    import zipfile
+    get = (lambda k: args[k]) if isinstance(args, dict) else (lambda k: getattr(args, k))
+    out = get("output_dir")
+    os.makedirs(os.path.join(out, "log"), exist_ok=True)
+    os.makedirs(os.path.join(out, "ckpt"), exist_ok=True)
+    plain = dict(args) if isinstance(args, dict) else dict(vars(args))
+    with open(os.path.join(out, "log", "args.json"), "w") as f:
+        json.dump(plain, f, indent=4, sort_keys=True, default=str)
+    with open(get("model_config")) as f:
+        model_config = json.load(f)
+    with open(os.path.join(out, "log", "model_config.json"), "w") as f:
+        json.dump(model_config, f, indent=4, sort_keys=True)
+    code_dir = os.environ.get("ALPRO_CODE_DIR") or os.path.dirname(os.path.dirname(os.path.dirname(os.path.realpath(__file__))))
+    zip_path = os.path.join(out, "code.zip")
+    LOGGER.info("Saving code from %s to %s...", code_dir, zip_path)
+    skip_dirs, skip_ext = {"__pycache__", "output", "data", "ext", ".git", "gpurun_out"}, {".pyc", ".ipynb", ".swap", ".pt", ".so", ".o"}
+    root = os.path.abspath(code_dir)
+    with zipfile.ZipFile(zip_path, "w") as zf:
+        for d, subdirs, files in os.walk(root):
+            subdirs[:] = [x for x in subdirs if x not in skip_dirs and "results" not in x]
+            for name in files:
+                if os.path.splitext(name)[1] in skip_ext:
+                    continue
+                full = os.path.join(d, name)
+                if os.path.realpath(full) == os.path.realpath(zip_path):
+                    continue
+                zf.write(full, os.path.join("code", os.path.relpath(full, root)))
+    LOGGER.info("Saving code done.")
+
+
+def compare_dict_difference(dict1, dict2, dict1_name="dict1", dict2_name="dict2", print_value_diff=True, verbose=False):
+    """(values that differ on shared keys as {key: [(name1, v1), (name2, v2)]}, keys present in only one of the two) --
+    load_save.py:138-176; the restorers use it to report changed run arguments."""
+    import json
+    k1, k2 = set(dict1), set(dict2)
+    shared = k1 & k2
+    only1, only2 = k1 - shared, k2 - shared
+    value_diff = {k: [(dict1_name, dict1[k]), (dict2_name, dict2[k])] for k in shared if dict1[k] != dict2[k]}
+    if verbose:
+        LOGGER.info("keys in %s but not in %s: total %d, %s", dict1_name, dict2_name, len(only1), sorted(only1))
+        LOGGER.info("keys in %s but not in %s: total %d, %s", dict2_name, dict1_name, len(only2), sorted(only2))
+        if print_value_diff:
+            LOGGER.info("%s", json.dumps(value_diff, indent=4, default=str))
+    return value_diff, list(only1) + list(only2)
+
+
 class ModelSaver:
     """`{output_dir}/{prefix}_step_{step}.pt` = model.state_dict() on the CPU; with an optimizer also
     `..._train_state.pt` = {'step', 'optimizer'} (load_save.py:45-70)."""
@@ -160,13 +214,22 @@ class _RestorerBase:
             return torch.load(self.backup_path, map_location="cpu")
 
     def _write(self, checkpoint):
+        """Two generations on disk, and a failed / interrupted save never costs one of them: the new checkpoint is written to
+        `restore.pt.tmp` and fsync'ed FIRST; only then does the current restore.pt become the backup and the new file take its
+        name (both os.replace, atomic on POSIX).  The reference renames before it saves (load_save.py:255-258, 316-319), so a torn
+        save followed by its own retry renames the torn file over the only good backup."""
         import os
         if self.amp:
             from apex import amp
             checkpoint["amp_state_dict"] = amp.state_dict()
+        tmp = self.save_path + ".tmp"
+        with open(tmp, "wb") as f:
+            torch.save(checkpoint, f)
+            f.flush()
+            os.fsync(f.fileno())
         if os.path.exists(self.save_path):
-            os.rename(self.save_path, self.backup_path)   # keep two generations in case a save is interrupted
-        torch.save(checkpoint, self.save_path)
+            os.replace(self.save_path, self.backup_path)
+        os.replace(tmp, self.save_path)
 
     def step(self):
         self.global_step += 1

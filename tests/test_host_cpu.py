@@ -78,8 +78,20 @@ def test_transpose_job_layout_and_wgrad_workspace_plan():
         return nbytes // per_range
     assert ranges(M, 3072, 768) == 7 and ranges(M, 768, 3072) == 7      # 36 tiles -> 252 workgroups
     assert ranges(M, 2304, 768) == 9 and ranges(M, 768, 768) == 28      # 27 -> 243, 9 -> 252
-    assert lib.alpro_gemm_tn_workspace_bytes(64, 8, 8) == 0              # one range: nothing to combine
+    assert lib.alpro_gemm_tn_workspace_bytes(64, 8, 8) == 256 * 4        # one range: no partial tiles, one bias-gradient partial row (summed in a fixed order by the reduce kernel)
+    assert lib.alpro_gemm_tn_workspace_bytes(2560, 30522, 768) == 3 * 120 * 256 * 4   # vocabulary projection, not split: 3 k-tiles x (120 x 256) column partials
     assert lib.alpro_gemm_tn_workspace_bytes(0, 8, 8) == 0
+
+
+def test_product_library_refuses_result_corrupting_knobs():
+    """the ablations (gemm_tune 3/4/10/11/12, tn_kind 1) are compiled only into the measurement build."""
+    from alpro_amd import hip
+    for name, bad in (("gemm_tune", 3), ("gemm_tune", 4), ("gemm_tune", 10), ("gemm_tune", 11), ("gemm_tune", 12), ("tn_kind", 1)):
+        with pytest.raises(RuntimeError, match="ablation"):
+            hip.set_option(name, bad)
+    hip.set_option("gemm_tune", 2)
+    hip.set_option("gemm_tune", 1)
+    assert hip._DETERMINISTIC_WGRAD[0] is True        # bit-reproducible weight gradients are the default, atomics the opt-in
 
 
 def test_ops_refuse_cpu_tensors():
@@ -493,6 +505,132 @@ def test_src_package_extends_the_reference_and_launcher_command():
     assert r.returncode == 0, r.stderr[-2000:]
     a, l, s, v = r.stdout.split()
     assert a.startswith(ROOT) and l.startswith(ROOT) and v.startswith(ROOT) and s.startswith(ref)
+
+
+def test_reference_drivers_import_lines_resolve_under_the_launcher_path(tmp_path):
+    """The import statements of the reference's UNCHANGED drivers that touch what this repo provides -- `src.utils.load_save` (incl.
+    save_training_meta, and LOGGER as the datasets import it), `src.utils.distributed` (needs horovod.torch.mpi_ops), `horovod.torch`,
+    `apex.amp`, `src.modeling.*` -- are taken from the driver sources with ast and EXECUTED under the launcher's PYTHONPATH; then
+    save_training_meta runs once.  (The drivers' other imports need lmdb / decord / cv2 / tensorboardX, absent from this image.)"""
+    import ast
+    import subprocess
+    import sys
+    ref = os.environ.get("ALPRO_REFERENCE", "/root/reference")
+    if not os.path.isdir(os.path.join(ref, "src")):
+        pytest.skip("reference checkout not present on this box")
+    mine = ("src.utils.load_save", "src.utils.distributed", "horovod", "apex", "src.modeling", "src.optimization", "src.utils.misc")
+    lines = []
+    for drv in ("src/pretrain/run_pretrain_sparse.py", "src/tasks/run_video_retrieval.py", "src/pretrain/run_pretrain_contrastive_only.py"):
+        src = open(os.path.join(ref, drv)).read()
+        for node in ast.parse(src).body:
+            if isinstance(node, ast.ImportFrom) and node.module and node.module.startswith(mine):
+                lines.append(ast.get_source_segment(src, node))
+            elif isinstance(node, ast.Import) and any(a.name.startswith(mine) for a in node.names):
+                lines.append(ast.get_source_segment(src, node))
+    assert any("save_training_meta" in ln for ln in lines) and any("horovod" in ln for ln in lines) and any("apex" in ln for ln in lines)
+    cfg = tmp_path / "model.json"
+    cfg.write_text('{"hidden_size": 768}')
+    code = "\n".join(dict.fromkeys(lines)) + (
+        "\nfrom src.utils.load_save import LOGGER\nfrom horovod.torch.mpi_ops import rank, size\nassert rank() == 0 and size() == 1\n"
+        "import types\nsave_training_meta(types.SimpleNamespace(output_dir=%r, model_config=%r, lr=1e-4))\nprint('ok')\n" % (str(tmp_path / "out"), str(cfg)))
+    code_dir = tmp_path / "code"
+    (code_dir / "pkg" / "__pycache__").mkdir(parents=True)
+    (code_dir / "pkg" / "a.py").write_text("x = 1\n")
+    (code_dir / "pkg" / "__pycache__" / "a.pyc").write_text("")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd="/tmp",
+                       env=dict(os.environ, ALPRO_CODE_DIR=str(code_dir), PYTHONPATH=os.pathsep.join([ROOT, os.path.join(ROOT, "alpro_amd", "compat"), ref])))
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stderr[-3000:]
+    import json
+    import zipfile
+    assert json.load(open(tmp_path / "out" / "log" / "args.json"))["lr"] == 1e-4
+    assert json.load(open(tmp_path / "out" / "log" / "model_config.json")) == {"hidden_size": 768} and (tmp_path / "out" / "ckpt").is_dir()
+    assert zipfile.ZipFile(tmp_path / "out" / "code.zip").namelist() == ["code/pkg/a.py"]
+
+
+def test_restorer_write_keeps_a_good_generation_when_a_save_fails(tmp_path, monkeypatch):
+    """A save that dies midway must not cost a checkpoint generation: restore.pt stays the last good file."""
+    import types
+    from alpro_amd.utils import load_save as ls
+    opts = types.SimpleNamespace(output_dir=str(tmp_path), save_steps=1, fp16=0)
+    holder = torch.nn.Linear(2, 2)
+    r = ls.TrainingRestorer(opts, model=holder)
+    r.step()
+    good = torch.load(tmp_path / "restore.pt")["global_step"]
+    assert good == 1
+    real = torch.save
+
+    def torn(obj, f, *a, **k):
+        f.write(b"torn")
+        raise OSError("blob store hiccup")
+    monkeypatch.setattr(torch, "save", torn)
+    r.step()                                              # 10 failing trials, logged, training goes on
+    monkeypatch.setattr(torch, "save", real)
+    assert torch.load(tmp_path / "restore.pt")["global_step"] == 1 and not (tmp_path / "restore_backup.pt").exists()
+    r.step()
+    assert torch.load(tmp_path / "restore.pt")["global_step"] == 3 and torch.load(tmp_path / "restore_backup.pt")["global_step"] == 1
+
+
+def test_operand_cache_key_moves_when_a_foreign_optimizer_writes_through_data():
+    """the reference's AdamW updates with `p.data.addcdiv_` / `p.data.add_` (adamw.py:88,101), which does not bump
+    p._version; the operand caches must still see the change.  Any torch.optim.Optimizer.step() bumps the external epoch (global
+    post-step hook), the hvd facade does too; frozen parameters keep their key."""
+    from alpro_amd.modeling.weights import notify_params_updated, param_version
+
+    class DataWriter(torch.optim.Optimizer):           # the reference optimizer's write pattern
+        def __init__(self, params):
+            super().__init__(params, dict(lr=0.1))
+
+        def step(self, closure=None):
+            for g in self.param_groups:
+                for p in g["params"]:
+                    p.data.add_(p.grad.data, alpha=-g["lr"])
+
+    p = torch.nn.Parameter(torch.ones(4))
+    frozen = torch.nn.Parameter(torch.ones(4), requires_grad=False)
+    p.grad = torch.ones(4)
+    k0, f0, v0 = param_version(p), param_version(frozen), p._version
+    DataWriter([p]).step()
+    assert p._version == v0 and float(p[0]) == pytest.approx(0.9)       # the value changed behind the version counter
+    assert param_version(p) != k0 and param_version(frozen) == f0
+    k1 = param_version(p)
+    notify_params_updated()
+    assert param_version(p) != k1
+    import alpro_amd.compat.horovod.torch as hvd
+    k2 = param_version(p)
+    hvd.DistributedOptimizer(torch.optim.SGD([p], lr=0.1)).step()
+    assert param_version(p) != k2
+
+
+def test_anchor_tells_a_run_whether_other_anchored_backwards_are_still_pending():
+    """_VisualRun.backward may only declare the gradients outside the ViT final when it really is the last
+    anchored node to run.  Two anchored runs in the order AlproForSequenceClassification creates them (text first, visual second):
+    the second one's backward executes FIRST and must see the first one pending; the first one then sees nothing pending.  An
+    abandoned graph does not stay pending."""
+    import gc
+    from alpro_amd.modeling import train as tr
+
+    class Run:
+        def __init__(self, log, name):
+            self.log, self.name = log, name
+
+        def forward(self, x):
+            return x * 2.0
+
+        def backward(self, g):
+            self.log.append((self.name, self.others_pending))
+            return g * 2.0
+
+    log = []
+    w = torch.nn.Parameter(torch.ones(1))
+    x = torch.ones(3, requires_grad=True)
+    a = tr.run_anchored(Run(log, "text"), [x], [w])
+    b = tr.run_anchored(Run(log, "visual"), [x], [w])
+    abandoned = tr.run_anchored(Run(log, "abandoned"), [x], [w])
+    del abandoned
+    gc.collect()
+    (a.sum() + b.sum()).backward()
+    assert log == [("visual", True), ("text", False)], log
+    assert len(tr._LIVE_ANCHORS) == 0
 
 
 def test_retrieval_eval_known_answers_from_the_reference():
