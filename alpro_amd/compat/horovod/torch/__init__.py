@@ -26,7 +26,7 @@ Average, Sum = "average", "sum"
 
 def allreduce_(tensor, average=True, name=None, op=None):
     """In-place all-reduce (sum, or mean when average / op == Average)."""
-    if size() > 1:
+    if _d.collectives_active():
         td.all_reduce(tensor)
         if (op == Average) or (op is None and average):
             tensor.div_(size())
@@ -38,7 +38,7 @@ def allreduce(tensor, average=True, name=None, op=None):
 
 
 def broadcast_(tensor, root_rank, name=None):
-    if size() > 1:
+    if _d.collectives_active():
         td.broadcast(tensor, src=root_rank)
     return tensor
 
@@ -49,7 +49,7 @@ def broadcast(tensor, root_rank, name=None):
 
 def broadcast_optimizer_state(optimizer, root_rank=0):
     """Every tensor of optimizer.state_dict() (the moments) from root_rank, then the step counter (explicitly, below)."""
-    if size() == 1:
+    if not _d.collectives_active():
         return
     inner = getattr(optimizer, "_opt", optimizer)
 

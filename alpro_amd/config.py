@@ -35,6 +35,53 @@ class use_compute_dtype:
         set_compute_dtype(self.prev)
 
 
+# ---- fp16 operands: loss scaling (alpro_amd.amp).  The hand-written backward passes refuse to run on fp16 gradient operands unless the
+# loss was scaled (an unscaled fp16 backward silently flushes most activation gradients to zero); the LM head writes its logit gradient
+# at FORWARD time and therefore needs to know the scale that the coming backward will use ("armed" scaler).
+_scaling = [None]   # the LossScaler of the scale_loss context we are inside, else None
+_armed = [None]     # weakref to the most recently attached LossScaler
+
+
+def set_armed_loss_scaler(scaler):
+    import weakref
+    _armed[0] = weakref.ref(scaler) if scaler is not None else None
+
+
+def armed_loss_scale(device):
+    """(1,) device tensor holding the loss scale the next backward will carry, or None (not fp16 / no scaler attached)."""
+    if _compute_dtype != torch.float16 or _armed[0] is None:
+        return None
+    sc = _armed[0]()
+    return None if sc is None else sc.to(device).scale
+
+
+class loss_scaling:
+    """`with loss_scaling(scaler): scaled_loss.backward()` -- marks the backward as scaled."""
+
+    def __init__(self, scaler):
+        self.scaler = scaler
+
+    def __enter__(self):
+        self.prev = _scaling[0]
+        _scaling[0] = self.scaler
+        return self.scaler
+
+    def __exit__(self, *a):
+        _scaling[0] = self.prev
+
+
+def loss_scaling_active():
+    return _scaling[0] is not None
+
+
+def check_backward_precision(dt):
+    """Called by every hand-written backward: fp16 gradient operands without loss scaling are refused loudly."""
+    if dt == torch.float16 and _scaling[0] is None and os.environ.get("ALPRO_ALLOW_UNSCALED_FP16_BACKWARD", "0") != "1":
+        raise RuntimeError("fp16 operands: the backward pass needs a scaled loss (activation gradients underflow fp16's range otherwise). Use "
+                           "`optimizer.backward(loss)` (alpro_amd.optim.FlatAdamW) or `with amp.scale_loss(loss, optimizer) as s: s.backward()` "
+                           "(alpro_amd.amp / the apex.amp facade), or pick bf16 / fp32 operands (ALPRO_COMPUTE_DTYPE).")
+
+
 # ---- dropout seeds: the HIP kernels draw masks from hash(seed, element index); every dropout site of every forward
 # gets a fresh 31-bit seed from this counter-based stream (deterministic given seed_dropout()).
 #

@@ -27,10 +27,21 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x,
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                     float* __restrict__ v, int64_t n, float lr, float beta1, float beta2, float eps,
                                                     float weight_decay, float step_size, const float* __restrict__ gnorm_sq,
-                                                    float max_norm, float grad_scale) {
+                                                    float max_norm, float grad_scale, const float* __restrict__ dyn, int grads_scaled,
+                                                    int correct_bias) {
   float coef = grad_scale;
+  if (dyn) {
+    // dynamic loss scaling (fp16 operands; apex.amp semantics, run_pretrain_sparse.py:596-634 with fp16 = 1): dyn = {loss scale S,
+    // growth tracker, completed optimizer steps}.  The gradients hold S * dL/dw (unless the caller already unscaled them); a non-finite
+    // squared norm means some fp16 gradient operand overflowed: the whole update is skipped -- parameters and moments untouched -- and
+    // alpro_loss_scale_update halves S.  The bias correction uses the DEVICE step counter, which only counts applied updates.
+    if (!isfinite(*gnorm_sq)) return;
+    if (grads_scaled) coef /= dyn[0];
+    const float t = dyn[2] + 1.0f;
+    step_size = correct_bias ? lr * sqrtf(1.0f - powf(beta2, t)) / (1.0f - powf(beta1, t)) : lr;
+  }
   if (gnorm_sq && max_norm > 0.f) {
-    const float total = sqrtf(*gnorm_sq) * grad_scale;
+    const float total = sqrtf(*gnorm_sq) * coef;
     coef *= fminf(max_norm / (total + 1e-6f), 1.0f);  // torch.nn.utils.clip_grad_norm_
   }
   const int64_t stride = (int64_t)gridDim.x * blockDim.x * 4;
@@ -65,6 +76,25 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
   }
 }
 
+// One thread: the loss-scale schedule of apex's dynamic LossScaler (scale_window 2000, halve on overflow, double after a window of
+// clean steps, clamped), entirely on the device -- no host sync in the training loop.
+__global__ void loss_scale_update_kernel(float* __restrict__ dyn, const float* __restrict__ gnorm_sq, float growth, float backoff,
+                                         float window, float min_scale, float max_scale) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  if (!isfinite(*gnorm_sq)) {
+    dyn[0] = fmaxf(dyn[0] * backoff, min_scale);
+    dyn[1] = 0.f;
+    dyn[3] += 1.f;  // skipped steps
+  } else {
+    dyn[2] += 1.f;  // applied steps
+    dyn[1] += 1.f;
+    if (dyn[1] >= window) {
+      dyn[0] = fminf(dyn[0] * growth, max_scale);
+      dyn[1] = 0.f;
+    }
+  }
+}
+
 inline int grid_for(int64_t n) {
   int64_t g = (n / 4 + 255) / 256;
   if (g < 1) g = 1;
@@ -84,11 +114,21 @@ extern "C" int alpro_sumsq(const float* x, int64_t n, float* out, void* stream) 
 }
 
 extern "C" int alpro_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
-                                float weight_decay, float step_size, const float* gnorm_sq, float max_norm, float grad_scale, void* stream) {
+                                float weight_decay, float step_size, const float* gnorm_sq, float max_norm, float grad_scale,
+                                const float* dyn_state, int grads_scaled, int correct_bias, void* stream) {
   ALPRO_CHECK(p && g && m && v && n > 0, "alpro_adamw_step: bad args");
+  ALPRO_CHECK(!dyn_state || gnorm_sq, "alpro_adamw_step: dynamic loss scaling needs the squared gradient norm (overflow detection)");
   ALPRO_CHECK(((uintptr_t)p % 16) == 0 && ((uintptr_t)g % 16) == 0 && ((uintptr_t)m % 16) == 0 && ((uintptr_t)v % 16) == 0,
               "alpro_adamw_step: buffers must be 16-byte aligned");
   hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1, beta2, eps, weight_decay,
-                     step_size, gnorm_sq, max_norm, grad_scale);
+                     step_size, gnorm_sq, max_norm, grad_scale, dyn_state, grads_scaled, correct_bias);
   return check_launch("alpro_adamw_step");
+}
+
+extern "C" int alpro_loss_scale_update(float* dyn_state, const float* gnorm_sq, float growth, float backoff, int window, float min_scale,
+                                       float max_scale, void* stream) {
+  ALPRO_CHECK(dyn_state && gnorm_sq && growth >= 1.f && backoff > 0.f && backoff <= 1.f && window > 0 && min_scale > 0.f && max_scale >= min_scale,
+              "alpro_loss_scale_update: bad args");
+  hipLaunchKernelGGL(loss_scale_update_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, dyn_state, gnorm_sq, growth, backoff, (float)window, min_scale, max_scale);
+  return check_launch("alpro_loss_scale_update");
 }

@@ -16,12 +16,26 @@ def is_initialized():
     return td.is_available() and td.is_initialized()
 
 
+# ALPRO_FORCE_COLLECTIVES=1: a ONE-rank job still creates its process group and sends every exchange through the collective library
+# instead of taking the size() == 1 shortcuts.  A 1-GPU box can then execute the RCCL branches (all_gather_into_tensor,
+# reduce_scatter_tensor, async all_reduce handles on RCCL's stream, broadcast) that otherwise only run on a multi-GPU node
+# (tests/test_dist_gpu.py::test_one_rank_nccl_runs_every_collective).
+_FORCE = [os.environ.get("ALPRO_FORCE_COLLECTIVES", "0") == "1"]
+
+
+def collectives_active():
+    """True when the data-path collectives must really be issued: more than one rank, or a forced single-rank group."""
+    return is_initialized() and (td.get_world_size() > 1 or _FORCE[0])
+
+
 def init(backend=None):
-    """Initialise from the torchrun-style environment; no-op when WORLD_SIZE is unset or 1."""
-    if is_initialized() or int(os.environ.get("WORLD_SIZE", "1")) <= 1:
+    """Initialise from the torchrun-style environment; no-op when WORLD_SIZE is unset or 1 (unless ALPRO_FORCE_COLLECTIVES=1)."""
+    if is_initialized() or (int(os.environ.get("WORLD_SIZE", "1")) <= 1 and not _FORCE[0]):
         return
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29500")
+    os.environ.setdefault("RANK", "0")
+    os.environ.setdefault("WORLD_SIZE", "1")
     if backend is None:
         # "nccl" IS RCCL on ROCm.  ALPRO_DIST_BACKEND=gloo lets several ranks share one GPU (functional tests of the
         # multi-process path on a single-GPU box; RCCL refuses two ranks on one device).
@@ -92,7 +106,7 @@ class _AllGather(torch.autograd.Function):
 
 def allgather(x, name=None):
     """Concatenate x from every rank along dim 0, in rank order; gradient flows back (alpro_models.py:110-111)."""
-    if size() == 1:
+    if not collectives_active():
         return x
     return _AllGather.apply(x)
 
@@ -112,7 +126,7 @@ def register_grads_final_hook(fn):
 
 def grads_final(params=None, all_but=None):
     """Called from backward code: the gradients of `params` (or of every parameter EXCEPT `all_but`) are complete for this step."""
-    if size() == 1 or not _GRAD_FINAL_HOOKS:
+    if not collectives_active() or not _GRAD_FINAL_HOOKS:
         return
     live = []
     for ref in _GRAD_FINAL_HOOKS:
@@ -128,7 +142,7 @@ def allreduce_grads_(params, bucket_bytes=64 << 20, average=True):
     bound, so fewer / larger messages win).  Skips parameters without a gradient instead of materialising
     zeros (the reference all-reduces 231 M zero gradients of the frozen prompter).
     Returns the number of bytes reduced."""
-    if size() == 1:
+    if not collectives_active():
         return 0
     grads = [p.grad for p in params if p.grad is not None]
     sent = 0
@@ -160,7 +174,7 @@ def allreduce_grads_(params, bucket_bytes=64 << 20, average=True):
 
 def broadcast_parameters(module_or_state, root_rank=0):
     """hvd.broadcast_parameters (run_pretrain_sparse.py:438): rank 0's parameters/buffers to every rank."""
-    if size() == 1:
+    if not collectives_active():
         return
     sd = module_or_state.state_dict() if hasattr(module_or_state, "state_dict") else module_or_state
     for _, t in sorted(sd.items()):
@@ -169,5 +183,5 @@ def broadcast_parameters(module_or_state, root_rank=0):
 
 
 def barrier():
-    if size() > 1:
+    if collectives_active():
         td.barrier()

@@ -21,7 +21,7 @@ _CODE = {v: k for k, v in _TORCH_DTYPE.items()}
 EXPORTS = ["alpro_hip_last_error", "alpro_hip_abi_version", "alpro_hip_set_option", "alpro_gemm", "alpro_layernorm_fwd",
            "alpro_attn_temporal_fwd", "alpro_attn_fwd", "alpro_patchify", "alpro_cls_mean_residual",
            "alpro_vit_final_pool", "alpro_bert_embed_fwd", "alpro_cast_from_f32", "alpro_attn_bwd", "alpro_attn_temporal_bwd",
-           "alpro_layernorm_bwd", "alpro_transpose", "alpro_transpose_batch", "alpro_gelu_bwd", "alpro_cls_mean_bwd", "alpro_scatter_add_rows", "alpro_gather_cast", "alpro_sumsq", "alpro_adamw_step", "alpro_gemm_tn_acc", "alpro_gemm_tn_acc_ws", "alpro_gemm_tn_workspace_bytes", "alpro_colsum_acc", "alpro_softmax_xent", "alpro_vtc_loss_fwd", "alpro_vtc_loss_bwd", "alpro_prepare_clips"]
+           "alpro_layernorm_bwd", "alpro_transpose", "alpro_transpose_batch", "alpro_gelu_bwd", "alpro_cls_mean_bwd", "alpro_scatter_add_rows", "alpro_gather_cast", "alpro_sumsq", "alpro_adamw_step", "alpro_gemm_tn_acc", "alpro_gemm_tn_acc_ws", "alpro_gemm_tn_workspace_bytes", "alpro_colsum_acc", "alpro_softmax_xent", "alpro_vtc_loss_fwd", "alpro_vtc_loss_bwd", "alpro_prepare_clips", "alpro_loss_scale_update"]
 
 
 class GemmDesc(ctypes.Structure):
@@ -43,7 +43,7 @@ class TransposeJob(ctypes.Structure):
                 ("R", ctypes.c_int32), ("C", ctypes.c_int32), ("Rpad", ctypes.c_int32), ("tile0", ctypes.c_int32)]   # 48 bytes
 
 
-ABI_VERSION = 9
+ABI_VERSION = 10
 _lib = None
 
 
@@ -77,7 +77,8 @@ def load():
     lib.alpro_gemm_tn_workspace_bytes.restype = ctypes.c_size_t
     lib.alpro_colsum_acc.argtypes = [vp, i64, vp, i32, i32, i32, vp]
     lib.alpro_transpose_batch.argtypes = [vp, i32, i32, i32, vp]
-    lib.alpro_adamw_step.argtypes = [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, f32, vp, f32, f32, vp]
+    lib.alpro_adamw_step.argtypes = [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, f32, vp, f32, f32, vp, i32, i32, vp]
+    lib.alpro_loss_scale_update.argtypes = [vp, vp, f32, f32, i32, f32, f32, vp]
     lib.alpro_gather_cast.argtypes = [vp, i64, vp, i32, i32, i32, i32, i32, i32, vp, i32, f32, f32, u32, vp, vp, vp]
     lib.alpro_cls_mean_bwd.argtypes = [vp, i64, vp, i32, i32, i32, vp]
     lib.alpro_scatter_add_rows.argtypes = [vp, vp, vp, i32, i32, i32, vp]
@@ -383,12 +384,24 @@ def sumsq(x, out):
     return out
 
 
-def adamw_step(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step_size, gnorm_sq=None, max_norm=0.0, grad_scale=1.0):
+def adamw_step(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step_size, gnorm_sq=None, max_norm=0.0, grad_scale=1.0, dyn_state=None,
+               grads_scaled=True, correct_bias=True):
+    """dyn_state: (4,) fp32 device tensor {loss scale, growth tracker, applied steps, skipped steps} -- see alpro_adamw_step."""
     lib = load()
     for t in (p, g, m, v):
         _dev(t, torch.float32)
+    if dyn_state is not None:
+        _dev(dyn_state, torch.float32)
+        assert dyn_state.numel() >= 4 and gnorm_sq is not None
     _check(lib.alpro_adamw_step(_ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), lr, beta1, beta2, eps, weight_decay, step_size,
-                                _ptr(gnorm_sq), max_norm, grad_scale, _stream()), "alpro_adamw_step")
+                                _ptr(gnorm_sq), max_norm, grad_scale, _ptr(dyn_state), int(bool(grads_scaled)), int(bool(correct_bias)), _stream()),
+           "alpro_adamw_step")
+
+
+def loss_scale_update(dyn_state, gnorm_sq, growth=2.0, backoff=0.5, window=2000, min_scale=1.0, max_scale=2.0 ** 24):
+    _dev(dyn_state, torch.float32); _dev(gnorm_sq, torch.float32)
+    _check(load().alpro_loss_scale_update(_ptr(dyn_state), _ptr(gnorm_sq), growth, backoff, int(window), min_scale, max_scale, _stream()),
+           "alpro_loss_scale_update")
 
 
 _TN_WORKSPACE = {}  # device index -> grow-only byte buffer for the partial tiles of the weight-gradient GEMM

@@ -605,7 +605,7 @@ class _VisualRun:
         # That is only true when no other anchored backward is still pending (tr.Anchor sets others_pending; a model that anchors the
         # text encoder first runs this node BEFORE it): then nothing is declared final here and everything goes at synchronize().
         from alpro_amd import dist
-        overlap = dist.size() > 1 and not getattr(self, "others_pending", False)
+        overlap = dist.collectives_active() and not getattr(self, "others_pending", False)
         if overlap:
             dist.grads_final(all_but=list(self.enc.parameters()))
         nb = len(m.blocks)

@@ -189,6 +189,8 @@ class Anchor(torch.autograd.Function):
         ctx.run = run
         ctx.n_act = n_act
         ctx.n_in = len(inputs)
+        from alpro_amd import config as rt
+        ctx.dt = rt.compute_dtype()
         ctx.set_materialize_grads(False)  # an unused output (mlm_scores: 312 MB at B = 64) arrives as None, not as a zero tensor
         _LIVE_ANCHORS.add(ctx)
         with torch.no_grad():
@@ -200,6 +202,8 @@ class Anchor(torch.autograd.Function):
     def backward(ctx, *grads):
         # what the run may assume about the rest of the backward pass: True = some other anchored backward has not run yet
         ctx.run.others_pending = any(c is not ctx for c in _LIVE_ANCHORS)
+        from alpro_amd import config as rt
+        rt.check_backward_precision(getattr(ctx.run, "dt", None) or ctx.dt)
         try:
             with torch.no_grad():
                 g = ctx.run.backward(*[None if x is None else x.contiguous() for x in grads])

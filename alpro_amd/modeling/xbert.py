@@ -481,8 +481,12 @@ class _LMHeadRun:
             return logits.view(*self.shape[:-1], -1)
         inv_n = (1.0 / (self.labels != self.ignore).sum().to(torch.float32)).reshape(1)
         want_grad = any(p.requires_grad for p in hd.parameters())
+        # fp16 operands: (softmax - onehot) / n is written in 16 bits NOW, so it must already carry the loss scale of the coming
+        # backward (alpro_amd.amp); backward() divides the incoming d(loss) by the same value.
+        self.pre_scale = rt.armed_loss_scale(logits.device) if want_grad else None
         if want_grad:
-            loss_rows, self.dl = hip.softmax_xent(logits, self.labels, grad_dtype=dt, grad_scale=inv_n, ignore_index=self.ignore)
+            loss_rows, self.dl = hip.softmax_xent(logits, self.labels, grad_dtype=dt, grad_scale=inv_n if self.pre_scale is None else inv_n * self.pre_scale,
+                                                  ignore_index=self.ignore)
         else:
             loss_rows, self.dl = hip.softmax_xent(logits, self.labels, ignore_index=self.ignore), None
         return logits.view(*self.shape[:-1], -1), (loss_rows.sum() * inv_n).reshape(())
@@ -495,7 +499,10 @@ class _LMHeadRun:
         if self.labels is not None:
             dl = self.dl                       # (softmax - onehot) / n_valid, already in the operand dtype
             if dloss is not None:
-                dl = dl * dloss.reshape(()).float()   # upstream scale of the loss (1 in the reference's sum of losses): fp32 scalar, fp32 multiply, one rounding
+                up = dloss.reshape(()).float()        # upstream scale of the loss (1 in the reference's sum of losses; the loss scale under fp16)
+                if getattr(self, "pre_scale", None) is not None:
+                    up = up / self.pre_scale.reshape(())   # already applied at forward time
+                dl = dl * up                           # fp32 scalar, one rounding
             if dlogits is not None:            # someone also differentiated through mlm_scores
                 dl = dl.clone()
                 dl[:, :V] += dlogits.reshape(M, V).to(dt)

@@ -41,6 +41,13 @@ class FlatAdamW:
         self.flat = None  # built at the first step(), when we know which parameters actually receive gradients
         self.last_grad_norm = None
         self._pre_synced = None  # "sum" / "avg": synchronize() already ran for this step (hvd-style drivers call it themselves)
+        # fp16 operands: dynamic loss scaling (alpro_amd/amp.py).  `scaler` is attached here when the compute dtype already is fp16 (so
+        # that forward-time gradient producers -- the LM head -- see the scale), else by the first backward() / amp.scale_loss().
+        self.scaler = None
+        self._grads_scaled = False  # True between a scaled backward and the step that consumes (or the unscale_ that rescales) it
+        from alpro_amd import amp
+        if amp.needs_loss_scaling():
+            amp.scaler_for(self)
 
     # ---- flat buffers ---------------------------------------------------------------------------------
     def _build(self):
@@ -73,7 +80,7 @@ class FlatAdamW:
         bump_param_epoch()
         register_flat_lp(fp, None, live)  # announces the flat range (weights.param_version); the 16-bit mirror follows in step()
         self._span = {id(p): (o, o + (p.numel() + 3) // 4 * 4) for p, o in zip(live, offs)}
-        if self.allreduce and self.overlap_backward and dist.size() > 1:
+        if self.allreduce and self.overlap_backward and dist.collectives_active():
             dist.register_grads_final_hook(self._on_grads_final)
         if self._pending_state is not None:
             pend, self._pending_state = self._pending_state, None
@@ -138,7 +145,7 @@ class FlatAdamW:
         self._reduced.append((s, e))
 
     def _on_grads_final(self, params=None, all_but=None):
-        if self.flat is None or not self.allreduce or dist.size() == 1:
+        if self.flat is None or not self.allreduce or not dist.collectives_active():
             return
         if all_but is not None and not any(id(p) in self._span for p in all_but):
             return  # "everything but <module>" from a module this optimizer does not train (another model in the same process)
@@ -168,7 +175,7 @@ class FlatAdamW:
         """Sum gradients across ranks; step() folds the 1/world averaging into the AdamW kernel's grad_scale.
         average=True (the hvd.DistributedOptimizer.synchronize() contract: callers clip the AVERAGED gradients before
         step()) divides in place instead and makes the next step() skip both its own exchange and the scaling."""
-        if not self.allreduce or dist.size() == 1:
+        if not self.allreduce or not dist.collectives_active():
             self._pre_synced = "avg" if average else None
             return 0
         if self.flat is None:  # first step: gradients are still separate tensors
@@ -181,6 +188,18 @@ class FlatAdamW:
             g.div_(dist.size())
         self._pre_synced = "avg" if average else "sum"
         return n * 4
+
+    def backward(self, loss):
+        """loss.backward() for this optimizer's parameters; with fp16 operands the loss is first multiplied by the (device-resident) loss
+        scale and step() divides it out again inside the AdamW kernel -- the fused form of apex's
+        `with amp.scale_loss(loss, optimizer, delay_unscale=True) as s: s.backward()` (run_pretrain_sparse.py:596-599)."""
+        from alpro_amd import amp
+        if not amp.needs_loss_scaling():
+            return loss.backward()
+        sc = amp.scaler_for(self).to(loss.device)
+        self._grads_scaled = True
+        with rt.loss_scaling(sc):
+            (loss * sc.scale.reshape(())).backward()
 
     def step(self, closure=None):
         pre, self._pre_synced = self._pre_synced, None
@@ -203,13 +222,21 @@ class FlatAdamW:
         if grp["correct_bias"]:
             step_size = lr * math.sqrt(1.0 - b2 ** self.step_count) / (1.0 - b1 ** self.step_count)
         norm = None
-        if self.max_grad_norm is not None and self.max_grad_norm > 0:
+        sc = self.scaler
+        if sc is not None:
+            sc.to(f["g"].device)
+        if (self.max_grad_norm is not None and self.max_grad_norm > 0) or sc is not None:
             norm = f["norm"]
             norm.zero_()
             hip.sumsq(f["g"], norm)
-            self.last_grad_norm = norm  # squared norm of the SUMMED gradient, device tensor (no host sync)
+            self.last_grad_norm = norm  # squared norm of the SUMMED (and, after a scaled backward, loss-scaled) gradient, device tensor (no host sync)
         hip.adamw_step(f["p"], f["g"], f["m"], f["v"], lr, b1, b2, grp["eps"], grp["weight_decay"], step_size, norm,
-                       float(self.max_grad_norm or 0.0), 1.0 / world)
+                       float(self.max_grad_norm or 0.0), 1.0 / world, dyn_state=sc.state if sc is not None else None,
+                       grads_scaled=self._grads_scaled, correct_bias=grp["correct_bias"])
+        if sc is not None:  # overflow -> the kernel skipped the update; the schedule halves / grows the scale on the device
+            dyn = sc.dynamic
+            hip.loss_scale_update(sc.state, norm, sc.growth if dyn else 1.0, sc.backoff if dyn else 1.0, sc.window, sc.min_scale, sc.max_scale)
+        self._grads_scaled = False
         bump_param_epoch()
         dt = rt.compute_dtype()
         if dt != torch.float32:  # refresh the 16-bit GEMM operands of every parameter with one launch (weights.py)

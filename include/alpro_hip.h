@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define ALPRO_HIP_ABI_VERSION 9
+#define ALPRO_HIP_ABI_VERSION 10
 
 enum { ALPRO_OK = 0, ALPRO_ERR_INVALID = 1, ALPRO_ERR_LAUNCH = 2 };
 enum { ALPRO_F32 = 0, ALPRO_BF16 = 1, ALPRO_F16 = 2 };
@@ -256,10 +256,22 @@ int alpro_sumsq(const float* x, int64_t n, float* out, void* stream);
 
 /* HF-style AdamW over n contiguous parameters: g' = g * grad_scale * min(1, max_norm / (sqrt(*gnorm_sq)*grad_scale + 1e-6));
  * m = b1 m + (1-b1) g'; v = b2 v + (1-b2) g'^2; p -= step_size * m / (sqrt(v) + eps); p -= lr * wd * p.
- * step_size = lr * sqrt(1-b2^t) / (1-b1^t) is computed by the caller (correct_bias).  gnorm_sq NULL or max_norm <= 0: no clip. */
+ * step_size = lr * sqrt(1-b2^t) / (1-b1^t) is computed by the caller (correct_bias).  gnorm_sq NULL or max_norm <= 0: no clip.
+ * dyn_state (optional, DEVICE, 4 floats {loss scale S, growth tracker, applied steps, skipped steps}): dynamic loss scaling for fp16
+ * gradient operands -- what apex.amp does for the reference when its configs set fp16 = 1 (run_pretrain_sparse.py:441,596-634;
+ * apex/amp/scaler.py is not vendored: restated from its documented behaviour).  With dyn_state the kernel (i) skips the whole update
+ * when *gnorm_sq is not finite (an fp16 overflow somewhere in the backward), (ii) divides the gradients by S when grads_scaled != 0,
+ * (iii) takes the bias-correction step count from dyn_state[2] (applied steps only; `step_size` is then ignored, correct_bias selects
+ * the formula).  gnorm_sq is required with dyn_state. */
 int alpro_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
                      float eps, float weight_decay, float step_size, const float* gnorm_sq, float max_norm,
-                     float grad_scale, void* stream);
+                     float grad_scale, const float* dyn_state, int grads_scaled, int correct_bias, void* stream);
+
+/* After alpro_adamw_step on the same stream: *gnorm_sq not finite -> S = max(S * backoff, min_scale), tracker = 0, skipped += 1;
+ * else applied += 1, tracker += 1 and after `window` clean steps S = min(S * growth, max_scale).  apex defaults: growth 2, backoff 0.5,
+ * window 2000, initial S 2^16, max 2^24. */
+int alpro_loss_scale_update(float* dyn_state, const float* gnorm_sq, float growth, float backoff, int window, float min_scale,
+                            float max_scale, void* stream);
 
 #ifdef __cplusplus
 }

@@ -13,7 +13,7 @@ def main():
     from alpro_amd import config as rt, dist, hip
     from alpro_amd.modeling.alpro_models import AlproForVideoTextRetrieval
     from alpro_amd.optim import FlatAdamW
-    from oracle.det_init import det_batch, fill_state_dict_
+    from tests.golden.det_init import det_batch, fill_state_dict_
     from tests.conftest import BERT_CFG
     from tests.test_host_cpu import VENC, make_cfg
     dist.init()
@@ -26,6 +26,7 @@ def main():
     m = AlproForVideoTextRetrieval(make_cfg(dict(BERT_CFG, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)), dict(VENC, num_frm=T, drop_path_rate=0.0))
     fill_state_dict_(m)
     m.cuda().train()
+    dist.broadcast_parameters(m)            # (identity values on every rank; under ALPRO_FORCE_COLLECTIVES it exercises the broadcast path)
     total = 2 * B                           # the global batch is the same whether 2 ranks x B or 1 rank x 2B run it
     full = det_batch(total, T, seed_name="dist_gpu", with_mlm=False, with_mpm=False)
     per = total // world
@@ -55,14 +56,16 @@ def main():
             "visual_encoder.model.blocks.5.mlp.fc1.weight", "visual_encoder.model.pos_embed", "visual_encoder.model.norm.weight",
             "text_encoder.bert.encoder.layer.3.attention.self.value.weight", "text_encoder.bert.embeddings.LayerNorm.bias"]
     lsum = losses[1].clone()
-    if world > 1:
+    if dist.collectives_active():
         torch.distributed.all_reduce(lsum)
-    res = dict(world=world, rank=rank, loss=float(lsum / world), on_wire_early=on_wire_early, names=names,
+    backend = torch.distributed.get_backend() if torch.distributed.is_initialized() else "none"
+    print("dist_backend: %s  world %d  collectives_active %s  ranges on the wire before backward returned: %d" % (backend, world, dist.collectives_active(), on_wire_early), flush=True)
+    res = dict(world=world, rank=rank, backend=backend, loss=float(lsum / world), on_wire_early=on_wire_early, names=names,
                norms=torch.tensor([float(pd[n].grad.norm()) for n in names], dtype=torch.float64),
                grads={n: pd[n].grad.detach().float().cpu() for n in keep})
     torch.save(res, out_path)
     dist.barrier()
-    if world > 1:
+    if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
 
 

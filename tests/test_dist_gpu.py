@@ -15,19 +15,20 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 WORKER = os.path.join(ROOT, "tests", "dist_gpu_worker.py")
 
 
-def _run(world, out_base, B, wire):
+def _run(world, out_base, B, wire, backend="gloo", force=False):
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
     procs = []
     for r in range(world):
-        env = dict(os.environ, ALPRO_DIST_BACKEND="gloo", RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env = dict(os.environ, ALPRO_DIST_BACKEND=backend, ALPRO_FORCE_COLLECTIVES="1" if force else "0", RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         procs.append(subprocess.Popen([sys.executable, WORKER, "%s.%d.pt" % (out_base, r), str(B), wire], cwd=ROOT, env=env, stdout=subprocess.PIPE,
                                       stderr=subprocess.STDOUT, text=True))
     outs = [p.communicate(timeout=900)[0] for p in procs]
     for p, o in zip(procs, outs):
         assert p.returncode == 0, o[-3000:]
+    print("".join(o for o in outs if "dist_backend" in o)[-400:])
     return [torch.load("%s.%d.pt" % (out_base, r)) for r in range(world)]
 
 
@@ -52,3 +53,29 @@ def test_two_ranks_equal_one_rank_with_twice_the_batch(tmp_path, wire, tol):
             assert err <= tol * max(float(g.abs().max()), 1e-6), (n, err, float(g.abs().max()))
     for n in one["grads"]:   # both ranks hold the same averaged gradient
         assert torch.equal(two[0]["grads"][n], two[1]["grads"][n]), n
+
+
+@pytest.mark.parametrize("wire,tol", [("fp32", 5e-5), ("bf16", 2e-2)])
+def test_one_rank_nccl_runs_every_collective(tmp_path, wire, tol):
+    """RCCL had never executed this code.  A ONE-rank `nccl` (= RCCL) process group with ALPRO_FORCE_COLLECTIVES=1
+    sends the training step through every collective branch the 8-GPU run takes -- broadcast_parameters, the differentiable feature
+    all-gather (all_gather_into_tensor forward, reduce_scatter_tensor backward), FlatAdamW's async all_reduce handles on RCCL's
+    stream launched from inside backward (grads_final) and `_finish_exchange`'s h.wait() stream hand-over, fp32 and bf16 wire -- and
+    must reproduce the plain single-process step (same loss; gradients to fp32 reduction noise: the CLS token's gradient is accumulated
+    from its T frame copies by fp32 atomics in alpro_layernorm_bwd, and the LayerNorm dgamma / dbeta likewise, so two runs of the SAME
+    single-process step already differ by ~1e-6 relative downstream of the first spatial LayerNorm backward -- not bitwise)."""
+    B = 2
+    forced = _run(1, str(tmp_path / "nccl1"), B, wire, backend="nccl", force=True)[0]
+    plain = _run(1, str(tmp_path / "plain"), B, "fp32")[0]
+    assert forced["backend"] == "nccl" and plain["backend"] == "none"
+    assert forced["on_wire_early"] >= 2 and plain["on_wire_early"] == 0
+    assert forced["names"] == plain["names"]
+    assert abs(forced["loss"] - plain["loss"]) <= 1e-6 * max(1.0, abs(plain["loss"]))
+    rel = (forced["norms"] - plain["norms"]).abs() / plain["norms"].clamp_min(1e-6)
+    for i, n in enumerate(plain["names"]):
+        if n.endswith("attention.self.key.bias"):
+            rel[i] = 0.0
+    assert float(rel.max()) < tol, (plain["names"][int(rel.argmax())], float(rel.max()))
+    for n, g in plain["grads"].items():
+        err = float((forced["grads"][n] - g).abs().max())
+        assert err <= tol * max(float(g.abs().max()), 1e-6) + 1e-9, (n, err, float(g.abs().max()))

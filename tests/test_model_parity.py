@@ -1,11 +1,12 @@
 """GPU: the nn.Module API (alpro_amd.modeling) against golden vectors captured from the reference
 (tests/golden/*.npz) and against the CPU oracle, on the same closed-form weights and inputs.
 
-Tolerances (absolute unless noted):
+Tolerances (absolute unless noted), each at most ~2x the error measured on MI355X:
   * exact mode (ALPRO_COMPUTE_DTYPE=fp32, fp32 MFMA): VTC logits / ITM scores within 1e-3 of the reference
     -- the bar BASELINE.json's north_star states; observed errors are ~1e-5.
-  * bf16 mode (the benchmark dtype): encoder activations are rounded to bf16 at every GEMM/attention input;
-    observed end-to-end drift on these fixtures is ~1e-2 on logits, asserted at 6e-2 / 5% on embeddings.
+  * fp16 mode (the benchmark dtype since round 3): operands rounded to fp16 (11 bits) at every GEMM / attention input, fp32 everything
+    else; VTC logits asserted at the north star's 1e-3 (measured 2.4e-4), gradients through a loss-SCALED backward (alpro_amd.amp).
+  * bf16 mode: 8 mantissa bits; measured 8e-3 on VTC logits / 1.7e-2 on gradients, asserted at 1.6e-2 / 4e-2.
 """
 import math
 import os
@@ -24,6 +25,31 @@ def argmax_multinomial(w, n=1, *a, **k):
     return w.argmax(dim=-1, keepdim=True)
 
 
+def backward(loss, mode):
+    """loss.backward() the way each operand dtype needs it; returns the factor the parameter gradients carry.  fp16: a scaled backward
+    (alpro_amd.amp: fixed scale 4096 here; training uses the dynamic schedule) -- an unscaled fp16 backward is refused by the path."""
+    from alpro_amd import amp, config as rt
+    if mode != "fp16":
+        loss.backward()
+        return 1.0
+    sc = amp.LossScaler(init_scale=4096.0, dynamic=False, device=loss.device)
+    rt.set_armed_loss_scaler(sc)
+    with rt.loss_scaling(sc):
+        (loss * sc.scale.reshape(())).backward()
+    return 4096.0
+
+
+def arm_scale(mode, device="cuda"):
+    """fp16: attach the fixed test scale BEFORE the forward (the LM head writes its logit gradient at forward time); returns a keep-alive."""
+    from alpro_amd import amp, config as rt
+    if mode != "fp16":
+        rt.set_armed_loss_scaler(None)
+        return None
+    sc = amp.LossScaler(init_scale=4096.0, dynamic=False, device=device)
+    rt.set_armed_loss_scaler(sc)
+    return sc
+
+
 def to_dev(batch):
     return {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in batch.items()}
 
@@ -33,6 +59,9 @@ def close(got, ref, atol, rtol=0.0, what=""):
     ref = np.asarray(ref, dtype=np.float64)
     err = np.abs(got - ref)
     lim = atol + rtol * np.abs(ref)
+    if os.environ.get("ALPRO_PARITY_REPORT"):  # measurement run (tools/parity_report.sh): print every error next to its limit, assert nothing
+        print("[parity-report] %s | %s | err %.3e | limit %.1e" % (os.environ.get("PYTEST_CURRENT_TEST", "").split("::")[-1].split(" ")[0], what, err.max(), atol))
+        return float(err.max())
     assert (err <= lim).all(), "%s: max err %.3e (limit %.1e), ref max %.3e" % (what, err.max(), atol, np.abs(ref).max())
     return float(err.max())
 
@@ -48,7 +77,7 @@ def retrieval(bert_cfg):
     return m, batch, np.load(os.path.join(GOLDEN, "retrieval_T2_B3.npz"))
 
 
-@pytest.mark.parametrize("mode,tol_logit,tol_emb", [("fp32", 1e-3, 1e-3), ("bf16", 6e-2, 8e-2), ("fp16", 1e-2, 2e-2)])
+@pytest.mark.parametrize("mode,tol_logit,tol_emb", [("fp32", 1e-3, 1e-3), ("bf16", 1.6e-2, 6e-2), ("fp16", 2e-3, 6e-3)])
 def test_retrieval_vs_reference(retrieval, monkeypatch, mode, tol_logit, tol_emb):
     from alpro_amd import config as rt
     m, batch, g = retrieval
@@ -64,13 +93,14 @@ def test_retrieval_vs_reference(retrieval, monkeypatch, mode, tol_logit, tol_emb
     e["itc_loss"] = close(out["itc_loss"], g["itc_loss"], tol_logit, what="itc_loss")
     e["itm_loss"] = close(out["itm_loss"], g["itm_loss"], tol_logit, what="itm_loss")
     e["itm_scores"] = close(out["itm_scores"], g["itm_scores"], tol_logit, what="itm_scores")
-    e["inf_itc_scores"] = close(inf["itc_scores"], g["inf_itc_scores"], tol_logit, what="VTC logits (1 video x n captions)")
+    e["inf_itc_scores"] = close(inf["itc_scores"], g["inf_itc_scores"], min(tol_logit, 1e-3) if mode != "bf16" else tol_logit,
+                                what="VTC logits (1 video x n captions) -- the north star's 1e-3 bar for fp32 and fp16")
     e["inf_logits"] = close(inf["logits"], g["inf_logits"], tol_logit, what="inference ITM logits")
     assert torch.equal(out["itm_labels"].cpu(), torch.from_numpy(g["itm_labels"]).long())
     print("\n[parity %s] max abs errors vs reference:" % mode, {k: "%.2e" % v for k, v in e.items()})
 
 
-@pytest.mark.parametrize("mode,tol", [("fp32", 1e-3), ("bf16", 6e-2)])
+@pytest.mark.parametrize("mode,tol", [("fp32", 1e-3), ("bf16", 3e-2), ("fp16", 4e-3)])
 def test_pretrain_forward_vs_reference(bert_cfg, monkeypatch, mode, tol):
     """All ten outputs of AlproForPretrain.forward (VTC + VTM + MLM + MPM) at 8 frames."""
     from oracle.det_init import det_batch, fill_state_dict_
@@ -92,15 +122,17 @@ def test_pretrain_forward_vs_reference(bert_cfg, monkeypatch, mode, tol):
         e[k] = close(out[k], g[k], tol, what=k)
     close(out["mpm_labels"], g["mpm_labels"], tol * 1e-2, what="mpm_labels (soft)")
     e["mlm_scores"] = close(out["mlm_scores"][:, :, ::61], g["mlm_scores_cols"], tol, what="mlm_scores")
-    e["sim_v2t"] = close(vf @ tf.t() / m.temp, g["sim_v2t"], tol, what="VTC logits")
+    # fp16 measures 1.03e-3 on THIS fixture (3.6e-4 on retrieval_T2, 5.0e-4 on retrieval_T16, where the north star's 1e-3 is asserted):
+    # 11-bit operands through the 60 GEMM / attention layers of the ViT put the logits right at the bar, see DESIGN.md section 2
+    e["sim_v2t"] = close(vf @ tf.t() / m.temp, g["sim_v2t"], {"fp32": 1e-3, "fp16": 2e-3, "bf16": 1.6e-2}[mode], what="VTC logits")
     e["video_feat"] = close(vf, g["video_feat"], tol, what="video_feat")
-    e["text_embeds"] = close(te, g["text_embeds"], tol * (1 if mode == "fp32" else 3), what="text_embeds")
-    e["video_embeds"] = close(ve[:, [0, 1, 57, 196]], g["video_embeds_rows"], tol * (1 if mode == "fp32" else 3), what="video_embeds")
+    e["text_embeds"] = close(te, g["text_embeds"], tol * (1 if mode == "fp32" else 2), what="text_embeds")
+    e["video_embeds"] = close(ve[:, [0, 1, 57, 196]], g["video_embeds_rows"], tol * (1 if mode == "fp32" else 2), what="video_embeds")
     assert torch.equal(out["itm_labels"].cpu(), torch.from_numpy(g["itm_labels"]).long())
     print("\n[pretrain parity %s] max abs errors vs reference:" % mode, {k: "%.2e" % v for k, v in e.items()})
 
 
-@pytest.mark.parametrize("mode,rtol", [("fp32", 5e-3), ("bf16", 0.25)])
+@pytest.mark.parametrize("mode,rtol", [("fp32", 5e-3), ("bf16", 4e-2), ("fp16", 1e-2)])
 def test_pretrain_gradients_vs_reference(bert_cfg, monkeypatch, mode, rtol):
     """loss = mlm + itm + itc + mpm (run_pretrain_sparse.py:557) backward through the hand-written HIP backward:
     per-parameter gradient norms of all 460 trainable tensors and 15 full gradients vs the reference's autograd."""
@@ -114,11 +146,17 @@ def test_pretrain_gradients_vs_reference(bert_cfg, monkeypatch, mode, rtol):
     batch = to_dev(det_batch(2, 8, seed_name="pretrain_T8"))
     monkeypatch.setattr(torch, "multinomial", argmax_multinomial)
     with rt.use_compute_dtype(mode):
+        keep = arm_scale(mode)
         out = m(batch)
         loss = out["mlm_loss"] + out["itm_loss"] + out["itc_loss"] + out["mpm_loss"]
-        loss.backward()
-    close(out["itc_loss"], g["itc_loss"], 1e-3 if mode == "fp32" else 6e-2, what="itc_loss (train graph)")
+        gs = backward(loss, mode)
+        del keep
+    close(out["itc_loss"], g["itc_loss"], {"fp32": 1e-3, "fp16": 1e-3, "bf16": 1.6e-2}[mode], what="itc_loss (train graph)")
     pd = dict(m.named_parameters())
+    if gs != 1.0:
+        for p_ in pd.values():
+            if p_.grad is not None:
+                p_.grad.div_(gs)
     names = [str(n) for n in g["grad_norm_names"]]
     missing = [n for n in names if pd[n].grad is None]
     assert not missing, "no gradient for %s" % missing[:5]
@@ -134,6 +172,9 @@ def test_pretrain_gradients_vs_reference(bert_cfg, monkeypatch, mode, rtol):
     rel[zero_grad] = 0.0
     worst = int(rel.argmax())
     print("\n[grad parity %s] worst grad-norm rel err %.2e at %s; median %.2e" % (mode, rel.max(), names[worst], np.median(rel)))
+    if os.environ.get("ALPRO_PARITY_REPORT"):
+        print("[parity-report] pretrain_gradients[%s] | worst grad-norm rel err | err %.3e | limit %.1e" % (mode, rel.max(), rtol))
+        return
     assert rel.max() < rtol, (names[worst], got[worst], ref[worst])
     for k in g.files:
         if k.startswith("grad/"):
@@ -204,7 +245,7 @@ def test_cached_retrieval_eval_equals_forward_inference(retrieval):
     assert set(metrics) == {"text2video", "video2text"} and 0 <= metrics["text2video"]["r1"] <= 100
 
 
-@pytest.mark.parametrize("mode,tol", [("fp32", 2e-5), ("bf16", 3e-2)])
+@pytest.mark.parametrize("mode,tol", [("fp32", 2e-5), ("bf16", 3e-2), ("fp16", 4e-3)])
 def test_forward_cls_equals_cls_row_of_forward_features(retrieval, mode, tol):
     """TimeSformer.forward_cls (CLS-only tail of the last block, used by the frozen prompter) == forward_features(x)[:, 0]."""
     from alpro_amd import config as rt
@@ -260,7 +301,7 @@ def _det_block(layer, drop_path):
     return blk.cuda()
 
 
-@pytest.mark.parametrize("mode,tol", [("fp32", 2e-4), ("bf16", 4e-2)])
+@pytest.mark.parametrize("mode,tol", [("fp32", 2e-4), ("bf16", 6e-3), ("fp16", 8e-4)])
 @pytest.mark.parametrize("path", ["forward_train", "forward"])
 def test_block_train_mode_droppath_vs_reference(mode, tol, path):
     """a8: ONE ViT block in TRAIN mode with drop_path 0.1 (vit.py:136-213 + vit_utils.py:137-162) against the reference run with a
@@ -307,7 +348,7 @@ def _other_rank_feats(B):
     return ov, ot
 
 
-@pytest.mark.parametrize("mode,tol", [("fp32", 1e-3), ("bf16", 6e-2)])
+@pytest.mark.parametrize("mode,tol", [("fp32", 1e-3), ("bf16", 1.6e-2), ("fp16", 2e-3)])
 def test_world2_vtc_vs_reference(retrieval, monkeypatch, mode, tol):
     """a14 under data parallelism: this process as rank 1 of 2 (the other rank's features are closed-form tensors): VTC targets sit
     at columns [B, 2B) of the gathered similarity and the hard negatives are mined from the rank's own block
@@ -334,7 +375,7 @@ def prompter(bert_cfg):
     return m, batch, np.load(os.path.join(GOLDEN, "prompter_T2_B3_E8.npz"))
 
 
-@pytest.mark.parametrize("mode,tol", [("fp32", 1e-3), ("bf16", 6e-2)])
+@pytest.mark.parametrize("mode,tol", [("fp32", 1e-3), ("bf16", 3e-2), ("fp16", 3e-3)])
 def test_prompter_vs_reference(prompter, monkeypatch, mode, tol):
     """a20 + Prompter.forward: build_text_prompts on 8 entities x 12 (video) / 10 (image) templates, the teacher's VTC forward on
     one rank and as rank 1 of 2, and get_pseudo_labels on both prompt sets, all against the reference
@@ -369,7 +410,7 @@ def test_prompter_vs_reference(prompter, monkeypatch, mode, tol):
     print("\n[prompter parity %s]" % mode, {k: "%.2e" % v for k, v in e.items()})
 
 
-@pytest.mark.parametrize("mode,rtol", [("fp32", 5e-3), ("bf16", 0.25)])
+@pytest.mark.parametrize("mode,rtol", [("fp32", 5e-3), ("bf16", 4e-2), ("fp16", 1e-2)])
 def test_retrieval_finetune_gradients_vs_reference(bert_cfg, monkeypatch, mode, rtol):
     """BASELINE configs[4] (retrieval finetune step): loss = itm_loss + itc_loss (run_video_retrieval.py:432-434) backward through
     AlproForVideoTextRetrieval on the HIP backward; gradient norms of every trained tensor + 12 full gradients vs the reference."""
@@ -384,11 +425,15 @@ def test_retrieval_finetune_gradients_vs_reference(bert_cfg, monkeypatch, mode, 
     monkeypatch.setattr(torch, "multinomial", argmax_multinomial)
     with rt.use_compute_dtype(mode):
         out = m(batch)
-        (out["itm_loss"] + out["itc_loss"]).backward()
-    tol = 1e-3 if mode == "fp32" else 6e-2
+        gs = backward(out["itm_loss"] + out["itc_loss"], mode)
+    tol = {"fp32": 1e-3, "fp16": 2e-3, "bf16": 1.6e-2}[mode]
     for k in ("itc_loss", "itm_loss", "itm_scores"):
         close(out[k], g[k], tol, what=k + " (train graph)")
     pd = dict(m.named_parameters())
+    if gs != 1.0:
+        for p_ in pd.values():
+            if p_.grad is not None:
+                p_.grad.div_(gs)
     names = [str(n) for n in g["grad_norm_names"]]
     missing = [n for n in names if pd[n].grad is None]
     assert not missing, "no gradient for %s" % missing[:5]
@@ -402,6 +447,9 @@ def test_retrieval_finetune_gradients_vs_reference(bert_cfg, monkeypatch, mode, 
     rel[zero_grad] = 0.0
     worst = int(rel.argmax())
     print("\n[retrieval grad parity %s] worst grad-norm rel err %.2e at %s; median %.2e" % (mode, rel.max(), names[worst], np.median(rel)))
+    if os.environ.get("ALPRO_PARITY_REPORT"):
+        print("[parity-report] retrieval_gradients[%s] | worst grad-norm rel err | err %.3e | limit %.1e" % (mode, rel.max(), rtol))
+        return
     assert rel.max() < rtol, (names[worst], got[worst], ref[worst])
     for k in g.files:
         if k.startswith("grad/"):
@@ -410,7 +458,7 @@ def test_retrieval_finetune_gradients_vs_reference(bert_cfg, monkeypatch, mode, 
             assert e <= rtol * max(np.abs(r).max(), 1e-6) + 1e-7, (k, e, np.abs(r).max())
 
 
-@pytest.mark.parametrize("mode,tol", [("fp32", 1e-3), ("bf16", 6e-2)])
+@pytest.mark.parametrize("mode,tol", [("fp32", 1e-3), ("bf16", 3e-2), ("fp16", 3e-3)])
 def test_retrieval_16_frames_vs_reference(bert_cfg, monkeypatch, mode, tol):
     """Model-level case at 16 frames per clip (BASELINE configs[4]): forward, visual embeddings, 1-video-x-n-captions inference."""
     from oracle.det_init import det_batch, fill_state_dict_
@@ -430,12 +478,12 @@ def test_retrieval_16_frames_vs_reference(bert_cfg, monkeypatch, mode, tol):
     for k in ("itc_loss", "itm_loss", "itm_scores"):
         close(out[k], g[k], tol, what=k)
     assert torch.equal(out["itm_labels"].cpu(), torch.from_numpy(g["itm_labels"]).long())
-    close(ve[:, [0, 1, 100, 196]], g["video_embeds_rows"], tol * (1 if mode == "fp32" else 3), what="video_embeds rows (16 frames)")
-    close(inf["itc_scores"], g["inf_itc_scores"], tol, what="VTC logits (16 frames)")
+    close(ve[:, [0, 1, 100, 196]], g["video_embeds_rows"], tol * (1 if mode == "fp32" else 2), what="video_embeds rows (16 frames)")
+    close(inf["itc_scores"], g["inf_itc_scores"], min(tol, 1e-3) if mode != "bf16" else tol, what="VTC logits (16 frames) -- 1e-3 for fp32 and fp16")
     close(inf["logits"], g["inf_logits"], tol, what="inference ITM logits (16 frames)")
 
 
-@pytest.mark.parametrize("mode,tol", [("fp32", 2e-4), ("bf16", 2e-2)])
+@pytest.mark.parametrize("mode,tol", [("fp32", 2e-4), ("bf16", 8e-3), ("fp16", 1e-3)])
 def test_batched_retrieval_scoring_vs_reference_records(bert_cfg, mode, tol):
     """N3: every caption against every cached video in flat fusion mini-batches (score_all_pairs) reproduces the records the
     REFERENCE's evaluation loop produced for 5 videos x 5 captions (tests/golden/retrieval_eval_T2_V5.npz: forward_inference per
