@@ -210,6 +210,119 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
   }
 }
 
+
+// ---- residual add fused into the LayerNorm that follows it ---------------------------------------------------------------------
+// Every residual branch of the path ends in "x' = x + scale * Linear(...)" and is followed by a LayerNorm of x' (vit.py:162 -> :180,
+// :196 -> :200; xbert.py:358-359, 436-437).  Done in the Linear's GEMM epilogue, the fp32 read-modify-write of x (8 B / element through a
+// CU's ~26 GB/s epilogue path) made the two N = 768, K = 768 projections of a ViT block the slowest GEMMs of the model (0.16-0.19 of the
+// MFMA peak, round 2).  Here the GEMM writes only its 16-bit output `delta` in plain row order (the 16-byte-store fast path) and THIS
+// streaming kernel does the add, writes x' (fp32, the next residual / the LayerNorm-backward input) and the normalised rows: the same
+// HBM bytes in total, moved at the streaming rate.  The row maps of the divided space-time block live here too, so the CLS side
+// buffer and alpro_cls_mean_residual are gone:
+//   ALPRO_ADD_IDENTITY      row m:  v = x_in[m] + delta[m]                                             -> x_out[m], y[m]
+//   ALPRO_ADD_PRE_SPATIAL   row m = (b*T + t)*(N+1) + j of the frame-token gather (vit.py:165-172), r = its token row:
+//                           j > 0: v = x_in[r] + delta[r - b - 1] + dbias   (delta = temporal branch in x[:, 1:] order, vit.py:162)
+//                           j = 0: v = x_in[r]                              (the CLS token skips the temporal branch)   -> x_out[r], y[m]
+//   ALPRO_ADD_PRE_MLP       row r = b*S + k of the token tensor: k > 0 (patch n, frame t): v = x_in[r] + delta[(b*T+t)*(N+1) + 1 + n];
+//                           k = 0: v = x_in[r] + mean_t delta[(b*T+t)*(N+1)]  (vit.py:184-196)                             -> x_out[r], y[r]
+//   ALPRO_ADD_PRE_TEMPORAL  row r = b*S + k: v = x_in[r] + delta[r] -> x_out[r];  k > 0: y[r - b - 1] = LN(v)  (MLP branch of the
+//                           previous block folded into the next block's temporal LayerNorm, vit.py:212 -> :154)
+template <typename T>
+__device__ __forceinline__ void add_delta_row(const T* drow, int lane, float (&v)[12], float w) {
+#pragma unroll
+  for (int i = 0; i < LN_V; ++i) {
+    if constexpr (sizeof(T) == 4) {
+      const f32x4 f = __builtin_nontemporal_load((const f32x4*)(drow + i * 256 + lane * 4));
+      v[4 * i] += w * f.x; v[4 * i + 1] += w * f.y; v[4 * i + 2] += w * f.z; v[4 * i + 3] += w * f.w;
+    } else {
+      const u32x2 u = __builtin_nontemporal_load((const u32x2*)(drow + i * 256 + lane * 4));
+      const uint32_t ux = u.x, uy = u.y;
+      v[4 * i] += w * to_f32(T{(uint16_t)(ux & 0xFFFFu)});
+      v[4 * i + 1] += w * to_f32(T{(uint16_t)(ux >> 16)});
+      v[4 * i + 2] += w * to_f32(T{(uint16_t)(uy & 0xFFFFu)});
+      v[4 * i + 3] += w * to_f32(T{(uint16_t)(uy >> 16)});
+    }
+  }
+}
+
+template <typename T, int MODE>
+__global__ __launch_bounds__(256) void add_layernorm_fwd_kernel(const float* __restrict__ x_in, const T* __restrict__ delta, const float* __restrict__ dbias,
+                                                                float* __restrict__ x_out, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                float eps, T* __restrict__ y, float* __restrict__ y32, int64_t rows, int p0, int p1) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t nwaves = (int64_t)gridDim.x * 4;
+  const int Tn = p0, N = p1;
+  const int64_t S = 1 + (int64_t)N * Tn;
+  for (int64_t m = wave; m < rows; m += nwaves) {
+    int64_t r = m, yrow = m;       // token row of x_in / x_out; row of y
+    const T* d0 = nullptr;         // delta row added with weight 1
+    bool write_x = true, write_y = true, cls_mean = false;
+    int64_t b = 0;
+    if constexpr (MODE == ALPRO_ADD_IDENTITY) {
+      d0 = delta + m * LN_D;
+    } else if constexpr (MODE == ALPRO_ADD_PRE_SPATIAL) {
+      const int64_t bt = m / (N + 1);
+      const int j = (int)(m - bt * (N + 1));
+      b = bt / Tn;
+      const int t = (int)(bt - b * Tn);
+      if (j == 0) {
+        r = b * S;
+        write_x = (t == 0) && (x_out != x_in);  // one writer per CLS row; in place there is nothing to write
+      } else {
+        r = b * S + 1 + (int64_t)(j - 1) * Tn + t;
+        d0 = delta + (r - b - 1) * LN_D;
+      }
+    } else if constexpr (MODE == ALPRO_ADD_PRE_MLP) {
+      b = m / S;
+      const int64_t k = m - b * S;
+      if (k == 0) {
+        cls_mean = true;
+      } else {
+        const int64_t n = (k - 1) / Tn;
+        const int t = (int)((k - 1) - n * Tn);
+        d0 = delta + ((b * Tn + t) * (N + 1) + 1 + n) * LN_D;
+      }
+    } else {  // PRE_TEMPORAL
+      b = m / S;
+      const int64_t k = m - b * S;
+      d0 = delta + m * LN_D;
+      write_y = k != 0;
+      yrow = m - b - 1;
+    }
+    float v[12];
+    ln_load_nt(x_in + r * LN_D, lane, v);
+    if (d0) {
+      add_delta_row<T>(d0, lane, v, 1.0f);
+      if (dbias) {
+#pragma unroll
+        for (int i = 0; i < LN_V; ++i) {
+          const float4 f = *(const float4*)(dbias + i * 256 + lane * 4);
+          v[4 * i] += f.x; v[4 * i + 1] += f.y; v[4 * i + 2] += f.z; v[4 * i + 3] += f.w;
+        }
+      }
+    }
+    if (MODE == ALPRO_ADD_PRE_MLP && cls_mean) {  // frame mean of the T CLS rows of the spatial branch (vit.py:187)
+      float a[12];
+#pragma unroll
+      for (int i = 0; i < 12; ++i) a[i] = 0.f;
+      for (int t = 0; t < Tn; ++t) add_delta_row<T>(delta + ((b * Tn + t) * (N + 1)) * LN_D, lane, a, 1.0f);
+      const float inv = 1.0f / (float)Tn;
+#pragma unroll
+      for (int i = 0; i < 12; ++i) v[i] += a[i] * inv;
+    }
+    if (x_out && write_x) ln_store<float>(x_out + r * LN_D, lane, v);
+    if (!write_y) continue;
+    float mean, rstd;
+    ln_stats(v, eps, mean, rstd);
+    ln_affine(v, mean, rstd, gamma, beta, lane);
+    ln_store<T>(y + yrow * LN_D, lane, v);
+    if constexpr (sizeof(T) != 4) {
+      if (y32) ln_store<float>(y32 + yrow * LN_D, lane, v);
+    }
+  }
+}
+
 // final norm + temporal mean pool: out row (b, 0) = LN(x[b,0]); (b, 1+n) = mean_t LN(x[b, 1+n*T+t])
 template <typename T>
 __global__ __launch_bounds__(256) void vit_final_pool_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
@@ -413,6 +526,39 @@ extern "C" int alpro_layernorm_fwd(const float* x, int64_t ldx, const float* gam
   ALPRO_CHECK(ldx % 4 == 0 && ldy % 4 == 0, "alpro_layernorm_fwd: row strides must be multiples of 4");
   ALPRO_DISPATCH_DTYPE(y_dtype, T, hipLaunchKernelGGL(layernorm_fwd_kernel<T>, dim3(grid_for(rows, 4, 256 * 32)), dim3(256), 0, (hipStream_t)stream, x, ldx, gamma, beta, eps, (T*)y, ldy, y32, mean, rstd, (int64_t)rows, map_mode, map_p0, map_p1));
   return check_launch("alpro_layernorm_fwd");
+}
+
+namespace {
+template <typename T>
+int launch_add_ln(int mode, const float* x_in, const void* delta, const float* dbias, float* x_out, const float* gamma, const float* beta, float eps, void* y,
+                  float* y32, int64_t rows, int p0, int p1, hipStream_t st) {
+  const dim3 grid(grid_for(rows, 4, 256 * 32)), blk(256);
+#define ALPRO_ADD_LN_CASE(M) \
+  case M: hipLaunchKernelGGL((add_layernorm_fwd_kernel<T, M>), grid, blk, 0, st, x_in, (const T*)delta, dbias, x_out, gamma, beta, eps, (T*)y, y32, rows, p0, p1); break;
+  switch (mode) {
+    ALPRO_ADD_LN_CASE(ALPRO_ADD_IDENTITY)
+    ALPRO_ADD_LN_CASE(ALPRO_ADD_PRE_SPATIAL)
+    ALPRO_ADD_LN_CASE(ALPRO_ADD_PRE_MLP)
+    ALPRO_ADD_LN_CASE(ALPRO_ADD_PRE_TEMPORAL)
+  }
+#undef ALPRO_ADD_LN_CASE
+  return check_launch("alpro_add_layernorm_fwd");
+}
+}  // namespace
+
+extern "C" int alpro_add_layernorm_fwd(const float* x_in, const void* delta, int dtype, const float* delta_bias, int add_mode, float* x_out,
+                                       const float* gamma, const float* beta, float eps, void* y, float* y32, int64_t rows, int D, int p0, int p1,
+                                       void* stream) {
+  ALPRO_CHECK(x_in && delta && gamma && beta && y && rows > 0, "alpro_add_layernorm_fwd: bad args");
+  ALPRO_CHECK(D == LN_D, "alpro_add_layernorm_fwd: D=%d unsupported (hidden size is 768 on this path)", D);
+  ALPRO_CHECK(add_mode >= ALPRO_ADD_IDENTITY && add_mode <= ALPRO_ADD_PRE_TEMPORAL, "alpro_add_layernorm_fwd: bad add_mode %d", add_mode);
+  ALPRO_CHECK(add_mode == ALPRO_ADD_IDENTITY || (p0 > 0 && p1 > 0), "alpro_add_layernorm_fwd: the divided space-time modes need p0 = T, p1 = N");
+  ALPRO_CHECK(add_mode == ALPRO_ADD_IDENTITY || rows % (add_mode == ALPRO_ADD_PRE_SPATIAL ? (int64_t)p0 * (p1 + 1) : 1 + (int64_t)p0 * p1) == 0,
+              "alpro_add_layernorm_fwd: rows=%lld is not a whole number of clips", (long long)rows);
+  ALPRO_CHECK(!(dtype == ALPRO_F32 && y32), "alpro_add_layernorm_fwd: y already is fp32 in exact mode");
+  ALPRO_CHECK(((uintptr_t)x_in % 16) == 0 && ((uintptr_t)delta % 16) == 0 && ((uintptr_t)y % 16) == 0, "alpro_add_layernorm_fwd: pointers must be 16-byte aligned");
+  ALPRO_DISPATCH_DTYPE(dtype, T, return launch_add_ln<T>(add_mode, x_in, delta, delta_bias, x_out, gamma, beta, eps, y, y32, rows, p0, p1, (hipStream_t)stream));
+  return ALPRO_OK;
 }
 
 extern "C" int alpro_vit_final_pool(const float* x, const float* gamma, const float* beta, float eps, float* out32, void* out_t,

@@ -14,6 +14,7 @@ LIB_PATH = os.environ.get("ALPRO_HIP_LIB") or os.path.join(_HERE, "lib", "libalp
 F32, BF16, F16 = 0, 1, 2
 ACT_NONE, ACT_GELU, ACT_RELU, ACT_GELU_BWD = 0, 1, 2, 3
 MAP_IDENTITY, MAP_SKIP_CLS, MAP_FRAME_TOKENS, MAP_PATCH_EMBED = 0, 1, 2, 3
+ADD_IDENTITY, ADD_PRE_SPATIAL, ADD_PRE_MLP, ADD_PRE_TEMPORAL = 0, 1, 2, 3
 
 _TORCH_DTYPE = {F32: torch.float32, BF16: torch.bfloat16, F16: torch.float16}
 _CODE = {v: k for k, v in _TORCH_DTYPE.items()}
@@ -21,7 +22,7 @@ _CODE = {v: k for k, v in _TORCH_DTYPE.items()}
 EXPORTS = ["alpro_hip_last_error", "alpro_hip_abi_version", "alpro_hip_set_option", "alpro_gemm", "alpro_layernorm_fwd",
            "alpro_attn_temporal_fwd", "alpro_attn_fwd", "alpro_patchify", "alpro_cls_mean_residual",
            "alpro_vit_final_pool", "alpro_bert_embed_fwd", "alpro_cast_from_f32", "alpro_attn_bwd", "alpro_attn_temporal_bwd",
-           "alpro_layernorm_bwd", "alpro_transpose", "alpro_transpose_batch", "alpro_gelu_bwd", "alpro_cls_mean_bwd", "alpro_scatter_add_rows", "alpro_gather_cast", "alpro_sumsq", "alpro_adamw_step", "alpro_gemm_tn_acc", "alpro_gemm_tn_acc_ws", "alpro_gemm_tn_workspace_bytes", "alpro_colsum_acc", "alpro_softmax_xent", "alpro_vtc_loss_fwd", "alpro_vtc_loss_bwd", "alpro_prepare_clips", "alpro_loss_scale_update"]
+           "alpro_layernorm_bwd", "alpro_transpose", "alpro_transpose_batch", "alpro_gelu_bwd", "alpro_cls_mean_bwd", "alpro_scatter_add_rows", "alpro_gather_cast", "alpro_sumsq", "alpro_adamw_step", "alpro_gemm_tn_acc", "alpro_gemm_tn_acc_ws", "alpro_gemm_tn_workspace_bytes", "alpro_colsum_acc", "alpro_softmax_xent", "alpro_vtc_loss_fwd", "alpro_vtc_loss_bwd", "alpro_prepare_clips", "alpro_loss_scale_update", "alpro_add_layernorm_fwd"]
 
 
 class GemmDesc(ctypes.Structure):
@@ -43,7 +44,7 @@ class TransposeJob(ctypes.Structure):
                 ("R", ctypes.c_int32), ("C", ctypes.c_int32), ("Rpad", ctypes.c_int32), ("tile0", ctypes.c_int32)]   # 48 bytes
 
 
-ABI_VERSION = 10
+ABI_VERSION = 11
 _lib = None
 
 
@@ -62,6 +63,7 @@ def load():
     vp, i32, i64, f32 = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float
     lib.alpro_gemm.argtypes = [ctypes.POINTER(GemmDesc), vp]
     lib.alpro_layernorm_fwd.argtypes = [vp, i64, vp, vp, f32, vp, i32, i64, vp, vp, vp, i32, i32, i32, i32, i32, vp]
+    lib.alpro_add_layernorm_fwd.argtypes = [vp, vp, i32, vp, i32, vp, vp, vp, f32, vp, vp, i64, i32, i32, i32, vp]
     lib.alpro_attn_temporal_fwd.argtypes = [vp, vp, i32, i64, i32, i32, f32, vp, vp]
     u32 = ctypes.c_uint32
     lib.alpro_attn_bwd.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, vp, f32, u32, vp]
@@ -210,6 +212,39 @@ def layernorm(x, gamma, beta, eps, out_dtype, rows=None, out32=False, stats=Fals
     if stats:
         res += (mean, rstd)
     return res if len(res) > 1 else y
+
+
+def add_layernorm(x_in, delta, gamma, beta, eps, mode=ADD_IDENTITY, x_out=None, want_x=True, delta_bias=None, T=0, N=0, out32=False):
+    """x' = x_in + gathered delta (+ delta_bias); returns (y [, y32], x') with y = LayerNorm(x') in delta's dtype -- see alpro_add_layernorm_fwd.
+    x_in fp32 token tensor (..., 768); delta (rows, 768) in the operand dtype.  x_out: tensor to receive x' (may be x_in itself), or None
+    with want_x=True to allocate it, or want_x=False when nobody needs x'."""
+    lib = load()
+    _dev(x_in, torch.float32); _dev(delta)
+    D = x_in.shape[-1]
+    tokens = x_in.numel() // D
+    dt = delta.dtype
+    if mode == ADD_IDENTITY:
+        rows = yrows = want = tokens
+    else:
+        if T <= 0 or N <= 0 or tokens % (1 + N * T) != 0:
+            raise RuntimeError("add_layernorm: %d token rows are not a whole number of clips of 1 + %d x %d tokens" % (tokens, N, T))
+        B = tokens // (1 + N * T)
+        rows, yrows, want = {ADD_PRE_SPATIAL: (B * T * (N + 1), B * T * (N + 1), B * N * T), ADD_PRE_MLP: (tokens, tokens, B * T * (N + 1)),
+                             ADD_PRE_TEMPORAL: (tokens, B * N * T, tokens)}[mode]
+    if delta.shape[0] != want or delta.shape[-1] != D:
+        raise RuntimeError("add_layernorm: delta has %s rows, mode %d over %d token rows needs (%d, %d)" % (tuple(delta.shape), mode, tokens, want, D))
+    if x_out is None and want_x:
+        x_out = torch.empty_like(x_in)
+    if x_out is not None:
+        _dev(x_out, torch.float32)
+    y = torch.empty((yrows, D), dtype=dt, device=x_in.device)
+    y32 = torch.empty((yrows, D), dtype=torch.float32, device=x_in.device) if (out32 and dt != torch.float32) else None
+    _check(lib.alpro_add_layernorm_fwd(_ptr(x_in), _ptr(delta), _CODE[dt], _ptr(_dev(delta_bias, torch.float32)) if delta_bias is not None else None, mode,
+                                       _ptr(x_out), _ptr(_dev(gamma, torch.float32)), _ptr(_dev(beta, torch.float32)), eps, _ptr(y), _ptr(y32), rows, D, T, N,
+                                       _stream()), "alpro_add_layernorm_fwd")
+    if out32:
+        return y, (y32 if y32 is not None else y), x_out
+    return y, x_out
 
 
 def attn_temporal(qkv, T, H, scale, want_lse=False):

@@ -10,16 +10,18 @@ arguments, `forward_features` signatures and the state_dict layout (`model.block
   embeds via two rearranges (:342-361)                 residual is a (N*T, D) table bias+pos+time
   rearrange 'b (h w t) m -> (b h w) t m' (:147)        LayerNorm with SKIP_CLS gather (no copy)
   Attention (:81-100) on (B*N, T, D)                   alpro_gemm(qkv) -> alpro_attn_temporal -> alpro_gemm(proj)
-  temporal_fc + residual (:161-162)                    alpro_gemm epilogue (residual, SKIP_CLS map)
-  rearrange/cat to (B*T, 1+N, D) (:165-172)            LayerNorm with FRAME_TOKENS gather (no copy)
-  Attention on (B*T, 1+N, D) (:180)                    alpro_gemm(qkv) -> alpro_attn -> alpro_gemm(proj) whose
-  CLS mean + scatter back + residual (:184-196)        epilogue scatters patches (+residual) and parks the
-                                                       CLS rows for alpro_cls_mean_residual
+  temporal_fc + residual (:161-162), rearrange/cat     the projection GEMM writes its 16-bit output only; the residual add,
+  to (B*T, 1+N, D) (:165-172), norm1 (:180)            the frame-token gather and norm1 are ONE streaming kernel
+                                                       (alpro_add_layernorm_fwd, PRE_SPATIAL)
+  Attention on (B*T, 1+N, D) (:180)                    alpro_gemm(qkv) -> alpro_attn -> alpro_gemm(proj), 16-bit output
+  CLS mean + scatter back + residual (:184-196),       alpro_add_layernorm_fwd (PRE_MLP): scatter map, frame mean of the CLS
+  norm2 (:200)                                         rows, residual add and norm2 in one pass
   norm2 + Mlp + residual (:198-212)                    LayerNorm -> alpro_gemm(GELU) -> alpro_gemm(residual)
   norm (:372) + temporal mean pool (:484-492)          alpro_vit_final_pool
   DropPath per (b n)/(b t)/b rows (vit_utils.py:137)   row_scale vector in the GEMM epilogue
 """
 import math
+import os
 from functools import partial
 
 import torch
@@ -112,6 +114,7 @@ class Block(nn.Module):
     # GEMM per block in forward and, in backward, one dgrad and one wgrad: dWe = (s*dY)^T a is taken once and pushed through
     # the product rule (dWfc = dWe Wp^T + db1 bp^T, dWp = Wfc^T dWe, dbp = Wfc^T db1, dbfc = colsum(dY)).
     merge_temporal_proj = True
+    fuse_residual_ln = os.environ.get("ALPRO_FUSE_RESIDUAL_LN", "1") != "0"   # residual adds of the two attention halves inside the following LayerNorm (alpro_add_layernorm_fwd); 0 = round-2 form (A/B measurements)
 
     def _merged_tproj(self, dt):
         wp, bp, wf = self.temporal_attn.proj.weight, self.temporal_attn.proj.bias, self.temporal_fc.weight
@@ -134,6 +137,28 @@ class Block(nn.Module):
             return pre.pop(rows)
         return self.drop_path.row_scale(rows, device)
 
+    def _forward_halves_unfused(self, x, xf, a, B, T, N, H, D, dt):
+        """Round-2 form of the two attention halves' tails (fp32 residual read-modify-write in the GEMM epilogue, CLS side buffer);
+        kept for A/B measurements (Block.fuse_residual_ln = False) and for the unmerged temporal projection."""
+        ta, sa = self.temporal_attn, self.attn
+        if self.merge_temporal_proj:
+            mg = self._merged_tproj(dt)
+            hip.gemm(a, mg["w"], out=xf, bias=mg["b1"], bias2=self.temporal_fc.bias, out_dtype=torch.float32, residual=xf,
+                     row_scale=self._drop(B * N, x.device), row_scale_group=T, map_mode=hip.MAP_SKIP_CLS, map_p0=N * T)
+        else:
+            pr = hip.gemm(a, self._w("t_proj", ta.proj, dt), bias=ta.proj.bias, row_scale=self._drop(B * N, x.device), row_scale_group=T)
+            hip.gemm(pr, self._w("t_fc", self.temporal_fc, dt), out=xf, bias=self.temporal_fc.bias, out_dtype=torch.float32,
+                     residual=xf, map_mode=hip.MAP_SKIP_CLS, map_p0=N * T)
+        hs = hip.layernorm(x, self.norm1.weight, self.norm1.bias, VIT_EPS, dt, rows=B * T * (N + 1),
+                           map_mode=hip.MAP_FRAME_TOKENS, map_p0=T, map_p1=N)
+        qkv = hip.gemm(hs, self._w("s_qkv", sa.qkv, dt), bias=sa.qkv.bias)
+        a = hip.attn(qkv, B * T, N + 1, H, sa.scale)
+        side = torch.empty((B * T, D), dtype=torch.float32, device=x.device)
+        hip.gemm(a, self._w("s_proj", sa.proj, dt), out=xf, bias=sa.proj.bias, out_dtype=torch.float32, residual=xf,
+                 row_scale=self._drop(B * T, x.device), row_scale_group=N + 1,
+                 map_mode=hip.MAP_FRAME_TOKENS, map_p0=T, map_p1=N, side=side)
+        hip.cls_mean_residual(x, side, x, B, T)
+
     def forward(self, x, B, T, W):
         """x: (B, 1 + N*T, D) fp32 contiguous token tensor; updated IN PLACE and returned (inference path)."""
         dt = rt.compute_dtype()
@@ -147,26 +172,20 @@ class Block(nn.Module):
                           map_mode=hip.MAP_SKIP_CLS, map_p0=N * T)
         qkv = hip.gemm(h, self._w("t_qkv", ta.qkv, dt), bias=ta.qkv.bias)
         a = hip.attn_temporal(qkv, T, H, ta.scale)
-        if self.merge_temporal_proj:
+        if self.fuse_residual_ln and self.merge_temporal_proj:
+            # round 3: the two N = 768 projections write 16-bit deltas in plain row order; residual add + row maps + LayerNorm are one
+            # streaming kernel each (alpro_add_layernorm_fwd) -- see the kernel's header comment in csrc/core.hip
             mg = self._merged_tproj(dt)
-            hip.gemm(a, mg["w"], out=xf, bias=mg["b1"], bias2=self.temporal_fc.bias, out_dtype=torch.float32, residual=xf,
-                     row_scale=self._drop(B * N, x.device), row_scale_group=T, map_mode=hip.MAP_SKIP_CLS, map_p0=N * T)
+            d_t = hip.gemm(a, mg["w"], bias=mg["b1"], row_scale=self._drop(B * N, x.device), row_scale_group=T)
+            hs, _ = hip.add_layernorm(x, d_t, self.norm1.weight, self.norm1.bias, VIT_EPS, mode=hip.ADD_PRE_SPATIAL, x_out=x,
+                                      delta_bias=self.temporal_fc.bias, T=T, N=N)
+            qkv = hip.gemm(hs, self._w("s_qkv", sa.qkv, dt), bias=sa.qkv.bias)
+            a = hip.attn(qkv, B * T, N + 1, H, sa.scale)
+            d_s = hip.gemm(a, self._w("s_proj", sa.proj, dt), bias=sa.proj.bias, row_scale=self._drop(B * T, x.device), row_scale_group=N + 1)
+            h2, _ = hip.add_layernorm(x, d_s, self.norm2.weight, self.norm2.bias, VIT_EPS, mode=hip.ADD_PRE_MLP, x_out=x, T=T, N=N)
         else:
-            pr = hip.gemm(a, self._w("t_proj", ta.proj, dt), bias=ta.proj.bias, row_scale=self._drop(B * N, x.device), row_scale_group=T)
-            hip.gemm(pr, self._w("t_fc", self.temporal_fc, dt), out=xf, bias=self.temporal_fc.bias, out_dtype=torch.float32,
-                     residual=xf, map_mode=hip.MAP_SKIP_CLS, map_p0=N * T)
-        # ---- spatial (vit.py:165-196)
-        hs = hip.layernorm(x, self.norm1.weight, self.norm1.bias, VIT_EPS, dt, rows=B * T * (N + 1),
-                           map_mode=hip.MAP_FRAME_TOKENS, map_p0=T, map_p1=N)
-        qkv = hip.gemm(hs, self._w("s_qkv", sa.qkv, dt), bias=sa.qkv.bias)
-        a = hip.attn(qkv, B * T, N + 1, H, sa.scale)
-        side = torch.empty((B * T, D), dtype=torch.float32, device=x.device)
-        hip.gemm(a, self._w("s_proj", sa.proj, dt), out=xf, bias=sa.proj.bias, out_dtype=torch.float32, residual=xf,
-                 row_scale=self._drop(B * T, x.device), row_scale_group=N + 1,
-                 map_mode=hip.MAP_FRAME_TOKENS, map_p0=T, map_p1=N, side=side)
-        hip.cls_mean_residual(x, side, x, B, T)
-        # ---- MLP (vit.py:198-212)
-        h2 = hip.layernorm(x, self.norm2.weight, self.norm2.bias, VIT_EPS, dt)
+            self._forward_halves_unfused(x, xf, a, B, T, N, H, D, dt)
+            h2 = hip.layernorm(x, self.norm2.weight, self.norm2.bias, VIT_EPS, dt)
         f1 = hip.gemm(h2, self._w("fc1", self.mlp.fc1, dt), bias=self.mlp.fc1.bias, act=hip.ACT_GELU)
         hip.gemm(f1, self._w("fc2", self.mlp.fc2, dt), out=xf, bias=self.mlp.fc2.bias, out_dtype=torch.float32, residual=xf,
                  row_scale=self._drop(B, x.device), row_scale_group=S)
@@ -187,29 +206,42 @@ class Block(nn.Module):
                           map_mode=hip.MAP_SKIP_CLS, map_p0=N * T)
         qkv_t = hip.gemm(h, self._w("t_qkv", ta.qkv, dt), bias=ta.qkv.bias)
         a_t, lse_t = hip.attn_temporal(qkv_t, T, H, ta.scale, want_lse=True)
-        xt = torch.empty_like(x)
-        xt[:, 0] = x[:, 0]
         sv["merged"] = self.merge_temporal_proj
-        if self.merge_temporal_proj:
+        if self.fuse_residual_ln and self.merge_temporal_proj:
             pr = None
             mg = self._merged_tproj(dt)
-            hip.gemm(a_t, mg["w"], out=xt.view(B * S, D), bias=mg["b1"], bias2=self.temporal_fc.bias, out_dtype=torch.float32,
-                     residual=x.view(B * S, D), row_scale=sv["drop_t"], row_scale_group=T, map_mode=hip.MAP_SKIP_CLS, map_p0=N * T)
+            d_t = hip.gemm(a_t, mg["w"], bias=mg["b1"], row_scale=sv["drop_t"], row_scale_group=T)
+            hs, xt = hip.add_layernorm(x, d_t, self.norm1.weight, self.norm1.bias, VIT_EPS, mode=hip.ADD_PRE_SPATIAL,
+                                       delta_bias=self.temporal_fc.bias, T=T, N=N)
+            del d_t
+            qkv_s = hip.gemm(hs, self._w("s_qkv", sa.qkv, dt), bias=sa.qkv.bias)
+            a_s, lse_s = hip.attn(qkv_s, B * T, N + 1, H, sa.scale, want_lse=True)
+            d_s = hip.gemm(a_s, self._w("s_proj", sa.proj, dt), bias=sa.proj.bias, row_scale=sv["drop_s"], row_scale_group=N + 1)
+            h2, x2 = hip.add_layernorm(xt, d_s, self.norm2.weight, self.norm2.bias, VIT_EPS, mode=hip.ADD_PRE_MLP, T=T, N=N)
+            del d_s
         else:
-            pr = hip.gemm(a_t, self._w("t_proj", ta.proj, dt), bias=ta.proj.bias, row_scale=sv["drop_t"], row_scale_group=T)
-            hip.gemm(pr, self._w("t_fc", self.temporal_fc, dt), out=xt.view(B * S, D), bias=self.temporal_fc.bias, out_dtype=torch.float32,
-                     residual=x.view(B * S, D), map_mode=hip.MAP_SKIP_CLS, map_p0=N * T)
-        hs = hip.layernorm(xt, self.norm1.weight, self.norm1.bias, VIT_EPS, dt, rows=B * T * (N + 1),
-                           map_mode=hip.MAP_FRAME_TOKENS, map_p0=T, map_p1=N)
-        qkv_s = hip.gemm(hs, self._w("s_qkv", sa.qkv, dt), bias=sa.qkv.bias)
-        a_s, lse_s = hip.attn(qkv_s, B * T, N + 1, H, sa.scale, want_lse=True)
-        x2 = torch.empty_like(x)
-        side = torch.empty((B * T, D), dtype=torch.float32, device=dev)
-        hip.gemm(a_s, self._w("s_proj", sa.proj, dt), out=x2.view(B * S, D), bias=sa.proj.bias, out_dtype=torch.float32,
-                 residual=xt.view(B * S, D), row_scale=sv["drop_s"], row_scale_group=N + 1,
-                 map_mode=hip.MAP_FRAME_TOKENS, map_p0=T, map_p1=N, side=side)
-        hip.cls_mean_residual(xt, side, x2, B, T)
-        h2 = hip.layernorm(x2, self.norm2.weight, self.norm2.bias, VIT_EPS, dt)
+            xt = torch.empty_like(x)
+            xt[:, 0] = x[:, 0]
+            if self.merge_temporal_proj:
+                pr = None
+                mg = self._merged_tproj(dt)
+                hip.gemm(a_t, mg["w"], out=xt.view(B * S, D), bias=mg["b1"], bias2=self.temporal_fc.bias, out_dtype=torch.float32,
+                         residual=x.view(B * S, D), row_scale=sv["drop_t"], row_scale_group=T, map_mode=hip.MAP_SKIP_CLS, map_p0=N * T)
+            else:
+                pr = hip.gemm(a_t, self._w("t_proj", ta.proj, dt), bias=ta.proj.bias, row_scale=sv["drop_t"], row_scale_group=T)
+                hip.gemm(pr, self._w("t_fc", self.temporal_fc, dt), out=xt.view(B * S, D), bias=self.temporal_fc.bias, out_dtype=torch.float32,
+                         residual=x.view(B * S, D), map_mode=hip.MAP_SKIP_CLS, map_p0=N * T)
+            hs = hip.layernorm(xt, self.norm1.weight, self.norm1.bias, VIT_EPS, dt, rows=B * T * (N + 1),
+                               map_mode=hip.MAP_FRAME_TOKENS, map_p0=T, map_p1=N)
+            qkv_s = hip.gemm(hs, self._w("s_qkv", sa.qkv, dt), bias=sa.qkv.bias)
+            a_s, lse_s = hip.attn(qkv_s, B * T, N + 1, H, sa.scale, want_lse=True)
+            x2 = torch.empty_like(x)
+            side = torch.empty((B * T, D), dtype=torch.float32, device=dev)
+            hip.gemm(a_s, self._w("s_proj", sa.proj, dt), out=x2.view(B * S, D), bias=sa.proj.bias, out_dtype=torch.float32,
+                     residual=xt.view(B * S, D), row_scale=sv["drop_s"], row_scale_group=N + 1,
+                     map_mode=hip.MAP_FRAME_TOKENS, map_p0=T, map_p1=N, side=side)
+            hip.cls_mean_residual(xt, side, x2, B, T)
+            h2 = hip.layernorm(x2, self.norm2.weight, self.norm2.bias, VIT_EPS, dt)
         u = torch.empty((B * S, self.mlp.fc1.out_features), dtype=dt, device=dev)
         f1 = hip.gemm(h2, self._w("fc1", self.mlp.fc1, dt), bias=self.mlp.fc1.bias, act=hip.ACT_GELU, pre_act=u)
         out = torch.empty_like(x)
@@ -233,16 +265,22 @@ class Block(nn.Module):
                           map_mode=hip.MAP_SKIP_CLS, map_p0=N * T)
         qkv = hip.gemm(h, self._w("t_qkv", ta.qkv, dt), bias=ta.qkv.bias)
         a = hip.attn_temporal(qkv, T, H, ta.scale)
-        if self.merge_temporal_proj:
+        if self.fuse_residual_ln and self.merge_temporal_proj:
             mg = self._merged_tproj(dt)
-            hip.gemm(a, mg["w"], out=xf, bias=mg["b1"], bias2=self.temporal_fc.bias, out_dtype=torch.float32, residual=xf,
-                     map_mode=hip.MAP_SKIP_CLS, map_p0=N * T)
+            d_t = hip.gemm(a, mg["w"], bias=mg["b1"])
+            hs, _ = hip.add_layernorm(x, d_t, self.norm1.weight, self.norm1.bias, VIT_EPS, mode=hip.ADD_PRE_SPATIAL, want_x=False,
+                                      delta_bias=self.temporal_fc.bias, T=T, N=N)   # the patch rows of x are not read again; x[:, 0] is untouched
         else:
-            pr = hip.gemm(a, self._w("t_proj", ta.proj, dt), bias=ta.proj.bias)
-            hip.gemm(pr, self._w("t_fc", self.temporal_fc, dt), out=xf, bias=self.temporal_fc.bias, out_dtype=torch.float32,
-                     residual=xf, map_mode=hip.MAP_SKIP_CLS, map_p0=N * T)
-        hs = hip.layernorm(x, self.norm1.weight, self.norm1.bias, VIT_EPS, dt, rows=B * T * (N + 1),
-                           map_mode=hip.MAP_FRAME_TOKENS, map_p0=T, map_p1=N)
+            if self.merge_temporal_proj:
+                mg = self._merged_tproj(dt)
+                hip.gemm(a, mg["w"], out=xf, bias=mg["b1"], bias2=self.temporal_fc.bias, out_dtype=torch.float32, residual=xf,
+                         map_mode=hip.MAP_SKIP_CLS, map_p0=N * T)
+            else:
+                pr = hip.gemm(a, self._w("t_proj", ta.proj, dt), bias=ta.proj.bias)
+                hip.gemm(pr, self._w("t_fc", self.temporal_fc, dt), out=xf, bias=self.temporal_fc.bias, out_dtype=torch.float32,
+                         residual=xf, map_mode=hip.MAP_SKIP_CLS, map_p0=N * T)
+            hs = hip.layernorm(x, self.norm1.weight, self.norm1.bias, VIT_EPS, dt, rows=B * T * (N + 1),
+                               map_mode=hip.MAP_FRAME_TOKENS, map_p0=T, map_p1=N)
         qkv = hip.gemm(hs, self._w("s_qkv", sa.qkv, dt), bias=sa.qkv.bias)
         a = hip.attn(qkv, B * T, N + 1, H, sa.scale)
         a_cls = a.view(B * T, N + 1, D)[:, 0].contiguous()                                  # CLS query of every frame

@@ -15,6 +15,7 @@ attention-probability dropout inside alpro_attn; the masks are a pure hash of (s
 regenerates them instead of storing them.  Identity in eval mode.
 """
 import math
+import os
 from types import SimpleNamespace
 
 import torch
@@ -89,6 +90,8 @@ class BertOutput(nn.Module):
 
 
 class BertLayer(nn.Module):
+    fuse_residual_ln = os.environ.get("ALPRO_FUSE_RESIDUAL_LN", "1") != "0"   # residual adds inside the post-LayerNorms (alpro_add_layernorm_fwd); False = round-2 GEMM-epilogue form (A/B)
+
     def __init__(self, config, layer_num):
         super().__init__()
         self.config = config
@@ -124,14 +127,23 @@ class BertLayer(nn.Module):
         bqkv = self._ops.get("qkv_b", (sa.query.bias, sa.key.bias, sa.value.bias), torch.float32)
         qkv = hip.gemm(h_t, wqkv, bias=bqkv)
         ctx, lse = hip.attn(qkv, B, L, H, scale, key_bias, want_lse=True, drop_p=ap, drop_seed=seed_a)
-        s1 = hip.gemm(ctx, self._ops.get("ao_w", so.dense.weight, dt), bias=so.dense.bias, out_dtype=torch.float32, residual=h32,
-                      drop_p=hp, drop_seed=seed1)
-        a_t, a32 = hip.layernorm(s1, so.LayerNorm.weight, so.LayerNorm.bias, eps, dt, out32=True)
         u = torch.empty((h_t.shape[0], self.intermediate.dense.out_features), dtype=dt, device=h_t.device) if save else None
-        it = hip.gemm(a_t, self._ops.get("i_w", self.intermediate.dense.weight, dt), bias=self.intermediate.dense.bias, act=hip.ACT_GELU, pre_act=u)
-        s2 = hip.gemm(it, self._ops.get("o_w", self.output.dense.weight, dt), bias=self.output.dense.bias, out_dtype=torch.float32, residual=a32,
-                      drop_p=hp, drop_seed=seed2)
-        o_t, o32 = hip.layernorm(s2, self.output.LayerNorm.weight, self.output.LayerNorm.bias, eps, dt, out32=True)
+        if self.fuse_residual_ln:
+            # the two dense Linears write their (dropped-out) 16-bit output only; residual add + post-LayerNorm are one streaming kernel
+            # (alpro_add_layernorm_fwd), which also leaves the pre-LayerNorm sums s1 / s2 the backward needs (training only)
+            d1 = hip.gemm(ctx, self._ops.get("ao_w", so.dense.weight, dt), bias=so.dense.bias, drop_p=hp, drop_seed=seed1)
+            a_t, a32, s1 = hip.add_layernorm(h32, d1, so.LayerNorm.weight, so.LayerNorm.bias, eps, out32=True, want_x=save)
+            it = hip.gemm(a_t, self._ops.get("i_w", self.intermediate.dense.weight, dt), bias=self.intermediate.dense.bias, act=hip.ACT_GELU, pre_act=u)
+            d2 = hip.gemm(it, self._ops.get("o_w", self.output.dense.weight, dt), bias=self.output.dense.bias, drop_p=hp, drop_seed=seed2)
+            o_t, o32, s2 = hip.add_layernorm(a32, d2, self.output.LayerNorm.weight, self.output.LayerNorm.bias, eps, out32=True, want_x=save)
+        else:
+            s1 = hip.gemm(ctx, self._ops.get("ao_w", so.dense.weight, dt), bias=so.dense.bias, out_dtype=torch.float32, residual=h32,
+                          drop_p=hp, drop_seed=seed1)
+            a_t, a32 = hip.layernorm(s1, so.LayerNorm.weight, so.LayerNorm.bias, eps, dt, out32=True)
+            it = hip.gemm(a_t, self._ops.get("i_w", self.intermediate.dense.weight, dt), bias=self.intermediate.dense.bias, act=hip.ACT_GELU, pre_act=u)
+            s2 = hip.gemm(it, self._ops.get("o_w", self.output.dense.weight, dt), bias=self.output.dense.bias, out_dtype=torch.float32, residual=a32,
+                          drop_p=hp, drop_seed=seed2)
+            o_t, o32 = hip.layernorm(s2, self.output.LayerNorm.weight, self.output.LayerNorm.bias, eps, dt, out32=True)
         sv = dict(h_t=h_t, qkv=qkv, ctx=ctx, lse=lse, s1=s1, a_t=a_t, u=u, it=it, s2=s2, kb=key_bias, dims=(B, L, H, scale), dt=dt,
                   drop=(hp, seed1, seed2, ap, seed_a)) if save else None
         return o32, o_t, sv

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define ALPRO_HIP_ABI_VERSION 10
+#define ALPRO_HIP_ABI_VERSION 11
 
 enum { ALPRO_OK = 0, ALPRO_ERR_INVALID = 1, ALPRO_ERR_LAUNCH = 2 };
 enum { ALPRO_F32 = 0, ALPRO_BF16 = 1, ALPRO_F16 = 2 };
@@ -100,6 +100,23 @@ int alpro_gemm(const alpro_gemm_desc_t* d, void* stream);
 int alpro_layernorm_fwd(const float* x, int64_t ldx, const float* gamma, const float* beta, float eps, void* y,
                         int y_dtype, int64_t ldy, float* y32, float* mean, float* rstd, int rows, int D,
                         int map_mode, int map_p0, int map_p1, void* stream);
+
+/* Residual add fused into the LayerNorm that follows it (vit.py:162 -> :180, :196 -> :200, :212 -> next block's :154; xbert.py:358-359,
+ * 436-437).  The producing Linear writes only its output `delta` (operand dtype, plain (rows, 768) row order, drop-path / dropout already
+ * applied by the GEMM epilogue); this kernel computes x' = x_in + gathered delta (+ delta_bias on the rows that receive a delta), stores
+ * x' to x_out (fp32; may be NULL when nobody needs it, may alias x_in) and LayerNorm(x') to y (`dtype`) [and y32, fp32, 16-bit modes
+ * only].  Replaces the fp32 read-modify-write of x in the GEMM epilogue, the CLS side buffer and alpro_cls_mean_residual.
+ *   ALPRO_ADD_IDENTITY      rows = M:              v = x_in[m] + delta[m]                                  -> x_out[m], y[m]
+ *   ALPRO_ADD_PRE_SPATIAL   rows = B*T*(N+1), p0 = T, p1 = N, m = (b*T+t)*(N+1)+j, r = token row of (b, j, t):
+ *                           j > 0: v = x_in[r] + delta[r - b - 1] (+ bias)   (delta in x[:, 1:] order);  j = 0: v = x_in[r]
+ *                                                                                                          -> x_out[r], y[m]
+ *   ALPRO_ADD_PRE_MLP       rows = B*(1+N*T), r = b*S + k: k > 0: v = x_in[r] + delta[(b*T+t)*(N+1)+1+n];
+ *                           k = 0: v = x_in[r] + mean_t delta[(b*T+t)*(N+1)]                               -> x_out[r], y[r]
+ *   ALPRO_ADD_PRE_TEMPORAL  rows = B*(1+N*T): v = x_in[r] + delta[r] -> x_out[r]; k > 0: y[r - b - 1] = LN(v) */
+enum { ALPRO_ADD_IDENTITY = 0, ALPRO_ADD_PRE_SPATIAL = 1, ALPRO_ADD_PRE_MLP = 2, ALPRO_ADD_PRE_TEMPORAL = 3 };
+int alpro_add_layernorm_fwd(const float* x_in, const void* delta, int dtype, const float* delta_bias, int add_mode, float* x_out,
+                            const float* gamma, const float* beta, float eps, void* y, float* y32, int64_t rows, int D, int p0, int p1,
+                            void* stream);
 
 /* Divided space-time attention, temporal half (vit.py:146-157 -> Attention.forward :81-96):
  * rows = B*N*T tokens in (b, n, t) order, each group of T consecutive rows attends within itself.

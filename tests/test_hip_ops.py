@@ -151,6 +151,63 @@ def test_layernorm_maps(dt):
     close(y, ref, 1e-5, 1e-5, "ln frame_tokens gather")
 
 
+@pytest.mark.parametrize("dt", DTYPES)
+def test_add_layernorm_modes(dt):
+    """alpro_add_layernorm_fwd (round 3): the residual add of a branch fused into the LayerNorm that follows, in the four row
+    arrangements of the path, against the reference's own tensor algebra (vit.py:157-200: rearranges, cat, CLS frame mean) in fp64."""
+    hip = _hip()
+    B, T, N, D = 2, 4, 9, 768
+    S = 1 + N * T
+    x = rnd(B, S, D, seed=40) * 2 + 0.3
+    g, b = 1 + 0.1 * rnd(D, seed=41), 0.1 * rnd(D, seed=42)
+    bias = 0.2 * rnd(D, seed=43)
+    ln = lambda v: torch.nn.functional.layer_norm(v, (D,), g.double(), b.double(), 1e-6)  # noqa: E731
+    xd = x.double()
+    tol32 = (2e-5, 2e-5)
+    # identity (BERT: s = h + dense(ctx); LN(s)) with the fp32 copy of the normalised rows
+    d = rnd(B * S, D, seed=44).to(dt)
+    y, y32, xo = hip.add_layernorm(x.cuda(), d.cuda(), g.cuda(), b.cuda(), 1e-6, out32=True)
+    ref_x = xd.view(-1, D) + d.double()
+    close(xo.view(-1, D), ref_x, *tol32, "identity x'")
+    close(y32, ln(ref_x), *tol32, "identity y32")
+    close(y, ln(ref_x), *OUT_TOL[dt], "identity y")
+    # PRE_SPATIAL: xt[:, 1:] = x[:, 1:] + (delta + bias) in '(b n t)' order; CLS untouched; LN over the frame-token gather (vit.py:162-180)
+    d = rnd(B * N * T, D, seed=45).to(dt)
+    y, xo = hip.add_layernorm(x.cuda(), d.cuda(), g.cuda(), b.cuda(), 1e-6, mode=hip.ADD_PRE_SPATIAL, delta_bias=bias.cuda(), T=T, N=N)
+    xt = xd.clone()
+    xt[:, 1:] += d.double().view(B, N * T, D) + bias.double()
+    close(xo, xt, *tol32, "pre_spatial x'")
+    lx = ln(xt)
+    xs = lx[:, 1:].reshape(B, N, T, D).permute(0, 2, 1, 3)
+    ref = torch.cat([lx[:, :1].unsqueeze(1).expand(B, T, 1, D), xs], 2).reshape(-1, D)
+    close(y, ref, *OUT_TOL[dt], "pre_spatial y (frame-token order)")
+    # ... in place, and without keeping x' (the prompter's last block)
+    xi = x.cuda().clone()
+    y2, xo2 = hip.add_layernorm(xi, d.cuda(), g.cuda(), b.cuda(), 1e-6, mode=hip.ADD_PRE_SPATIAL, x_out=xi, delta_bias=bias.cuda(), T=T, N=N)
+    assert xo2 is xi and torch.equal(xi, xo) and torch.equal(y2, y)
+    y3, none = hip.add_layernorm(x.cuda(), d.cuda(), g.cuda(), b.cuda(), 1e-6, mode=hip.ADD_PRE_SPATIAL, want_x=False, delta_bias=bias.cuda(), T=T, N=N)
+    assert none is None and torch.equal(y3, y)
+    # PRE_MLP: delta in frame-token order '(b t) (1 + n)'; patches scattered back, CLS gets the frame mean (vit.py:184-196), LN2 over all tokens
+    d = rnd(B * T * (N + 1), D, seed=46).to(dt)
+    y, xo = hip.add_layernorm(x.cuda(), d.cuda(), g.cuda(), b.cuda(), 1e-6, mode=hip.ADD_PRE_MLP, T=T, N=N)
+    dd = d.double().view(B, T, N + 1, D)
+    x2 = xd.clone()
+    x2[:, 0] += dd[:, :, 0].mean(1)
+    x2[:, 1:] += dd[:, :, 1:].permute(0, 2, 1, 3).reshape(B, N * T, D)
+    close(xo, x2, *tol32, "pre_mlp x'")
+    close(y, ln(x2).view(-1, D), *OUT_TOL[dt], "pre_mlp y")
+    # PRE_TEMPORAL: the MLP delta of the previous block folded into the next block's temporal LayerNorm over x[:, 1:]
+    d = rnd(B * S, D, seed=47).to(dt)
+    y, xo = hip.add_layernorm(x.cuda(), d.cuda(), g.cuda(), b.cuda(), 1e-6, mode=hip.ADD_PRE_TEMPORAL, T=T, N=N)
+    x3 = xd + d.double().view(B, S, D)
+    close(xo, x3, *tol32, "pre_temporal x'")
+    close(y, ln(x3)[:, 1:].reshape(-1, D), *OUT_TOL[dt], "pre_temporal y (x[:, 1:] order)")
+    with pytest.raises(RuntimeError, match="whole number of clips"):
+        hip.add_layernorm(x.cuda()[:, :-1].contiguous(), d.cuda(), g.cuda(), b.cuda(), 1e-6, mode=hip.ADD_PRE_MLP, T=T, N=N)
+    with pytest.raises(RuntimeError, match="delta has"):
+        hip.add_layernorm(x.cuda(), d.cuda()[:-1], g.cuda(), b.cuda(), 1e-6, mode=hip.ADD_PRE_TEMPORAL, T=T, N=N)
+
+
 def test_small_kernels():
     hip = _hip()
     B, T, N, D = 3, 4, 6, 768
