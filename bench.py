@@ -146,7 +146,7 @@ def cpu_baseline_train(T):
     steps of B=2 pairs after a warm-up forward+backward (thread pool, allocator, autograd graph caches) -- a bounded sample
     (~20-30 s of CPU work)."""
     from oracle import alpro_oracle as ao
-    from oracle.det_init import det_batch
+    from tests.golden.det_init import det_batch
     threads = min(os.cpu_count() or 1, 32)
     torch.set_num_threads(threads)
     spec = ao.alpro_state_spec("pretrain", BERT_CFG, T)

@@ -141,3 +141,21 @@ def det_prompts(E, n_templates, Lp, seed_name):
         mask[r, nv:] = 0
         ids[r, nv:] = 0
     return PromptEncoding(ids, mask)
+
+
+def det_raw_clips(B, T, img=224, seed_name="input_raw"):
+    """uint8 pixels (B, T, 3, img, img), closed form."""
+    x = (unit_uniform(seed_name, B * T * 3 * img * img) + 1.0) * 0.5
+    return torch.from_numpy(np.minimum(np.floor(x * 256.0), 255).astype(np.uint8).reshape(B, T, 3, img, img))
+
+
+def det_caption_ids(B, Lt=40, seed_name="input_ids"):
+    x = (unit_uniform(seed_name, B * Lt) + 1.0) * 0.5
+    ids = torch.from_numpy((1000 + np.floor(x * 29000)).astype(np.int64).reshape(B, Lt))
+    ids[:, 0] = 101
+    for b in range(B):
+        n_valid = Lt - (5 * b + 3) % (Lt - 10)
+        ids[b, n_valid - 1] = 102
+        ids[b, n_valid:] = 0
+    ids[0, 5] = 100  # an [UNK] inside a caption: special, never masked
+    return ids

@@ -4,7 +4,7 @@
 
 The reference has no tests/fixtures of its own, so these files are the
 pin for oracle/alpro_oracle.py.  Weights and inputs are NOT stored: both sides regenerate
-them from oracle/det_init.py closed forms.  Stochastic ops are pinned:
+them from tests/golden/det_init.py closed forms.  Stochastic ops are pinned:
   * torch.multinomial (hard negatives, alpro_models.py:303,311) -> argmax of the weights,
   * torch.rand inside drop_path (vit_utils.py:148) -> det_init.unit_uniform stream, recorded.
 Needs /root/reference; never runs on the GPU box.
@@ -19,7 +19,7 @@ import torch
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 
-from oracle.det_init import det_batch, det_prompts, fill_state_dict_, unit_uniform  # noqa: E402
+from tests.golden.det_init import det_batch, det_caption_ids, det_prompts, det_raw_clips, fill_state_dict_, unit_uniform  # noqa: E402
 from tests.golden import ref_harness as rh  # noqa: E402
 
 MLM_COL_STRIDE = 61
@@ -99,6 +99,40 @@ def case_pretrain(am, T, B, fname, with_grads):
     return keys
 
 
+def case_pretrain_release(am, fname, T=4, Lt=30, B=2):
+    """The geometry the reference actually pretrains with (config_release/pretrain_alpro.json:34,37,59: num_frm 4, max_txt_len 30,
+    train_batch_size 16): AlproForPretrain at 4 frames x 30 tokens (fusion length 227), all losses + parameter-gradient norms."""
+    cfg, venc = rh.make_configs(num_frm=T)
+    m = am.AlproForPretrain(cfg, venc)
+    fill_state_dict_(m)
+    m.eval()
+    batch = det_batch(B, T, Lt=Lt, seed_name="pretrain_release")
+    orig = torch.multinomial
+    torch.multinomial = argmax_multinomial
+    try:
+        out = m(batch)
+    finally:
+        torch.multinomial = orig
+    g = {k: npf(out[k]) for k in ("itc_loss", "itm_loss", "mlm_loss", "mpm_loss", "itm_scores", "itm_labels", "mpm_logits")}
+    g["mlm_scores_cols"] = npf(out["mlm_scores"][:, :, ::MLM_COL_STRIDE])
+    with torch.no_grad():
+        ve = m._forward_visual_embeds(batch["visual_inputs"])
+        te, tf = m._forward_text_feats(batch)
+        summarize_embeds("video_embeds", ve, [0, 1, 57, 196], g)
+        vf = torch.nn.functional.normalize(m.vision_proj(ve[:, 0, :]), dim=-1)
+        g["sim_v2t"] = npf(vf @ tf.t() / m.temp)
+        g["text_embeds_rows"] = npf(te[:, [0, 1, 29]])
+    (out["mlm_loss"] + out["itm_loss"] + out["itc_loss"] + out["mpm_loss"]).backward()
+    names, norms = [], []
+    for n_, p_ in m.named_parameters():
+        if p_.grad is not None:
+            names.append(n_)
+            norms.append(float(p_.grad.norm()))
+    g["grad_norm_names"] = np.array(names)
+    g["grad_norms"] = np.array(norms, dtype=np.float64)
+    np.savez_compressed(os.path.join(HERE, fname), **g)
+
+
 def case_retrieval(am, T, B, fname):
     cfg, venc = rh.make_configs(num_frm=T)
     m = am.AlproForVideoTextRetrieval(cfg, venc)
@@ -140,7 +174,7 @@ def case_block_droppath(fname, T=2, B=4, layer=11):
     """One ViT Block in TRAIN mode with drop_path=0.1 and a recorded torch.rand stream (vit.py:136-213)."""
     import src.modeling.timesformer.vit as vit
     from functools import partial
-    from oracle.det_init import det_param
+    from tests.golden.det_init import det_param
     blk = vit.Block(dim=768, num_heads=12, layer_num=layer, mlp_ratio=4, qkv_bias=True, drop=0., attn_drop=0.,
                     drop_path=0.1, norm_layer=partial(torch.nn.LayerNorm, eps=1e-6))
     with torch.no_grad():
@@ -331,6 +365,70 @@ def case_retrieval_eval(am, T, V, fname, eval_bsz=3):
     np.savez_compressed(os.path.join(HERE, fname), **g)
 
 
+def reference_input_functions():
+    """random_erase (src/datasets/dataset_pretrain_sparse.py:277-311), ImageNorm and mask_batch_text_tokens (src/datasets/data_utils.py:
+    437-457, 23-70) of the reference, EXECUTED from their source without importing the modules (which pull in lmdb / decord / cv2 /
+    torchvision, absent from this image): the definitions are cut out with `ast` and compiled as they stand."""
+    import ast
+    ns = {"np": np, "torch": torch}
+    for rel, want in (("src/datasets/dataset_pretrain_sparse.py", {"random_erase"}), ("src/datasets/data_utils.py", {"ImageNorm", "mask_batch_text_tokens"})):
+        path = os.path.join(rh.REF, rel)
+        tree = ast.parse(open(path).read())
+        mod = ast.Module(body=[n for n in tree.body if isinstance(n, (ast.FunctionDef, ast.ClassDef)) and n.name in want], type_ignores=[])
+        assert {n.name for n in mod.body} == want, (rel, want)
+        exec(compile(mod, path, "exec"), ns)
+    return ns
+
+
+class _BertUncasedTokenizerStub:
+    """What mask_batch_text_tokens asks of the tokenizer (data_utils.py:31-66), with bert-base-uncased's special ids ([PAD] 0, [UNK] 100,
+    [CLS] 101, [SEP] 102, [MASK] 103; transformers' get_special_tokens_mask(already_has_special_tokens=True) flags all_special_ids)."""
+    mask_token, _pad_token, pad_token_id = "[MASK]", "[PAD]", 0
+
+    def get_special_tokens_mask(self, val, already_has_special_tokens=True):
+        return [1 if t in (0, 100, 101, 102, 103) else 0 for t in val]
+
+    def convert_tokens_to_ids(self, tok):
+        assert tok == "[MASK]"
+        return 103
+
+    def __len__(self):
+        return 30522
+
+
+INPUT_NP_SEED, INPUT_TORCH_SEED, INPUT_STRIDE = 777, 4321, 7
+
+
+def case_input_pipeline(fname, B=4, T=2):
+    """SURVEY 8(f) N4 pinned to the reference: PretrainCollator's per-sample random_erase on the raw uint8 clips
+    (dataset_pretrain_sparse.py:244, under np.random.seed), PrefetchLoader's .float() + ImageNorm on visual / crop / context
+    (dataloader.py:104-115), and mask_batch_text_tokens under torch.manual_seed -- outputs of the reference's own code."""
+    ns = reference_input_functions()
+    raw = det_raw_clips(B, T)
+    np.random.seed(INPUT_NP_SEED)
+    elems = [ns["random_erase"](e, patch_size=16) for e in raw.clone()]
+    crop, masks, ctx = (torch.stack([e[i] for e in elems]) for i in range(3))
+    cuda = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self   # ImageNorm.__init__ hard-codes .cuda() (data_utils.py:441-442)
+    try:
+        norm = ns["ImageNorm"](mean=[0.485, 0.456, 0.406], std=[0.229, 0.224, 0.225])   # src/configs/config.py defaults
+    finally:
+        torch.Tensor.cuda = cuda
+    g = {"mpm_mask": npf(masks), "np_seed": np.int64(INPUT_NP_SEED), "torch_seed": np.int64(INPUT_TORCH_SEED), "stride": np.int64(INPUT_STRIDE)}
+    for name, t in (("visual_inputs", raw), ("crop_visual_inputs", crop), ("context_visual_inputs", ctx)):
+        out = norm(t.float())
+        g[name + "_sub"] = npf(out[..., ::INPUT_STRIDE, ::INPUT_STRIDE])
+        g[name + "_sum"] = out.double().sum((-1, -2)).numpy()
+        g[name + "_sqsum"] = (out.double() ** 2).sum((-1, -2)).numpy()
+    unit = norm(raw.float() / 255.0)       # pixels already in 0..1: ImageNorm's data-dependent test must NOT rescale again
+    g["unit_visual_inputs_sub"] = npf(unit[..., ::INPUT_STRIDE, ::INPUT_STRIDE])
+    ids = det_caption_ids(6)
+    torch.manual_seed(INPUT_TORCH_SEED)
+    masked, labels = ns["mask_batch_text_tokens"](ids.clone(), _BertUncasedTokenizerStub())
+    g["mlm_input_ids"], g["mlm_masked_ids"], g["mlm_labels"] = ids.numpy(), masked.numpy(), labels.numpy()
+    np.savez_compressed(os.path.join(HERE, fname), **g)
+
+
 def main():
     am, _ = rh.import_reference()
     torch.set_num_threads(8)
@@ -353,6 +451,10 @@ def main():
         case_retrieval_eval(am, 2, 5, "retrieval_eval_T2_V5.npz")
     if want("retrieval_T16"):
         case_retrieval_frames(am, 16, 2, "retrieval_T16_B2.npz")
+    if want("input_pipeline"):
+        case_input_pipeline("input_pipeline_B4_T2.npz")
+    if want("pretrain_release"):
+        case_pretrain_release(am, "pretrain_release_T4_L30_B2.npz")
     if len(keys) == 2:
         json.dump(keys, open(os.path.join(HERE, "state_keys.json"), "w"), indent=0, sort_keys=True)
     for f in sorted(os.listdir(HERE)):

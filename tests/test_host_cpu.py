@@ -633,6 +633,28 @@ def test_anchor_tells_a_run_whether_other_anchored_backwards_are_still_pending()
     assert len(tr._LIVE_ANCHORS) == 0
 
 
+def test_input_pipeline_host_logic_reproduces_the_reference_fixture():
+    """N4 pinned to the reference: tests/golden/input_pipeline_B4_T2.npz holds what the REFERENCE's own random_erase
+    (dataset_pretrain_sparse.py:277-311) and mask_batch_text_tokens (data_utils.py:23-70) produced under recorded numpy / torch seeds
+    (ast-extracted and executed by make_golden.py).  Same seeds here -> sample_erase_box must draw the same rectangles (mpm_mask equal)
+    and the batched MLM masking must return the same masked ids and labels, bit for bit, on the CPU generator."""
+    import numpy as np
+    from alpro_amd.input_gpu import mask_batch_text_tokens, random_erase_batch, sample_erase_box
+    g = np.load(os.path.join(GOLDEN, "input_pipeline_B4_T2.npz"))
+    B = g["mpm_mask"].shape[0]
+    rng = np.random.RandomState(int(g["np_seed"]))
+    boxes = [sample_erase_box(224, 224, 16, rng=rng) for _ in range(B)]
+    x = torch.zeros(B, 1, 3, 224, 224)
+    out = random_erase_batch(x, patch_size=16, boxes=boxes)
+    assert np.array_equal(out["mpm_mask"].numpy(), g["mpm_mask"]), "erase rectangles differ from the reference's draws"
+    assert 0.2 < float(1 - g["mpm_mask"].mean()) < 0.6
+    torch.manual_seed(int(g["torch_seed"]))
+    masked, labels = mask_batch_text_tokens(torch.from_numpy(g["mlm_input_ids"]), mask_token_id=103, vocab_size=30522)
+    assert np.array_equal(masked.numpy(), g["mlm_masked_ids"]) and np.array_equal(labels.numpy(), g["mlm_labels"])
+    sel = g["mlm_labels"] != -100
+    assert sel.any() and not sel[:, 0].any() and not sel[g["mlm_input_ids"] == 0].any() and not sel[0, 5]   # [CLS], [PAD], [UNK] never masked
+
+
 def test_retrieval_eval_known_answers_from_the_reference():
     """eval_retrieval on records rebuilt from score tables the REFERENCE produced, against the metrics the reference's own
     eval_retrieval computed from them (tests/golden/retrieval_eval_T2_V5.npz: a 5 x 5 model table and a 12 x 12 synthetic table

@@ -1,6 +1,9 @@
 """GPU: device-side batch preparation -- alpro_prepare_clips (ImageNorm + MPM random erase in one pass) and the
-batched torch ops of alpro_amd/input_gpu.py -- against the reference's per-sample host construction, restated here with the exact
-statements of dataset_pretrain_sparse.py:277-311 (erase on raw pixels) and data_utils.py:437-457 (ImageNorm on each tensor)."""
+batched torch ops of alpro_amd/input_gpu.py.  Pinned to the reference since round 3: tests/golden/input_pipeline_B4_T2.npz holds the
+outputs of the reference's OWN random_erase / ImageNorm / mask_batch_text_tokens (ast-extracted from dataset_pretrain_sparse.py:277-311
+and data_utils.py:23-70,437-457 and executed under recorded seeds by tests/golden/make_golden.py); the per-sample restatement below
+stays as a second, size-independent checker."""
+import os
 import numpy as np
 import pytest
 import torch
@@ -79,3 +82,28 @@ def test_device_side_mlm_masking_and_sampled_boxes():
     sel = pix.expand_as(out["visual_inputs"])
     assert float((out["context_visual_inputs"][sel] - z.expand_as(out["visual_inputs"])[sel]).abs().max()) < 1e-6
     assert torch.equal(out["crop_visual_inputs"][sel], out["visual_inputs"][sel])
+
+
+def test_prepare_clips_vs_reference_fixture():
+    """alpro_prepare_clips on the fixture's raw uint8 clips, with the rectangles sample_erase_box draws from the recorded numpy seed,
+    against what the reference's random_erase + PrefetchLoader ImageNorm produced: strided pixel subsamples of visual / crop / context
+    (every 7th row / column), their per-(clip, frame, channel) sums and sums of squares, and mpm_mask."""
+    from alpro_amd.input_gpu import prepare_pretrain_clips, sample_erase_box
+    from tests.conftest import GOLDEN
+    from tests.golden.det_init import det_raw_clips
+    g = np.load(os.path.join(GOLDEN, "input_pipeline_B4_T2.npz"))
+    B, T = g["visual_inputs_sub"].shape[:2]
+    raw = det_raw_clips(B, T).cuda()
+    rng = np.random.RandomState(int(g["np_seed"]))
+    boxes = [sample_erase_box(224, 224, 16, rng=rng) for _ in range(B)]
+    st = int(g["stride"])
+    for src in (raw, raw.float()):       # uint8 pixels as the dataloader delivers them, and the .float() the reference makes first
+        out = prepare_pretrain_clips(src, MEAN, STD, patch_size=16, boxes=boxes)
+        assert np.array_equal(out["mpm_mask"].cpu().numpy(), g["mpm_mask"])
+        for k in ("visual_inputs", "crop_visual_inputs", "context_visual_inputs"):
+            got = out[k]
+            assert float(np.abs(got[..., ::st, ::st].cpu().numpy() - g[k + "_sub"]).max()) <= 2e-6, k
+            s1, s2 = got.double().sum((-1, -2)).cpu().numpy(), (got.double() ** 2).sum((-1, -2)).cpu().numpy()
+            assert np.allclose(s1, g[k + "_sum"], rtol=1e-6, atol=1e-3) and np.allclose(s2, g[k + "_sqsum"], rtol=1e-6, atol=1e-3), k
+    unit = prepare_pretrain_clips(raw.float() / 255.0, MEAN, STD, boxes=boxes)    # 0..1 pixels: no second rescale (data_utils.py:455)
+    assert float(np.abs(unit["visual_inputs"][..., ::st, ::st].cpu().numpy() - g["unit_visual_inputs_sub"]).max()) <= 2e-6

@@ -68,7 +68,7 @@ def close(got, ref, atol, rtol=0.0, what=""):
 
 @pytest.fixture(scope="module")
 def retrieval(bert_cfg):
-    from oracle.det_init import det_batch, fill_state_dict_
+    from tests.golden.det_init import det_batch, fill_state_dict_
     from alpro_amd.modeling.alpro_models import AlproForVideoTextRetrieval
     m = AlproForVideoTextRetrieval(make_cfg(bert_cfg), dict(VENC, num_frm=2))
     fill_state_dict_(m)
@@ -103,7 +103,7 @@ def test_retrieval_vs_reference(retrieval, monkeypatch, mode, tol_logit, tol_emb
 @pytest.mark.parametrize("mode,tol", [("fp32", 1e-3), ("bf16", 3e-2), ("fp16", 4e-3)])
 def test_pretrain_forward_vs_reference(bert_cfg, monkeypatch, mode, tol):
     """All ten outputs of AlproForPretrain.forward (VTC + VTM + MLM + MPM) at 8 frames."""
-    from oracle.det_init import det_batch, fill_state_dict_
+    from tests.golden.det_init import det_batch, fill_state_dict_
     from alpro_amd import config as rt
     from alpro_amd.modeling.alpro_models import AlproForPretrain
     g = np.load(os.path.join(GOLDEN, "pretrain_T8_B2.npz"))
@@ -136,7 +136,7 @@ def test_pretrain_forward_vs_reference(bert_cfg, monkeypatch, mode, tol):
 def test_pretrain_gradients_vs_reference(bert_cfg, monkeypatch, mode, rtol):
     """loss = mlm + itm + itc + mpm (run_pretrain_sparse.py:557) backward through the hand-written HIP backward:
     per-parameter gradient norms of all 460 trainable tensors and 15 full gradients vs the reference's autograd."""
-    from oracle.det_init import det_batch, fill_state_dict_
+    from tests.golden.det_init import det_batch, fill_state_dict_
     from alpro_amd import config as rt
     from alpro_amd.modeling.alpro_models import AlproForPretrain
     g = np.load(os.path.join(GOLDEN, "pretrain_T8_B2.npz"))
@@ -292,7 +292,7 @@ def test_full_size_batch_properties(bert_cfg):
 
 # ---- round 2: parity rows that had no GPU test against reference-generated fixtures ------
 def _det_block(layer, drop_path):
-    from oracle.det_init import det_param
+    from tests.golden.det_init import det_param
     from alpro_amd.modeling.timesformer.vit import Block
     blk = Block(dim=768, num_heads=12, layer_num=layer, mlp_ratio=4.0, qkv_bias=True, drop_path=drop_path, attention_type='divided_space_time')
     with torch.no_grad():
@@ -307,7 +307,7 @@ def test_block_train_mode_droppath_vs_reference(mode, tol, path):
     """a8: ONE ViT block in TRAIN mode with drop_path 0.1 (vit.py:136-213 + vit_utils.py:137-162) against the reference run with a
     recorded torch.rand stream (tests/golden/block11_droppath_T2_B4.npz): the three Bernoulli row masks are injected into
     DropPath.row_scale's place, everything else is the product path (GEMM-epilogue row scale through the row maps)."""
-    from oracle.det_init import unit_uniform
+    from tests.golden.det_init import unit_uniform
     from alpro_amd import config as rt
     g = np.load(os.path.join(GOLDEN, "block11_droppath_T2_B4.npz"))
     B, T, N = 4, 2, 196
@@ -342,7 +342,7 @@ def _sim_ranks(monkeypatch, local_rank, video_feats, text_feats):
 
 
 def _other_rank_feats(B):
-    from oracle.det_init import unit_uniform
+    from tests.golden.det_init import unit_uniform
     ov = torch.nn.functional.normalize(torch.from_numpy(unit_uniform("w2/video", B * 256).astype(np.float32)).view(B, 256), dim=-1)
     ot = torch.nn.functional.normalize(torch.from_numpy(unit_uniform("w2/text", B * 256).astype(np.float32)).view(B, 256), dim=-1)
     return ov, ot
@@ -366,7 +366,7 @@ def test_world2_vtc_vs_reference(retrieval, monkeypatch, mode, tol):
 
 @pytest.fixture(scope="module")
 def prompter(bert_cfg):
-    from oracle.det_init import det_batch, fill_state_dict_
+    from tests.golden.det_init import det_batch, fill_state_dict_
     from alpro_amd.modeling.alpro_models import Prompter
     m = Prompter(make_cfg(bert_cfg, num_entities=8), dict(VENC, num_frm=2))
     fill_state_dict_(m)
@@ -380,7 +380,7 @@ def test_prompter_vs_reference(prompter, monkeypatch, mode, tol):
     """a20 + Prompter.forward: build_text_prompts on 8 entities x 12 (video) / 10 (image) templates, the teacher's VTC forward on
     one rank and as rank 1 of 2, and get_pseudo_labels on both prompt sets, all against the reference
     (alpro_models.py:430-507, 531-551, 553-594)."""
-    from oracle.det_init import det_prompts
+    from tests.golden.det_init import det_prompts
     from alpro_amd import config as rt
     m, batch, g = prompter
     m.prompt_initialized = False
@@ -414,7 +414,7 @@ def test_prompter_vs_reference(prompter, monkeypatch, mode, tol):
 def test_retrieval_finetune_gradients_vs_reference(bert_cfg, monkeypatch, mode, rtol):
     """BASELINE configs[4] (retrieval finetune step): loss = itm_loss + itc_loss (run_video_retrieval.py:432-434) backward through
     AlproForVideoTextRetrieval on the HIP backward; gradient norms of every trained tensor + 12 full gradients vs the reference."""
-    from oracle.det_init import det_batch, fill_state_dict_
+    from tests.golden.det_init import det_batch, fill_state_dict_
     from alpro_amd import config as rt
     from alpro_amd.modeling.alpro_models import AlproForVideoTextRetrieval
     g = np.load(os.path.join(GOLDEN, "retrieval_grads_T2_B3.npz"))
@@ -461,7 +461,7 @@ def test_retrieval_finetune_gradients_vs_reference(bert_cfg, monkeypatch, mode, 
 @pytest.mark.parametrize("mode,tol", [("fp32", 1e-3), ("bf16", 3e-2), ("fp16", 3e-3)])
 def test_retrieval_16_frames_vs_reference(bert_cfg, monkeypatch, mode, tol):
     """Model-level case at 16 frames per clip (BASELINE configs[4]): forward, visual embeddings, 1-video-x-n-captions inference."""
-    from oracle.det_init import det_batch, fill_state_dict_
+    from tests.golden.det_init import det_batch, fill_state_dict_
     from alpro_amd import config as rt
     from alpro_amd.modeling.alpro_models import AlproForVideoTextRetrieval
     g = np.load(os.path.join(GOLDEN, "retrieval_T16_B2.npz"))
@@ -489,7 +489,7 @@ def test_batched_retrieval_scoring_vs_reference_records(bert_cfg, mode, tol):
     REFERENCE's evaluation loop produced for 5 videos x 5 captions (tests/golden/retrieval_eval_T2_V5.npz: forward_inference per
     (video, 3-caption mini-batch), softmax of the ITM logits, ITC similarity, both rounded to 4 decimals), and the cached loop
     (inference_retrieval_cached) gives the same numbers."""
-    from oracle.det_init import det_batch, fill_state_dict_
+    from tests.golden.det_init import det_batch, fill_state_dict_
     from alpro_amd import config as rt
     from alpro_amd.modeling.alpro_models import AlproForVideoTextRetrieval
     from alpro_amd.retrieval_eval import inference_retrieval_cached, records_from_matrices, retrieval_metrics_on_device, score_all_pairs
@@ -511,3 +511,48 @@ def test_batched_retrieval_scoring_vs_reference_records(bert_cfg, mode, tol):
     assert max(abs(a["score"] - b["score"]) for a, b in zip(mine, recs)) <= 2e-4 + tol
     dm = retrieval_metrics_on_device(score, torch.arange(V))
     assert 0 <= dm["r1"] <= 100 and 1 <= dm["medianR"] <= V
+
+
+@pytest.mark.parametrize("mode,tol,rtol", [("fp32", 1e-3, 5e-3), ("fp16", 4e-3, 6e-3), ("bf16", 3e-2, 4e-2)])
+def test_pretrain_released_geometry_vs_reference(bert_cfg, monkeypatch, mode, tol, rtol):
+    """the geometry the reference actually pretrains with (config_release/pretrain_alpro.json:34,37,59 -- 4 frames,
+    30-token captions, fusion sequences of 227 tokens): every loss, the VTC logits, ITM scores, MLM columns, embeddings and the
+    parameter-gradient norms of loss = mlm + itm + itc + mpm against the reference-generated fixture."""
+    from tests.golden.det_init import det_batch, fill_state_dict_
+    from alpro_amd import config as rt
+    from alpro_amd.modeling.alpro_models import AlproForPretrain
+    g = np.load(os.path.join(GOLDEN, "pretrain_release_T4_L30_B2.npz"))
+    m = AlproForPretrain(make_cfg(bert_cfg), dict(VENC, num_frm=4))
+    fill_state_dict_(m)
+    m.eval().cuda()
+    batch = to_dev(det_batch(2, 4, Lt=30, seed_name="pretrain_release"))
+    monkeypatch.setattr(torch, "multinomial", argmax_multinomial)
+    with rt.use_compute_dtype(mode):
+        with torch.no_grad():
+            ve = m._forward_visual_embeds(batch["visual_inputs"])
+            te, tf = m._forward_text_feats(batch)
+            vf = m._video_feat(ve)
+        keep = arm_scale(mode)
+        out = m(batch)
+        gs = backward(out["mlm_loss"] + out["itm_loss"] + out["itc_loss"] + out["mpm_loss"], mode)
+        del keep
+    assert out["mlm_scores"].shape == (2, 30, 30522)
+    for k in ("itc_loss", "itm_loss", "mlm_loss", "mpm_loss", "itm_scores", "mpm_logits"):
+        close(out[k], g[k], tol, what=k)
+    close(out["mlm_scores"][:, :, ::61], g["mlm_scores_cols"], tol, what="mlm_scores")
+    close(vf @ tf.t() / m.temp, g["sim_v2t"], {"fp32": 1e-3, "fp16": 2e-3, "bf16": 1.6e-2}[mode], what="VTC logits (released geometry)")
+    close(te[:, [0, 1, 29]], g["text_embeds_rows"], tol * (1 if mode == "fp32" else 2), what="text_embeds rows")
+    close(ve[:, [0, 1, 57, 196]], g["video_embeds_rows"], tol * (1 if mode == "fp32" else 2), what="video_embeds rows")
+    assert torch.equal(out["itm_labels"].cpu(), torch.from_numpy(g["itm_labels"]).long())
+    pd = dict(m.named_parameters())
+    names = [str(n) for n in g["grad_norm_names"]]
+    assert not [n for n in names if pd[n].grad is None]
+    got = np.array([float(pd[n].grad.norm()) / gs for n in names])
+    ref = g["grad_norms"]
+    rel = np.abs(got - ref) / np.maximum(ref, 1e-5)
+    rel[np.array([n.endswith("attention.self.key.bias") for n in names])] = 0.0
+    print("\n[released-geometry grad parity %s] worst grad-norm rel err %.2e at %s; median %.2e" % (mode, rel.max(), names[int(rel.argmax())], np.median(rel)))
+    if os.environ.get("ALPRO_PARITY_REPORT"):
+        print("[parity-report] released_geometry_gradients[%s] | worst grad-norm rel err | err %.3e | limit %.1e" % (mode, rel.max(), rtol))
+        return
+    assert rel.max() < rtol, (names[int(rel.argmax())], float(rel.max()))

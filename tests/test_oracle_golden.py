@@ -9,7 +9,7 @@ import pytest
 import torch
 
 from oracle import alpro_oracle as ao
-from oracle.det_init import det_batch, det_param, unit_uniform
+from tests.golden.det_init import det_batch, det_param, unit_uniform
 from tests.conftest import GOLDEN
 
 RT, AT = 2e-4, 2e-5
@@ -112,6 +112,32 @@ def test_pretrain_forward_backward(bert_cfg):
             close(p[k[5:]].grad, g[k], rtol=2e-3, atol=2e-6, what=k)
 
 
+@pytest.mark.slow
+def test_pretrain_released_geometry(bert_cfg):
+    """The geometry the reference pretrains with (config_release/pretrain_alpro.json:34,37,59: 4 frames, 30 tokens -> fusion length
+    227): all losses, VTC logits, embeddings and the 460 parameter-gradient norms of loss = mlm + itm + itc + mpm."""
+    T, B, Lt = 4, 2, 30
+    g = np.load(os.path.join(GOLDEN, "pretrain_release_T4_L30_B2.npz"))
+    skip = ("prompter.text_encoder.", "prompter.itm_head", "prompter.text_proj", "visual_encoder.model.head", "prompter.visual_encoder.model.head")
+    spec = ao.alpro_state_spec("pretrain", bert_cfg, T)
+    p = ao.det_state("pretrain", bert_cfg, T, only=[k for k in spec if not k.startswith(skip)])
+    names = [str(n) for n in g["grad_norm_names"]]
+    for n in names:
+        p[n].requires_grad_(True)
+    orc = ao.AlproOracle(p, bert_cfg, T)
+    out = orc.forward_pretrain(det_batch(B, T, Lt=Lt, seed_name="pretrain_release"))
+    assert out["mlm_scores"].shape[:2] == (B, Lt)
+    for k in ("itc_loss", "itm_loss", "mlm_loss", "mpm_loss", "itm_scores", "mpm_logits", "sim_v2t"):
+        close(out[k], g[k], what=k)
+    close(out["mlm_scores"][:, :, ::61], g["mlm_scores_cols"], what="mlm cols")
+    close(out["text_embeds"][:, [0, 1, 29]], g["text_embeds_rows"], what="text_embeds rows")
+    ve = out["video_embeds"]
+    close(ve[:, [0, 1, 57, 196]], g["video_embeds_rows"]); close(ve.norm(dim=-1), g["video_embeds_rownorm"])
+    (out["mlm_loss"] + out["itm_loss"] + out["itc_loss"] + out["mpm_loss"]).backward()
+    got = np.array([float(p[n].grad.norm()) for n in names])
+    np.testing.assert_allclose(got, g["grad_norms"], rtol=2e-3, atol=1e-7)
+
+
 def _other_rank_feats(B):
     ov = torch.nn.functional.normalize(torch.from_numpy(unit_uniform("w2/video", B * 256).astype(np.float32)).view(B, 256), dim=-1)
     ot = torch.nn.functional.normalize(torch.from_numpy(unit_uniform("w2/text", B * 256).astype(np.float32)).view(B, 256), dim=-1)
@@ -121,7 +147,7 @@ def _other_rank_feats(B):
 def test_prompter_build_prompts_forward_and_pseudo_labels(bert_cfg):
     """Prompter (alpro_models.py:389-632) against the reference run on 8 entities x 12 / 10 templates: build_text_prompts
     buffers, forward (VTC of the teacher, single rank and as rank 1 of 2), get_pseudo_labels on both prompt sets."""
-    from oracle.det_init import det_prompts
+    from tests.golden.det_init import det_prompts
     T, B, E = 2, 3, 8
     g = np.load(os.path.join(GOLDEN, "prompter_T2_B3_E8.npz"))
     p = ao.det_state("prompter", bert_cfg, T, num_entities=E)
