@@ -108,22 +108,105 @@ __device__ __forceinline__ SrcRow ln_src_row(int mode, int p0, int p1, int64_t m
   return s;
 }
 
-// dx[src(m)] += rstd * (dy*g - mean(dy*g) - xhat * mean(dy*g*xhat));  dgamma += dy*xhat;  dbeta += dy
+// What the backward does NEXT with the gradient row this kernel has just finished (round 3): every LayerNorm backward of the path is
+// followed by an alpro_gather_cast that re-reads the fp32 row it wrote, scales it and casts it into the operand rows of the next
+// wgrad / dgrad GEMMs (3.6 ms per training step, 308 MB re-read per call at B = 64).  With an emit mode the row leaves this kernel in
+// both forms -- fp32 into the gradient stream and `dtype` into the GEMM operand -- and that pass disappears.  `r` = token row of dx:
+//   ALPRO_EMIT_ROWS      out[r] = drop(v) * scale[r / group]                      (BERT: the dense-output dropout of xbert.py:358,436;
+//                        ViT temporal LayerNorm -> the previous block's MLP gradient, scale = its drop-path row scale, group = 1 + N*T)
+//   ALPRO_EMIT_FRAME     r = b*S + k.  k > 0 (patch n, frame t): out[(b*T+t)*(N+1) + 1 + n] = v * scale[b*T+t];
+//                        k = 0: out[(b*T+t)*(N+1)] = v * scale[b*T+t] / T for every t   (inverse of vit.py:184-196; after norm2's backward)
+//   ALPRO_EMIT_SKIP_CLS  k > 0: out[r - b - 1] = v * scale[(r - b - 1) / group]; colsum_pre[c] += v (unscaled: the bias gradient of
+//                        temporal_fc); CLS rows emit nothing                      (after norm1's backward)
+struct EmitArgs {
+  void* out;
+  int mode, p0, p1;          // p0 = T, p1 = N for the divided space-time modes
+  const float* scale;
+  int group;
+  float drop_p;
+  uint32_t drop_seed;
+  float* colsum_pre;
+  int extra_cls;             // ROWS mode after a SKIP_CLS-mapped LayerNorm: also emit the B CLS rows (final since the previous kernel)
+};
+
 template <typename T>
+__device__ __forceinline__ void emit_store(T* p, int lane, const float (&v)[12], float sc) {
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    T* q = p + i * 256 + lane * 4;
+    if constexpr (sizeof(T) == 4) {
+      *(f32x4*)q = f32x4{v[4 * i] * sc, v[4 * i + 1] * sc, v[4 * i + 2] * sc, v[4 * i + 3] * sc};
+    } else {
+      u32x2 u;
+      u.x = pack2(v[4 * i] * sc, v[4 * i + 1] * sc, (T*)0);
+      u.y = pack2(v[4 * i + 2] * sc, v[4 * i + 3] * sc, (T*)0);
+      *(u32x2*)q = u;  // plain store: the wgrad / dgrad GEMMs read it next out of the Infinity Cache (like alpro_gather_cast)
+    }
+  }
+}
+
+// emit the finished gradient row `v` of token row r (see EmitArgs); cp accumulates the unscaled column sums (SKIP_CLS mode)
+template <typename T>
+__device__ __forceinline__ void emit_row(const EmitArgs& e, int64_t r, int lane, float (&v)[12], float (&cp)[12]) {
+  T* out = (T*)e.out;
+  if (e.mode == ALPRO_EMIT_ROWS) {
+    if (e.drop_seed) {
+      const uint32_t th = drop_thresh24(e.drop_p);
+      const float ks = 1.0f / (1.0f - e.drop_p);
+#pragma unroll
+      for (int i = 0; i < 12; ++i) {
+        const uint64_t idx = (uint64_t)r * LN_D + (uint64_t)((i >> 2) * 256 + lane * 4 + (i & 3));
+        v[i] = drop_keep(e.drop_seed, idx, th) ? v[i] * ks : 0.f;
+      }
+    }
+    emit_store<T>(out + r * LN_D, lane, v, e.scale ? e.scale[r / e.group] : 1.0f);
+    return;
+  }
+  const int Tn = e.p0, N = e.p1;
+  const int64_t S = 1 + (int64_t)N * Tn;
+  const int64_t b = r / S, k = r - b * S;
+  if (e.mode == ALPRO_EMIT_FRAME) {
+    if (k == 0) {
+      const float inv = 1.0f / (float)Tn;
+      for (int t = 0; t < Tn; ++t) emit_store<T>(out + ((b * Tn + t) * (N + 1)) * LN_D, lane, v, (e.scale ? e.scale[b * Tn + t] : 1.0f) * inv);
+    } else {
+      const int64_t n = (k - 1) / Tn;
+      const int t = (int)((k - 1) - n * Tn);
+      emit_store<T>(out + ((b * Tn + t) * (N + 1) + 1 + n) * LN_D, lane, v, e.scale ? e.scale[b * Tn + t] : 1.0f);
+    }
+  } else {  // SKIP_CLS
+    if (k == 0) return;
+    const int64_t o = r - b - 1;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) cp[i] += v[i];
+    emit_store<T>(out + o * LN_D, lane, v, e.scale ? e.scale[o / e.group] : 1.0f);
+  }
+}
+
+// dx[src(m)] += rstd * (dy*g - mean(dy*g) - xhat * mean(dy*g*xhat));  dgamma += dy*xhat;  dbeta += dy
+// T = storage type of dy, TE = storage type of the emitted operand rows (the compute dtype; dy itself may be the fp32 stream)
+template <typename T, typename TE>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict__ dy, int64_t ld_dy, const float* __restrict__ dy2,
                                                             const float* __restrict__ x, int64_t ldx, const float* __restrict__ gamma, float eps,
                                                             float* __restrict__ dx, int64_t ld_dx, int accumulate, float* __restrict__ dgamma,
                                                             float* __restrict__ dbeta, int64_t rows, int mode, int p0, int p1, float drop_p,
-                                                            uint32_t drop_seed) {
+                                                            uint32_t drop_seed, const EmitArgs em) {
   __shared__ float red[2][4][LN_D];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int64_t wave = (int64_t)blockIdx.x * 4 + w;
   const int64_t nwaves = (int64_t)gridDim.x * 4;
-  float g[12], ag[12], ab[12];
+  float g[12], ag[12], ab[12], cp[12];
   ld12(gamma, lane, g);
 #pragma unroll
-  for (int i = 0; i < 12; ++i) ag[i] = ab[i] = 0.f;
-  for (int64_t m = wave; m < rows; m += nwaves) {
+  for (int i = 0; i < 12; ++i) ag[i] = ab[i] = cp[i] = 0.f;
+  for (int64_t m = wave; m < rows + em.extra_cls; m += nwaves) {
+    if (m >= rows) {  // cast-only rows: the CLS rows a SKIP_CLS-mapped LayerNorm does not touch (their gradient is already final)
+      const int64_t r = (m - rows) * (1 + (int64_t)em.p1 * em.p0);
+      float v[12];
+      ld12_nt(dx + r * ld_dx, lane, v);
+      emit_row<TE>(em, r, lane, v, cp);
+      continue;
+    }
     const SrcRow src = ln_src_row(mode, p0, p1, m);
     float xv[12], d[12];
     ld12_nt(x + src.row * ldx, lane, xv);
@@ -164,6 +247,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
     s1 = wave_sum(s1) * (1.0f / LN_D);
     s2 = wave_sum(s2) * (1.0f / LN_D);
     float* o = dx + src.row * ld_dx;
+    float fin[12];  // the finished gradient row (for the emit)
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
       float4 r;
@@ -176,11 +260,14 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
         atomicAdd(p, r.x); atomicAdd(p + 1, r.y); atomicAdd(p + 2, r.z); atomicAdd(p + 3, r.w);
       } else if (accumulate) {
         const float4 c = *(const float4*)p;
-        __builtin_nontemporal_store(f32x4{c.x + r.x, c.y + r.y, c.z + r.z, c.w + r.w}, (f32x4*)p);
+        r.x += c.x; r.y += c.y; r.z += c.z; r.w += c.w;
+        __builtin_nontemporal_store(f32x4{r.x, r.y, r.z, r.w}, (f32x4*)p);
       } else {
         __builtin_nontemporal_store(f32x4{r.x, r.y, r.z, r.w}, (f32x4*)p);
       }
+      fin[4 * i] = r.x; fin[4 * i + 1] = r.y; fin[4 * i + 2] = r.z; fin[4 * i + 3] = r.w;
     }
+    if (em.mode != ALPRO_EMIT_NONE && !src.shared) emit_row<TE>(em, src.row, lane, fin, cp);
   }
   // block reduction of dgamma / dbeta, then one atomic per column per block
 #pragma unroll
@@ -194,6 +281,15 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
   for (int c = threadIdx.x; c < LN_D; c += 256) {
     atomicAdd(dgamma + c, red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c]);
     atomicAdd(dbeta + c, red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c]);
+  }
+  if (em.colsum_pre) {  // bias gradient of the Linear whose output gradient the emitted rows are (before the row scale)
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) red[0][w][i * 256 + lane * 4 + e] = cp[4 * i + e];
+    __syncthreads();
+    for (int c = threadIdx.x; c < LN_D; c += 256) atomicAdd(em.colsum_pre + c, red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c]);
   }
 }
 
@@ -375,15 +471,46 @@ extern "C" int alpro_transpose_batch(const alpro_transpose_job_t* jobs, int njob
   return check_launch("alpro_transpose_batch");
 }
 
-extern "C" int alpro_layernorm_bwd(const void* dy, int dy_dtype, int64_t ld_dy, const float* dy2, const float* x, int64_t ldx,
-                                   const float* gamma, float eps, float* dx, int64_t ld_dx, int accumulate, float* dgamma, float* dbeta,
-                                   int rows, int D, int map_mode, int map_p0, int map_p1, float drop_p, uint32_t drop_seed, void* stream) {
+extern "C" int alpro_layernorm_bwd_emit(const void* dy, int dy_dtype, int64_t ld_dy, const float* dy2, const float* x, int64_t ldx,
+                                        const float* gamma, float eps, float* dx, int64_t ld_dx, int accumulate, float* dgamma, float* dbeta,
+                                        int rows, int D, int map_mode, int map_p0, int map_p1, float drop_p, uint32_t drop_seed, void* emit_out,
+                                        int emit_dtype, int emit_mode, int emit_p0, int emit_p1, const float* emit_scale, int emit_scale_group, float emit_drop_p,
+                                        uint32_t emit_drop_seed, float* emit_colsum_pre, int emit_extra_cls, void* stream) {
   ALPRO_CHECK(dy && x && gamma && dx && dgamma && dbeta && rows > 0, "alpro_layernorm_bwd: bad args");
   ALPRO_CHECK(D == LN_D, "alpro_layernorm_bwd: D=%d unsupported", D);
   ALPRO_CHECK(map_mode >= 0 && map_mode <= ALPRO_MAP_FRAME_TOKENS, "alpro_layernorm_bwd: bad map_mode %d", map_mode);
   ALPRO_CHECK(map_mode != ALPRO_MAP_FRAME_TOKENS || accumulate, "alpro_layernorm_bwd: the FRAME_TOKENS scatter needs accumulate=1 (CLS rows are shared)");
-  ALPRO_DISPATCH_DTYPE(dy_dtype, T, hipLaunchKernelGGL(layernorm_bwd_kernel<T>, dim3(grid_for(rows, 4 * 8, 256 * 8)), dim3(256), 0, (hipStream_t)stream, (const T*)dy, ld_dy, dy2, x, ldx, gamma, eps, dx, ld_dx, accumulate, dgamma, dbeta, (int64_t)rows, map_mode, map_p0, map_p1, drop_p, drop_seed));
+  ALPRO_CHECK(emit_mode >= ALPRO_EMIT_NONE && emit_mode <= ALPRO_EMIT_SKIP_CLS, "alpro_layernorm_bwd_emit: bad emit_mode %d", emit_mode);
+  ALPRO_CHECK(emit_mode == ALPRO_EMIT_NONE || emit_out, "alpro_layernorm_bwd_emit: an emit mode needs the output rows");
+  ALPRO_CHECK(emit_mode == ALPRO_EMIT_NONE || ld_dx == LN_D, "alpro_layernorm_bwd_emit: the emit needs a dense gradient stream (ld_dx == 768)");
+  ALPRO_CHECK(emit_mode == ALPRO_EMIT_NONE || emit_mode == ALPRO_EMIT_ROWS || (emit_p0 > 0 && emit_p1 > 0), "alpro_layernorm_bwd_emit: FRAME / SKIP_CLS emits need p0 = T, p1 = N");
+  ALPRO_CHECK(!emit_scale || emit_scale_group > 0, "alpro_layernorm_bwd_emit: emit_scale_group must be > 0");
+  ALPRO_CHECK(!emit_drop_seed || (emit_mode == ALPRO_EMIT_ROWS && emit_drop_p > 0.f && emit_drop_p < 1.f), "alpro_layernorm_bwd_emit: dropout only in ROWS mode, 0 < p < 1");
+  ALPRO_CHECK(!emit_colsum_pre || emit_mode == ALPRO_EMIT_SKIP_CLS, "alpro_layernorm_bwd_emit: colsum_pre belongs to the SKIP_CLS emit");
+  ALPRO_CHECK(emit_extra_cls == 0 || (emit_mode == ALPRO_EMIT_ROWS && map_mode == ALPRO_MAP_SKIP_CLS && emit_p0 > 0 && emit_p1 > 0),
+              "alpro_layernorm_bwd_emit: extra CLS rows go with ROWS emit after a SKIP_CLS-mapped LayerNorm (p0 = T, p1 = N)");
+  EmitArgs em;
+  em.out = emit_out; em.mode = emit_mode; em.p0 = emit_p0; em.p1 = emit_p1; em.scale = emit_scale; em.group = emit_scale_group;
+  em.drop_p = emit_drop_p; em.drop_seed = emit_drop_seed; em.colsum_pre = emit_colsum_pre; em.extra_cls = emit_extra_cls;
+  ALPRO_CHECK(emit_mode == ALPRO_EMIT_NONE || emit_dtype == dy_dtype || dy_dtype == ALPRO_F32, "alpro_layernorm_bwd_emit: emit_dtype must be dy's dtype, or any dtype when dy is the fp32 stream");
+  const dim3 grid(grid_for(rows, 4 * 8, 256 * 8)), blk(256);
+  hipStream_t st = (hipStream_t)stream;
+#define ALPRO_LNB(T, TE) hipLaunchKernelGGL((layernorm_bwd_kernel<T, TE>), grid, blk, 0, st, (const T*)dy, ld_dy, dy2, x, ldx, gamma, eps, dx, ld_dx, accumulate, dgamma, dbeta, (int64_t)rows, map_mode, map_p0, map_p1, drop_p, drop_seed, em)
+  if (dy_dtype == ALPRO_F32 && emit_mode != ALPRO_EMIT_NONE && emit_dtype == ALPRO_BF16) ALPRO_LNB(float, bf16_t);
+  else if (dy_dtype == ALPRO_F32 && emit_mode != ALPRO_EMIT_NONE && emit_dtype == ALPRO_F16) ALPRO_LNB(float, f16_t);
+  else if (dy_dtype == ALPRO_F32) ALPRO_LNB(float, float);
+  else if (dy_dtype == ALPRO_BF16) ALPRO_LNB(bf16_t, bf16_t);
+  else if (dy_dtype == ALPRO_F16) ALPRO_LNB(f16_t, f16_t);
+  else { set_error("alpro_layernorm_bwd: bad dtype %d", dy_dtype); return ALPRO_ERR_INVALID; }
+#undef ALPRO_LNB
   return check_launch("alpro_layernorm_bwd");
+}
+
+extern "C" int alpro_layernorm_bwd(const void* dy, int dy_dtype, int64_t ld_dy, const float* dy2, const float* x, int64_t ldx,
+                                   const float* gamma, float eps, float* dx, int64_t ld_dx, int accumulate, float* dgamma, float* dbeta,
+                                   int rows, int D, int map_mode, int map_p0, int map_p1, float drop_p, uint32_t drop_seed, void* stream) {
+  return alpro_layernorm_bwd_emit(dy, dy_dtype, ld_dy, dy2, x, ldx, gamma, eps, dx, ld_dx, accumulate, dgamma, dbeta, rows, D, map_mode, map_p0, map_p1,
+                                  drop_p, drop_seed, nullptr, dy_dtype, ALPRO_EMIT_NONE, 0, 0, nullptr, 1, 0.f, 0u, nullptr, 0, stream);
 }
 
 extern "C" int alpro_gather_cast(const float* src, int64_t ld, void* out, int dtype, int rows, int D, int map_mode, int map_p0, int map_p1,

@@ -15,6 +15,7 @@ F32, BF16, F16 = 0, 1, 2
 ACT_NONE, ACT_GELU, ACT_RELU, ACT_GELU_BWD = 0, 1, 2, 3
 MAP_IDENTITY, MAP_SKIP_CLS, MAP_FRAME_TOKENS, MAP_PATCH_EMBED = 0, 1, 2, 3
 ADD_IDENTITY, ADD_PRE_SPATIAL, ADD_PRE_MLP, ADD_PRE_TEMPORAL = 0, 1, 2, 3
+EMIT_NONE, EMIT_ROWS, EMIT_FRAME, EMIT_SKIP_CLS = 0, 1, 2, 3
 
 _TORCH_DTYPE = {F32: torch.float32, BF16: torch.bfloat16, F16: torch.float16}
 _CODE = {v: k for k, v in _TORCH_DTYPE.items()}
@@ -22,7 +23,7 @@ _CODE = {v: k for k, v in _TORCH_DTYPE.items()}
 EXPORTS = ["alpro_hip_last_error", "alpro_hip_abi_version", "alpro_hip_set_option", "alpro_gemm", "alpro_layernorm_fwd",
            "alpro_attn_temporal_fwd", "alpro_attn_fwd", "alpro_patchify", "alpro_cls_mean_residual",
            "alpro_vit_final_pool", "alpro_bert_embed_fwd", "alpro_cast_from_f32", "alpro_attn_bwd", "alpro_attn_temporal_bwd",
-           "alpro_layernorm_bwd", "alpro_transpose", "alpro_transpose_batch", "alpro_gelu_bwd", "alpro_cls_mean_bwd", "alpro_scatter_add_rows", "alpro_gather_cast", "alpro_sumsq", "alpro_adamw_step", "alpro_gemm_tn_acc", "alpro_gemm_tn_acc_ws", "alpro_gemm_tn_workspace_bytes", "alpro_colsum_acc", "alpro_softmax_xent", "alpro_vtc_loss_fwd", "alpro_vtc_loss_bwd", "alpro_prepare_clips", "alpro_loss_scale_update", "alpro_add_layernorm_fwd"]
+           "alpro_layernorm_bwd", "alpro_transpose", "alpro_transpose_batch", "alpro_gelu_bwd", "alpro_cls_mean_bwd", "alpro_scatter_add_rows", "alpro_gather_cast", "alpro_sumsq", "alpro_adamw_step", "alpro_gemm_tn_acc", "alpro_gemm_tn_acc_ws", "alpro_gemm_tn_workspace_bytes", "alpro_colsum_acc", "alpro_softmax_xent", "alpro_vtc_loss_fwd", "alpro_vtc_loss_bwd", "alpro_prepare_clips", "alpro_loss_scale_update", "alpro_add_layernorm_fwd", "alpro_layernorm_bwd_emit"]
 
 
 class GemmDesc(ctypes.Structure):
@@ -44,7 +45,7 @@ class TransposeJob(ctypes.Structure):
                 ("R", ctypes.c_int32), ("C", ctypes.c_int32), ("Rpad", ctypes.c_int32), ("tile0", ctypes.c_int32)]   # 48 bytes
 
 
-ABI_VERSION = 11
+ABI_VERSION = 12
 _lib = None
 
 
@@ -69,6 +70,8 @@ def load():
     lib.alpro_attn_bwd.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, vp, f32, u32, vp]
     lib.alpro_attn_temporal_bwd.argtypes = [vp, vp, vp, vp, vp, i32, i64, i32, i32, f32, vp]
     lib.alpro_layernorm_bwd.argtypes = [vp, i32, i64, vp, vp, i64, vp, f32, vp, i64, i32, vp, vp, i32, i32, i32, i32, i32, f32, u32, vp]
+    lib.alpro_layernorm_bwd_emit.argtypes = [vp, i32, i64, vp, vp, i64, vp, f32, vp, i64, i32, vp, vp, i32, i32, i32, i32, i32, f32, u32,
+                                             vp, i32, i32, i32, i32, vp, i32, f32, u32, vp, i32, vp]
     lib.alpro_transpose.argtypes = [vp, i32, i64, vp, i32, i64, i32, i32, i32, vp, vp]
     lib.alpro_gelu_bwd.argtypes = [vp, vp, vp, i32, i64, vp]
     lib.alpro_sumsq.argtypes = [vp, i64, vp, vp]
@@ -277,16 +280,28 @@ def attn_bwd(qkv, out, dout, lse, batch, L, H, scale, key_bias=None, drop_p=0.0,
 
 
 def layernorm_bwd(dy, x, gamma, eps, dx, dgamma, dbeta, rows=None, dy2=None, accumulate=True, map_mode=MAP_IDENTITY, map_p0=0, map_p1=0,
-                  drop_p=0.0, drop_seed=0):
-    """dx[map(m)] (+)= dLN; dgamma/dbeta (fp32, pre-initialised) are accumulated.  x, dx: fp32 (..., 768)."""
+                  drop_p=0.0, drop_seed=0, emit=None):
+    """dx[map(m)] (+)= dLN; dgamma/dbeta (fp32, pre-initialised) are accumulated.  x, dx: fp32 (..., 768).
+    emit: None, or a dict(mode=EMIT_*, rows=<output rows>, dtype=<operand dtype, default dy's>, T=, N=, scale=<fp32 row scales>, group=, drop_p=, drop_seed=, colsum_pre=,
+    extra_cls=) -- the finished gradient rows ALSO leave as the dy-dtype operand rows of the next GEMMs (alpro_layernorm_bwd_emit, what a
+    following gather_cast would build); then returns (dx, emitted (rows, 768) tensor)."""
     lib = load()
     _dev(dy); _dev(x, torch.float32); _dev(dx, torch.float32); _dev(dgamma, torch.float32); _dev(dbeta, torch.float32)
     D = x.shape[-1]
     rows = rows if rows is not None else dy.numel() // D
-    _check(lib.alpro_layernorm_bwd(_ptr(dy), _CODE[dy.dtype], D, _ptr(_dev(dy2, torch.float32)) if dy2 is not None else None, _ptr(x), D,
-                                   _ptr(_dev(gamma, torch.float32)), eps, _ptr(dx), D, 1 if accumulate else 0, _ptr(dgamma), _ptr(dbeta), rows, D,
-                                   map_mode, map_p0, map_p1, drop_p, drop_seed, _stream()), "alpro_layernorm_bwd")
-    return dx
+    common = (_ptr(dy), _CODE[dy.dtype], D, _ptr(_dev(dy2, torch.float32)) if dy2 is not None else None, _ptr(x), D,
+              _ptr(_dev(gamma, torch.float32)), eps, _ptr(dx), D, 1 if accumulate else 0, _ptr(dgamma), _ptr(dbeta), rows, D,
+              map_mode, map_p0, map_p1, drop_p, drop_seed)
+    if emit is None:
+        _check(lib.alpro_layernorm_bwd(*common, _stream()), "alpro_layernorm_bwd")
+        return dx
+    out = torch.empty((emit["rows"], D), dtype=emit.get("dtype", dy.dtype), device=dy.device)
+    sc, cp = emit.get("scale"), emit.get("colsum_pre")
+    _check(lib.alpro_layernorm_bwd_emit(*common, _ptr(out), _CODE[out.dtype], emit["mode"], emit.get("T", 0), emit.get("N", 0),
+                                        _ptr(_dev(sc, torch.float32)) if sc is not None else None, emit.get("group", 1), emit.get("drop_p", 0.0),
+                                        emit.get("drop_seed", 0), _ptr(_dev(cp, torch.float32)) if cp is not None else None, emit.get("extra_cls", 0),
+                                        _stream()), "alpro_layernorm_bwd_emit")
+    return dx, out
 
 
 def transpose(x, out_dtype=None, pad_to=64, colsum=None):

@@ -114,6 +114,7 @@ class Block(nn.Module):
     # GEMM per block in forward and, in backward, one dgrad and one wgrad: dWe = (s*dY)^T a is taken once and pushed through
     # the product rule (dWfc = dWe Wp^T + db1 bp^T, dWp = Wfc^T dWe, dbp = Wfc^T db1, dbfc = colsum(dY)).
     merge_temporal_proj = True
+    fuse_ln_bwd_emit = os.environ.get("ALPRO_FUSE_LN_BWD", "1") != "0"   # LayerNorm backward also emits the next GEMMs' operand rows (alpro_layernorm_bwd_emit) instead of a gather_cast pass; 0 = round-2 form (A/B)
     fuse_residual_ln = os.environ.get("ALPRO_FUSE_RESIDUAL_LN", "1") != "0"   # residual adds of the two attention halves inside the following LayerNorm (alpro_add_layernorm_fwd); 0 = round-2 form (A/B measurements)
 
     def _merged_tproj(self, dt):
@@ -293,15 +294,17 @@ class Block(nn.Module):
     def _wt(self, name, lin, dt):
         return tr.transposed_operand(self._ops, name + "^T", lin.weight, dt)
 
-    def _merged_tproj_backward(self, sv, dx, B, T, N, D, dt):
-        """Backward of xt[:, 1:] = x[:, 1:] + s * (a We^T + Wfc bp) + bfc (see merge_temporal_proj); returns d(a)."""
+    def _merged_tproj_backward(self, sv, dx, B, T, N, D, dt, G=None):
+        """Backward of xt[:, 1:] = x[:, 1:] + s * (a We^T + Wfc bp) + bfc (see merge_temporal_proj); returns d(a).
+        G: s * d(xt)[:, 1:] in the operand dtype when norm1's backward already emitted it (with dbfc accumulated), else built here."""
         ta, fc = self.temporal_attn, self.temporal_fc
         wp, bp, wf = ta.proj.weight.detach(), ta.proj.bias.detach(), fc.weight.detach()
         mg = self._merged_tproj(dt)
         dev = dx.device
         # G = s * dY in the operand dtype; dbfc = colsum(dY) (unscaled) from the same pass
-        G = hip.gather_cast(dx, dt, rows=B * N * T, map_mode=hip.MAP_SKIP_CLS, map_p0=N * T, row_scale=sv["drop_t"], row_scale_group=T,
-                            colsum_pre=tr.bias_grad(fc.bias))
+        if G is None:
+            G = hip.gather_cast(dx, dt, rows=B * N * T, map_mode=hip.MAP_SKIP_CLS, map_p0=N * T, row_scale=sv["drop_t"], row_scale_group=T,
+                                colsum_pre=tr.bias_grad(fc.bias))
         ws = sv.get("ws")  # zeroed slice of the per-backward workspace (one fill for all 12 blocks), else allocate
         if ws is None:
             ws = torch.zeros(D * D + D, dtype=torch.float32, device=dev)
@@ -325,33 +328,51 @@ class Block(nn.Module):
         tr.bias_grad(ta.proj.bias).add_(torch.mv(wf.t(), db1))                                                    # += Wfc^T db1
         return da
 
-    def backward(self, sv, dx):
-        """dx: gradient w.r.t. the block output, (B, S, D) fp32; overwritten with the gradient w.r.t. the block input."""
+    def backward(self, sv, dx, dz=None, emit_for=None):
+        """dx: gradient w.r.t. the block output, (B, S, D) fp32; overwritten with the gradient w.r.t. the block input.
+        dz: the operand rows drop_m * dx in the compute dtype if whoever produced dx already emitted them (the final norm's backward, or
+        the next block's temporal-LayerNorm backward), else None -> built here by alpro_gather_cast.
+        emit_for: saved state of the PREVIOUS block (the next one to run its backward): its dz is emitted by this block's last kernel.
+        Returns (dx, dz for the previous block or None)."""
         B, T, N, S, D, H = sv["dims"]
         dt = sv["dt"]
         ta, sa = self.temporal_attn, self.attn
+        fuse = self.fuse_ln_bwd_emit
         # ---- MLP: out = x2 + drop_m * (fc2(gelu(fc1(LN2(x2)))))
-        dz = hip.gather_cast(dx, dt, row_scale=sv["drop_m"], row_scale_group=S)
+        if dz is None:
+            dz = hip.gather_cast(dx, dt, row_scale=sv["drop_m"], row_scale_group=S)
         tr.wgrad(dz, sv["f1"], self.mlp.fc2.weight, self.mlp.fc2.bias)
         du = tr.dgrad(dz, self._wt("fc2", self.mlp.fc2, dt), gelu_pre=sv["u"])
+        del dz
         tr.wgrad(du, sv["h2"], self.mlp.fc1.weight, self.mlp.fc1.bias)
         dh2 = tr.dgrad(du, self._wt("fc1", self.mlp.fc1, dt))
         g, b_ = tr.grad_buffer(self.norm2.weight, zero=True)[0], tr.grad_buffer(self.norm2.bias, zero=True)[0]
-        hip.layernorm_bwd(dh2, sv["x2"], self.norm2.weight, VIT_EPS, dx, g, b_)
         # ---- spatial: x2 = scatter(xt + drop_s * proj(attn(qkv(LN1(gather(xt)))))), CLS averaged over frames
-        dpo = hip.gather_cast(dx, dt, rows=B * T * (N + 1), map_mode=hip.MAP_FRAME_TOKENS, map_p0=T, map_p1=N,
-                              row_scale=sv["drop_s"], row_scale_group=N + 1, cls_scale=1.0 / T)
+        if fuse:   # norm2's backward hands the finished d(x2) rows straight to the spatial projection's GEMMs (frame-token order, drop_s, CLS / T)
+            _, dpo = hip.layernorm_bwd(dh2, sv["x2"], self.norm2.weight, VIT_EPS, dx, g, b_,
+                                       emit=dict(mode=hip.EMIT_FRAME, rows=B * T * (N + 1), dtype=dt, T=T, N=N, scale=sv["drop_s"]))
+        else:
+            hip.layernorm_bwd(dh2, sv["x2"], self.norm2.weight, VIT_EPS, dx, g, b_)
+            dpo = hip.gather_cast(dx, dt, rows=B * T * (N + 1), map_mode=hip.MAP_FRAME_TOKENS, map_p0=T, map_p1=N,
+                                  row_scale=sv["drop_s"], row_scale_group=N + 1, cls_scale=1.0 / T)
         tr.wgrad(dpo, sv["a_s"], sa.proj.weight, sa.proj.bias)
         da = tr.dgrad(dpo, self._wt("s_proj", sa.proj, dt))
+        del dpo
         dqkv = hip.attn_bwd(sv["qkv_s"], sv["a_s"], da, sv["lse_s"], B * T, N + 1, H, sa.scale)
         tr.wgrad(dqkv, sv["hs"], sa.qkv.weight, sa.qkv.bias)
         dhs = tr.dgrad(dqkv, self._wt("s_qkv", sa.qkv, dt))
         g, b_ = tr.grad_buffer(self.norm1.weight, zero=True)[0], tr.grad_buffer(self.norm1.bias, zero=True)[0]
-        hip.layernorm_bwd(dhs, sv["xt"], self.norm1.weight, VIT_EPS, dx, g, b_, rows=B * T * (N + 1),
-                          map_mode=hip.MAP_FRAME_TOKENS, map_p0=T, map_p1=N)
         # ---- temporal: xt[:, 1:] = x[:, 1:] + fc(drop_t * proj(attn(qkv(LN_t(x[:, 1:])))))
+        G = None
+        if fuse and sv["merged"]:  # norm1's backward emits drop_t * d(xt)[:, 1:] and the temporal_fc bias gradient (unscaled column sums)
+            _, G = hip.layernorm_bwd(dhs, sv["xt"], self.norm1.weight, VIT_EPS, dx, g, b_, rows=B * T * (N + 1), map_mode=hip.MAP_FRAME_TOKENS,
+                                     map_p0=T, map_p1=N, emit=dict(mode=hip.EMIT_SKIP_CLS, rows=B * N * T, dtype=dt, T=T, N=N, scale=sv["drop_t"], group=T,
+                                                                   colsum_pre=tr.bias_grad(self.temporal_fc.bias)))
+        else:
+            hip.layernorm_bwd(dhs, sv["xt"], self.norm1.weight, VIT_EPS, dx, g, b_, rows=B * T * (N + 1),
+                              map_mode=hip.MAP_FRAME_TOKENS, map_p0=T, map_p1=N)
         if sv["merged"]:
-            da = self._merged_tproj_backward(sv, dx, B, T, N, D, dt)
+            da = self._merged_tproj_backward(sv, dx, B, T, N, D, dt, G=G)
         else:
             dfo = hip.gather_cast(dx, dt, rows=B * N * T, map_mode=hip.MAP_SKIP_CLS, map_p0=N * T)
             tr.wgrad(dfo, sv["pr"], self.temporal_fc.weight, self.temporal_fc.bias)
@@ -362,9 +383,15 @@ class Block(nn.Module):
         tr.wgrad(dqkv, sv["h"], ta.qkv.weight, ta.qkv.bias)
         dh = tr.dgrad(dqkv, self._wt("t_qkv", ta.qkv, dt))
         g, b_ = tr.grad_buffer(self.temporal_norm1.weight, zero=True)[0], tr.grad_buffer(self.temporal_norm1.bias, zero=True)[0]
-        hip.layernorm_bwd(dh, sv["x"], self.temporal_norm1.weight, VIT_EPS, dx, g, b_, rows=B * N * T,
-                          map_mode=hip.MAP_SKIP_CLS, map_p0=N * T)
-        return dx
+        dz_prev = None
+        if fuse and emit_for is not None:  # ... and the temporal norm's backward emits the previous block's MLP operand (its drop_m, all rows incl. CLS)
+            _, dz_prev = hip.layernorm_bwd(dh, sv["x"], self.temporal_norm1.weight, VIT_EPS, dx, g, b_, rows=B * N * T, map_mode=hip.MAP_SKIP_CLS,
+                                           map_p0=N * T, emit=dict(mode=hip.EMIT_ROWS, rows=B * S, dtype=dt, T=T, N=N, scale=emit_for["drop_m"], group=S,
+                                                                   extra_cls=B))
+        else:
+            hip.layernorm_bwd(dh, sv["x"], self.temporal_norm1.weight, VIT_EPS, dx, g, b_, rows=B * N * T,
+                              map_mode=hip.MAP_SKIP_CLS, map_p0=N * T)
+        return dx, dz_prev
 
 
 _KEEP_CACHE = {}
@@ -634,7 +661,13 @@ class _VisualRun:
         torch.mul(dout[:, 1:].unsqueeze(2).expand(B, N, T, D), 1.0 / T, out=dy[:, 1:].view(B, N, T, D))  # one broadcast pass (was mul + repeat_interleave + copy)
         dtok = torch.empty_like(dy)
         g, b_ = tr.grad_buffer(m.norm.weight, zero=True)[0], tr.grad_buffer(m.norm.bias, zero=True)[0]
-        hip.layernorm_bwd(dy.view(-1, D), self.tok, m.norm.weight, VIT_EPS, dtok, g, b_, accumulate=False)
+        dz = None
+        if m.blocks[-1].fuse_ln_bwd_emit:   # the final norm's backward emits the last block's MLP operand rows (its drop-path scale)
+            S_ = 1 + N * T
+            _, dz = hip.layernorm_bwd(dy.view(-1, D), self.tok, m.norm.weight, VIT_EPS, dtok, g, b_, accumulate=False,
+                                      emit=dict(mode=hip.EMIT_ROWS, rows=B * S_, dtype=self.saved[-1]["dt"], scale=self.saved[-1]["drop_m"], group=S_))
+        else:
+            hip.layernorm_bwd(dy.view(-1, D), self.tok, m.norm.weight, VIT_EPS, dtok, g, b_, accumulate=False)
         del dy
         ws = torch.zeros((len(m.blocks), D * D + D), dtype=torch.float32, device=dout.device)
         # Data parallel: in the pretraining / retrieval models this node is the LAST one autograd runs (created first, its input needs
@@ -649,7 +682,7 @@ class _VisualRun:
         nb = len(m.blocks)
         for i, (blk, sv) in enumerate(zip(reversed(m.blocks), reversed(self.saved))):
             sv["ws"] = ws[i]
-            dtok = blk.backward(sv, dtok)
+            dtok, dz = blk.backward(sv, dtok, dz=dz, emit_for=self.saved[nb - 2 - i] if i + 1 < nb else None)
             if overlap and (i + 1) % 4 == 0 and i + 1 < nb:
                 dist.grads_final(params=[p for b in m.blocks[nb - 1 - i:nb - 1 - i + 4] for p in b.parameters()] + (list(m.norm.parameters()) if i == 3 else []))
             sv.clear()

@@ -90,6 +90,7 @@ class BertOutput(nn.Module):
 
 
 class BertLayer(nn.Module):
+    fuse_ln_bwd_emit = os.environ.get("ALPRO_FUSE_LN_BWD", "1") != "0"   # LayerNorm backward also emits the dropped-out operand rows of the next GEMMs
     fuse_residual_ln = os.environ.get("ALPRO_FUSE_RESIDUAL_LN", "1") != "0"   # residual adds inside the post-LayerNorms (alpro_add_layernorm_fwd); False = round-2 GEMM-epilogue form (A/B)
 
     def __init__(self, config, layer_num):
@@ -158,23 +159,26 @@ class BertLayer(nn.Module):
         dev = sv["s1"].device
         M, D = sv["s1"].shape
 
-        def ln_bwd(ln, x, dy_t, dy32):
+        def ln_bwd(ln, x, dy_t, dy32, drop_seed):
+            """-> (dx fp32, dx through the dropout of the dense output that feeds this LayerNorm, in the operand dtype)"""
             if dy_t is None:
                 dy_t, dy32 = dy32, None
             dx = torch.empty((M, D), dtype=torch.float32, device=dev)
             g, b_ = tr.grad_buffer(ln.weight, zero=True)[0], tr.grad_buffer(ln.bias, zero=True)[0]
+            if self.fuse_ln_bwd_emit:
+                _, dx_t = hip.layernorm_bwd(dy_t, x, ln.weight, eps, dx, g, b_, dy2=dy32, accumulate=False,
+                                            emit=dict(mode=hip.EMIT_ROWS, rows=M, dtype=dt, drop_p=hp if drop_seed else 0.0, drop_seed=drop_seed))
+                return dx, dx_t
             hip.layernorm_bwd(dy_t, x, ln.weight, eps, dx, g, b_, dy2=dy32, accumulate=False)
-            return dx
+            return dx, hip.gather_cast(dx, dt, drop_p=hp, drop_seed=drop_seed)
 
         hp, seed1, seed2, ap, seed_a = sv["drop"]
-        ds2 = ln_bwd(self.output.LayerNorm, sv["s2"], do_t, do32)          # also d(a32): identity residual
-        ds2_t = hip.gather_cast(ds2, dt, drop_p=hp, drop_seed=seed2)     # through the FFN-output dropout
+        ds2, ds2_t = ln_bwd(self.output.LayerNorm, sv["s2"], do_t, do32, seed2)   # ds2 is also d(a32): identity residual; ds2_t: through the FFN-output dropout
         tr.wgrad(ds2_t, sv["it"], self.output.dense.weight, self.output.dense.bias)
         du = tr.dgrad(ds2_t, tr.transposed_operand(self._ops, "o_w^T", self.output.dense.weight, dt), gelu_pre=sv["u"])
         tr.wgrad(du, sv["a_t"], self.intermediate.dense.weight, self.intermediate.dense.bias)
         da_t = tr.dgrad(du, tr.transposed_operand(self._ops, "i_w^T", self.intermediate.dense.weight, dt))
-        ds1 = ln_bwd(so.LayerNorm, sv["s1"], da_t, ds2)                     # also d(h32): identity residual
-        ds1_t = hip.gather_cast(ds1, dt, drop_p=hp, drop_seed=seed1)     # through the attention-output dropout
+        ds1, ds1_t = ln_bwd(so.LayerNorm, sv["s1"], da_t, ds2, seed1)       # ds1 is also d(h32): identity residual; ds1_t: through the attention-output dropout
         tr.wgrad(ds1_t, sv["ctx"], so.dense.weight, so.dense.bias)
         dctx = tr.dgrad(ds1_t, tr.transposed_operand(self._ops, "ao_w^T", so.dense.weight, dt))
         dqkv = hip.attn_bwd(sv["qkv"], sv["ctx"], dctx, sv["lse"], B, L, H, scale, sv["kb"], drop_p=ap, drop_seed=seed_a)

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define ALPRO_HIP_ABI_VERSION 11
+#define ALPRO_HIP_ABI_VERSION 12
 
 enum { ALPRO_OK = 0, ALPRO_ERR_INVALID = 1, ALPRO_ERR_LAUNCH = 2 };
 enum { ALPRO_F32 = 0, ALPRO_BF16 = 1, ALPRO_F16 = 2 };
@@ -186,6 +186,24 @@ int alpro_layernorm_bwd(const void* dy, int dy_dtype, int64_t ld_dy, const float
                         uint32_t drop_seed, void* stream);
 /* drop_p > 0: the incoming gradient dy (+dy2) is first multiplied by the dropout mask hash(seed, m*D+n)/(1-p) that the
  * forward applied to this LayerNorm's OUTPUT (embedding dropout). */
+
+/* alpro_layernorm_bwd that ALSO emits the finished gradient row as the `dy_dtype` operand row(s) of the GEMMs that consume it next --
+ * what a following alpro_gather_cast would produce from re-reading dx (autograd has no counterpart: the reference materialises the
+ * rearranged / scaled gradients as separate tensors, vit.py:147,160,165-172,184-196 under autograd).  v = finished dx row of token row r:
+ *   ALPRO_EMIT_ROWS      out[r] = dropout(v; emit_drop_p, emit_drop_seed, index r*D+c) * emit_scale[r / group]
+ *                        emit_extra_cls = B (with map_mode SKIP_CLS, p0 = T, p1 = N): the B CLS rows, which that LayerNorm never touches,
+ *                        are emitted too (read from dx)
+ *   ALPRO_EMIT_FRAME     r = b*(1+N*T) + k: k > 0 -> out[(b*T+t)*(N+1)+1+n] = v * emit_scale[b*T+t]; k = 0 -> the T rows (b*T+t)*(N+1),
+ *                        each v * emit_scale[b*T+t] / T
+ *   ALPRO_EMIT_SKIP_CLS  k > 0 -> out[r-b-1] = v * emit_scale[(r-b-1) / group]; emit_colsum_pre[c] += v[c] (unscaled); shared (CLS) rows
+ *                        emit nothing
+ * Rows accumulated by several source rows (the CLS row under the FRAME_TOKENS map) are never emitted.  ld_dx must be D. */
+enum { ALPRO_EMIT_NONE = 0, ALPRO_EMIT_ROWS = 1, ALPRO_EMIT_FRAME = 2, ALPRO_EMIT_SKIP_CLS = 3 };
+int alpro_layernorm_bwd_emit(const void* dy, int dy_dtype, int64_t ld_dy, const float* dy2, const float* x, int64_t ldx,
+                             const float* gamma, float eps, float* dx, int64_t ld_dx, int accumulate, float* dgamma, float* dbeta,
+                             int rows, int D, int map_mode, int map_p0, int map_p1, float drop_p, uint32_t drop_seed, void* emit_out,
+                             int emit_dtype /* dy_dtype, or any dtype when dy is fp32 */, int emit_mode, int emit_p0, int emit_p1, const float* emit_scale, int emit_scale_group, float emit_drop_p,
+                             uint32_t emit_drop_seed, float* emit_colsum_pre, int emit_extra_cls, void* stream);
 
 /* out[c, r] = in[r, c] (r < R), 0 for R <= r < Rpad: puts the token dimension last so that dgrad / wgrad run on
  * the NT GEMM (dX = dY (W^T)^T, dW = dY^T (X^T)^T).  `in` is fp32 or out_dtype.  colsum (C) fp32, optional:

@@ -419,7 +419,7 @@ def test_merged_temporal_projection_equals_two_linears(mode, tol):
             p.grad = None
         with rt.use_compute_dtype(mode), torch.no_grad():
             out, sv = blk.forward_train(x.clone(), B, T, 3)
-            dx = blk.backward(sv, dout.clone())
+            dx, _ = blk.backward(sv, dout.clone())
         res[merged] = (out.clone(), dx.clone(), {n: p.grad.clone() for n, p in blk.named_parameters() if p.grad is not None})
     ref, got = res[False], res[True]
 
@@ -429,6 +429,79 @@ def test_merged_temporal_projection_equals_two_linears(mode, tol):
     assert set(got[2]) == set(ref[2])
     for n in ref[2]:
         assert rel(got[2][n], ref[2][n]) < 5 * tol, (n, rel(got[2][n], ref[2][n]))
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16, torch.float16])
+def test_layernorm_bwd_emit_equals_layernorm_bwd_then_gather_cast(dt):
+    """alpro_layernorm_bwd_emit (round 3): the operand rows it emits are exactly what alpro_gather_cast builds from the gradient stream
+    the plain backward leaves behind -- for the three hand-overs of a divided space-time block (norm2 -> spatial projection in
+    frame-token order with the CLS / T rule, norm1 -> temporal projection with the temporal_fc bias gradient, temporal norm -> the
+    previous block's MLP incl. the CLS rows it never touches) and BERT's dropout hand-over, from 16-bit and from fp32 incoming
+    gradients."""
+    from alpro_amd import hip
+    hip.load()
+    B, T, N, D = 2, 4, 9, 768
+    S = 1 + N * T
+    x = (rnd(B, S, D, seed=700) * 2 + 0.3).cuda()
+    g = (1 + 0.1 * rnd(D, seed=701)).cuda()
+    dx0 = rnd(B, S, D, seed=702).cuda()
+    sc_bt = ((torch.rand(B * T, generator=torch.Generator().manual_seed(3)) > 0.3).float() / 0.7).cuda()
+    sc_bn = ((torch.rand(B * N, generator=torch.Generator().manual_seed(4)) > 0.3).float() / 0.7).cuda()
+    sc_b = torch.tensor([1 / 0.7, 0.0]).cuda()
+
+    def run(dy, rows, map_kw, emit, gather_kw, dy2=None):
+        outs = []
+        for use_emit in (False, True):
+            dx = dx0.clone()
+            dg, db, cs = torch.zeros(D, device="cuda"), torch.zeros(D, device="cuda"), torch.zeros(D, device="cuda")
+            if use_emit:
+                e = dict(emit, dtype=dt)
+                if "colsum_pre" in e:
+                    e["colsum_pre"] = cs
+                _, op = hip.layernorm_bwd(dy, x, g, 1e-6, dx, dg, db, rows=rows, dy2=dy2, emit=e, **map_kw)
+            else:
+                hip.layernorm_bwd(dy, x, g, 1e-6, dx, dg, db, rows=rows, dy2=dy2, **map_kw)
+                gk = dict(gather_kw)
+                if gk.pop("want_colsum_pre", False):
+                    gk["colsum_pre"] = cs
+                op = hip.gather_cast(dx, dt, **gk)
+            outs.append((dx, op, dg, db, cs))
+        (dx_a, op_a, dg_a, db_a, cs_a), (dx_b, op_b, dg_b, db_b, cs_b) = outs
+        assert op_a.shape == op_b.shape and op_b.dtype == dt
+        return dx_a, dx_b, op_a, op_b, cs_a, cs_b
+
+    # norm2 (identity rows) -> frame-token operand of the spatial projection
+    dy = rnd(B * S, D, seed=710).to(dt).cuda()
+    dx_a, dx_b, op_a, op_b, _, _ = run(dy, B * S, {}, dict(mode=hip.EMIT_FRAME, rows=B * T * (N + 1), T=T, N=N, scale=sc_bt),
+                                       dict(rows=B * T * (N + 1), map_mode=hip.MAP_FRAME_TOKENS, map_p0=T, map_p1=N, row_scale=sc_bt, row_scale_group=N + 1, cls_scale=1.0 / T))
+    assert torch.equal(dx_a, dx_b) and torch.equal(op_a, op_b)
+    # norm1 (frame-token gather, CLS rows accumulated atomically) -> x[:, 1:] operand of the merged temporal projection + temporal_fc bias gradient
+    dy = rnd(B * T * (N + 1), D, seed=711).to(dt).cuda()
+    fm = dict(map_mode=hip.MAP_FRAME_TOKENS, map_p0=T, map_p1=N)
+    dx_a, dx_b, op_a, op_b, cs_a, cs_b = run(dy, B * T * (N + 1), fm, dict(mode=hip.EMIT_SKIP_CLS, rows=B * N * T, T=T, N=N, scale=sc_bn, group=T, colsum_pre=True),
+                                             dict(rows=B * N * T, map_mode=hip.MAP_SKIP_CLS, map_p0=N * T, row_scale=sc_bn, row_scale_group=T, want_colsum_pre=True))
+    assert torch.equal(dx_a[:, 1:], dx_b[:, 1:]) and torch.equal(op_a, op_b)
+    assert float((dx_a[:, 0] - dx_b[:, 0]).abs().max()) < 1e-4 * float(dx_a[:, 0].abs().max())          # T atomic adds per CLS row: order-dependent rounding only
+    assert float((cs_a - cs_b).abs().max()) < 1e-4 * float(cs_a.abs().max())
+    # temporal norm (x[:, 1:] rows) -> all rows of the previous block's MLP operand, CLS rows included
+    dy = rnd(B * N * T, D, seed=712).to(dt).cuda()
+    dx_a, dx_b, op_a, op_b, _, _ = run(dy, B * N * T, dict(map_mode=hip.MAP_SKIP_CLS, map_p0=N * T),
+                                       dict(mode=hip.EMIT_ROWS, rows=B * S, T=T, N=N, scale=sc_b, group=S, extra_cls=B), dict(row_scale=sc_b, row_scale_group=S))
+    assert torch.equal(dx_a, dx_b) and torch.equal(op_a, op_b)
+    # BERT: fp32 incoming gradient + second stream, not accumulating; emitted through the dense-output dropout
+    dy32, dy2 = rnd(B * S, D, seed=713).cuda(), rnd(B * S, D, seed=714).cuda()
+    outs = []
+    for use_emit in (False, True):
+        dx = torch.empty(B * S, D, device="cuda")
+        dg, db = torch.zeros(D, device="cuda"), torch.zeros(D, device="cuda")
+        if use_emit:
+            _, op = hip.layernorm_bwd(dy32, x, g, 1e-12, dx, dg, db, dy2=dy2, accumulate=False, emit=dict(mode=hip.EMIT_ROWS, rows=B * S, dtype=dt, drop_p=0.1, drop_seed=77))
+        else:
+            hip.layernorm_bwd(dy32, x, g, 1e-12, dx, dg, db, dy2=dy2, accumulate=False)
+            op = hip.gather_cast(dx, dt, drop_p=0.1, drop_seed=77)
+        outs.append((dx, op))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert 0.05 < float((outs[1][1] == 0).float().mean()) < 0.15
 
 
 def test_gemms_at_full_benchmark_size():
