@@ -154,6 +154,21 @@ template <typename T> __device__ __forceinline__ float gelu_grad(float x) {
   }
 }
 
+// gelu(x) and gelu'(x) together (the forward of a GELU Linear that keeps gelu' for its backward): Phi(x) is shared
+template <typename T> __device__ __forceinline__ void gelu_and_grad(float x, float& y, float& dy) {
+  if constexpr (sizeof(T) == 4) {
+    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+    y = x * cdf;
+    dy = cdf + x * 0.39894228040143267794f * __expf(-0.5f * x * x);
+  } else {
+    const float h = half_erfc_pos(fabsf(x) * 0.70710678118654752440f);
+    const float cdf = 0.5f + copysignf(0.5f - h, x);
+    const float pdf = 0.39894228040143267794f * __builtin_amdgcn_exp2f(x * x * -0.72134752044448170368f);
+    y = x * cdf;
+    dy = cdf + x * pdf;
+  }
+}
+
 // ---- counter-based dropout mask: a pure function of (seed, element index), so the backward regenerates it ------
 __device__ __forceinline__ uint32_t mix32(uint32_t h) {  // "lowbias32" finalizer
   h ^= h >> 16; h *= 0x7FEB352Du; h ^= h >> 15; h *= 0x846CA68Bu; h ^= h >> 16;

@@ -73,7 +73,7 @@ __device__ __forceinline__ void wave_lds_sync() {
 }
 
 template <typename T, int ACT> __device__ __forceinline__ float apply_act(float x) {
-  if (ACT == ALPRO_ACT_GELU) return gelu_fast<T>(x);
+  if (ACT == ALPRO_ACT_GELU) return gelu_fast<T>(x);   // (GELU_SAVE_GRAD computes gelu together with gelu' before this point)
   if (ACT == ALPRO_ACT_RELU) return fmaxf(x, 0.f);
   return x;
 }
@@ -133,7 +133,23 @@ __device__ __forceinline__ void epi_rows16(const alpro_gemm_desc_t& g, const flo
         *(float4*)((float*)g.C2 + orow[p] * g.ldc2 + n) = make_float4(v[0], v[1], v[2], v[3]);
       }
     }
-    if (ACT == ALPRO_ACT_GELU_BWD) {  // v *= gelu'(saved pre-activation)
+    if (ACT == ALPRO_ACT_GELU_SAVE_GRAD) {  // v = gelu(v), C2 = gelu'(v)
+      float dv[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) gelu_and_grad<T>(v[e], v[e], dv[e]);
+      if (FAST) {
+        if constexpr (sizeof(T) == 2) {
+          __builtin_nontemporal_store(mk2(pack2(dv[0], dv[1], (T*)0), pack2(dv[2], dv[3], (T*)0)), (u32x2*)((T*)g.C2 + orow[p] * g.ldc2 + n));
+        } else {
+          *(float4*)((float*)g.C2 + orow[p] * g.ldc2 + n) = make_float4(dv[0], dv[1], dv[2], dv[3]);
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (n + e < g.N) ((T*)g.C2)[orow[p] * g.ldc2 + n + e] = from_f32<T>(dv[e]);
+      }
+    }
+    if (ACT == ALPRO_ACT_GELU_BWD || ACT == ALPRO_ACT_MUL_SAVED) {  // v *= gelu'(saved pre-activation) / v *= saved factor
       const T* pp = (const T*)g.C2 + orow[p] * g.ldc2 + n;
       float pre[4];
       if (FAST) {
@@ -153,7 +169,7 @@ __device__ __forceinline__ void epi_rows16(const alpro_gemm_desc_t& g, const flo
         for (int e = 0; e < 4; ++e) pre[e] = (n + e < g.N) ? to_f32(pp[e]) : 0.f;
       }
 #pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] *= gelu_grad<T>(pre[e]);
+      for (int e = 0; e < 4; ++e) v[e] *= (ACT == ALPRO_ACT_MUL_SAVED) ? pre[e] : gelu_grad<T>(pre[e]);
     }
 #pragma unroll
     for (int e = 0; e < 4; ++e) v[e] = apply_act<T, ACT>(v[e]) * rs;
@@ -229,11 +245,17 @@ __device__ __forceinline__ void epi_rows16_c16(const alpro_gemm_desc_t& g, const
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] = g.alpha * v[e] + bias[e];
     if ((ACT == ALPRO_ACT_GELU || ACT == ALPRO_ACT_RELU) && g.C2) __builtin_nontemporal_store(pack_chunk<T>(v), (u32x4*)((T*)g.C2 + m * g.ldc2 + n));
-    if (ACT == ALPRO_ACT_GELU_BWD) {
+    if (ACT == ALPRO_ACT_GELU_SAVE_GRAD) {
+      float dv[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) gelu_and_grad<T>(v[e], v[e], dv[e]);
+      __builtin_nontemporal_store(pack_chunk<T>(dv), (u32x4*)((T*)g.C2 + m * g.ldc2 + n));
+    }
+    if (ACT == ALPRO_ACT_GELU_BWD || ACT == ALPRO_ACT_MUL_SAVED) {
       float pre[8];
       unpack_chunk<T>(pre_c2 ? pre_c2[p] : *(const u32x4*)((const T*)g.C2 + m * g.ldc2 + n), pre);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] *= gelu_grad<T>(pre[e]);
+      for (int e = 0; e < 8; ++e) v[e] *= (ACT == ALPRO_ACT_MUL_SAVED) ? pre[e] : gelu_grad<T>(pre[e]);
     }
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] = apply_act<T, ACT>(v[e]) * rs;
@@ -617,7 +639,8 @@ __global__ __launch_bounds__(NT2, 2) void gemm_nt256p_kernel(const alpro_gemm_de
           auto load_pre = [&](int c) {
             return __builtin_nontemporal_load((const u32x4*)((const T*)g.C2 + (int64_t)(mb + c * 8 + (lane >> 3)) * g.ldc2 + nb + (lane & 7) * 8));
           };
-          if (ACT == ALPRO_ACT_GELU_BWD) {
+          constexpr bool READS_C2 = ACT == ALPRO_ACT_GELU_BWD || ACT == ALPRO_ACT_MUL_SAVED;
+          if (READS_C2) {
             pring[0] = load_pre(0);
             pring[1] = load_pre(1);
           }
@@ -630,10 +653,10 @@ __global__ __launch_bounds__(NT2, 2) void gemm_nt256p_kernel(const alpro_gemm_de
 #pragma unroll
               for (int q = 0; q < 4; ++q) {
                 const int c = i * 4 + q;
-                if (ACT == ALPRO_ACT_GELU_BWD && c + 2 < 16) pring[(c + 2) % 3] = load_pre(c + 2);
+                if (READS_C2 && c + 2 < 16) pring[(c + 2) % 3] = load_pre(c + 2);
                 float* st = stage + (c & 1) * 512;
                 stage_chunk(st, acc[i][0], acc[i][1], q);
-                epi_rows16_c16<T, ACT, 1, (TUNE == 3 ? 1 : 0)>(g, st, mb + c * 8, nb, lane, bias8, ACT == ALPRO_ACT_GELU_BWD ? &pring[c % 3] : nullptr);
+                epi_rows16_c16<T, ACT, 1, (TUNE == 3 ? 1 : 0)>(g, st, mb + c * 8, nb, lane, bias8, READS_C2 ? &pring[c % 3] : nullptr);
               }
             }
           }
@@ -706,6 +729,8 @@ int launch_gemm(const alpro_gemm_desc_t& g, hipStream_t st) {
       return ALPRO_ERR_INVALID;
     }
     if (g.act == ALPRO_ACT_GELU_BWD) return launch_gemm_inst<T, ALPRO_ACT_GELU_BWD, ALPRO_MAP_IDENTITY>(g, st);
+    if (g.act == ALPRO_ACT_GELU_SAVE_GRAD) return launch_gemm_inst<T, ALPRO_ACT_GELU_SAVE_GRAD, ALPRO_MAP_IDENTITY>(g, st);
+    if (g.act == ALPRO_ACT_MUL_SAVED) return launch_gemm_inst<T, ALPRO_ACT_MUL_SAVED, ALPRO_MAP_IDENTITY>(g, st);
     return g.act == ALPRO_ACT_GELU ? launch_gemm_inst<T, ALPRO_ACT_GELU, ALPRO_MAP_IDENTITY>(g, st)
                                    : launch_gemm_inst<T, ALPRO_ACT_RELU, ALPRO_MAP_IDENTITY>(g, st);
   }
@@ -729,9 +754,10 @@ extern "C" int alpro_gemm(const alpro_gemm_desc_t* d, void* stream) {
   ALPRO_CHECK(((uintptr_t)d->A % 16) == 0 && ((uintptr_t)d->W % 16) == 0, "alpro_gemm: A/W must be 16-byte aligned");
   ALPRO_CHECK(d->c_dtype == d->dtype || d->c_dtype == ALPRO_F32, "alpro_gemm: c_dtype must be dtype or F32");
   ALPRO_CHECK(d->map_mode >= 0 && d->map_mode <= 3, "alpro_gemm: bad map_mode %d", d->map_mode);
-  ALPRO_CHECK(d->act >= 0 && d->act <= ALPRO_ACT_GELU_BWD, "alpro_gemm: bad act %d", d->act);
+  ALPRO_CHECK(d->act >= 0 && d->act <= ALPRO_ACT_MUL_SAVED, "alpro_gemm: bad act %d", d->act);
   ALPRO_CHECK(!d->bias2 || d->map_mode == ALPRO_MAP_SKIP_CLS, "alpro_gemm: bias2 is only defined under the SKIP_CLS map");
-  ALPRO_CHECK(d->act != ALPRO_ACT_GELU_BWD || (d->C2 && d->N % 8 == 0 && d->ldc2 % 8 == 0), "alpro_gemm: GELU_BWD needs the saved pre-activation in C2 (N, ldc2 multiples of 8)");
+  ALPRO_CHECK((d->act != ALPRO_ACT_GELU_BWD && d->act != ALPRO_ACT_MUL_SAVED && d->act != ALPRO_ACT_GELU_SAVE_GRAD) || (d->C2 && d->N % 8 == 0 && d->ldc2 % 8 == 0),
+              "alpro_gemm: GELU_BWD / MUL_SAVED / GELU_SAVE_GRAD need the C2 buffer (N, ldc2 multiples of 8)");
   ALPRO_CHECK(!d->drop_seed || (d->map_mode == ALPRO_MAP_IDENTITY && d->drop_p > 0.f && d->drop_p < 1.f), "alpro_gemm: dropout needs the identity map and 0 < p < 1");
   ALPRO_CHECK(!d->C2 || (d->N % 4 == 0 && d->ldc2 % 4 == 0 && d->ldc % 4 == 0), "alpro_gemm: C2 needs N, ldc, ldc2 multiples of 4");
   ALPRO_CHECK(d->map_mode != ALPRO_MAP_FRAME_TOKENS || d->side, "alpro_gemm: FRAME_TOKENS needs a side buffer");

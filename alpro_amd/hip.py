@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("ALPRO_HIP_LIB") or os.path.join(_HERE, "lib", "libalpro_hip.so")  # ALPRO_HIP_LIB: tools/ load the ablation build
 
 F32, BF16, F16 = 0, 1, 2
-ACT_NONE, ACT_GELU, ACT_RELU, ACT_GELU_BWD = 0, 1, 2, 3
+ACT_NONE, ACT_GELU, ACT_RELU, ACT_GELU_BWD, ACT_GELU_SAVE_GRAD, ACT_MUL_SAVED = 0, 1, 2, 3, 4, 5
 MAP_IDENTITY, MAP_SKIP_CLS, MAP_FRAME_TOKENS, MAP_PATCH_EMBED = 0, 1, 2, 3
 ADD_IDENTITY, ADD_PRE_SPATIAL, ADD_PRE_MLP, ADD_PRE_TEMPORAL = 0, 1, 2, 3
 EMIT_NONE, EMIT_ROWS, EMIT_FRAME, EMIT_SKIP_CLS = 0, 1, 2, 3
@@ -45,7 +45,7 @@ class TransposeJob(ctypes.Structure):
                 ("R", ctypes.c_int32), ("C", ctypes.c_int32), ("Rpad", ctypes.c_int32), ("tile0", ctypes.c_int32)]   # 48 bytes
 
 
-ABI_VERSION = 12
+ABI_VERSION = 13
 _lib = None
 
 
@@ -164,7 +164,8 @@ def torch_dtype(code):
 def gemm(a, w, out=None, bias=None, act=ACT_NONE, out_dtype=None, alpha=1.0, row_scale=None, row_scale_group=1,
          residual=None, map_mode=MAP_IDENTITY, map_p0=0, map_p1=0, side=None, out_rows=None, pre_act=None, drop_p=0.0, drop_seed=0, bias2=None):
     """out[map(m)] = residual[map(m)] + row_scale * act(alpha * a @ w.T + bias) [+ bias2]   (see alpro_gemm).
-    act=ACT_GELU_BWD: out = (alpha * a @ w.T + bias) * gelu'(pre_act) (pre_act read only)."""
+    act=ACT_GELU_BWD: out = (alpha * a @ w.T + bias) * gelu'(pre_act) (pre_act read only).
+    act=ACT_GELU_SAVE_GRAD: out = gelu(..), pre_act (required) RECEIVES gelu'(..); act=ACT_MUL_SAVED: out = (..) * pre_act (read only)."""
     lib = load()
     _dev(a); _dev(w, a.dtype)
     M, K = a.shape

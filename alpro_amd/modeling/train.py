@@ -153,10 +153,14 @@ def wgrad(dy_t, x_t, weight, bias, bias_done=False):
     hip.gemm(dyT, hip.transpose(x_t), out=gw2, out_dtype=torch.float32, residual=gw2)
 
 
-def dgrad(dy_t, wT, out_dtype=None, row_scale=None, row_scale_group=1, gelu_pre=None):
+SAVE_GELU_GRAD = os.environ.get("ALPRO_SAVE_GELU_GRAD", "1") != "0"   # GELU Linears keep gelu'(pre-activation) instead of the pre-activation (0 = round-2 form, A/B)
+
+
+def dgrad(dy_t, wT, out_dtype=None, row_scale=None, row_scale_group=1, gelu_pre=None, gelu_saved_grad=False):
     """dX = dy @ W using the cached transposed operand wT (K, N64); dy_t (M, N).
-    gelu_pre: saved pre-activation of the GELU that produced this Linear's input -> dX *= gelu'(pre) in the epilogue
-    (the elementwise GELU backward never runs as its own pass)."""
+    gelu_pre: what the forward of the GELU Linear that produced this Linear's input kept in its C2 buffer -- the pre-activation
+    (dX *= gelu'(pre) recomputed in the epilogue) or, with gelu_saved_grad, gelu'(pre) itself (dX *= saved, ALPRO_ACT_MUL_SAVED).
+    Either way the elementwise GELU backward never runs as its own pass."""
     n = dy_t.shape[1]
     w = wT if wT.shape[1] == n else wT[:, :n]
     if not w.is_contiguous() or n % (64 if dy_t.dtype != torch.float32 else 32) != 0:
@@ -165,7 +169,7 @@ def dgrad(dy_t, wT, out_dtype=None, row_scale=None, row_scale_group=1, gelu_pre=
         dy_t = torch.nn.functional.pad(dy_t, (0, pad))
         w = wT
     return hip.gemm(dy_t, w, out_dtype=out_dtype or dy_t.dtype, row_scale=row_scale, row_scale_group=row_scale_group,
-                    act=hip.ACT_GELU_BWD if gelu_pre is not None else hip.ACT_NONE, pre_act=gelu_pre)
+                    act=(hip.ACT_MUL_SAVED if gelu_saved_grad else hip.ACT_GELU_BWD) if gelu_pre is not None else hip.ACT_NONE, pre_act=gelu_pre)
 
 
 # Anchored runs whose backward has not executed yet (weak: an abandoned graph drops out when it is freed).  A run may only declare

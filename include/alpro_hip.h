@@ -25,13 +25,17 @@
 extern "C" {
 #endif
 
-#define ALPRO_HIP_ABI_VERSION 12
+#define ALPRO_HIP_ABI_VERSION 13
 
 enum { ALPRO_OK = 0, ALPRO_ERR_INVALID = 1, ALPRO_ERR_LAUNCH = 2 };
 enum { ALPRO_F32 = 0, ALPRO_BF16 = 1, ALPRO_F16 = 2 };
 /* GELU_BWD (backward of a GELU Linear, vit.py:61 / xbert.py:423): C = (alpha*acc + bias) * gelu'(C2[m, n]) where C2 is
  * the READ-ONLY pre-activation the forward GEMM saved; fuses the elementwise backward into the dgrad GEMM. */
-enum { ALPRO_ACT_NONE = 0, ALPRO_ACT_GELU = 1, ALPRO_ACT_RELU = 2, ALPRO_ACT_GELU_BWD = 3 };
+enum { ALPRO_ACT_NONE = 0, ALPRO_ACT_GELU = 1, ALPRO_ACT_RELU = 2, ALPRO_ACT_GELU_BWD = 3,
+       /* round 3: the GELU Linear's forward writes gelu'(pre-activation) into C2 instead of the pre-activation (GELU_SAVE_GRAD, C2 required),
+        * and its dgrad multiplies by the saved value (MUL_SAVED: C = (alpha*acc + bias) * C2[m, n], C2 read only) -- the ~13 VALU operations
+        * per element of recomputing gelu' in the backward epilogue (the slowest dgrad of the model in round 2) become one multiply. */
+       ALPRO_ACT_GELU_SAVE_GRAD = 4, ALPRO_ACT_MUL_SAVED = 5 };
 
 /* Row maps: how GEMM/LayerNorm row m addresses the (B, 1 + N*T, D) token tensor whose patch token
  * (n, t) lives at row 1 + n*T + t of its clip (vit.py:147 'b (h w t) m').
@@ -82,7 +86,8 @@ typedef struct {
   float* side;            /* FRAME_TOKENS: (B*T, N) fp32 buffer receiving the j == 0 rows (no residual) */
   int64_t ld_side;
   void* C2;               /* GELU/RELU: optional (M, N) `dtype` copy of the pre-activation alpha*acc+bias (kept for the
-                             backward).  GELU_BWD: the saved pre-activation, read only (required). */
+                             backward).  GELU_BWD: the saved pre-activation, read only (required).  GELU_SAVE_GRAD: receives
+                             gelu'(pre-activation) (required).  MUL_SAVED: the saved factor, read only (required). */
   int64_t ldc2;
   float drop_p;           /* dropout on the value BEFORE the residual add (xbert.py:358,436): keep iff hash(seed, m*N+n) */
   uint32_t drop_seed;     /* passes, kept values scaled by 1/(1-p); 0 = off.  Identity map only. */

@@ -309,6 +309,32 @@ def test_gemm_gelu_bwd_epilogue(dt, M, N, K, tile):
     close(out, ref, rt, at, "gelu-bwd epilogue")
 
 
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("M,N,K,tile", [(300, 3072, 768, "128"), (70000, 768, 768, "256"), (1000, 256, 768, "256")])
+def test_gemm_gelu_save_grad_and_mul_saved_epilogues(dt, M, N, K, tile):
+    """Round 3: the GELU Linear's forward keeps gelu'(pre-activation) (ACT_GELU_SAVE_GRAD writes it into C2 next to gelu(..)) and its dgrad
+    multiplies by the saved factor (ACT_MUL_SAVED) -- both tile kernels incl. partial edge tiles, against fp64 autograd of erf-GELU."""
+    hip = _hip()
+    a = rnd(M, K, seed=320, scale=0.5).to(dt)
+    w = rnd(N, K, seed=321, scale=0.08).to(dt)
+    bias = rnd(N, seed=322, scale=0.3)
+    rt, at = {torch.float32: (1e-4, 1e-4), torch.bfloat16: (1.5e-2, 1.5e-2), torch.float16: (3e-3, 3e-3)}[dt]
+    saved = torch.empty(M, N, dtype=dt, device="cuda")
+    with hip.option("gemm_tile", int(tile)):
+        out = hip.gemm(a.cuda(), w.cuda(), bias=bias.cuda(), act=hip.ACT_GELU_SAVE_GRAD, pre_act=saved)
+    pre = (a.double() @ w.double().T + bias.double()).requires_grad_(True)
+    y = torch.nn.functional.gelu(pre)
+    y.sum().backward()
+    close(out, y.detach(), rt, at, "gelu forward")
+    close(saved, pre.grad, rt, at, "saved gelu'")
+    dy = rnd(M, K, seed=323, scale=0.5).to(dt)
+    with hip.option("gemm_tile", int(tile)):
+        dx = hip.gemm(dy.cuda(), w.cuda(), act=hip.ACT_MUL_SAVED, pre_act=saved)
+    close(dx, (dy.double() @ w.double().T) * saved.double().cpu(), rt, at, "mul-saved epilogue")
+    with pytest.raises(RuntimeError, match="C2 buffer"):
+        hip.gemm(dy.cuda(), w.cuda(), act=hip.ACT_MUL_SAVED)
+
+
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
 def test_gather_cast_colsum(dt):
     hip = _hip()

@@ -4,7 +4,7 @@
 #   - rocprofv3 --kernel-trace --stats of both commands -> per-kernel stats CSV
 #   - separate --pmc passes (never combined with traces): FETCH_SIZE, WRITE_SIZE (HBM traffic) and the MFMA-utilisation counters
 # Everything lands in gpurun_out/<tag>/; copy what should be judged into profiles/.
-TAG=${1:-r2}
+TAG=${1:-r3}
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/$TAG
@@ -14,9 +14,12 @@ ALPRO_BENCH_SHAPES=1 python bench.py --steps 10 --warmup 3 > $O/bench_pretrain_s
 ALPRO_BENCH_SHAPES=1 python bench.py --workload visual_fwd --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_visual_fwd_B32.json 2> $O/gemm_shapes_visual_fwd_B32.txt
 cd /tmp
 for wl in pretrain_step visual_fwd; do
-  if [ $wl = pretrain_step ]; then ARGS="--steps 5 --warmup 2 --no-cpu-baseline"; B=B64; else ARGS="--workload visual_fwd --steps 10 --warmup 3 --no-cpu-baseline"; B=B32; fi
+  # clean, step-delimited traces: no divST pass, no parity model, no CPU baseline inside the traced process -> every per-step
+  # kernel appears (warmup + steps + 1 per-kernel timing pass) = 8 (pretrain_step) / 14 (visual_fwd) times its per-step launch count
+  if [ $wl = pretrain_step ]; then ARGS="--steps 5 --warmup 2 --no-cpu-baseline --no-parity --no-divst"; B=B64; else ARGS="--workload visual_fwd --steps 10 --warmup 3 --no-cpu-baseline --no-parity --no-divst"; B=B32; fi
   rocprofv3 --kernel-trace --stats -d $O/trace_$wl -o t --output-format csv -- python $R/bench.py $ARGS > $O/trace_$wl.log 2>&1
   cp $(find $O/trace_$wl -name '*kernel_stats.csv' | head -1) $O/${wl}_${B}_kernel_stats.csv 2>/dev/null
+  if [ $wl = visual_fwd ]; then continue; fi   # counters for the training step only (GPU-minute budget)
   for pm in FETCH_SIZE WRITE_SIZE; do
     rocprofv3 --pmc $pm -d $O/pmc_${wl}_$pm -o $pm --output-format csv -- python $R/bench.py $ARGS > $O/pmc_${wl}_$pm.log 2>&1
     mkdir -p $O/pmc_$wl && cp $(find $O/pmc_${wl}_$pm -name '*counter_collection.csv' | head -1) $O/pmc_$wl/${pm}_counter_collection.csv 2>/dev/null
