@@ -453,8 +453,12 @@ __device__ __forceinline__ constexpr int copy_slot(int tune, int q, int pos) {
   return (r >= 0 && r < 24 && r % 3 == 0) ? r / 3 : -1;
 }
 
+// Tail split (round 3): with nblk = Q * grid + R tiles, the last round keeps only R workgroups busy (M = 50176 x N = 768 at B = 32: 591
+// tiles on 256 CUs = 2.31 -> 3 rounds, 77 %).  When 2R <= grid, each tile of that round is cut in two along M and handed to TWO
+// workgroups: a half tile is a 128 x 256 tile whose upper wave row (waves 4-7, one per SIMD) idles -- it still issues its share of the
+// DMA and takes the barriers -- so the round costs about half of a full one (2.31 -> 2.5 round-equivalents instead of 3).
 template <typename T, int ACT, int MAP, int TUNE = 1>
-__global__ __launch_bounds__(NT2, 2) void gemm_nt256p_kernel(const alpro_gemm_desc_t g) {
+__global__ __launch_bounds__(NT2, 2) void gemm_nt256p_kernel(const alpro_gemm_desc_t g, const int tail_split) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 2, wc = wave & 3;
@@ -471,9 +475,26 @@ __global__ __launch_bounds__(NT2, 2) void gemm_nt256p_kernel(const alpro_gemm_de
   const char* a_src[4];
   const char* w_src[4];
   int m0 = 0, n0 = 0;
-  auto setup = [&](int tile) {
+  const int G = gridDim.x;
+  const int q_full = nblk / G, rem = nblk - q_full * G;
+  const bool split = tail_split && rem > 0 && 2 * rem <= G;
+  // it-th tile of this workgroup: (tile, half) with half = -1 for a full tile, 0 / 1 for the lower / upper 128 rows of a split tile
+  auto locate = [&](int it, int& t, int& hf) -> bool {
+    hf = -1;
+    if (it < q_full) { t = slot + it * G; return true; }
+    if (it > q_full) return false;
+    if (split) {
+      if (slot >= 2 * rem) return false;
+      t = q_full * G + (slot >> 1);
+      hf = slot & 1;
+      return true;
+    }
+    t = q_full * G + slot;
+    return slot < rem;
+  };
+  auto setup = [&](int tile, int hf) {
     const int tm = tile / ntn, tn = tile - tm * ntn;
-    m0 = tm * BM2;
+    m0 = tm * BM2 + (hf > 0 ? BM2 / 2 : 0);
     n0 = tn * BN2;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -486,14 +507,15 @@ __global__ __launch_bounds__(NT2, 2) void gemm_nt256p_kernel(const alpro_gemm_de
   const uint32_t lds_base = lds_addr_of(smem);
   // copy c = 0..7 of K-tile kt into stage buffer buf: (A, W) x 4 pieces of 1 KiB per wave.  Issued from inline asm
   // (common.hpp dma16) and tracked by the hand-placed vmcnt waits below.
-  auto copy_piece = [&](int c, int kt, int buf) {
+  auto copy_piece = [&](int c, int kt, int buf, bool half_a = false) {
     const int i = c >> 1;
+    if (half_a && !(c & 1) && i >= 2) return;  // rows 128..255 of a half tile's A image are never read
     const char* src = ((c & 1) ? w_src[i] : a_src[i]) + (int64_t)kt * ROWB;
     dma16(src, __builtin_amdgcn_readfirstlane(lds_base + buf * 2 * TILE2_BYTES + (c & 1) * TILE2_BYTES + (wave + 8 * i) * 1024));
   };
-  auto stage_tile = [&](int kt, int buf) {
+  auto stage_tile = [&](int kt, int buf, bool half_a = false) {
 #pragma unroll
-    for (int c = 0; c < 8; ++c) copy_piece(c, kt, buf);
+    for (int c = 0; c < 8; ++c) copy_piece(c, kt, buf, half_a);
   };
   int a_row[4], b_row[2];
 #pragma unroll
@@ -503,8 +525,8 @@ __global__ __launch_bounds__(NT2, 2) void gemm_nt256p_kernel(const alpro_gemm_de
   const int khalf = lane >> 5;
   float* stage = (float*)(smem + 4 * TILE2_BYTES + wave * (16 * 64 * 4));
 
-  int tile = slot;
-  if (tile >= nblk) return;
+  int it = 0, tile, hf;
+  if (!locate(0, tile, hf)) return;
   // Invariant at the top of every tile: K-tiles 0 and 1 are in buffers s0 and s0^1 and this wave has no DMA in flight,
   // so the first two K-steps need no vmcnt wait -- the previous tile's output stores drain underneath them.
   const int pos = wave >> 2;
@@ -514,15 +536,16 @@ __global__ __launch_bounds__(NT2, 2) void gemm_nt256p_kernel(const alpro_gemm_de
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
   };
-  setup(tile);
+  setup(tile, hf);
   int s0 = 0;
-  stage_tile(0, 0);
-  stage_tile(1, 1);
+  stage_tile(0, 0, hf >= 0);
+  stage_tile(1, 1, hf >= 0);
   wait_vm0();
   while (true) {
     const int tm0 = m0, tn0 = n0;
-    const int next = tile + gridDim.x;
-    const bool more = next < nblk;
+    int next, next_hf;
+    const bool more = locate(it + 1, next, next_hf);
+    const bool active = hf < 0 || wr == 0;   // half tile: the upper wave row has nothing to compute
     f32x16 acc[4][2];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -548,10 +571,19 @@ __global__ __launch_bounds__(NT2, 2) void gemm_nt256p_kernel(const alpro_gemm_de
       // all 8 waves right after the barrier they idle the whole CU for several hundred cycles per K-step.
       int ckt = kt + 1;
       bool do_copy = kt >= 1 && kt + 1 < nk;
+      bool copy_half = hf >= 0;
       if (kt >= 1 && kt + 1 == nk && more) {  // last step: start the NEXT tile's first K-tile
-        setup(next);
+        setup(next, next_hf);
         ckt = 0;
         do_copy = true;
+        copy_half = next_hf >= 0;
+      }
+      if (!active) {  // idle wave row of a half tile: its share of the DMA, nothing else (the barriers above / below are taken by everybody)
+        if (do_copy) {
+#pragma unroll
+          for (int c = 0; c < 8; ++c) copy_piece(c, ckt, cur ^ 1, copy_half);
+        }
+        continue;
       }
       const char* cA = smem + cur * 2 * TILE2_BYTES;
       const char* cW = cA + TILE2_BYTES;
@@ -575,19 +607,19 @@ __global__ __launch_bounds__(NT2, 2) void gemm_nt256p_kernel(const alpro_gemm_de
             mma_chunk<T>(acc[i][j], fa[s & 1][i], fb[s & 1][j]);
             const int q = s * 8 + i * 2 + j;  // 0..31; see copy_slot
             if (do_copy) {
-              if (copy_slot(TUNE, q, 0) >= 0 && pos == 0) copy_piece(copy_slot(TUNE, q, 0), ckt, cur ^ 1);
-              if (copy_slot(TUNE, q, 1) >= 0 && pos == 1) copy_piece(copy_slot(TUNE, q, 1), ckt, cur ^ 1);
+              if (copy_slot(TUNE, q, 0) >= 0 && pos == 0) copy_piece(copy_slot(TUNE, q, 0), ckt, cur ^ 1, copy_half);
+              if (copy_slot(TUNE, q, 1) >= 0 && pos == 1) copy_piece(copy_slot(TUNE, q, 1), ckt, cur ^ 1, copy_half);
             }
           }
       }
     }
     block_sync();  // everyone is done with the last K-tile: its buffer takes the next tile's K-tile 1
     const int last = s0 ^ ((nk - 1) & 1);
-    if (more) stage_tile(1, last);
+    if (more) stage_tile(1, last, next_hf >= 0);
     s0 = last ^ 1;
     // epilogue; the two prefetched K-tiles must have landed before the first output store is issued (after that,
     // vmcnt also counts the stores and nobody waits on it until K-step 2 of the next tile)
-    {
+    if (active) {
       const int mb = tm0 + wr * 128, nb = tn0 + wc * 64;
       float bias[4];
       load_bias4(g, nb + (lane & 15) * 4, bias);
@@ -669,7 +701,9 @@ __global__ __launch_bounds__(NT2, 2) void gemm_nt256p_kernel(const alpro_gemm_de
     }
     if (!more) break;
     tile = next;
-    setup(tile);  // recomputed (not kept live): frees the 16 source-pointer registers across the epilogue
+    hf = next_hf;
+    ++it;
+    setup(tile, hf);  // recomputed (not kept live): frees the 16 source-pointer registers across the epilogue
   }
 }
 
@@ -700,18 +734,19 @@ int launch_gemm_inst(const alpro_gemm_desc_t& g, hipStream_t st) {
     int grid = big_tiles < 256 ? (big_tiles + 7) / 8 * 8 : 256;  // multiple of 8: the XCD-contiguous slot map must be a bijection
     if (const int cap = get_option(OPT_GEMM_GRID)) grid = cap < grid ? (cap + 7) / 8 * 8 : grid;  // tuning aid: cap the persistent grid
     const int tune = get_option(OPT_GEMM_TUNE);
+    const int tail = get_option(OPT_GEMM_TAIL);
     if constexpr (std::is_same<T, bf16_t>::value && ACT == ALPRO_ACT_NONE && MAP == ALPRO_MAP_IDENTITY) {
-      if (tune == 0) { hipLaunchKernelGGL((gemm_nt256p_kernel<T, ACT, MAP, 0>), dim3(grid), dim3(NT2), 4 * TILE2_BYTES + EPI_BYTES, st, g); return check_launch("alpro_gemm"); }
-      if (tune == 2) { hipLaunchKernelGGL((gemm_nt256p_kernel<T, ACT, MAP, 2>), dim3(grid), dim3(NT2), 4 * TILE2_BYTES + EPI_BYTES, st, g); return check_launch("alpro_gemm"); }
+      if (tune == 0) { hipLaunchKernelGGL((gemm_nt256p_kernel<T, ACT, MAP, 0>), dim3(grid), dim3(NT2), 4 * TILE2_BYTES + EPI_BYTES, st, g, tail); return check_launch("alpro_gemm"); }
+      if (tune == 2) { hipLaunchKernelGGL((gemm_nt256p_kernel<T, ACT, MAP, 2>), dim3(grid), dim3(NT2), 4 * TILE2_BYTES + EPI_BYTES, st, g, tail); return check_launch("alpro_gemm"); }
 #ifdef ALPRO_ABLATIONS
-      if (tune == 3) { hipLaunchKernelGGL((gemm_nt256p_kernel<T, ACT, MAP, 3>), dim3(grid), dim3(NT2), 4 * TILE2_BYTES + EPI_BYTES, st, g); return check_launch("alpro_gemm"); }
-      if (tune == 4) { hipLaunchKernelGGL((gemm_nt256p_kernel<T, ACT, MAP, 4>), dim3(grid), dim3(NT2), 4 * TILE2_BYTES + EPI_BYTES, st, g); return check_launch("alpro_gemm"); }
-      if (tune == 12) { hipLaunchKernelGGL((gemm_nt256p_kernel<T, ACT, MAP, 12>), dim3(grid), dim3(NT2), 4 * TILE2_BYTES + EPI_BYTES, st, g); return check_launch("alpro_gemm"); }
-      if (tune == 11) { hipLaunchKernelGGL((gemm_nt256p_kernel<T, ACT, MAP, 11>), dim3(grid), dim3(NT2), 4 * TILE2_BYTES + EPI_BYTES, st, g); return check_launch("alpro_gemm"); }
-      if (tune == 10) { hipLaunchKernelGGL((gemm_nt256p_kernel<T, ACT, MAP, 10>), dim3(grid), dim3(NT2), 4 * TILE2_BYTES + EPI_BYTES, st, g); return check_launch("alpro_gemm"); }
+      if (tune == 3) { hipLaunchKernelGGL((gemm_nt256p_kernel<T, ACT, MAP, 3>), dim3(grid), dim3(NT2), 4 * TILE2_BYTES + EPI_BYTES, st, g, tail); return check_launch("alpro_gemm"); }
+      if (tune == 4) { hipLaunchKernelGGL((gemm_nt256p_kernel<T, ACT, MAP, 4>), dim3(grid), dim3(NT2), 4 * TILE2_BYTES + EPI_BYTES, st, g, tail); return check_launch("alpro_gemm"); }
+      if (tune == 12) { hipLaunchKernelGGL((gemm_nt256p_kernel<T, ACT, MAP, 12>), dim3(grid), dim3(NT2), 4 * TILE2_BYTES + EPI_BYTES, st, g, tail); return check_launch("alpro_gemm"); }
+      if (tune == 11) { hipLaunchKernelGGL((gemm_nt256p_kernel<T, ACT, MAP, 11>), dim3(grid), dim3(NT2), 4 * TILE2_BYTES + EPI_BYTES, st, g, tail); return check_launch("alpro_gemm"); }
+      if (tune == 10) { hipLaunchKernelGGL((gemm_nt256p_kernel<T, ACT, MAP, 10>), dim3(grid), dim3(NT2), 4 * TILE2_BYTES + EPI_BYTES, st, g, tail); return check_launch("alpro_gemm"); }
 #endif
     }
-    hipLaunchKernelGGL((gemm_nt256p_kernel<T, ACT, MAP>), dim3(grid), dim3(NT2), 4 * TILE2_BYTES + EPI_BYTES, st, g);
+    hipLaunchKernelGGL((gemm_nt256p_kernel<T, ACT, MAP>), dim3(grid), dim3(NT2), 4 * TILE2_BYTES + EPI_BYTES, st, g, tail);
   } else {
     const int ntn = (g.N + BN - 1) / BN, ntm = (g.M + BM - 1) / BM;
     hipLaunchKernelGGL((gemm_nt_kernel<T, ACT, MAP>), dim3(ntn * ntm), dim3(NT), 4 * TILE_BYTES, st, g);

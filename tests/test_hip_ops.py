@@ -123,6 +123,38 @@ def test_gemm_row_maps(dt):
     close(out, ref, 2e-5, 2e-4, "patch_embed")
 
 
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+def test_gemm_tail_split_is_bitwise_neutral(dt):
+    """Round 3: the last, partly filled round of the persistent 256 x 256 GEMM is cut into half tiles (128 x 256, two workgroups per
+    tile) when at most half of the workgroups would be busy.  Every output element is still one fp32 accumulation in the same order,
+    so results with and without the split must be IDENTICAL -- 16-bit output (c16 epilogue), fp32 residual epilogue with a row scale,
+    GELU with the saved derivative, and a ragged M (partial half tile through the predicated epilogue)."""
+    hip = _hip()
+    for (M, N, K, kind) in [(50176, 768, 768, "c16"), (50208, 768, 3072, "res"), (50208, 3072, 768, "gelu"), (50000, 768, 768, "c16"), (32100, 768, 768, "res")]:
+        tiles = ((M + 255) // 256) * ((N + 255) // 256)
+        assert 0 < tiles % 256 <= 128, (M, N, tiles)          # these shapes do take the split path
+        a = rnd(M, K, seed=60, scale=0.5).to(dt).cuda()
+        w = rnd(N, K, seed=61, scale=0.05).to(dt).cuda()
+        bias = rnd(N, seed=62, scale=0.3).cuda()
+        outs = []
+        for tail in (0, 1):
+            with hip.option("gemm_tail", tail):
+                if kind == "c16":
+                    outs.append((hip.gemm(a, w, bias=bias),))
+                elif kind == "res":
+                    res = rnd(M, N, seed=63).cuda()
+                    rs = (torch.rand(M // 16 + 1, generator=torch.Generator().manual_seed(5)) + 0.5).cuda()
+                    outs.append((hip.gemm(a, w, bias=bias, out_dtype=torch.float32, residual=res, row_scale=rs, row_scale_group=16),))
+                else:
+                    saved = torch.empty(M, N, dtype=dt, device="cuda")
+                    outs.append((hip.gemm(a, w, bias=bias, act=hip.ACT_GELU_SAVE_GRAD, pre_act=saved), saved))
+        for x0, x1 in zip(*outs):
+            assert torch.equal(x0, x1), (M, N, K, kind)
+        ref = a[-300:].double().cpu() @ w.double().cpu().T + bias.double().cpu()
+        if kind == "c16":
+            close(outs[1][0][-300:], ref, *OUT_TOL[dt], "tail rows vs fp64")
+
+
 def test_gemm_rejects_bad_k():
     hip = _hip()
     with pytest.raises(RuntimeError, match="K="):
