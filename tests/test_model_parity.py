@@ -122,9 +122,10 @@ def test_pretrain_forward_vs_reference(bert_cfg, monkeypatch, mode, tol):
         e[k] = close(out[k], g[k], tol, what=k)
     close(out["mpm_labels"], g["mpm_labels"], tol * 1e-2, what="mpm_labels (soft)")
     e["mlm_scores"] = close(out["mlm_scores"][:, :, ::61], g["mlm_scores_cols"], tol, what="mlm_scores")
-    # fp16 measures 1.03e-3 on THIS fixture (3.6e-4 on retrieval_T2, 5.0e-4 on retrieval_T16, where the north star's 1e-3 is asserted):
-    # 11-bit operands through the 60 GEMM / attention layers of the ViT put the logits right at the bar, see DESIGN.md section 2
-    e["sim_v2t"] = close(vf @ tf.t() / m.temp, g["sim_v2t"], {"fp32": 1e-3, "fp16": 2e-3, "bf16": 1.6e-2}[mode], what="VTC logits")
+    # fp16: 4e-4 .. 1e-3 depending on the fixture and on which roundings the kernels make (1.03e-3 on THIS fixture before the round-3
+    # fusions, 4.1e-4 after; 5.3e-4 / 7.4e-4 on retrieval_T2 / T16): 11-bit operands through the ~60 GEMM / attention layers of the ViT put
+    # the logits just inside the north star's 1e-3, which is what is asserted -- see DESIGN.md section 2 for what that means at B = 64
+    e["sim_v2t"] = close(vf @ tf.t() / m.temp, g["sim_v2t"], {"fp32": 1e-3, "fp16": 1e-3, "bf16": 1.6e-2}[mode], what="VTC logits")
     e["video_feat"] = close(vf, g["video_feat"], tol, what="video_feat")
     e["text_embeds"] = close(te, g["text_embeds"], tol * (1 if mode == "fp32" else 2), what="text_embeds")
     e["video_embeds"] = close(ve[:, [0, 1, 57, 196]], g["video_embeds_rows"], tol * (1 if mode == "fp32" else 2), what="video_embeds")
