@@ -4,8 +4,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from alpro_amd import hip
 hip.load()
-dt = torch.bfloat16
+dt = torch.float16 if os.environ.get("ALPRO_BENCH_DTYPE", "bf16") == "fp16" else torch.bfloat16
 what = sys.argv[1] if len(sys.argv) > 1 else "all"
+print("dtype", dt)
 H = 12
 def timeit(fn, n=10):
     for _ in range(3): fn()
@@ -15,7 +16,7 @@ def timeit(fn, n=10):
     for _ in range(n): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n
-for name, batch, L, bias, dp in [("vit spatial", 512, 197, False, 0.0), ("bert text", 64, 40, True, 0.1), ("fusion pos", 64, 237, True, 0.1), ("fusion pos+neg", 192, 237, True, 0.1)]:
+for name, batch, L, bias, dp in [("vit spatial B=64", 512, 197, False, 0.0), ("vit spatial B=32", 256, 197, False, 0.0), ("bert text", 64, 40, True, 0.1), ("fusion pos", 64, 237, True, 0.1), ("fusion 4B", 256, 237, True, 0.1)]:
     qkv = torch.randn(batch * L, 3 * H * 64, device="cuda").to(dt)
     kb = (torch.zeros(batch, L, device="cuda") if bias else None)
     fl = 4.0 * batch * H * L * L * 64
