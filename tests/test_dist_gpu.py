@@ -55,7 +55,7 @@ def test_two_ranks_equal_one_rank_with_twice_the_batch(tmp_path, wire, tol):
         assert torch.equal(two[0]["grads"][n], two[1]["grads"][n]), n
 
 
-@pytest.mark.parametrize("wire,tol", [("fp32", 5e-5), ("bf16", 2e-2)])
+@pytest.mark.parametrize("wire,tol", [("fp32", 2e-4), ("bf16", 2e-2)])
 def test_one_rank_nccl_runs_every_collective(tmp_path, wire, tol):
     """RCCL had never executed this code.  A ONE-rank `nccl` (= RCCL) process group with ALPRO_FORCE_COLLECTIVES=1
     sends the training step through every collective branch the 8-GPU run takes -- broadcast_parameters, the differentiable feature
