@@ -23,7 +23,7 @@ from alpro_amd.modeling.weights import bump_param_epoch, register_flat_lp
 
 class FlatAdamW:
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-6, weight_decay=0.0, correct_bias=True, max_grad_norm=None,
-                 allreduce=True, bucket_elems=64 << 20, overlap_backward=True, wire_dtype=None):
+                 allreduce=True, bucket_elems=64 << 20, overlap_backward=None, wire_dtype=None):
         self.params = [p for p in params if p.requires_grad]
         self.param_groups = [dict(params=self.params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, correct_bias=correct_bias)]
         self.max_grad_norm = max_grad_norm
@@ -33,6 +33,9 @@ class FlatAdamW:
         # code reports them final (dist.grads_final): BERT + heads before the ViT backward starts, ViT blocks four at a time.
         # Needs ONE backward per step (gradient accumulation over several backward passes: pass overlap_backward=False).
         # wire_dtype=torch.bfloat16 halves the bytes on xGMI (cast -> all-reduce -> cast back; sums of <= 8 ranks in bf16).
+        if overlap_backward is None:   # default on; ALPRO_OVERLAP_BACKWARD=0 exchanges after backward instead (see DESIGN.md section 6 on CU contention)
+            import os
+            overlap_backward = os.environ.get("ALPRO_OVERLAP_BACKWARD", "1") != "0"
         self.overlap_backward = overlap_backward
         self.wire_dtype = wire_dtype
         self._inflight, self._reduced = [], []     # async handles (+ staging tensors) and element ranges already on the wire
