@@ -432,6 +432,43 @@ __global__ __launch_bounds__(256) void scatter_add_rows_kernel(const float* __re
   }
 }
 
+// ---- small per-block terms of the merged temporal projection W_e = W_fc W_p (vit.py:157-162), all ViT blocks in one launch -------------
+//   mode 0 (after an optimizer step):  b1[n] = sum_m W_fc[n, m] b_p[m]                      (the merged bias under the drop-path scale)
+//   mode 1 (backward, product rule):   g_fc[n, m] += db1[n] b_p[m];   g_bp[m] += sum_n W_fc[n, m] db1[n]
+// One workgroup per (job, 64-column block m0..m0+63) in mode 1 -- a single writer per output element and a fixed summation order, so the
+// gradients stay bit-reproducible --, one wave per row n in mode 0.  D = 768.
+template <int MODE>
+__global__ __launch_bounds__(256) void tproj_small_kernel(const alpro_tproj_job_t* __restrict__ jobs, int D) {
+  const alpro_tproj_job_t jb = jobs[blockIdx.y];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (MODE == 0) {
+    const int n = blockIdx.x * 4 + w;
+    if (n >= D) return;
+    const float* row = jb.wfc + (int64_t)n * D;
+    float acc = 0.f;
+    for (int m = lane * 4; m < D; m += 256) {
+      const float4 a = *(const float4*)(row + m), b = *(const float4*)(jb.bp + m);
+      acc += (a.x * b.x + a.y * b.y) + (a.z * b.z + a.w * b.w);
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) jb.b1[n] = acc;
+  } else {
+    __shared__ float red[4][64];
+    const int m = blockIdx.x * 64 + lane;
+    const float bpm = jb.bp[m];
+    float acc = 0.f;
+    for (int n = w; n < D; n += 4) {
+      const float d = jb.db1[n];
+      const int64_t i = (int64_t)n * D + m;
+      jb.g_fc[i] += d * bpm;
+      acc = fmaf(jb.wfc[i], d, acc);
+    }
+    red[w][lane] = acc;
+    __syncthreads();
+    if (w == 0) jb.g_bp[m] += (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+  }
+}
+
 inline int grid_for(int64_t work_items, int per_block, int cap) {
   int64_t g = (work_items + per_block - 1) / per_block;
   if (g < 1) g = 1;
@@ -528,6 +565,14 @@ extern "C" int alpro_gather_cast(const float* src, int64_t ld, void* out, int dt
     ALPRO_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((gather_cast_kernel<T, 4>), dim3(grid_for(rows, 8, 256 * 32)), dim3(256), 0, (hipStream_t)stream, src, ld, (T*)out, (int64_t)rows, map_mode, map_p0, map_p1, row_scale, row_scale_group, cls_scale, drop_p, drop_seed, colsum, colsum_pre));
   }
   return check_launch("alpro_gather_cast");
+}
+
+extern "C" int alpro_tproj_small(const alpro_tproj_job_t* jobs_device, int njobs, int D, int mode, void* stream) {
+  ALPRO_CHECK(jobs_device && njobs > 0 && (mode == 0 || mode == 1), "alpro_tproj_small: bad args");
+  ALPRO_CHECK(D == LN_D, "alpro_tproj_small: D=%d unsupported", D);
+  if (mode == 0) hipLaunchKernelGGL(tproj_small_kernel<0>, dim3(D / 4, njobs), dim3(256), 0, (hipStream_t)stream, jobs_device, D);
+  else hipLaunchKernelGGL(tproj_small_kernel<1>, dim3(D / 64, njobs), dim3(256), 0, (hipStream_t)stream, jobs_device, D);
+  return check_launch("alpro_tproj_small");
 }
 
 extern "C" int alpro_gelu_bwd(const void* dh, const void* u, void* du, int dtype, int64_t n, void* stream) {

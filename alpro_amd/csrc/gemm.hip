@@ -291,16 +291,16 @@ __device__ __forceinline__ void load_bias4(const alpro_gemm_desc_t& g, int n, fl
 }
 
 template <typename T, int ACT, int MAP>
-__global__ __launch_bounds__(NT, 2) void gemm_nt_kernel(const alpro_gemm_desc_t g) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
+__device__ __forceinline__ void gemm_nt_tile(const alpro_gemm_desc_t& g, const int bid, char* smem) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1;
   const int ntn = (g.N + BN - 1) / BN, ntm = (g.M + BM - 1) / BM;
   const int nblk = ntn * ntm;
+  if (bid >= nblk) return;  // (batched launches size the grid for the largest job)
   // XCD-aware, bijective remap of blockIdx -> logical tile
   int tile;
   {
-    const int bid = blockIdx.x, xcd = bid & 7, idx = bid >> 3;
+    const int xcd = bid & 7, idx = bid >> 3;
     const int q = nblk >> 3, r = nblk & 7;
     tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
@@ -419,6 +419,22 @@ __global__ __launch_bounds__(NT, 2) void gemm_nt_kernel(const alpro_gemm_desc_t 
 #pragma unroll 1
     for (int c = 0; c < 4; ++c) epi_rows16<T, ACT, MAP, false>(g, stage + c * 16 * 64, mb + c * 16, nb, lane, bias);
   }
+}
+
+template <typename T, int ACT, int MAP>
+__global__ __launch_bounds__(NT, 2) void gemm_nt_kernel(const alpro_gemm_desc_t g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  gemm_nt_tile<T, ACT, MAP>(g, blockIdx.x, smem);
+}
+
+// Many small independent GEMMs in ONE launch (round 3): blockIdx.y = job, descriptors in device memory.  The merged temporal projection
+// needs, per ViT block and optimizer step, W_e = W_fc W_p (a 768^3 product on 36 workgroups, 64 us) and, in backward, two more 768^3
+// products for the product rule -- 12 blocks x 3 launches that each fill a seventh of the chip; batched they run side by side.
+template <typename T, int ACT, int MAP>
+__global__ __launch_bounds__(NT, 2) void gemm_nt_batch_kernel(const alpro_gemm_desc_t* __restrict__ descs) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const alpro_gemm_desc_t g = descs[blockIdx.y];
+  gemm_nt_tile<T, ACT, MAP>(g, blockIdx.x, smem);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -779,7 +795,41 @@ int launch_gemm(const alpro_gemm_desc_t& g, hipStream_t st) {
 }  // namespace
 }  // namespace alpro
 
-extern "C" int alpro_gemm(const alpro_gemm_desc_t* d, void* stream) {
+namespace alpro {
+namespace {
+template <typename T>
+int launch_gemm_batch(const alpro_gemm_desc_t* descs_dev, int njobs, int max_tiles, int with_residual_map, hipStream_t st) {
+  (void)with_residual_map;
+  static DeviceOnce attr_once;
+  attr_once.run([&] {
+    (void)hipFuncSetAttribute((const void*)gemm_nt_batch_kernel<T, ALPRO_ACT_NONE, ALPRO_MAP_IDENTITY>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE_BYTES);
+  });
+  hipLaunchKernelGGL((gemm_nt_batch_kernel<T, ALPRO_ACT_NONE, ALPRO_MAP_IDENTITY>), dim3(max_tiles, njobs), dim3(NT), 4 * TILE_BYTES, st, descs_dev);
+  return check_launch("alpro_gemm_batch");
+}
+}  // namespace
+}  // namespace alpro
+
+static int check_gemm_desc(const alpro_gemm_desc_t* d);
+
+extern "C" int alpro_gemm_batch(const alpro_gemm_desc_t* descs_host, const alpro_gemm_desc_t* descs_device, int njobs, void* stream) {
+  using namespace alpro;
+  ALPRO_CHECK(descs_host && descs_device && njobs > 0, "alpro_gemm_batch: bad args");
+  int max_tiles = 0;
+  for (int i = 0; i < njobs; ++i) {
+    const alpro_gemm_desc_t* d = descs_host + i;
+    if (const int rc = check_gemm_desc(d)) return rc;
+    ALPRO_CHECK(d->dtype == descs_host[0].dtype, "alpro_gemm_batch: all jobs must share the operand dtype");
+    ALPRO_CHECK(d->act == ALPRO_ACT_NONE && d->map_mode == ALPRO_MAP_IDENTITY && !d->drop_seed && !d->bias2 && !d->C2,
+                "alpro_gemm_batch: plain epilogues only (bias, alpha, row scale, fp32 residual)");
+    const int t = ((d->N + BN - 1) / BN) * ((d->M + BM - 1) / BM);
+    max_tiles = t > max_tiles ? t : max_tiles;
+  }
+  ALPRO_DISPATCH_DTYPE(descs_host[0].dtype, T, return launch_gemm_batch<T>(descs_device, njobs, max_tiles, 0, (hipStream_t)stream));
+  return ALPRO_OK;
+}
+
+static int check_gemm_desc(const alpro_gemm_desc_t* d) {
   using namespace alpro;
   ALPRO_CHECK(d && d->A && d->W && d->C, "alpro_gemm: null operand");
   ALPRO_CHECK(d->M > 0 && d->N > 0 && d->K > 0, "alpro_gemm: bad shape M=%d N=%d K=%d", d->M, d->N, d->K);
@@ -797,6 +847,12 @@ extern "C" int alpro_gemm(const alpro_gemm_desc_t* d, void* stream) {
   ALPRO_CHECK(!d->C2 || (d->N % 4 == 0 && d->ldc2 % 4 == 0 && d->ldc % 4 == 0), "alpro_gemm: C2 needs N, ldc, ldc2 multiples of 4");
   ALPRO_CHECK(d->map_mode != ALPRO_MAP_FRAME_TOKENS || d->side, "alpro_gemm: FRAME_TOKENS needs a side buffer");
   ALPRO_CHECK(!d->row_scale || d->row_scale_group > 0, "alpro_gemm: row_scale_group must be > 0");
+  return ALPRO_OK;
+}
+
+extern "C" int alpro_gemm(const alpro_gemm_desc_t* d, void* stream) {
+  using namespace alpro;
+  if (const int rc = check_gemm_desc(d)) return rc;
   ALPRO_DISPATCH_DTYPE(d->dtype, T, return launch_gemm<T>(*d, (hipStream_t)stream));
   return ALPRO_OK;
 }

@@ -23,7 +23,7 @@ _CODE = {v: k for k, v in _TORCH_DTYPE.items()}
 EXPORTS = ["alpro_hip_last_error", "alpro_hip_abi_version", "alpro_hip_set_option", "alpro_gemm", "alpro_layernorm_fwd",
            "alpro_attn_temporal_fwd", "alpro_attn_fwd", "alpro_patchify", "alpro_cls_mean_residual",
            "alpro_vit_final_pool", "alpro_bert_embed_fwd", "alpro_cast_from_f32", "alpro_attn_bwd", "alpro_attn_temporal_bwd",
-           "alpro_layernorm_bwd", "alpro_transpose", "alpro_transpose_batch", "alpro_gelu_bwd", "alpro_cls_mean_bwd", "alpro_scatter_add_rows", "alpro_gather_cast", "alpro_sumsq", "alpro_adamw_step", "alpro_gemm_tn_acc", "alpro_gemm_tn_acc_ws", "alpro_gemm_tn_workspace_bytes", "alpro_colsum_acc", "alpro_softmax_xent", "alpro_vtc_loss_fwd", "alpro_vtc_loss_bwd", "alpro_prepare_clips", "alpro_loss_scale_update", "alpro_add_layernorm_fwd", "alpro_layernorm_bwd_emit"]
+           "alpro_layernorm_bwd", "alpro_transpose", "alpro_transpose_batch", "alpro_gelu_bwd", "alpro_cls_mean_bwd", "alpro_scatter_add_rows", "alpro_gather_cast", "alpro_sumsq", "alpro_adamw_step", "alpro_gemm_tn_acc", "alpro_gemm_tn_acc_ws", "alpro_gemm_tn_workspace_bytes", "alpro_colsum_acc", "alpro_softmax_xent", "alpro_vtc_loss_fwd", "alpro_vtc_loss_bwd", "alpro_prepare_clips", "alpro_loss_scale_update", "alpro_add_layernorm_fwd", "alpro_layernorm_bwd_emit", "alpro_gemm_batch", "alpro_tproj_small"]
 
 
 class GemmDesc(ctypes.Structure):
@@ -40,12 +40,17 @@ class GemmDesc(ctypes.Structure):
                 ("drop_p", ctypes.c_float), ("drop_seed", ctypes.c_uint32), ("bias2", ctypes.c_void_p)]
 
 
+class TprojJob(ctypes.Structure):
+    _fields_ = [("wfc", ctypes.c_void_p), ("bp", ctypes.c_void_p), ("b1", ctypes.c_void_p), ("db1", ctypes.c_void_p), ("g_fc", ctypes.c_void_p),
+                ("g_bp", ctypes.c_void_p)]   # 48 bytes
+
+
 class TransposeJob(ctypes.Structure):
     _fields_ = [("in_", ctypes.c_void_p), ("out", ctypes.c_void_p), ("ld_in", ctypes.c_int64), ("ld_out", ctypes.c_int64),
                 ("R", ctypes.c_int32), ("C", ctypes.c_int32), ("Rpad", ctypes.c_int32), ("tile0", ctypes.c_int32)]   # 48 bytes
 
 
-ABI_VERSION = 13
+ABI_VERSION = 14
 _lib = None
 
 
@@ -63,6 +68,8 @@ def load():
         getattr(lib, name)  # AttributeError if the ABI is incomplete
     vp, i32, i64, f32 = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float
     lib.alpro_gemm.argtypes = [ctypes.POINTER(GemmDesc), vp]
+    lib.alpro_gemm_batch.argtypes = [ctypes.POINTER(GemmDesc), vp, ctypes.c_int, vp]
+    lib.alpro_tproj_small.argtypes = [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp]
     lib.alpro_layernorm_fwd.argtypes = [vp, i64, vp, vp, f32, vp, i32, i64, vp, vp, vp, i32, i32, i32, i32, i32, vp]
     lib.alpro_add_layernorm_fwd.argtypes = [vp, vp, i32, vp, i32, vp, vp, vp, f32, vp, vp, i64, i32, i32, i32, vp]
     lib.alpro_attn_temporal_fwd.argtypes = [vp, vp, i32, i64, i32, i32, f32, vp, vp]
@@ -162,7 +169,8 @@ def torch_dtype(code):
 
 # ------------------------------------------------------------------------------------------------
 def gemm(a, w, out=None, bias=None, act=ACT_NONE, out_dtype=None, alpha=1.0, row_scale=None, row_scale_group=1,
-         residual=None, map_mode=MAP_IDENTITY, map_p0=0, map_p1=0, side=None, out_rows=None, pre_act=None, drop_p=0.0, drop_seed=0, bias2=None):
+         residual=None, map_mode=MAP_IDENTITY, map_p0=0, map_p1=0, side=None, out_rows=None, pre_act=None, drop_p=0.0, drop_seed=0, bias2=None,
+         _desc_only=False):
     """out[map(m)] = residual[map(m)] + row_scale * act(alpha * a @ w.T + bias) [+ bias2]   (see alpro_gemm).
     act=ACT_GELU_BWD: out = (alpha * a @ w.T + bias) * gelu'(pre_act) (pre_act read only).
     act=ACT_GELU_SAVE_GRAD: out = gelu(..), pre_act (required) RECEIVES gelu'(..); act=ACT_MUL_SAVED: out = (..) * pre_act (read only)."""
@@ -193,8 +201,51 @@ def gemm(a, w, out=None, bias=None, act=ACT_NONE, out_dtype=None, alpha=1.0, row
     d.ldc2 = pre_act.shape[-1] if pre_act is not None else 0
     d.drop_p, d.drop_seed = drop_p, drop_seed
     d.bias2 = _dev(bias2, torch.float32).data_ptr() if bias2 is not None else None
+    if _desc_only:
+        return d, out
     _check(lib.alpro_gemm(ctypes.byref(d), _stream()), "alpro_gemm")
     return out
+
+
+class GemmBatch:
+    """A fixed list of independent plain GEMMs (alpro_gemm_batch): descriptors are built once from the tensors given to add() -- whose storage
+    must stay where it is (parameters, flat gradient views, persistent operand buffers) -- and launched together as often as wanted."""
+
+    def __init__(self):
+        self._descs, self._keep = [], []
+        self._host = self._dev = None
+
+    def add(self, a, w, out, bias=None, alpha=1.0, residual=None, out_dtype=None):
+        d, _ = gemm(a, w, out=out, bias=bias, alpha=alpha, residual=residual, out_dtype=out_dtype or out.dtype, _desc_only=True)
+        self._descs.append(d)
+        self._keep.append((a, w, out, bias, residual))
+        self._host = None
+
+    def signature(self):
+        return tuple((d.A, d.W, d.C, d.residual) for d in self._descs)
+
+    def launch(self):
+        if self._host is None:
+            self._host = (GemmDesc * len(self._descs))(*self._descs)
+            self._dev = torch.frombuffer(bytearray(bytes(self._host)), dtype=torch.uint8).to(self._keep[0][0].device)
+        _check(load().alpro_gemm_batch(self._host, _ptr(self._dev), len(self._descs), _stream()), "alpro_gemm_batch")
+
+
+def tproj_jobs(jobs, device):
+    """[dict(wfc=, bp=, b1=, db1=, g_fc=, g_bp=)] (fp32 device tensors or None) -> device job table for tproj_small."""
+    arr = (TprojJob * len(jobs))()
+    for j, d in zip(arr, jobs):
+        for k in ("wfc", "bp", "b1", "db1", "g_fc", "g_bp"):
+            t = d.get(k)
+            if t is not None:
+                _dev(t, torch.float32)
+                assert t.is_contiguous()
+            setattr(j, k, t.data_ptr() if t is not None else None)
+    return torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(device), len(jobs)
+
+
+def tproj_small(table, njobs, D, mode):
+    _check(load().alpro_tproj_small(_ptr(table), njobs, D, mode, _stream()), "alpro_tproj_small")
 
 
 def layernorm(x, gamma, beta, eps, out_dtype, rows=None, out32=False, stats=False, map_mode=MAP_IDENTITY, map_p0=0, map_p1=0):

@@ -117,7 +117,18 @@ class Block(nn.Module):
     fuse_ln_bwd_emit = os.environ.get("ALPRO_FUSE_LN_BWD", "1") != "0"   # LayerNorm backward also emits the next GEMMs' operand rows (alpro_layernorm_bwd_emit) instead of a gather_cast pass; 0 = round-2 form (A/B)
     fuse_residual_ln = os.environ.get("ALPRO_FUSE_RESIDUAL_LN", "1") != "0"   # residual adds of the two attention halves inside the following LayerNorm (alpro_add_layernorm_fwd); 0 = round-2 form (A/B measurements)
 
+    batch_merged_tproj = os.environ.get("ALPRO_BATCH_TPROJ", "1") != "0"   # the 12 blocks' merged-projection upkeep in batched launches (_MergedTProjBank); 0 = per block (A/B)
+
+    def _bank(self):
+        bank = getattr(self, "_bank_obj", None) if (self.batch_merged_tproj and self.merge_temporal_proj) else None
+        if bank is not None and (len(bank.blocks) <= self._bank_idx or bank.blocks[self._bank_idx] is not self):   # a deep copy of the model still points at the original's bank
+            return None
+        return bank
+
     def _merged_tproj(self, dt):
+        bank = self._bank()
+        if bank is not None:
+            return bank.get(self._bank_idx, dt)
         wp, bp, wf = self.temporal_attn.proj.weight, self.temporal_attn.proj.bias, self.temporal_fc.weight
         ver = (param_version(wp), param_version(bp), param_version(wf), dt)
         hit = self._ops._store.get("t_merged")
@@ -315,6 +326,8 @@ class Block(nn.Module):
         else:
             hip.gemm(hip.transpose(G, colsum=db1), hip.transpose(sv["a_t"]), out=dWe, out_dtype=torch.float32)
         da = tr.dgrad(G, mg["wT"])                                              # d(a) = G We
+        if sv.get("defer_product_rule"):   # the bank applies the product rule for a whole group of blocks at once (_MergedTProjBank.product_rule)
+            return da
         # product rule back onto the two real parameters (768^3 each).  Exact mode: fp32 MFMA.  16-bit modes: 16-bit operands with fp32
         # accumulation into the fp32 gradient, like every other weight gradient on this path (dWe itself came from 16-bit operands) --
         # the two fp32 768^3 GEMMs were 57 us each on 36 workgroups, 2 x 12 of them per step.
@@ -422,6 +435,123 @@ def sample_drop_paths(blocks, B, T, N, device):
             off += n
 
 
+class _MergedTProjBank:
+    """Batched upkeep of the merged temporal projections of ALL blocks of one encoder (round 3).
+
+    Per block and optimizer step the merged form needs W_e = W_fc W_p (fp32 768^3 product), its 16-bit copy, its transpose and
+    W_fc b_p -- five small launches of which the product alone takes 64 us on 36 workgroups -- and the backward needs the product rule
+    back onto the two real weights (two more 768^3 products, a cast, a transpose, a rank-1 update and a gemv): ~230 launches and 2.8 ms
+    per training step for 12 blocks.  Here the same arithmetic runs as five launches for the forward refresh (alpro_transpose_batch,
+    alpro_gemm_batch, one cast, alpro_transpose_batch, alpro_tproj_small) and five per group of blocks for the product rule, on buffers and
+    job tables that live across steps.  Blocks outside a VisionTransformer (tests build single Blocks) keep the per-block code."""
+
+    def __init__(self, blocks):
+        self.blocks = list(blocks)
+        self.state = None          # forward side: dict(key, dt, bufs, tables)
+        self.bwd = None            # backward side: persistent ws / 16-bit copies
+        self._bwd_tables = {}
+
+    def __reduce__(self):
+        """copy.deepcopy / pickle of a model must not drag the job tables (ctypes pointers into THIS model's storage) along: the copy starts
+        with an empty bank and VisionTransformer._attach_bank() rebuilds it over the copied blocks at the next forward."""
+        return (_MergedTProjBank, ([],))
+
+    def _params(self):
+        return [p for b in self.blocks for p in (b.temporal_fc.weight, b.temporal_attn.proj.weight, b.temporal_attn.proj.bias)]
+
+    def get(self, idx, dt):
+        """-> dict(w = W_e (D, D) in dt, wT = W_e^T in dt, b1 = W_fc b_p fp32) of block idx, refreshing ALL blocks if any parameter changed."""
+        from alpro_amd.modeling import weights
+        ps = self._params()
+        fast = (weights.param_epoch(), weights._EXT_EPOCH[0], dt, tuple(p._version for p in ps))
+        st = self.state
+        if st is None or st["fast"] != fast:
+            key = (dt,) + tuple(param_version(p) for p in ps)   # frozen parameters (the prompter) keep their key across optimizer steps
+            if st is None or st["key"] != key:
+                st = self._refresh(dt, key)
+            st["fast"] = fast
+        return dict(w=st["we_dt"][idx], wT=st["weT_dt"][idx], b1=st["b1"][idx])
+
+    def _refresh(self, dt, key):
+        nb = len(self.blocks)
+        wf = [b.temporal_fc.weight.detach() for b in self.blocks]
+        wp = [b.temporal_attn.proj.weight.detach() for b in self.blocks]
+        bp = [b.temporal_attn.proj.bias.detach() for b in self.blocks]
+        D, dev = wf[0].shape[0], wf[0].device
+        st = self.state
+        if st is None or st["dt"] != dt or st["we32"].device != dev:
+            we32 = torch.empty((nb, D, D), dtype=torch.float32, device=dev)
+            st = dict(dt=dt, we32=we32, wpT32=torch.empty_like(we32), b1=torch.empty((nb, D), dtype=torch.float32, device=dev),
+                      we_dt=we32 if dt == torch.float32 else torch.empty((nb, D, D), dtype=dt, device=dev),
+                      weT_dt=torch.empty((nb, D, D), dtype=dt, device=dev), sig=None)
+        sig = tuple(t.data_ptr() for t in wf + wp + bp)
+        if st["sig"] != sig:   # the parameters moved (FlatAdamW adopted them into its flat buffer): rebuild the job tables
+            st["t_wp"] = hip.transpose_jobs([(wp[i], st["wpT32"][i]) for i in range(nb)])
+            gb = hip.GemmBatch()
+            for i in range(nb):
+                gb.add(wf[i], st["wpT32"][i], out=st["we32"][i], out_dtype=torch.float32)   # W_e = W_fc W_p
+            st["gemm"] = gb
+            st["t_we"] = hip.transpose_jobs([(st["we32"][i], st["weT_dt"][i]) for i in range(nb)])
+            st["t_b1"] = hip.tproj_jobs([dict(wfc=wf[i], bp=bp[i], b1=st["b1"][i]) for i in range(nb)], dev)
+            st["sig"] = sig
+        with torch.no_grad():
+            hip.transpose_batch(*st["t_wp"], torch.float32)
+            st["gemm"].launch()
+            if dt != torch.float32:
+                hip.cast(st["we32"].view(-1), dt, out=st["we_dt"].view(-1))
+            hip.transpose_batch(*st["t_we"], dt)
+            hip.tproj_small(*st["t_b1"], D, 0)
+        st["key"] = key
+        self.state = st
+        return st
+
+    # ---- backward ------------------------------------------------------------------------------------------------
+    def workspace(self, dt, device):
+        """(nb, D*D + D) fp32, zeroed: row i receives dW_e (D, D) and db1 (D) of block i from its weight-gradient GEMM."""
+        nb, D = len(self.blocks), self.blocks[0].temporal_fc.weight.shape[0]
+        b = self.bwd
+        if b is None or b["ws"].device != device or b["dt"] != dt:
+            ws = torch.empty((nb, D * D + D), dtype=torch.float32, device=device)
+            b = self.bwd = dict(dt=dt, ws=ws, ws_dt=torch.empty((nb, D * D + D), dtype=dt, device=device) if dt != torch.float32 else None,
+                                dweT=torch.empty((nb, D, D), dtype=dt, device=device))
+            self._bwd_tables = {}
+        b["ws"].zero_()
+        return b["ws"]
+
+    def product_rule(self, lo, hi, dt):
+        """Blocks lo..hi-1: dW_fc += dW_e W_p^T + db1 b_p^T, dW_p += W_fc^T dW_e, db_p += W_fc^T db1 -- 16-bit operands with fp32 accumulation
+        into the fp32 gradients, like every other weight gradient on this path.  Five launches for the whole group."""
+        assert dt != torch.float32 and self.bwd is not None
+        b, blocks = self.bwd, self.blocks[lo:hi]
+        D = blocks[0].temporal_fc.weight.shape[0]
+        ops = []
+        for i, blk in zip(range(lo, hi), blocks):
+            ta, fc = blk.temporal_attn, blk.temporal_fc
+            g_fc, g_p = tr.grad_buffer(fc.weight, zero=True)[0], tr.grad_buffer(ta.proj.weight, zero=True)[0]
+            g_bp = tr.bias_grad(ta.proj.bias)
+            ops.append(dict(i=i, wp_dt=blk._w("t_proj", ta.proj, dt), wfT_dt=blk._wt("t_fc", fc, dt), g_fc=g_fc, g_p=g_p, g_bp=g_bp,
+                            wf=fc.weight.detach(), bp=ta.proj.bias.detach()))
+        sig = tuple((o["wp_dt"].data_ptr(), o["wfT_dt"].data_ptr(), o["g_fc"].data_ptr(), o["g_p"].data_ptr(), o["g_bp"].data_ptr(), o["wf"].data_ptr())
+                    for o in ops)
+        tb = self._bwd_tables.get((lo, hi))
+        if tb is None or tb["sig"] != sig:
+            ga, gbb = hip.GemmBatch(), hip.GemmBatch()
+            for o in ops:
+                dwe_dt = b["ws_dt"][o["i"], :D * D].view(D, D)
+                ga.add(dwe_dt, o["wp_dt"], out=o["g_fc"], out_dtype=torch.float32, residual=o["g_fc"])                        # += dW_e W_p^T
+                gbb.add(o["wfT_dt"][:, :D], b["dweT"][o["i"]], out=o["g_p"], out_dtype=torch.float32, residual=o["g_p"])     # += W_fc^T dW_e
+            tb = dict(sig=sig, ga=ga, gb=gbb, keep=ops,
+                      t_dwe=hip.transpose_jobs([(b["ws"][o["i"], :D * D].view(D, D), b["dweT"][o["i"]]) for o in ops]),
+                      t_small=hip.tproj_jobs([dict(wfc=o["wf"], bp=o["bp"], db1=b["ws"][o["i"], D * D:], g_fc=o["g_fc"], g_bp=o["g_bp"]) for o in ops],
+                                             b["ws"].device))
+            self._bwd_tables[(lo, hi)] = tb
+        hip.cast(b["ws"][lo:hi].reshape(-1), dt, out=b["ws_dt"][lo:hi].reshape(-1))
+        hip.transpose_batch(*tb["t_dwe"], dt)
+        tb["ga"].launch()
+        tb["gb"].launch()
+        hip.tproj_small(*tb["t_small"], D, 1)
+
+
 class PatchEmbed(nn.Module):
     """Image to patch embedding: the stride-16 conv (vit.py:230) evaluated as im2col rows x weight GEMM."""
 
@@ -465,6 +595,14 @@ class VisionTransformer(nn.Module):
                 nn.init.constant_(blk.temporal_fc.weight, 0)
                 nn.init.constant_(blk.temporal_fc.bias, 0)
         self._ops = OperandCache()
+        self._attach_bank()
+
+    def _attach_bank(self):
+        """(Re)build the merged-projection bank over THIS module's blocks (also after copy.deepcopy, whose blocks come back with an empty bank
+        and fall back to the per-block path until then)."""
+        self._tproj_bank = _MergedTProjBank(self.blocks)    # (plain attribute: not a module, nothing for state_dict)
+        for i, blk in enumerate(self.blocks):
+            blk._bank_obj, blk._bank_idx = self._tproj_bank, i   # (a plain reference: copies / pickles reduce the bank to an empty one)
 
     def _init_weights(self, m):
         if isinstance(m, nn.Linear):
@@ -481,6 +619,8 @@ class VisionTransformer(nn.Module):
 
     def _embed(self, x):
         """(B, C, T, H, W) -> (B, 1 + N*T, D) fp32 tokens (vit.py:321-361)."""
+        if not self._tproj_bank.blocks or self._tproj_bank.blocks[0] is not self.blocks[0]:
+            self._attach_bank()
         dt = rt.compute_dtype()
         B, C, T, Hh, Ww = x.shape
         D = self.embed_dim
@@ -670,7 +810,10 @@ class _VisualRun:
         else:
             hip.layernorm_bwd(dy.view(-1, D), self.tok, m.norm.weight, VIT_EPS, dtok, g, b_, accumulate=False)
         del dy
-        ws = torch.zeros((len(m.blocks), D * D + D), dtype=torch.float32, device=dout.device)
+        bank = m.blocks[0]._bank()
+        dt_run = self.saved[-1]["dt"]
+        banked = bank is not None and dt_run != torch.float32 and all(sv["merged"] for sv in self.saved)
+        ws = bank.workspace(dt_run, dout.device) if banked else torch.zeros((len(m.blocks), D * D + D), dtype=torch.float32, device=dout.device)
         # Data parallel: in the pretraining / retrieval models this node is the LAST one autograd runs (created first, its input needs
         # no gradient), so every gradient outside the visual encoder is final now and can be exchanged while the ViT backward (half of
         # the backward pass) runs; the blocks' own gradients follow four blocks at a time (alpro_amd.dist.grads_final -> FlatAdamW).
@@ -681,11 +824,18 @@ class _VisualRun:
         if overlap:
             dist.grads_final(all_but=list(self.enc.parameters()))
         nb = len(m.blocks)
+        group_hi = nb
         for i, (blk, sv) in enumerate(zip(reversed(m.blocks), reversed(self.saved))):
-            sv["ws"] = ws[i]
+            sv["ws"] = ws[nb - 1 - i]
+            sv["defer_product_rule"] = banked
             dtok, dz = blk.backward(sv, dtok, dz=dz, emit_for=self.saved[nb - 2 - i] if i + 1 < nb else None)
-            if overlap and (i + 1) % 4 == 0 and i + 1 < nb:
-                dist.grads_final(params=[p for b in m.blocks[nb - 1 - i:nb - 1 - i + 4] for p in b.parameters()] + (list(m.norm.parameters()) if i == 3 else []))
+            if (i + 1) % 4 == 0 or i + 1 == nb:   # a group of blocks is through: their merged-projection product rule in batched launches ...
+                lo = nb - 1 - i
+                if banked:
+                    bank.product_rule(lo, group_hi, dt_run)
+                if overlap and i + 1 < nb:       # ... and then their gradients are final (the last group goes at synchronize())
+                    dist.grads_final(params=[p for b in m.blocks[lo:group_hi] for p in b.parameters()] + (list(m.norm.parameters()) if group_hi == nb else []))
+                group_hi = lo
             sv.clear()
         m._embed_backward(self.rows, dtok, B, T, N, self.Wg)
         self.saved = self.rows = self.tok = None

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define ALPRO_HIP_ABI_VERSION 13
+#define ALPRO_HIP_ABI_VERSION 14
 
 enum { ALPRO_OK = 0, ALPRO_ERR_INVALID = 1, ALPRO_ERR_LAUNCH = 2 };
 enum { ALPRO_F32 = 0, ALPRO_BF16 = 1, ALPRO_F16 = 2 };
@@ -97,6 +97,26 @@ typedef struct {
 } alpro_gemm_desc_t;
 
 int alpro_gemm(const alpro_gemm_desc_t* d, void* stream);
+
+/* njobs independent GEMMs in ONE launch (round 3): the same descriptor, once in host memory (validated there) and once as a device-resident
+ * array the kernel reads (blockIdx.y = job).  All jobs share the operand dtype and use plain epilogues (alpha, bias, row scale, fp32 residual,
+ * identity map); 128 x 128 tiles.  Used for the per-block 768^3 products of the merged temporal projection (W_e = W_fc W_p after every
+ * optimizer step; dW_fc += dW_e W_p^T and dW_p += W_fc^T dW_e in backward; vit.py:157-162 under autograd): 12 ViT blocks x 3 products that
+ * each fill a seventh of the chip when launched one by one. */
+int alpro_gemm_batch(const alpro_gemm_desc_t* descs_host, const alpro_gemm_desc_t* descs_device, int njobs, void* stream);
+
+/* The small per-block terms of the merged temporal projection, all blocks in one launch (jobs in DEVICE memory, D == 768):
+ *   mode 0: b1[n] = sum_m wfc[n, m] bp[m]                                  (W_fc b_p, the merged bias; after an optimizer step)
+ *   mode 1: g_fc[n, m] += db1[n] bp[m];  g_bp[m] += sum_n wfc[n, m] db1[n]   (product rule of the bias path; single writer, fixed order) */
+typedef struct alpro_tproj_job {
+  const float* wfc; /* (D, D) temporal_fc.weight */
+  const float* bp;  /* (D) temporal_attn.proj.bias */
+  float* b1;        /* mode 0 output (D) */
+  const float* db1; /* mode 1: gradient w.r.t. b1 (D) */
+  float* g_fc;      /* mode 1: temporal_fc.weight.grad (D, D), accumulated */
+  float* g_bp;      /* mode 1: temporal_attn.proj.bias.grad (D), accumulated */
+} alpro_tproj_job_t; /* 48 bytes */
+int alpro_tproj_small(const alpro_tproj_job_t* jobs_device, int njobs, int D, int mode, void* stream);
 
 /* y[m] = LayerNorm(x[map(m)]) * gamma + beta over D == 768 fp32 inputs; writes `y` in y_dtype and,
  * if non-NULL, an fp32 copy y32 plus mean/rstd (rows) for the backward pass.

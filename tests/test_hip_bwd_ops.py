@@ -530,6 +530,104 @@ def test_layernorm_bwd_emit_equals_layernorm_bwd_then_gather_cast(dt):
     assert 0.05 < float((outs[1][1] == 0).float().mean()) < 0.15
 
 
+@pytest.mark.parametrize("mode", ["fp32", "bf16", "fp16"])
+def test_merged_projection_bank_equals_per_block_upkeep(mode):
+    """Round 3: _MergedTProjBank keeps the merged temporal projections of all 12 blocks in batched launches (alpro_transpose_batch,
+    alpro_gemm_batch, alpro_tproj_small; product rule per group of four blocks).
+    (1) refresh: W_e and W_e^T are BIT-identical to the per-block code's, b1 = W_fc b_p to summation order (1 ulp: a different order than
+        rocBLAS gemv -- which is why whole-encoder outputs agree only to rounding noise, amplified by 12 blocks, and are not compared bitwise);
+    (2) after an in-place parameter update (what an optimizer does) every block is refreshed;
+    (3) product rule on given dW_e / db1 against fp64 arithmetic on the operands the kernels see;
+    (4) end to end: gradients of the banked and the per-block backward agree; a deep copy of the encoder gets its own bank."""
+    import copy
+    from alpro_amd import amp, config as rt
+    from alpro_amd.modeling.timesformer import vit
+    from tests.test_host_cpu import VENC
+    hip = _hip()
+    torch.manual_seed(11)
+    enc = vit.TimeSformer(dict(VENC, num_frm=2, drop_path_rate=0.0), input_format="RGB").cuda().train()
+    with torch.no_grad():
+        for blk in enc.model.blocks:            # the reference zero-initialises temporal_fc of blocks > 0: give every block a live branch
+            blk.temporal_fc.weight.normal_(0, 0.02)
+            blk.temporal_fc.bias.normal_(0, 0.02)
+            blk.temporal_attn.proj.bias.normal_(0, 0.02)
+    bank = enc.model._tproj_bank
+    D = 768
+
+    def per_block(blk, dt):
+        vit.Block.batch_merged_tproj = False
+        blk._ops._store.pop("t_merged", None)
+        return {k: v.clone() for k, v in blk._merged_tproj(dt).items()}
+
+    try:
+        with rt.use_compute_dtype(mode), torch.no_grad():
+            dt = rt.compute_dtype()
+            for rnd_ in range(2):
+                for i in (0, 5, 11):
+                    blk = enc.model.blocks[i]
+                    ref = per_block(blk, dt)
+                    vit.Block.batch_merged_tproj = True
+                    got = blk._merged_tproj(dt)
+                    assert blk._bank() is bank
+                    assert torch.equal(got["w"], ref["w"]) and torch.equal(got["wT"], ref["wT"]), (rnd_, i)
+                    assert float((got["b1"] - ref["b1"]).abs().max()) <= 1e-6 * float(ref["b1"].abs().max()), (rnd_, i)
+                for p in enc.parameters():      # (2)
+                    p.mul_(1.01)
+            if mode != "fp32":                  # (3)
+                ws = bank.workspace(dt, torch.device("cuda", 0))
+                ws.copy_(rnd(*ws.shape, seed=900) * 0.01)
+                for blk in enc.model.blocks:
+                    for p in (blk.temporal_fc.weight, blk.temporal_attn.proj.weight, blk.temporal_attn.proj.bias):
+                        p.grad = torch.full_like(p, 0.5)
+                bank.product_rule(4, 8, dt)
+                bank.product_rule(8, 12, dt)
+                for i in (4, 7, 11):
+                    blk = enc.model.blocks[i]
+                    wf, wp, bp = (t.detach().double().cpu() for t in (blk.temporal_fc.weight, blk.temporal_attn.proj.weight, blk.temporal_attn.proj.bias))
+                    dWe, db1 = ws[i, :D * D].view(D, D).double().cpu(), ws[i, D * D:].double().cpu()
+                    qd = lambda t: t.to(dt).double()  # noqa: E731
+                    ref_fc = 0.5 + qd(dWe.float()) @ qd(wp.float()).T + torch.outer(db1, bp)
+                    ref_p = 0.5 + qd(wf.float()).T @ qd(dWe.float())
+                    ref_bp = 0.5 + wf.T @ db1
+                    for got, ref_, what in ((blk.temporal_fc.weight.grad, ref_fc, "dW_fc"), (blk.temporal_attn.proj.weight.grad, ref_p, "dW_p"),
+                                            (blk.temporal_attn.proj.bias.grad, ref_bp, "db_p")):
+                        err = float((got.double().cpu() - ref_).abs().max())
+                        assert err <= 2e-5 * max(1.0, float(ref_.abs().max())), (what, i, err)
+                assert float((enc.model.blocks[0].temporal_fc.weight.grad - 0.5).abs().max()) == 0.0      # untouched groups stay untouched
+        # (4) end to end
+        x = torch.randn(2, 3, 2, 224, 224, device="cuda")
+
+        def run(model, banked):
+            vit.Block.batch_merged_tproj = banked
+            for p in model.parameters():
+                p.grad = None
+            with rt.use_compute_dtype(mode):
+                out = model.forward_features(x)
+                loss = out.float().square().mean()
+                if mode == "fp16":
+                    sc = amp.LossScaler(init_scale=256.0, dynamic=False, device="cuda")
+                    with rt.loss_scaling(sc):
+                        (loss * 256.0).backward()
+                else:
+                    loss.backward()
+            return out.detach().clone(), {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
+
+        ref_out, ref_g = run(enc, False)
+        out, g = run(enc, True)
+        tol = {"fp32": 2e-4, "fp16": 2e-2, "bf16": 1e-1}[mode]     # 1-ulp differences in b1, amplified through 12 blocks of 16-bit roundings
+        assert float((out - ref_out).abs().max()) <= tol * float(ref_out.abs().max())
+        assert set(g) == set(ref_g)
+        for n in g:
+            err = float((g[n] - ref_g[n]).norm() / ref_g[n].norm().clamp_min(1e-20))
+            assert err <= tol, (n, err)
+        twin = copy.deepcopy(enc)               # a deep copy must not talk to the original's bank
+        out3, _ = run(twin, True)
+        assert twin.model._tproj_bank is not bank and twin.model._tproj_bank.state is not None and twin.model.blocks[3]._bank() is twin.model._tproj_bank
+        assert float((out3 - out).abs().max()) <= tol * float(out.abs().max())
+    finally:
+        vit.Block.batch_merged_tproj = True
+
+
 def test_gemms_at_full_benchmark_size():
     """The three GEMM kernels at the default benchmark's sizes (B=64 x 8f: M = 100416 token rows) against torch.matmul on the
     same bf16 operands in fp32: many persistent rounds, a partial last M-tile, 27-tile XCD slices."""
