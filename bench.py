@@ -104,6 +104,7 @@ class KernelTimer:
         wrap("attn", lambda qkv, batch, L, H, *r, **k: 4.0 * batch * H * L * L * 64)
         wrap("attn_temporal", lambda qkv, T, H, *r, **k: 4.0 * qkv.shape[0] * T * H * 64)
         wrap("layernorm", lambda *a, **k: 0.0)
+        wrap("add_layernorm", lambda *a, **k: 0.0)
         wrap("attn_bwd", lambda qkv, out, dout, lse, batch, L, H, *r, **k: 10.0 * batch * H * L * L * 64)
         wrap("attn_temporal_bwd", lambda qkv, out, dout, lse, T, H, *r, **k: 10.0 * qkv.shape[0] * T * H * 64)
         wrap("layernorm_bwd", lambda *a, **k: 0.0)
