@@ -219,6 +219,11 @@ class FlatAdamW:
             self.synchronize()
             self._pre_synced = None
         world = dist.size() if (self.allreduce and pre != "avg") else 1
+        if self.scaler is not None and getattr(self, "_scaler_steps_synced", None) is not self.scaler:
+            # a loss scaler attached after some plain steps, or after load_state_dict(): the DEVICE step counter that drives Adam's bias
+            # correction under loss scaling continues from the host counter instead of restarting at zero
+            self.scaler.to(f["g"].device).state[2] = float(self.step_count)
+            self._scaler_steps_synced = self.scaler
         self.step_count += 1
         lr, (b1, b2) = grp["lr"], grp["betas"]
         step_size = lr
@@ -266,6 +271,7 @@ class FlatAdamW:
         first backward + step(): before that the moments are parked and applied by the first step(), which checks that the same set
         of parameters is being trained (the layout is a pure function of which parameters receive gradients)."""
         self.step_count = int(sd["step"])
+        self._scaler_steps_synced = None   # re-seed the device step counter from the restored host counter at the next step()
         for g, saved in zip(self.param_groups, sd.get("param_groups", [])):
             for k, v in saved.items():
                 g[k] = tuple(v) if k == "betas" else v
