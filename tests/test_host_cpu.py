@@ -655,6 +655,46 @@ def test_input_pipeline_host_logic_reproduces_the_reference_fixture():
     assert sel.any() and not sel[:, 0].any() and not sel[g["mlm_input_ids"] == 0].any() and not sel[0, 5]   # [CLS], [PAD], [UNK] never masked
 
 
+def test_amp_facade_with_a_foreign_optimizer_scales_unscales_and_skips_on_overflow():
+    """The reference drivers' mixed-precision pattern (run_pretrain_sparse.py:596-634) on THEIR optimizer (any torch.optim.Optimizer, not
+    FlatAdamW), host logic only: under fp16 operands `amp.scale_loss` yields loss * S, leaves TRUE-scale gradients behind at exit
+    (delay_unscale=False), keeps them scaled with delay_unscale=True (gradient accumulation) until the last micro-step, and wraps
+    optimizer.step() so that a step with non-finite gradients is skipped and halves S; bf16 / fp32 operands: the identity."""
+    from alpro_amd import amp, config as rt
+    p = torch.nn.Parameter(torch.tensor([1.0, -2.0, 3.0]))
+    x = torch.tensor([0.5, 0.25, -1.0])
+    opt = torch.optim.SGD([p], lr=0.1)
+    with rt.use_compute_dtype("bf16"):
+        with amp.scale_loss((p * x).sum(), opt) as s:
+            assert float(s) == float((p * x).sum())                 # identity
+    with rt.use_compute_dtype("fp16"):
+        model, opt2 = amp.initialize(torch.nn.Identity(), opt, enabled=0, opt_level="O2")
+        assert opt2 is opt and opt.scaler.state_dict()["loss_scale"] == 65536.0
+        with amp.scale_loss((p * x).sum(), opt) as s:
+            assert float(s) == 65536.0 * float((p * x).sum())
+            s.backward()
+        assert torch.allclose(p.grad, x) and opt._grads_scaled is False   # true-scale again, like apex leaves them
+        before = p.detach().clone()
+        opt.step()
+        assert torch.allclose(p.detach(), before - 0.1 * x)
+        opt.zero_grad()
+        with amp.scale_loss((p * x).sum(), opt, delay_unscale=True) as s:   # accumulation: stays scaled ...
+            s.backward()
+        assert torch.allclose(p.grad, 65536.0 * x) and opt._grads_scaled is True
+        with amp.scale_loss((p * x).sum(), opt) as s:                        # ... until the last micro-step unscales the sum
+            s.backward()
+        assert torch.allclose(p.grad, 2 * x)
+        p.grad[1] = float("inf")                                             # an overflow somewhere in the backward
+        before = p.detach().clone()
+        assert opt.step() is None
+        assert torch.equal(p.detach(), before)                               # skipped
+        sd = amp.state_dict()
+        mine = [v for v in sd.values() if v["skipped_steps"] == 1]
+        assert mine and mine[-1]["loss_scale"] == 32768.0 and mine[-1]["applied_steps"] == 1
+        amp.load_state_dict({k: dict(v, loss_scale=1024.0) for k, v in sd.items()})
+        assert opt.scaler.loss_scale() == 1024.0
+
+
 def test_retrieval_eval_known_answers_from_the_reference():
     """eval_retrieval on records rebuilt from score tables the REFERENCE produced, against the metrics the reference's own
     eval_retrieval computed from them (tests/golden/retrieval_eval_T2_V5.npz: a 5 x 5 model table and a 12 x 12 synthetic table
