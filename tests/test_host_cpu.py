@@ -655,6 +655,32 @@ def test_input_pipeline_host_logic_reproduces_the_reference_fixture():
     assert sel.any() and not sel[:, 0].any() and not sel[g["mlm_input_ids"] == 0].any() and not sel[0, 5]   # [CLS], [PAD], [UNK] never masked
 
 
+def test_merged_projection_bank_survives_deepcopy_and_pickle():
+    """_MergedTProjBank holds ctypes job tables with pointers into ITS model's storage: a deep copy / pickle of the model must neither drag
+    them along nor keep talking to the original's bank (host logic; the arithmetic is checked on the GPU in tests/test_hip_bwd_ops.py)."""
+    import copy
+    import io
+    from alpro_amd import hip
+    from alpro_amd.modeling.timesformer.vit import TimeSformer
+    enc = TimeSformer(dict(VENC, num_frm=2), input_format="RGB")
+    bank = enc.model._tproj_bank
+    assert all(b._bank() is bank and b._bank_idx == i for i, b in enumerate(enc.model.blocks))
+    gb = hip.GemmBatch.__new__(hip.GemmBatch)          # what a populated bank holds: descriptor arrays that cannot be pickled
+    gb._descs, gb._host, gb._dev, gb._keep = [hip.GemmDesc()], (hip.GemmDesc * 1)(), None, []
+    bank.state = {"gemm": gb}
+    twin = copy.deepcopy(enc)
+    assert twin.model._tproj_bank is not bank and twin.model._tproj_bank.blocks == [] and twin.model.blocks[4]._bank() is None
+    twin.model._attach_bank()                           # what VisionTransformer._embed does at the next forward
+    assert twin.model.blocks[4]._bank() is twin.model._tproj_bank and twin.model._tproj_bank.blocks[4] is twin.model.blocks[4]
+    assert enc.model.blocks[4]._bank() is bank          # the original is untouched
+    buf = io.BytesIO()
+    torch.save(enc, buf)
+    buf.seek(0)
+    back = torch.load(buf, weights_only=False)
+    assert back.model.blocks[0]._bank() is None and set(back.state_dict()) == set(enc.state_dict())
+    assert "_tproj_bank" not in enc.state_dict() and not any("bank" in k for k in enc.state_dict())
+
+
 def test_amp_facade_with_a_foreign_optimizer_scales_unscales_and_skips_on_overflow():
     """The reference drivers' mixed-precision pattern (run_pretrain_sparse.py:596-634) on THEIR optimizer (any torch.optim.Optimizer, not
     FlatAdamW), host logic only: under fp16 operands `amp.scale_loss` yields loss * S, leaves TRUE-scale gradients behind at exit
