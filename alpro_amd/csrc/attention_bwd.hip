@@ -334,7 +334,7 @@ __device__ __forceinline__ void store_rows_via_lds(char* Ow, const f32x16 (&o)[2
   }
 }
 
-template <typename T, int NKT, bool HAS_BIAS>
+template <typename T, int NKT, bool HAS_BIAS, bool DROP>
 __global__ __launch_bounds__(256, 2) void attn_bwd16_kernel(const T* __restrict__ qkv, const T* __restrict__ out,
                                                                           const T* __restrict__ dout, const float* __restrict__ lse,
                                                                           T* __restrict__ dqkv, int L, int H, float scale,
@@ -452,7 +452,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd16_kernel(const T* __restrict_
             const int r = 4 * rq + e;
             const float p = __builtin_amdgcn_exp2f(fmaf(s[r], sl, bb[e]));
             float gd = dp[r];
-            if (drop_seed) gd = drop_keep(drop_seed, (dbase + qc) * L + kt * 32 + 8 * rq + 4 * g + e, dth) ? gd * dks : 0.f;
+            if constexpr (DROP) gd = drop_keep(drop_seed, (dbase + qc) * L + kt * 32 + 8 * rq + 4 * g + e, dth) ? gd * dks : 0.f;
             s[r] = p * fmaf(gd, scale, nds);  // dS^T = P o (dP - delta) * scale
           }
         }
@@ -536,7 +536,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd16_kernel(const T* __restrict_
           const int r = 4 * rq + e;
           const float p = __builtin_amdgcn_exp2f(fmaf(s[r], sl, ll[e]));
           float gd = dp[r], pm = p;
-          if (drop_seed) {
+          if constexpr (DROP) {
             const int qq = qt * 32 + 8 * rq + 4 * g + e;
             const bool keep = drop_keep(drop_seed, (dbase + (qq < L ? qq : L - 1)) * L + key, dth);
             pm = keep ? p * dks : 0.f;
@@ -565,6 +565,678 @@ __global__ __launch_bounds__(256, 2) void attn_bwd16_kernel(const T* __restrict_
     store_rows_via_lds<T, HALF>(Ow, dk, db + H * HD, ldq, kt * 32, L, lane);
     store_rows_via_lds<T, HALF>(Ow, dv, db + 2 * H * HD, ldq, kt * 32, L, lane);
   }
+}
+
+#ifdef ALPRO_ABLATIONS
+// measurement build only: shader-clock stamps of one workgroup (alpro_debug_attn_bwd_stamps), 16 per wave
+__device__ unsigned long long g_attn_ts[8 * 16];
+__device__ int g_attn_ts_block = -1;
+__device__ int g_attn_alias = 0;   // > 0: every unit reads / writes unit (u mod alias) -- wrong results, all inputs L2 resident (timing experiment)
+#define ALPRO_TS(i)                                                                                           \
+  do {                                                                                                        \
+    if ((int)blockIdx.x == g_attn_ts_block && lane == 0) g_attn_ts[wave * 16 + (i)] = __builtin_readcyclecounter(); \
+  } while (0)
+#else
+#define ALPRO_TS(i) do { } while (0)
+#endif
+
+// ================================================================================================
+// Key-owned 16-bit backward for 5..8 key tiles (ViT spatial L = 197, fusion L = 237): every (query tile, key tile)
+// pair is computed ONCE.  The two-phase kernel above evaluates S, dP, P and dS of every pair twice (once per
+// orientation, 28 MFMAs + 2 x 16 exp per pair); here wave w owns key tile w for the whole unit (K / V fragments and
+// the dK^T / dV^T accumulators stay in its registers) and walks the query tiles in lockstep with the other waves:
+//       S = Q K^T, dP = dO V^T, P, dS                       as phase 2 above (lane = key)
+//       dV^T += dO^T P,  dK^T += Q^T dS                     as phase 2 above
+//       dQ^T(partial over this key tile) = K^T dS^T         A = K^T via transpose reads (as phase 1), B = dS^T:
+//           the dS tile is written 16-bit into 2 KiB of wave-private LDS as [key][query] rows (the same packed pairs
+//           that feed the dK product) and read back with ds_read_b64_tr_b16 in the k order of the A chunk
+// 20 MFMAs and 16 exp per pair, and the dQ contraction over ALL keys happens in one accumulator, so nothing is reduced across
+// waves: the workgroup alternates between
+//   main pass  (RQ query tiles): wave w computes the pairs (q tile, key tile w), accumulates dV^T / dK^T in registers and writes
+//              each dS tile, 16-bit, as a [key][query] image of 2 KiB into shared LDS (the packed pairs that feed the dK product,
+//              8-byte slots swizzled by (key >> 2) & 7: conflict-free for the ds_write_b64 rows and for the transpose reads);
+//   dQ pass    wave j takes (query tile j >> 1, d half j & 1): dQ^T = sum over key tiles K^T dS^T with A = K^T via
+//              ds_read_b64_tr_b16 (as phase 1 above) and B = dS^T read back from the images with ds_read_b64_tr_b16 in the k
+//              order of the A chunk; two alternating accumulators, fixed order (deterministic, no atomics); rows leave as 8-byte
+//              stores straight from the accumulator layout.
+// Two workgroup barriers per round (RQ = 4 query tiles with <= 7 key tiles, 3 with 8).  V is never staged (only a register
+// operand); K, Q, dO tiles + the dS images take 143..147 KiB: one 8-wave workgroup per CU.  Dropout is a template parameter here
+// (and in the two-phase kernel): a runtime test per score splits the softmax into 16 basic blocks per pair and serialises the
+// v_exp_f32 latencies.
+template <typename T, int NKT, bool DROP>
+__global__ __launch_bounds__(512) void attn_bwd16k_kernel(const T* __restrict__ qkv, const T* __restrict__ out,
+                                                                        const T* __restrict__ dout, const float* __restrict__ lse,
+                                                                        T* __restrict__ dqkv, int L, int H, float scale,
+                                                                        const float* __restrict__ key_bias, float drop_p, uint32_t drop_seed) {
+  static_assert(sizeof(T) == 2 && NKT >= 5 && NKT <= 8, "16-bit storage, 5..8 key tiles");
+  constexpr int LP = NKT * 32, RB = 128;
+  constexpr int RQ = NKT <= 7 ? 4 : 3;   // query tiles per round
+  constexpr int IMG = 2048;               // one dS tile: 32 key rows x 32 queries x 2 bytes
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* tK = smem;
+  char* tQ = smem + LP * RB;
+  char* tD = smem + 2 * LP * RB;       // dO
+  char* DSb = smem + 3 * LP * RB;      // dS images [query tile of the round][key tile]; at the end the row staging of dK / dV
+  float* Bs = (float*)(DSb + RQ * NKT * IMG);  // key bias * log2(e); -inf on padded keys
+  float* Ls = Bs + LP;                 // -lse * log2(e); -inf on padded queries
+  float* Ds = Ls + LP;                 // -delta * scale
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int b = blockIdx.x / H, h = blockIdx.x - b * H;
+  const int64_t row0 = (int64_t)b * L;
+  const int64_t ldq = 3 * (int64_t)H * HD, ldo = (int64_t)H * HD;
+  const T* qb = qkv + row0 * ldq + h * HD;
+  const T* ob = out + row0 * ldo + h * HD;
+  const T* dob = dout + row0 * ldo + h * HD;
+  T* db = dqkv + row0 * ldq + h * HD;
+  const float* lse_b = lse + ((int64_t)b * H + h) * L;
+  const uint32_t dth = drop_thresh24(drop_p);
+  const float dks = drop_seed ? 1.0f / (1.0f - drop_p) : 1.0f;
+  const uint64_t dbase = ((uint64_t)b * H + h) * (uint64_t)L;  // + q, then * L + key
+  const float sl = scale * LOG2E_B;
+  const int g = lane >> 5, ql = lane & 31;
+  const int ntile = (L + 31) >> 5;           // >= 5 (dispatch)
+  const bool active = wave < ntile;          // wave-uniform: this wave owns key tile `wave`
+  ALPRO_TS(0);
+  for (int c = tid; c < LP; c += 512) {
+    Bs[c] = c < L ? (key_bias ? key_bias[(int64_t)b * L + c] * LOG2E_B : 0.f) : -INFINITY;
+    Ls[c] = c < L ? -lse_b[c] * LOG2E_B : -INFINITY;
+  }
+  {  // K, Q, dO rows -> LDS images (chunk ^ (bit1(row) << 2 | (row >> 2) & 3)), 1 KiB DMA pieces
+    const uint32_t k_lds = lds_addr_of(tK), q_lds = lds_addr_of(tQ), d_lds = lds_addr_of(tD);
+    const char* zero = (const char*)g_bwd_zero;
+#pragma unroll
+    for (int i = 0; i < (NKT * 4 + 7) / 8; ++i) {
+      const int piece = wave + 8 * i;
+      if (piece < ntile * 4) {
+        const int row = piece * 8 + (lane >> 3), slot = lane & 7;
+        const int ch = slot ^ ((((row >> 1) & 1) << 2) | ((row >> 2) & 3));
+        const char* pk = row < L ? (const char*)(qb + (int64_t)row * ldq + H * HD + ch * 8) : zero;
+        const char* pq = row < L ? (const char*)(qb + (int64_t)row * ldq + ch * 8) : zero;
+        const char* pd = row < L ? (const char*)(dob + (int64_t)row * ldo + ch * 8) : zero;
+        dma16(pk, __builtin_amdgcn_readfirstlane(k_lds + piece * 1024));
+        dma16(pq, __builtin_amdgcn_readfirstlane(q_lds + piece * 1024));
+        dma16(pd, __builtin_amdgcn_readfirstlane(d_lds + piece * 1024));
+      }
+    }
+  }
+  // K / V fragments of key tile `wave` (B operands, lane = key) and delta of QUERY tile `wave`
+  u32x4 kf[4], vf[4];
+  {
+    const int rc = min(min(wave, ntile - 1) * 32 + ql, L - 1);
+    u32x4 dof[4], of[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int off = (2 * ks + g) * 8;
+      dof[ks] = *(const u32x4*)(dob + (int64_t)rc * ldo + off);
+      of[ks] = *(const u32x4*)(ob + (int64_t)rc * ldo + off);
+      kf[ks] = *(const u32x4*)(qb + (int64_t)rc * ldq + H * HD + off);
+      vf[ks] = *(const u32x4*)(qb + (int64_t)rc * ldq + 2 * H * HD + off);
+    }
+    float delta = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      float a[8], c2[8];
+      unpack_chunk<T>(dof[ks], a);
+      unpack_chunk<T>(of[ks], c2);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) delta += a[e] * c2[e];
+    }
+    delta += __shfl_xor(delta, 32, 64);
+    if (active && g == 0) Ds[wave * 32 + ql] = -delta * scale;
+  }
+  ALPRO_TS(1);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  ALPRO_TS(2);
+  __syncthreads();
+  ALPRO_TS(3);
+
+  const int key = wave * 32 + ql;
+  const bool need_kb = key_bias != nullptr || (wave + 1) * 32 > L;   // padded keys of the last tile: P = exp2(-inf) = 0, so they add nothing to dQ
+  const float kb = (active && need_kb) ? Bs[key] : 0.f;
+  const int swk = (ql >> 2) & 7;                           // 8-byte slot swizzle of the dS image (row = key)
+  f32x16 dk[2], dv[2];
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dk[dt][r] = dv[dt][r] = 0.f;
+  // dS[query ql of the tile][keys k0 .. k0+3] from a [key][query] image (k0 multiple of 4)
+  auto ds_quad = [&](const char* img, int k0) -> u32x2 {
+    const int p = lane & 15, cb = (lane >> 4) & 1;
+    const int row = k0 + (p >> 2);
+    const char* a = img + row * 64 + ((((cb << 2) | (p & 3)) ^ ((row >> 2) & 7)) << 3);
+    const s16x4 r = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)a);
+    return __builtin_bit_cast(u32x2, r);
+  };
+#pragma unroll 1
+  for (int q0 = 0; q0 < ntile; q0 += RQ) {
+    const int nq = min(RQ, ntile - q0);
+    // ---------------------------------------------------------------- main pass: pairs (q0 + tl, key tile `wave`)
+    if (active) {
+#pragma unroll 1
+      for (int tl = 0; tl < nq; ++tl) {
+        const int qt = q0 + tl;
+        char* img = DSb + (tl * NKT + wave) * IMG;
+        f32x16 s, dp;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = dp[r] = 0.f;
+        const int qrow = qt * 32 + ql;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          const u32x4 qa = *(const u32x4*)(tQ + tile_off<T>(qrow, 2 * ks + g));
+          const u32x4 da = *(const u32x4*)(tD + tile_off<T>(qrow, 2 * ks + g));
+          mma_chunk<T>(s, qa, kf[ks]);
+          mma_chunk<T>(dp, da, vf[ks]);
+        }
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq) {
+          const float4 lq = *(const float4*)(Ls + qt * 32 + 8 * rq + 4 * g);
+          const float4 dq4 = *(const float4*)(Ds + qt * 32 + 8 * rq + 4 * g);
+          float ll[4] = {lq.x, lq.y, lq.z, lq.w};
+          const float dd[4] = {dq4.x, dq4.y, dq4.z, dq4.w};
+          if (need_kb) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) ll[e] += kb;
+          }
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int r = 4 * rq + e;
+            const float p = __builtin_amdgcn_exp2f(fmaf(s[r], sl, ll[e]));
+            float gd = dp[r], pm = p;
+            if constexpr (DROP) {
+              const int qq = qt * 32 + 8 * rq + 4 * g + e;
+              const bool keep = drop_keep(drop_seed, (dbase + (qq < L ? qq : L - 1)) * L + (key < L ? key : L - 1), dth);
+              pm = keep ? p * dks : 0.f;
+              gd = keep ? gd * dks : 0.f;
+            }
+            s[r] = pm;                           // dropped P (feeds dV)
+            dp[r] = p * fmaf(gd, scale, dd[e]);  // dS
+          }
+        }
+#pragma unroll
+        for (int cc = 0; cc < 2; ++cc) {
+          float pv[8], sv[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            pv[e] = s[cc * 8 + e];
+            sv[e] = dp[cc * 8 + e];
+          }
+          const u32x4 pb = pack_chunk<T>(pv), sb = pack_chunk<T>(sv);
+          // dS image: row = key (64 bytes = 32 queries), registers 4rq .. 4rq+3 are queries 8rq + 4g .. +3 -> 8-byte slot 2rq + g
+          *(u32x2*)(img + ql * 64 + (((4 * cc + g) ^ swk) << 3)) = mk2(sb.x, sb.y);
+          *(u32x2*)(img + ql * 64 + (((4 * cc + 2 + g) ^ swk) << 3)) = mk2(sb.z, sb.w);
+#pragma unroll
+          for (int dt = 0; dt < 2; ++dt) {
+            mma_chunk<T>(dv[dt], load_t_chunk<T>(tD, qt * 32, cc, lane, dt), pb);
+            mma_chunk<T>(dk[dt], load_t_chunk<T>(tQ, qt * 32, cc, lane, dt), sb);
+          }
+        }
+      }
+    }
+    ALPRO_TS(4 + (q0 ? 4 : 0));
+    __syncthreads();
+    ALPRO_TS(5 + (q0 ? 4 : 0));
+    // ---------------------------------------------------------------- dQ pass: wave j = (query tile j >> 1, d half j & 1)
+    if (wave < 2 * nq) {
+      const int tl = wave >> 1, dt = wave & 1;
+      f32x16 acc[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+#pragma unroll
+      for (int kt = 0; kt < NKT; ++kt)
+        if (kt < ntile) {
+          const char* img = DSb + (tl * NKT + kt) * IMG;
+#pragma unroll
+          for (int cc = 0; cc < 2; ++cc) {
+            const u32x2 lo = ds_quad(img, 16 * cc + 4 * g), hi = ds_quad(img, 16 * cc + 8 + 4 * g);
+            const uint32_t lx = lo.x, ly = lo.y, hx = hi.x, hy = hi.y;
+            mma_chunk<T>(acc[kt & 1], load_t_chunk<T>(tK, kt * 32, cc, lane, dt), mk4(lx, ly, hx, hy));
+          }
+        }
+      const int q = (q0 + tl) * 32 + ql;
+      if (q < L) {
+        T* dst = db + (int64_t)q * ldq + dt * 32 + 4 * g;
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq) {
+          const uint32_t lo = pack2(acc[0][4 * rq] + acc[1][4 * rq], acc[0][4 * rq + 1] + acc[1][4 * rq + 1], (T*)0);
+          const uint32_t hi = pack2(acc[0][4 * rq + 2] + acc[1][4 * rq + 2], acc[0][4 * rq + 3] + acc[1][4 * rq + 3], (T*)0);
+          __builtin_nontemporal_store(mk2(lo, hi), (u32x2*)(dst + 8 * rq));
+        }
+      }
+    }
+    ALPRO_TS(6 + (q0 ? 4 : 0));
+    __syncthreads();   // the images are rewritten by the next round / become the row staging below
+    ALPRO_TS(7 + (q0 ? 4 : 0));
+  }
+  if (active) {
+    store_rows_via_lds<T, false>(DSb + wave * 4096, dk, db + H * HD, ldq, wave * 32, L, lane);
+    store_rows_via_lds<T, false>(DSb + wave * 4096, dv, db + 2 * H * HD, ldq, wave * 32, L, lane);
+  }
+  ALPRO_TS(12);
+}
+
+// ================================================================================================
+// Persistent variant of the key-owned backward for EXACTLY 7 key tiles, no key bias, no dropout (ViT spatial attention,
+// L = 197): one 8-wave workgroup per CU walks its units (sequence, head) and the NEXT query tiles are always in flight.
+// The non-persistent kernel above spends a third of every unit waiting for its 126 KiB of inputs (phase stamps in
+// profiles/r3_attn_bwd_phase_stamps.txt: ~16k of ~45k cycles) with nothing to compute -- one workgroup per CU, so no
+// neighbour hides it.  Here:
+//   * Q / dO / O rows travel as 12 KiB query-tile records through a ring of NS slots, DMAed NS-1 steps ahead of use; K of
+//     the next unit goes into the other half of a K double buffer during steps 1..4 of the current unit;
+//   * waves 0..6 own one key tile each (as above) and do one pair per step; V / K fragments of the next unit are reloaded
+//     into kf / vf right after their last use in the unit's last pair;
+//   * wave 7 (idle above) is the service wave: the whole dQ tile of the PREVIOUS step (28 MFMAs over the seven dS images
+//     of that step; images are double buffered by step parity) and the row statistics of the NEXT step's query tile
+//     (-lse*log2e and -delta*scale from the dO / O rows of its ring record);
+//   * one workgroup barrier per step.  DMA completion is tracked per wave with s_waitcnt vmcnt(n), n = this wave's own
+//     copies issued after the ones that must have landed (every wave issues a fixed share per step, so n is a function of
+//     the step position only); compiler-visible loads / stores in between only make that wait stricter, never laxer.
+// Deterministic (fixed summation orders, no atomics); dK / dV / dQ leave as 8-byte stores straight from the accumulators.
+template <typename T>
+__global__ __launch_bounds__(512) void attn_bwd16p_kernel(const T* __restrict__ qkv, const T* __restrict__ out, const T* __restrict__ dout,
+                                                          const float* __restrict__ lse, T* __restrict__ dqkv, int L, int H, float scale,
+                                                          int units, int flags) {
+  static_assert(sizeof(T) == 2, "16-bit storage only");
+  constexpr int NT = 7, NS = 5, KB = NT * 4096, IMG = 2048, REC = 3 * 4096;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* Kb = smem;                       // 2 x K tile images
+  char* Im = Kb + 2 * KB;                // 2 (step parity) x 7 dS images
+  char* Rg = Im + 2 * NT * IMG;          // NS records: Q | dO | O rows of one query tile
+  float* St = (float*)(Rg + NS * REC);   // 2 (step parity) x {Ls[32], Ds[32]}
+  float* Lq = St + 2 * 64;               // 8 x lse[32] of the coming query tiles (service wave's own queue; registers would be live in the pair path too)
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 5, ql = lane & 31;
+  const int nu = (units - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;   // units of this workgroup: blockIdx + i * grid
+  const int S = nu * NT;                                                           // steps
+  const int64_t ldq = 3 * (int64_t)H * HD, ldo = (int64_t)H * HD;
+  const float sl = scale * LOG2E_B;
+  const uint32_t kb_lds = lds_addr_of(Kb), rg_lds = lds_addr_of(Rg);
+  // Per-lane LDS offsets: four base values; every access is (base ^ constant) + wave-uniform base + constant.  The tile swizzles only
+  // touch row bits 1..3 and XOR disjoint bit fields, so the per-chunk / per-row-block variants are single v_xor rematerialisations of the
+  // bases instead of ~20 live address registers (which spilled: a spill reload is a vector-memory load, and loads return in order --
+  // it would wait for every DMA prefetch issued before it).
+  const int p16 = lane & 15, r0 = 4 * g + (p16 >> 2);
+  const int fo0 = ql * 128 + ((g ^ ((((ql >> 1) & 1) << 2) | ((ql >> 2) & 3))) << 4);          // fragment chunk 2ks + g of row ql: fo0 ^ (ks << 5)
+  const int tro0 = r0 * 128 + (((2 * ((lane >> 4) & 1) + ((p16 >> 1) & 1)) ^ ((((r0 >> 1) & 1) << 2) | (r0 >> 2))) << 4) + ((p16 & 1) << 3);
+  const int iw0 = ql * 64 + ((g ^ ((ql >> 2) & 7)) << 3);                                     // dS image write, slot 4cc + 2h + g: iw0 ^ ((4cc + 2h) << 3)
+  const int ir0 = r0 * 64 + ((((((lane >> 4) & 1) << 2) | (p16 & 3)) ^ (r0 >> 2)) << 3);      // dS image transpose read, rows 16cc + 8h + r0
+  // copy source, lane part: a 1 KiB piece is 8 rows x 8 chunks; lane l copies chunk (l & 7) ^ swizzle(row) of row (l >> 3) of the piece.
+  // With row = 8 * piece + (l >> 3): swizzle = ((l >> 4) & 1) << 2 | ((2 * piece + (l >> 5)) & 3) = c0 ^ (2 * (piece & 1))
+  const int dm0 = ((lane & 7) ^ ((((lane >> 4) & 1) << 2) | (lane >> 5))) << 4;              // byte offset in the 128-byte row: dm0 ^ ((piece & 1) << 5)
+  // The bases pass through an empty asm at the top of every step (`fresh`): without it the compiler hoists all ~20 variants out of the
+  // step loop as invariants and then spills them, instead of recomputing one v_xor at the use.
+  int fb = fo0, tb = tro0, wb = iw0, rb = ir0, db = dm0, lz = lane;
+  auto fresh = [&] { asm volatile("" : "+v"(fb), "+v"(tb), "+v"(wb), "+v"(rb), "+v"(db), "+v"(lz)); };
+  auto fo = [&](int ks) { return fb ^ (ks << 5); };
+  auto tro = [&](int h2, int dt) { return (tb ^ (((4 * dt) ^ (2 * h2)) << 4)) + h2 * 1024; };   // rows 8h + r0, 16-column segment 2dt + (lane >> 4 & 1)
+  auto iw = [&](int cc, int h2) { return wb ^ ((4 * cc + 2 * h2) << 3); };
+  auto ir = [&](int cc, int h2) { return (rb ^ ((4 * cc + 2 * h2) << 3)) + (16 * cc + 8 * h2) * 64; };
+  auto tr8 = [](const char* a) -> u32x2 {
+    const s16x4 r = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)a);
+    return __builtin_bit_cast(u32x2, r);
+  };
+  // transposed A chunk of rows [rowbase, rowbase + 16) (rowbase a multiple of 16), d half dt (the chunk the other kernels' transposed-chunk loader returns)
+  auto tr_chunk = [&](const char* tile, int rowbase, int dt) -> u32x4 {
+    const u32x2 x = tr8(tile + tro(0, dt) + rowbase * 128), y = tr8(tile + tro(1, dt) + rowbase * 128);
+    const uint32_t x0 = x.x, x1 = x.y, y0 = y.x, y1 = y.y;
+    return mk4(x0, x1, y0, y1);
+  };
+  // (sequence b, head h) of four units at a time (previous, current, next, the one after), renewed once per unit; base pointers are a
+  // few scalar multiply-adds from them at the use.  Computing u / H and five 64-bit products at every use was most of the ~1700 cycles a
+  // wave spent "issuing" two copies (profiles/r3_attn_bwd_phase_stamps.txt); whole pointer sets for four units do not fit the scalar
+  // registers.  Beyond the last unit they repeat it (harmless re-reads keep the copy counts fixed).
+  struct Unit { uint32_t b, h; };
+  const uint32_t h_magic = (uint32_t)(((1ull << 32) + (uint32_t)H - 1) / (uint32_t)H);   // u / H == umulhi(u, h_magic) while u * H < 2^32
+  auto unit_at = [&](int ui) -> Unit {
+    uint32_t u = blockIdx.x + (uint32_t)(ui < nu ? ui : nu - 1) * gridDim.x;
+#ifdef ALPRO_ABLATIONS
+    if (g_attn_alias > 0) u %= (uint32_t)g_attn_alias;
+#endif
+    const uint32_t ub = __umulhi(u, h_magic);
+    return Unit{ub, u - ub * (uint32_t)H};
+  };
+  const int64_t seq_o = (int64_t)L * ldo;   // elements of one sequence in out / dout; qkv / dqkv: 3 x
+  auto pq = [&](const Unit& U) { return qkv + ((int64_t)U.b * seq_o * 3 + U.h * HD); };
+  auto pg = [&](const Unit& U) { return dqkv + ((int64_t)U.b * seq_o * 3 + U.h * HD); };
+  auto po = [&](const Unit& U) { return out + ((int64_t)U.b * seq_o + U.h * HD); };
+  auto pd = [&](const Unit& U) { return dout + ((int64_t)U.b * seq_o + U.h * HD); };
+  auto pl = [&](const Unit& U) { return lse + ((int64_t)U.b * H + U.h) * L; };
+  Unit Up = unit_at(0), Uc = Up, Un = unit_at(1), Unn = unit_at(2);
+  // ---- copies.  Source = wave-uniform base + 32-bit lane offset; padded rows (>= L) repeat row L-1: whatever they hold is multiplied
+  // by P = 0 / dS = 0 (padded queries have Ls = -inf, padded keys start S at -inf) or never stored.
+  auto copy_piece = [&](const T* base, int64_t ld, int row0, int piece, uint32_t dst) {
+    const int row = min(row0 + piece * 8 + (lz >> 3), L - 1);
+    const uint32_t off = (uint32_t)row * (uint32_t)(ld * 2) + (uint32_t)(db ^ ((piece & 1) << 5));
+    const uint64_t bp = (uint64_t)base;
+    const uint64_t sb = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(bp >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)bp);
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(off), "s"(sb), "s"(dst) : "memory", "m0");
+  };
+  // record of query tile tx of unit U -> ring slot: 12 pieces, this wave's are o = wave, wave + 8 -> array o >> 2 (Q, dO, O), piece o & 3
+  auto issue_record_op = [&](const Unit& U, int tx, int slot, int i) {   // i = 0, 1: this wave's first / second piece
+    const uint32_t dst = rg_lds + (uint32_t)slot * REC;
+    const int o = wave + 8 * i;
+    if (o < 12) {
+      const int arr = o >> 2, p = o & 3;
+      copy_piece(arr == 0 ? pq(U) : (arr == 1 ? pd(U) : po(U)), arr == 0 ? ldq : ldo, tx * 32, p, __builtin_amdgcn_readfirstlane(dst + arr * 4096 + p * 1024));
+    }
+  };
+  auto issue_record = [&](const Unit& U, int tx, int slot) {
+    issue_record_op(U, tx, slot, 0);
+    issue_record_op(U, tx, slot, 1);
+  };
+  const int rec_ops = wave < 4 ? 2 : 1;
+  // K of unit U -> Kb[par]; 28 pieces, 7 per call (part 0..3), one per wave 0..6
+  auto issue_k = [&](const Unit& U, int par, int part) {
+    if (wave < 7) {
+      const int piece = part * 7 + wave;
+      copy_piece(pq(U) + H * HD, ldq, 0, piece, __builtin_amdgcn_readfirstlane(kb_lds + (uint32_t)par * KB + piece * 1024));
+    }
+  };
+  const int k_ops = wave < 7 ? 1 : 0;
+  auto ops_at = [&](int t) { return rec_ops + ((t >= 1 && t <= 4) ? k_ops : 0); };   // copies this wave issues in a step at position t
+  auto wait_vm = [&](int n) {   // n is wave-uniform, 0..6
+    switch (n) {
+      case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+      case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+      case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+      case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+      case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+      case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+      default: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+    }
+  };
+  auto block_sync = [] {   // barrier that does not drain vmcnt
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  };
+  // row statistics of the query tile in ring slot `slot` (tile tx of its unit) -> St[par]; service wave only
+  auto stats = [&](int slot, int tx, int par, float lse_v) {
+    const char* rec = Rg + slot * REC;
+    float delta = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      float a[8], c2[8];
+      unpack_chunk<T>(*(const u32x4*)(rec + 4096 + fo(ks)), a);
+      unpack_chunk<T>(*(const u32x4*)(rec + 8192 + fo(ks)), c2);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) delta += a[e] * c2[e];
+    }
+    delta += __shfl_xor(delta, 32, 64);
+    if (g == 0) {
+      float* st = St + par * 64;
+      st[ql] = tx * 32 + ql < L ? -lse_v * LOG2E_B : -INFINITY;
+      st[32 + ql] = -delta * scale;
+    }
+  };
+
+  // ---------------------------------------------------------------- fill: K of unit 0, records 0 .. NS-2 (all of unit 0: NS-1 <= NT)
+#pragma unroll
+  for (int part = 0; part < 4; ++part) issue_k(Uc, 0, part);
+#pragma unroll
+  for (int x = 0; x < NS - 1; ++x) issue_record(Uc, x, x);
+  u32x4 kf[4], vf[4];
+  const int key = wave * 32 + ql;          // pair waves: the key of this lane
+  const float s_init = key < L ? 0.f : -INFINITY;   // padded keys: S = -inf -> P = 0 -> no contribution to dQ
+  if (wave == 7) {
+    float l[4];
+#pragma unroll
+    for (int x = 0; x < 4; ++x) l[x] = pl(Uc)[min(x * 32 + ql, L - 1)];
+    if (g == 0) {
+#pragma unroll
+      for (int x = 1; x < 4; ++x) Lq[x * 32 + ql] = l[x];
+    }
+    wait_vm(2 * rec_ops);   // K, records 0 and 1 (records 2, 3 may still fly)
+    block_sync();
+    stats(0, 0, 0, l[0]);
+  } else {
+    const int kc = min(key, L - 1);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) vf[ks] = *(const u32x4*)(pq(Uc) + (int64_t)kc * ldq + 2 * H * HD + (2 * ks + g) * 8);
+    wait_vm(2 * rec_ops);
+    block_sync();
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) kf[ks] = *(const u32x4*)(Kb + wave * 4096 + fo(ks));
+  }
+  // ---------------------------------------------------------------- steps
+  // service wave: dQ rows [tx * 32, +32) of unit U from the seven dS images of parity par and the K tile kpar
+  auto dq_tile = [&](const Unit& U, int tx, int par, int kpar) {
+    const char* img0 = Im + par * (NT * IMG);
+    const char* tK = Kb + kpar * KB;
+    f32x16 acc[2][2];   // [d half][cc]: four independent MFMA chains, added at the end
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    // software pipeline over the key tiles: the operands of key tile kt+1 are read while the MFMAs of key tile kt run; the scheduling
+    // fences keep it at two stages (fully unrolled and unfenced, hipcc hoists all 84 transpose reads and spills)
+    u32x4 av[2][2][2], bv[2][2];   // [stage][cc][dt], [stage][cc]
+    auto load_stage = [&](int kt, int st) {
+#pragma unroll
+      for (int cc = 0; cc < 2; ++cc) {
+        const u32x2 lo = tr8(img0 + kt * IMG + ir(cc, 0)), hi = tr8(img0 + kt * IMG + ir(cc, 1));
+        const uint32_t lx = lo.x, ly = lo.y, hx = hi.x, hy = hi.y;
+        bv[st][cc] = mk4(lx, ly, hx, hy);
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) av[st][cc][dt] = tr_chunk(tK, kt * 32 + 16 * cc, dt);
+      }
+    };
+    load_stage(0, 0);
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt) {
+      if (kt + 1 < NT) load_stage(kt + 1, (kt + 1) & 1);
+#pragma unroll
+      for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) mma_chunk<T>(acc[dt][cc], av[kt & 1][cc][dt], bv[kt & 1][cc]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    const int q = tx * 32 + ql;
+    T* gq = pg(U);
+    if (q < L) {
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq) {
+          const uint32_t lo = pack2(acc[dt][0][4 * rq] + acc[dt][1][4 * rq], acc[dt][0][4 * rq + 1] + acc[dt][1][4 * rq + 1], (T*)0);
+          const uint32_t hi = pack2(acc[dt][0][4 * rq + 2] + acc[dt][1][4 * rq + 2], acc[dt][0][4 * rq + 3] + acc[dt][1][4 * rq + 3], (T*)0);
+          __builtin_nontemporal_store(mk2(lo, hi), (u32x2*)(gq + (int64_t)q * ldq + dt * 32 + 8 * rq + 4 * g));
+        }
+    }
+  };
+  int slot_use = 0, slot_new = NS - 1;   // ring slots of record s (read by the pairs) and of record s + NS - 1 (filled now); both advance mod NS
+  // start of step s (position t in its unit): every wave waits for its own copies of record s+1 (at t == 6: of the next unit's K too),
+  // then the barrier makes them visible and retires step s-1; then this wave's copies for record s + NS - 1 (and K at t = 1..4)
+  auto step_begin = [&](int s, int t, int ui) {
+    const int tm1 = t == 0 ? 6 : t - 1, tm2 = tm1 == 0 ? 6 : tm1 - 1;
+    if (s >= 80 && s <= 82) ALPRO_TS((s - 80) * 5);       // measurement build: steps 80..82 of the stamped workgroup, 5 stamps each
+    if (wave == 7) {
+      // service wave: it consumes its plain loads (lse, touches) at the end of every step, and loads return in order, so its one copy per
+      // step has landed by then as well (an L2 hit, thanks to the touches three steps earlier)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else
+      wait_vm(ops_at(tm1) + (t == 6 ? 0 : ops_at(tm2)));
+    if (s >= 80 && s <= 82) ALPRO_TS((s - 80) * 5 + 1);
+    block_sync();
+    fresh();
+    if (s >= 80 && s <= 82) ALPRO_TS((s - 80) * 5 + 2);
+  };
+  // this wave's copies of the step, one at a time (j = 0, 1: record pieces, 2: the K piece at t = 1..4).  A copy holds its wave at issue
+  // for as long as the CU's copy path needs for the 1 KiB pieces queued before it (~80 cycles each: all 8 waves issuing right behind the
+  // barrier stood still for 1500-2400 cycles per step), so the pair waves spread theirs between their MFMA blocks, the lower and the upper
+  // wave of a SIMD at different points.
+  auto step_copy = [&](int t, int ui, int j) {
+    if (j == 2) {
+      if (t >= 1 && t <= 4) issue_k(Un, (ui + 1) & 1, t - 1);
+    } else if (t + NS - 1 < NT) issue_record_op(Uc, t + NS - 1, slot_new, j);
+    else issue_record_op(Un, t + NS - 1 - NT, slot_new, j);
+  };
+  auto next_step = [&] {
+    slot_use = slot_use + 1 == NS ? 0 : slot_use + 1;
+    slot_new = slot_new + 1 == NS ? 0 : slot_new + 1;
+  };
+  auto next_unit = [&](int ui) {
+    Up = Uc;
+    Uc = Un;
+    Un = Unn;
+    Unn = unit_at(ui + 3);
+  };
+  // Two loops with the same barrier sequence, so that what the service wave carries from step to step (touches in flight, lse queue) is
+  // not live in the pair waves' loop, and the pair state (dK^T / dV^T accumulators, K / V fragments: 96 registers) not in the service loop.
+  if (wave == 7) {
+    // ================================================================ service wave
+    // L2 warm-up: one dword of every 128-byte line the copies of the coming steps will ask for, 3 steps before they do -- the copy engine
+    // holds few requests, and at HBM latency they turn over slowly (profiles/r3_attn_bwd_phase_stamps.txt).  Per step: lanes 0-31 row ql
+    // of record s+7 (tile t of the next unit) in Q / dO / O; the other lanes rows of the next units' K / V by step position.  A touch is
+    // consumed (its register released) three steps after its issue.
+    uint32_t tq[3][4];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) tq[i][j] = 0;
+#pragma unroll 1
+    for (int ui = 0; ui < nu; ++ui) {
+#pragma unroll 1
+      for (int t = 0; t < NT; ++t) {
+        const int s = ui * NT + t;
+        step_begin(s, t, ui);
+        step_copy(t, ui, 0);   // (the service wave has one piece per step and no K piece)
+        const int t4 = t + NS - 1;
+        const float lse_in = pl(t4 < NT ? Uc : Un)[min((t4 < NT ? t4 : t4 - NT) * 32 + ql, L - 1)];
+        asm volatile("" ::"v"(tq[0][0]), "v"(tq[0][1]), "v"(tq[0][2]), "v"(tq[0][3]));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          tq[0][j] = tq[1][j];
+          tq[1][j] = tq[2][j];
+        }
+        if (flags & 1) {
+          const int64_t rrow = min(t * 32 + ql, L - 1);
+          const int64_t vrow = min(192 + ql, L - 1);
+          const int64_t krow = min((t == 0 ? 192 : (t <= 3 ? (t - 1) * 64 : (t - 4) * 64)) + lane, L - 1);
+          const T* qn = pq(Un);
+          const T* kv = t == 0 ? qn + H * HD : (t <= 3 ? qn + 2 * H * HD : pq(Unn) + H * HD);   // K(next) tail | V(next) | K(next+1)
+          tq[2][0] = *(const uint32_t*)(g == 0 ? qn + rrow * ldq : qn + vrow * ldq + 2 * H * HD);   // Q rows | V(next) tail
+          tq[2][1] = *(const uint32_t*)(pd(Un) + rrow * ldo);
+          tq[2][2] = *(const uint32_t*)(po(Un) + rrow * ldo);
+          tq[2][3] = *(const uint32_t*)(kv + krow * ldq);
+        }
+        if (s > 0) {
+          if (t == 0) dq_tile(Up, NT - 1, (s - 1) & 1, (ui - 1) & 1);
+          else dq_tile(Uc, t - 1, (s - 1) & 1, ui & 1);
+        }
+        if (s + 1 < S) {
+          const int sl1 = slot_use + 1 == NS ? 0 : slot_use + 1;
+          stats(sl1, t + 1 == NT ? 0 : t + 1, (s + 1) & 1, Lq[((s + 1) & 7) * 32 + ql]);
+        }
+        if (g == 0) Lq[((s + NS - 1) & 7) * 32 + ql] = lse_in;
+        if (s >= 80 && s <= 82) ALPRO_TS((s - 80) * 5 + 4);
+        next_step();
+      }
+      next_unit(ui);
+    }
+    step_begin(S, 0, nu);   // step S: the last dQ tile
+    step_copy(0, nu, 0);
+    dq_tile(Up, NT - 1, (S - 1) & 1, (nu - 1) & 1);
+    asm volatile("" ::"v"(tq[0][0]), "v"(tq[0][1]), "v"(tq[0][2]), "v"(tq[0][3]), "v"(tq[1][0]), "v"(tq[1][1]), "v"(tq[1][2]), "v"(tq[1][3]),
+                 "v"(tq[2][0]), "v"(tq[2][1]), "v"(tq[2][2]), "v"(tq[2][3]));
+  } else {
+    // ================================================================ pair waves: (query tile s, key tile `wave`)
+#pragma unroll 1
+    for (int ui = 0; ui < nu; ++ui) {
+      f32x16 dk[2], dv[2];
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dk[dt][r] = dv[dt][r] = 0.f;
+#pragma unroll 1
+      for (int t = 0; t < NT; ++t) {
+        const int s = ui * NT + t;
+        step_begin(s, t, ui);
+        const char* rec = Rg + slot_use * REC;
+        const char* tQ = rec;
+        const char* tD = rec + 4096;
+        const float* st = St + (s & 1) * 64;
+        char* img = Im + ((s & 1) * NT + wave) * IMG;
+        f32x16 sc, dp;
+        float si = s_init;
+        asm volatile("" : "+v"(si));   // (not hoisted as a 16-register splat, which then spills)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          sc[r] = si;
+          dp[r] = 0.f;
+        }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          const u32x4 qa = *(const u32x4*)(tQ + fo(ks));
+          const u32x4 da = *(const u32x4*)(tD + fo(ks));
+          mma_chunk<T>(sc, qa, kf[ks]);
+          mma_chunk<T>(dp, da, vf[ks]);
+        }
+        if (wave < 4) step_copy(t, ui, 0);
+        if (t == NT - 1 && ui + 1 < nu) {   // kf / vf are dead for this unit: fetch the next unit's
+          const int kc = min(key, L - 1);
+          const char* tKn = Kb + ((ui + 1) & 1) * KB;
+#pragma unroll
+          for (int ks = 0; ks < 4; ++ks) {
+            vf[ks] = *(const u32x4*)(pq(Un) + (int64_t)kc * ldq + 2 * H * HD + (2 * ks + g) * 8);
+            kf[ks] = *(const u32x4*)(tKn + wave * 4096 + fo(ks));
+          }
+        }
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq) {
+          const float4 lq = *(const float4*)(st + 8 * rq + 4 * g);
+          const float4 dq4 = *(const float4*)(st + 32 + 8 * rq + 4 * g);
+          const float ll[4] = {lq.x, lq.y, lq.z, lq.w};
+          const float dd[4] = {dq4.x, dq4.y, dq4.z, dq4.w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int r = 4 * rq + e;
+            const float p = __builtin_amdgcn_exp2f(fmaf(sc[r], sl, ll[e]));
+            sc[r] = p;
+            dp[r] = p * fmaf(dp[r], scale, dd[e]);  // dS
+          }
+        }
+        if (wave >= 4) step_copy(t, ui, 0);
+#pragma unroll
+        for (int cc = 0; cc < 2; ++cc) {
+          float pv[8], sv[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            pv[e] = sc[cc * 8 + e];
+            sv[e] = dp[cc * 8 + e];
+          }
+          const u32x4 pb = pack_chunk<T>(pv), sb = pack_chunk<T>(sv);
+          *(u32x2*)(img + iw(cc, 0)) = mk2(sb.x, sb.y);
+          *(u32x2*)(img + iw(cc, 1)) = mk2(sb.z, sb.w);
+#pragma unroll
+          for (int dt = 0; dt < 2; ++dt) {
+            mma_chunk<T>(dv[dt], tr_chunk(tD, 16 * cc, dt), pb);
+            mma_chunk<T>(dk[dt], tr_chunk(tQ, 16 * cc, dt), sb);
+          }
+          if (cc == 0) {
+            if (wave < 4) step_copy(t, ui, 1);
+            else step_copy(t, ui, 2);
+          }
+        }
+        if (wave < 4) step_copy(t, ui, 2);
+        if (s >= 80 && s <= 82) ALPRO_TS((s - 80) * 5 + 4);
+        next_step();
+      }
+      if (key < L) {
+        T* gk = pg(Uc) + (int64_t)key * ldq;
+        store_row64<T>(gk + H * HD, dk, lane);
+        store_row64<T>(gk + 2 * H * HD, dv, lane);
+      }
+      next_unit(ui);
+    }
+    step_begin(S, 0, nu);   // step S: nothing left to pair
+    step_copy(0, nu, 0);
+    step_copy(0, nu, 1);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the repeats issued by the last steps
 }
 
 // ================================================================================================
@@ -713,16 +1385,44 @@ __global__ __launch_bounds__(256, 2) void attn_temporal_bwd16_kernel(const T* __
   }
 }
 
-template <typename T, int NKT, bool HAS_BIAS>
+template <typename T, int NKT, bool HAS_BIAS, bool DROP>
 int launch_bwd16(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, int batch, int L, int H, float scale,
                  const float* key_bias, float dp, uint32_t ds, hipStream_t st) {
   const size_t lds = 2 * (size_t)NKT * 32 * 128 + 4 * (NKT == 8 ? 2048 : 4096) + 3 * (size_t)NKT * 32 * sizeof(float);
   static DeviceOnce attr_once;
   attr_once.run([&] {
-    (void)hipFuncSetAttribute((const void*)attn_bwd16_kernel<T, NKT, HAS_BIAS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)attn_bwd16_kernel<T, NKT, HAS_BIAS, DROP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   });
-  hipLaunchKernelGGL((attn_bwd16_kernel<T, NKT, HAS_BIAS>), dim3((unsigned)(batch * H)), dim3(256), lds, st, (const T*)qkv, (const T*)out, (const T*)dout,
+  hipLaunchKernelGGL((attn_bwd16_kernel<T, NKT, HAS_BIAS, DROP>), dim3((unsigned)(batch * H)), dim3(256), lds, st, (const T*)qkv, (const T*)out, (const T*)dout,
                      lse, (T*)dqkv, L, H, scale, key_bias, dp, ds);
+  return check_launch("alpro_attn_bwd");
+}
+
+template <typename T, int NKT, bool DROP>
+int launch_bwd16k(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, int batch, int L, int H, float scale,
+                  const float* key_bias, float dp, uint32_t ds, hipStream_t st) {
+  constexpr int LP = NKT * 32;
+  const size_t lds = 3 * (size_t)LP * 128 + (size_t)(NKT <= 7 ? 4 : 3) * NKT * 2048 + 3 * (size_t)LP * sizeof(float);
+  static DeviceOnce attr_once;
+  attr_once.run([&] {
+    (void)hipFuncSetAttribute((const void*)attn_bwd16k_kernel<T, NKT, DROP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  });
+  hipLaunchKernelGGL((attn_bwd16k_kernel<T, NKT, DROP>), dim3((unsigned)(batch * H)), dim3(512), lds, st, (const T*)qkv, (const T*)out, (const T*)dout,
+                     lse, (T*)dqkv, L, H, scale, key_bias, dp, ds);
+  return check_launch("alpro_attn_bwd");
+}
+
+template <typename T>
+int launch_bwd16p(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, int batch, int L, int H, float scale,
+                  int flags, hipStream_t st) {
+  const size_t lds = 2 * 7 * 4096 + 2 * 7 * 2048 + 5 * 3 * 4096 + (2 * 64 + 8 * 32) * sizeof(float);
+  static DeviceOnce attr_once;
+  attr_once.run([&] {
+    (void)hipFuncSetAttribute((const void*)attn_bwd16p_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  });
+  const int units = batch * H;
+  hipLaunchKernelGGL((attn_bwd16p_kernel<T>), dim3((unsigned)(units < 256 ? units : 256)), dim3(512), lds, st, (const T*)qkv, (const T*)out,
+                     (const T*)dout, lse, (T*)dqkv, L, H, scale, units, flags);
   return check_launch("alpro_attn_bwd");
 }
 
@@ -745,11 +1445,31 @@ int dispatch_bwd(const void* qkv, const void* out, const void* dout, const float
   const int nkt = (L + 31) / 32;
   const int64_t rows = (int64_t)batch * L;
   if constexpr (sizeof(T) == 2) {
-#define ALPRO_BWD16(N)                                                                                              \
-  return key_bias ? launch_bwd16<T, N, true>(qkv, out, dout, lse, dqkv, batch, L, H, scale, key_bias, dp, ds, st)   \
-                  : launch_bwd16<T, N, false>(qkv, out, dout, lse, dqkv, batch, L, H, scale, key_bias, dp, ds, st)
+#define ALPRO_BWD16(N)                                                                                                          \
+  do {                                                                                                                          \
+    if (ds)                                                                                                                     \
+      return key_bias ? launch_bwd16<T, N, true, true>(qkv, out, dout, lse, dqkv, batch, L, H, scale, key_bias, dp, ds, st)     \
+                      : launch_bwd16<T, N, false, true>(qkv, out, dout, lse, dqkv, batch, L, H, scale, key_bias, dp, ds, st);   \
+    return key_bias ? launch_bwd16<T, N, true, false>(qkv, out, dout, lse, dqkv, batch, L, H, scale, key_bias, dp, ds, st)      \
+                    : launch_bwd16<T, N, false, false>(qkv, out, dout, lse, dqkv, batch, L, H, scale, key_bias, dp, ds, st);    \
+  } while (0)
     if (nkt <= 2) ALPRO_BWD16(2);
     if (nkt <= 4) ALPRO_BWD16(4);
+    // attn_bwd option: 0 two-phase everywhere; 1 (default) the measured best per shape: key-owned with 8 key tiles (fusion encoder,
+    // L = 237: 0.48 vs 0.54 ms at 256 sequences), two-phase below (ViT spatial L = 197: 0.55 vs 0.63 ms at 512 sequences -- one 8-wave
+    // workgroup per CU leaves its input latency uncovered); 2 key-owned wherever it applies (>= 5 key tiles); 3 / 4 the persistent
+    // key-owned kernel with / without its L2 touches where IT applies (7 key tiles, no bias, no dropout), else as 2.
+    const int kind = get_option(OPT_ATTN_BWD);
+    if (nkt == 7 && !key_bias && !ds && kind >= 3)
+      return launch_bwd16p<T>(qkv, out, dout, lse, dqkv, batch, L, H, scale, kind == 3 ? 1 : 0, st);
+    if ((nkt >= 5 && kind >= 2) || (nkt == 8 && kind == 1)) {   // every (query tile, key tile) pair once, one 8-wave workgroup per CU
+#define ALPRO_BWD16K(N)                                                                                        \
+  return ds ? launch_bwd16k<T, N, true>(qkv, out, dout, lse, dqkv, batch, L, H, scale, key_bias, dp, ds, st)   \
+            : launch_bwd16k<T, N, false>(qkv, out, dout, lse, dqkv, batch, L, H, scale, key_bias, dp, ds, st)
+      if (nkt <= 7) ALPRO_BWD16K(7);
+      ALPRO_BWD16K(8);
+#undef ALPRO_BWD16K
+    }
     if (nkt <= 7) ALPRO_BWD16(7);
     ALPRO_BWD16(8);
 #undef ALPRO_BWD16
@@ -800,3 +1520,17 @@ extern "C" int alpro_attn_temporal_bwd(const void* qkv, const void* out, const v
   ALPRO_DISPATCH_DTYPE(dtype, T_, return (launch_bwd<T_, 1, 1, true>(qkv, out, dout, lse, dqkv, chunks, 32, H, scale, nullptr, T, rows, 0.f, 0u, (hipStream_t)stream)));
   return ALPRO_OK;
 }
+
+#ifdef ALPRO_ABLATIONS
+// measurement build only: choose the workgroup whose phases are stamped (block < 0: none) / read the 8 x 16 stamps back
+extern "C" int alpro_debug_attn_bwd_stamps(int block, unsigned long long* out128) {
+  if (out128) {
+    if (hipMemcpyFromSymbol(out128, HIP_SYMBOL(g_attn_ts), sizeof(unsigned long long) * 128) != hipSuccess) return ALPRO_ERR_LAUNCH;
+  }
+  if (hipMemcpyToSymbol(HIP_SYMBOL(g_attn_ts_block), &block, sizeof(int)) != hipSuccess) return ALPRO_ERR_LAUNCH;
+  return ALPRO_OK;
+}
+extern "C" int alpro_debug_attn_bwd_alias(int n) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_attn_alias), &n, sizeof(int)) == hipSuccess ? ALPRO_OK : ALPRO_ERR_LAUNCH;
+}
+#endif

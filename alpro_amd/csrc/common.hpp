@@ -203,7 +203,7 @@ void set_error(const char* fmt, ...);
 // Tuning knobs (measurement aids, not part of the arithmetic): initialised ONCE from the environment when the library is
 // loaded (ALPRO_GEMM_TILE / ALPRO_GEMM_GRID / ALPRO_GEMM_TUNE / ALPRO_TN_SPLITS), changed at run time only through
 // alpro_hip_set_option -- no getenv() on the launch path.  0 = "not set" for every knob except GEMM_TUNE.
-enum { OPT_GEMM_TILE = 0, OPT_GEMM_GRID = 1, OPT_GEMM_TUNE = 2, OPT_TN_SPLITS = 3, OPT_TN_KIND = 4, OPT_GEMM_TAIL = 5, OPT_COUNT = 6 };
+enum { OPT_GEMM_TILE = 0, OPT_GEMM_GRID = 1, OPT_GEMM_TUNE = 2, OPT_TN_SPLITS = 3, OPT_TN_KIND = 4, OPT_GEMM_TAIL = 5, OPT_ATTN_BWD = 6, OPT_COUNT = 7 };
 int get_option(int which);
 
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) must be applied once per (kernel, device): a per-instantiation bit mask

@@ -23,7 +23,8 @@ def attn_ref(qkv, batch, L, H, scale, bias=None, group=None):
 
 
 @pytest.mark.parametrize("dt", DTYPES)
-@pytest.mark.parametrize("batch,L,masked", [(2, 40, True), (2, 197, False), (1, 237, True), (1, 70, False)])
+@pytest.mark.parametrize("batch,L,masked", [(2, 40, True), (2, 197, False), (1, 237, True), (1, 70, False), (1, 130, False), (2, 161, True),
+                                            (1, 192, False), (1, 225, False), (2, 256, True)])
 def test_attn_bwd(dt, batch, L, masked):
     hip = _hip()
     H = 12
@@ -233,11 +234,13 @@ def test_dropout_gemm_and_backward_mask(dt):
     close(gc, g.double() * keep.double() / (1 - p), 1e-6, 1e-6, "gather_cast dropout mask")
 
 
-@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
-def test_attention_dropout_fwd_bwd(dt):
-    """Attention-probability dropout (xbert.py:331) forward and backward against autograd with the same mask."""
+@pytest.mark.parametrize("L", [70, 237])
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16, torch.float16])
+def test_attention_dropout_fwd_bwd(dt, L):
+    """Attention-probability dropout (xbert.py:331) forward and backward against autograd with the same mask (L = 237: the fusion
+    encoder's length, served by the key-owned 16-bit backward)."""
     hip = _hip()
-    batch, L, H, p, seed = 2, 70, 12, 0.1, 777
+    batch, H, p, seed = 2, 12, 0.1, 777
     qkv = (rnd(batch * L, 3 * H * 64, seed=140) * 0.7).to(dt)
     dout = rnd(batch * L, H * 64, seed=141).to(dt)
     keep = _keep_mask(seed, batch * H * L * L, p).view(batch, H, L, L).double()
@@ -247,10 +250,41 @@ def test_attention_dropout_fwd_bwd(dt):
     ref = (pr @ t[2]).transpose(1, 2).reshape(batch * L, H * 64)
     ref.backward(dout.double())
     out, lse = hip.attn(qkv.cuda(), batch, L, H, 0.125, want_lse=True, drop_p=p, drop_seed=seed)
-    tol = (2e-5, 2e-5) if dt == torch.float32 else (2e-2, 2e-2)
+    tol = {torch.float32: (2e-5, 2e-5), torch.bfloat16: (2e-2, 2e-2), torch.float16: (3e-3, 3e-3)}[dt]
     close(out, ref, *tol, "attn dropout fwd")
     dqkv = hip.attn_bwd(qkv.cuda(), out, dout.cuda(), lse, batch, L, H, 0.125, drop_p=p, drop_seed=seed)
     close(dqkv, q64.grad, *GRAD_TOL[dt], "attn dropout bwd")
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("kind", [2, 3, 4])
+@pytest.mark.parametrize("batch,L,masked,p", [(3, 197, False, 0.0), (2, 237, True, 0.1), (2, 140, False, 0.0), (1, 256, True, 0.1), (30, 197, False, 0.0),
+                                              (64, 224, False, 0.0), (22, 193, False, 0.0)])
+def test_attn_bwd_key_owned_vs_two_phase(dt, kind, batch, L, masked, p):
+    """The key-owned backward (option attn_bwd = 2: every query-tile x key-tile pair once, dS handed to the dQ contraction through LDS;
+    attn_bwd = 3 / 4: its persistent form for 7 key tiles without bias / dropout, with / without L2 touches, units walked by one workgroup
+    per CU with the next query tiles in flight -- 30 x 12 and 64 x 12 units exercise 1, 2 and 3 units per workgroup; the default,
+    attn_bwd = 1, picks per shape and is what test_attn_bwd runs) against the two-phase kernel (attn_bwd = 0)
+    on the same inputs: dK and dV run the same MFMA sequence on the same operands -> bitwise equal; dQ differs only by the fp32
+    summation order over the key tiles; and two runs are bitwise equal (no atomics)."""
+    hip = _hip()
+    H, seed = 12, (4242 if p else 0)
+    qkv = (rnd(batch * L, 3 * H * 64, seed=310 + L) * 0.7).to(dt).cuda()
+    dout = rnd(batch * L, H * 64, seed=311 + L).to(dt).cuda()
+    bias = None
+    if masked:
+        bias = torch.zeros(batch, L)
+        bias[:, L - 9:] = -10000.0
+        bias = bias.cuda()
+    out, lse = hip.attn(qkv, batch, L, H, 0.125, bias, want_lse=True, drop_p=p, drop_seed=seed)
+    with hip.option("attn_bwd", 0):
+        two = hip.attn_bwd(qkv, out, dout, lse, batch, L, H, 0.125, bias, drop_p=p, drop_seed=seed).view(batch * L, 3, H * 64)
+    with hip.option("attn_bwd", kind):
+        one = hip.attn_bwd(qkv, out, dout, lse, batch, L, H, 0.125, bias, drop_p=p, drop_seed=seed).view(batch * L, 3, H * 64)
+        again = hip.attn_bwd(qkv, out, dout, lse, batch, L, H, 0.125, bias, drop_p=p, drop_seed=seed).view(batch * L, 3, H * 64)
+    assert torch.equal(one, again)
+    assert torch.equal(one[:, 1], two[:, 1]) and torch.equal(one[:, 2], two[:, 2])
+    close(one[:, 0], two[:, 0].double().cpu(), *((2e-2, 2e-2) if dt == torch.bfloat16 else (3e-3, 3e-3)), "dQ")
 
 
 def test_embedding_dropout_and_ln_bwd_mask():
