@@ -115,7 +115,8 @@ _option_values = {}
 
 
 def set_option(name, value):
-    """Measurement knob of the library (alpro_hip_set_option): 'gemm_tile', 'gemm_grid', 'gemm_tune', 'tn_splits' (token ranges of the
+    """Measurement knob of the library (alpro_hip_set_option): 'attn_bwd' (16-bit attention backward with 5-8 key tiles: 0 two-phase,
+    1 = default, best per shape, 2 key-owned, 3 / 4 persistent key-owned with / without L2 touches), 'gemm_tile', 'gemm_grid', 'gemm_tune', 'tn_splits' (token ranges of the
     weight-gradient GEMM), 'tn_kind' (1 = no wgrad epilogue, timing only)."""
     _check(load().alpro_hip_set_option(name.encode(), int(value)), "alpro_hip_set_option")
     _option_values[name] = int(value)
