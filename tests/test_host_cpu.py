@@ -92,6 +92,14 @@ def test_product_library_refuses_result_corrupting_knobs():
     hip.set_option("gemm_tune", 2)
     hip.set_option("gemm_tune", 1)
     assert hip._DETERMINISTIC_WGRAD[0] is True        # bit-reproducible weight gradients are the default, atomics the opt-in
+    # every knob the binding knows is a knob of the library (names resolved by alpro_hip_set_option), and its built-in default is accepted;
+    # attn_bwd (round 3): 0 two-phase .. 4 persistent without touches, all result-preserving, so none of them is an ablation
+    for name, dflt in hip._OPTION_DEFAULTS.items():
+        hip.set_option(name, dflt)
+    for kind in (0, 2, 3, 4, 1):
+        hip.set_option("attn_bwd", kind)
+    with pytest.raises(RuntimeError):
+        hip.set_option("no_such_knob", 1)
 
 
 def test_ops_refuse_cpu_tensors():
