@@ -264,7 +264,7 @@ constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
 template <typename T, int NKT, bool HAS_BIAS>
 __global__ __launch_bounds__(256, 2) void attn_fwd16_kernel(const T* __restrict__ qkv, T* __restrict__ out, int L, int H, float scale,
                                                             const float* __restrict__ key_bias, float* __restrict__ lse, float drop_p,
-                                                            uint32_t drop_seed) {
+                                                            uint32_t drop_seed, int order) {
   static_assert(sizeof(T) == 2, "16-bit storage only");
   constexpr int LP = NKT * 32, RB = 128;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -275,7 +275,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd16_kernel(const T* __restrict_
   constexpr int OW = HALF ? 2048 : 4096;
   float* Bs = (float*)(Os + 4 * OW);      // additive key bias * log2(e); -inf on the padded keys
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int b = blockIdx.x / H, h = blockIdx.x - b * H;
+  int b, h;
+  attn_unit(blockIdx.x, gridDim.x, H, order, b, h);
   for (int c = tid; c < LP; c += 256) Bs[c] = c < L ? (HAS_BIAS ? key_bias[(int64_t)b * L + c] * LOG2E : 0.f) : -INFINITY;
   const int64_t ldq = 3 * (int64_t)H * HD;  // elements per token row of qkv
   const T* base = qkv + (int64_t)b * L * ldq + h * HD;
@@ -606,7 +607,7 @@ int launch_attn16(const void* qkv, void* out, int batch, int L, int H, float sca
   attr_once.run([&] {
     (void)hipFuncSetAttribute((const void*)attn_fwd16_kernel<T, NKT, HAS_BIAS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   });
-  hipLaunchKernelGGL((attn_fwd16_kernel<T, NKT, HAS_BIAS>), dim3(batch * H), dim3(256), lds, st, (const T*)qkv, (T*)out, L, H, scale, key_bias, lse, drop_p, drop_seed);
+  hipLaunchKernelGGL((attn_fwd16_kernel<T, NKT, HAS_BIAS>), dim3(batch * H), dim3(256), lds, st, (const T*)qkv, (T*)out, L, H, scale, key_bias, lse, drop_p, drop_seed, get_option(OPT_ATTN_ORDER));
   return check_launch("alpro_attn_fwd");
 }
 

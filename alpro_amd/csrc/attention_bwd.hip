@@ -338,7 +338,7 @@ template <typename T, int NKT, bool HAS_BIAS, bool DROP>
 __global__ __launch_bounds__(256, 2) void attn_bwd16_kernel(const T* __restrict__ qkv, const T* __restrict__ out,
                                                                           const T* __restrict__ dout, const float* __restrict__ lse,
                                                                           T* __restrict__ dqkv, int L, int H, float scale,
-                                                                          const float* __restrict__ key_bias, float drop_p, uint32_t drop_seed) {
+                                                                          const float* __restrict__ key_bias, float drop_p, uint32_t drop_seed, int order) {
   static_assert(sizeof(T) == 2, "16-bit storage only");
   constexpr int LP = NKT * 32, RB = 128;
   constexpr bool HALF = NKT == 8;             // 8 key tiles: 2 KiB staging per wave keeps two workgroups per CU (2 x 75 KiB)
@@ -351,7 +351,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd16_kernel(const T* __restrict_
   float* Ls = Bs + LP;                   // -lse * log2(e); -inf on padded queries
   float* Ds = Ls + LP;                   // delta * scale
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int b = blockIdx.x / H, h = blockIdx.x - b * H;
+  int b, h;
+  attn_unit(blockIdx.x, gridDim.x, H, order, b, h);
   const int64_t row0 = (int64_t)b * L;
   const int64_t ldq = 3 * (int64_t)H * HD, ldo = (int64_t)H * HD;
   const T* qb = qkv + row0 * ldq + h * HD;
@@ -607,7 +608,7 @@ template <typename T, int NKT, bool DROP>
 __global__ __launch_bounds__(512) void attn_bwd16k_kernel(const T* __restrict__ qkv, const T* __restrict__ out,
                                                                         const T* __restrict__ dout, const float* __restrict__ lse,
                                                                         T* __restrict__ dqkv, int L, int H, float scale,
-                                                                        const float* __restrict__ key_bias, float drop_p, uint32_t drop_seed) {
+                                                                        const float* __restrict__ key_bias, float drop_p, uint32_t drop_seed, int order) {
   static_assert(sizeof(T) == 2 && NKT >= 5 && NKT <= 8, "16-bit storage, 5..8 key tiles");
   constexpr int LP = NKT * 32, RB = 128;
   constexpr int RQ = NKT <= 7 ? 4 : 3;   // query tiles per round
@@ -621,7 +622,8 @@ __global__ __launch_bounds__(512) void attn_bwd16k_kernel(const T* __restrict__ 
   float* Ls = Bs + LP;                 // -lse * log2(e); -inf on padded queries
   float* Ds = Ls + LP;                 // -delta * scale
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int b = blockIdx.x / H, h = blockIdx.x - b * H;
+  int b, h;
+  attn_unit(blockIdx.x, gridDim.x, H, order, b, h);
   const int64_t row0 = (int64_t)b * L;
   const int64_t ldq = 3 * (int64_t)H * HD, ldo = (int64_t)H * HD;
   const T* qb = qkv + row0 * ldq + h * HD;
@@ -1394,7 +1396,7 @@ int launch_bwd16(const void* qkv, const void* out, const void* dout, const float
     (void)hipFuncSetAttribute((const void*)attn_bwd16_kernel<T, NKT, HAS_BIAS, DROP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   });
   hipLaunchKernelGGL((attn_bwd16_kernel<T, NKT, HAS_BIAS, DROP>), dim3((unsigned)(batch * H)), dim3(256), lds, st, (const T*)qkv, (const T*)out, (const T*)dout,
-                     lse, (T*)dqkv, L, H, scale, key_bias, dp, ds);
+                     lse, (T*)dqkv, L, H, scale, key_bias, dp, ds, get_option(OPT_ATTN_ORDER));
   return check_launch("alpro_attn_bwd");
 }
 
@@ -1408,7 +1410,7 @@ int launch_bwd16k(const void* qkv, const void* out, const void* dout, const floa
     (void)hipFuncSetAttribute((const void*)attn_bwd16k_kernel<T, NKT, DROP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   });
   hipLaunchKernelGGL((attn_bwd16k_kernel<T, NKT, DROP>), dim3((unsigned)(batch * H)), dim3(512), lds, st, (const T*)qkv, (const T*)out, (const T*)dout,
-                     lse, (T*)dqkv, L, H, scale, key_bias, dp, ds);
+                     lse, (T*)dqkv, L, H, scale, key_bias, dp, ds, get_option(OPT_ATTN_ORDER));
   return check_launch("alpro_attn_bwd");
 }
 

@@ -203,7 +203,22 @@ void set_error(const char* fmt, ...);
 // Tuning knobs (measurement aids, not part of the arithmetic): initialised ONCE from the environment when the library is
 // loaded (ALPRO_GEMM_TILE / ALPRO_GEMM_GRID / ALPRO_GEMM_TUNE / ALPRO_TN_SPLITS), changed at run time only through
 // alpro_hip_set_option -- no getenv() on the launch path.  0 = "not set" for every knob except GEMM_TUNE.
-enum { OPT_GEMM_TILE = 0, OPT_GEMM_GRID = 1, OPT_GEMM_TUNE = 2, OPT_TN_SPLITS = 3, OPT_TN_KIND = 4, OPT_GEMM_TAIL = 5, OPT_ATTN_BWD = 6, OPT_COUNT = 7 };
+// Unit order of the per-(sequence, head) 16-bit attention kernels.  Workgroups go to the 8 XCDs round-robin (blockIdx % 8), each XCD with
+// its own L2.  In the identity order the 12 heads of a sequence -- adjacent 128-byte pieces of the same 4608-byte rows -- are spread over
+// 8 XCDs; order 1 gives XCD x the whole sequences b = x (mod 8), their heads in dispatch order (a bijection when the batch is a multiple of 8;
+// otherwise the identity order is kept).
+__device__ __forceinline__ void attn_unit(int blk, int nblk, int H, int order, int& b, int& h) {
+  const int batch = nblk / H;
+  if (order == 1 && (batch & 7) == 0) {
+    const int x = blk & 7, i = blk >> 3, j = i / H;
+    h = i - j * H;
+    b = j * 8 + x;
+  } else {
+    b = blk / H;
+    h = blk - b * H;
+  }
+}
+enum { OPT_GEMM_TILE = 0, OPT_GEMM_GRID = 1, OPT_GEMM_TUNE = 2, OPT_TN_SPLITS = 3, OPT_TN_KIND = 4, OPT_GEMM_TAIL = 5, OPT_ATTN_BWD = 6, OPT_ATTN_ORDER = 7, OPT_COUNT = 8 };
 int get_option(int which);
 
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) must be applied once per (kernel, device): a per-instantiation bit mask

@@ -287,6 +287,33 @@ def test_attn_bwd_key_owned_vs_two_phase(dt, kind, batch, L, masked, p):
     close(one[:, 0], two[:, 0].double().cpu(), *((2e-2, 2e-2) if dt == torch.bfloat16 else (3e-3, 3e-3)), "dQ")
 
 
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("batch,L,masked,p", [(16, 197, False, 0.0), (8, 237, True, 0.1), (24, 40, True, 0.1)])
+def test_attention_unit_order_is_result_neutral(dt, batch, L, masked, p):
+    """Option attn_order = 1 hands whole sequences (all 12 heads) to one XCD instead of spreading the heads of a sequence over the 8 XCDs:
+    a permutation of which workgroup computes which (sequence, head) unit -- forward output, log-sum-exp and every gradient bitwise equal
+    to the identity order (batch a multiple of 8: the permutation is active)."""
+    hip = _hip()
+    H, seed = 12, (99 if p else 0)
+    qkv = (rnd(batch * L, 3 * H * 64, seed=410 + L) * 0.7).to(dt).cuda()
+    dout = rnd(batch * L, H * 64, seed=411 + L).to(dt).cuda()
+    bias = None
+    if masked:
+        bias = torch.zeros(batch, L)
+        bias[:, L - 5:] = -10000.0
+        bias = bias.cuda()
+    res = []
+    for order in (0, 1):
+        with hip.option("attn_order", order):
+            out, lse = hip.attn(qkv, batch, L, H, 0.125, bias, want_lse=True, drop_p=p, drop_seed=seed)
+            dq = hip.attn_bwd(qkv, out, dout, lse, batch, L, H, 0.125, bias, drop_p=p, drop_seed=seed)
+            with hip.option("attn_bwd", 2):
+                dq2 = hip.attn_bwd(qkv, out, dout, lse, batch, L, H, 0.125, bias, drop_p=p, drop_seed=seed)
+        res.append((out, lse, dq, dq2))
+    for a, b2 in zip(res[0], res[1]):
+        assert torch.equal(a, b2)
+
+
 def test_embedding_dropout_and_ln_bwd_mask():
     hip = _hip()
     D, p, seed = 768, 0.1, 999
