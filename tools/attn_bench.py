@@ -16,7 +16,11 @@ def timeit(fn, n=10):
     for _ in range(n): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n
-for name, batch, L, bias, dp in [("vit spatial B=64", 512, 197, False, 0.0), ("vit spatial B=32", 256, 197, False, 0.0), ("bert text", 64, 40, True, 0.1), ("fusion pos", 64, 237, True, 0.1), ("fusion 4B", 256, 237, True, 0.1)]:
+# "head-major": the same 6144 (sequence, head) units as ONE-head sequences, i.e. rows of [q | k | v] = 384 bytes, a unit's 197 rows contiguous
+# (75 KiB) instead of 128-byte pieces of 4608-byte rows -- same arithmetic, same bytes, only the layout differs (layout experiment, round 3)
+for name, batch, L, bias, dp, H in [("vit spatial B=64", 512, 197, False, 0.0, 12), ("vit spatial B=32", 256, 197, False, 0.0, 12), ("bert text", 64, 40, True, 0.1, 12),
+                                    ("fusion pos", 64, 237, True, 0.1, 12), ("fusion 4B", 256, 237, True, 0.1, 12), ("vit B=64 head-major", 512 * 12, 197, False, 0.0, 1),
+                                    ("fusion 4B head-major", 256 * 12, 237, True, 0.1, 1)]:
     qkv = torch.randn(batch * L, 3 * H * 64, device="cuda").to(dt)
     kb = (torch.zeros(batch, L, device="cuda") if bias else None)
     fl = 4.0 * batch * H * L * L * 64
@@ -29,6 +33,7 @@ for name, batch, L, bias, dp in [("vit spatial B=64", 512, 197, False, 0.0), ("v
         ms = timeit(lambda: hip.attn_bwd(qkv, out, do, lse, batch, L, H, 0.125, key_bias=kb, drop_p=dp, drop_seed=(123 if dp else 0)))
         print("%-16s bwd batch=%d L=%d: %.3f ms  %.1f TF/s" % (name, batch, L, ms, 2.5 * fl / ms / 1e9))
 
+H = 12
 rows, T = 64 * 196 * 8, 8
 qkv = torch.randn(rows, 3 * H * 64, device="cuda").to(dt)
 if what in ("fwd", "all"):
