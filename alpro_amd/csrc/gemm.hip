@@ -616,6 +616,10 @@ __global__ __launch_bounds__(NT2, 2) void gemm_nt256p_kernel(const alpro_gemm_de
 #pragma unroll
           for (int i = 0; i < 4; ++i) fa[(s + 1) & 1][i] = *(const u32x4*)(cA + lds_off(a_row[i], 2 * (s + 1) + khalf));
         }
+        // measurement build, TUNE 5 / 6: raise this wave's issue priority over its SIMD partner's for the 8 MFMAs of the sub-step (the partner
+        // is then reading fragments or issuing copies), back to 0 for the fragment reads.  Measured neutral (round 3,
+        // profiles/r3_gemm_setprio_experiment.txt): 971-998 TF/s against 986-1004 on the long shapes, bit-identical results
+        if constexpr (TUNE == 5 || TUNE == 6) __builtin_amdgcn_s_setprio(TUNE == 5 ? 1 : 3);
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -627,6 +631,7 @@ __global__ __launch_bounds__(NT2, 2) void gemm_nt256p_kernel(const alpro_gemm_de
               if (copy_slot(TUNE, q, 1) >= 0 && pos == 1) copy_piece(copy_slot(TUNE, q, 1), ckt, cur ^ 1, copy_half);
             }
           }
+        if constexpr (TUNE == 5 || TUNE == 6) __builtin_amdgcn_s_setprio(0);
       }
     }
     block_sync();  // everyone is done with the last K-tile: its buffer takes the next tile's K-tile 1
@@ -738,6 +743,8 @@ int launch_gemm_inst(const alpro_gemm_desc_t& g, hipStream_t st) {
       (void)hipFuncSetAttribute((const void*)gemm_nt256p_kernel<T, ACT, MAP, 12>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE2_BYTES + EPI_BYTES);
       (void)hipFuncSetAttribute((const void*)gemm_nt256p_kernel<T, ACT, MAP, 11>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE2_BYTES + EPI_BYTES);
       (void)hipFuncSetAttribute((const void*)gemm_nt256p_kernel<T, ACT, MAP, 10>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE2_BYTES + EPI_BYTES);
+      (void)hipFuncSetAttribute((const void*)gemm_nt256p_kernel<T, ACT, MAP, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE2_BYTES + EPI_BYTES);   // setprio variants
+      (void)hipFuncSetAttribute((const void*)gemm_nt256p_kernel<T, ACT, MAP, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE2_BYTES + EPI_BYTES);
 #endif
     }
   });
@@ -760,6 +767,8 @@ int launch_gemm_inst(const alpro_gemm_desc_t& g, hipStream_t st) {
       if (tune == 12) { hipLaunchKernelGGL((gemm_nt256p_kernel<T, ACT, MAP, 12>), dim3(grid), dim3(NT2), 4 * TILE2_BYTES + EPI_BYTES, st, g, tail); return check_launch("alpro_gemm"); }
       if (tune == 11) { hipLaunchKernelGGL((gemm_nt256p_kernel<T, ACT, MAP, 11>), dim3(grid), dim3(NT2), 4 * TILE2_BYTES + EPI_BYTES, st, g, tail); return check_launch("alpro_gemm"); }
       if (tune == 10) { hipLaunchKernelGGL((gemm_nt256p_kernel<T, ACT, MAP, 10>), dim3(grid), dim3(NT2), 4 * TILE2_BYTES + EPI_BYTES, st, g, tail); return check_launch("alpro_gemm"); }
+      if (tune == 5) { hipLaunchKernelGGL((gemm_nt256p_kernel<T, ACT, MAP, 5>), dim3(grid), dim3(NT2), 4 * TILE2_BYTES + EPI_BYTES, st, g, tail); return check_launch("alpro_gemm"); }
+      if (tune == 6) { hipLaunchKernelGGL((gemm_nt256p_kernel<T, ACT, MAP, 6>), dim3(grid), dim3(NT2), 4 * TILE2_BYTES + EPI_BYTES, st, g, tail); return check_launch("alpro_gemm"); }
 #endif
     }
     hipLaunchKernelGGL((gemm_nt256p_kernel<T, ACT, MAP>), dim3(grid), dim3(NT2), 4 * TILE2_BYTES + EPI_BYTES, st, g, tail);
