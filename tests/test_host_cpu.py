@@ -753,3 +753,46 @@ def test_retrieval_eval_known_answers_from_the_reference():
         assert abs(dev_v2t[k] - float(ref["video2text"][k])) < 1e-9 and abs(dev_t2v[k] - float(ref["text2video"][k])) < 1e-9, k
     vals, idx = topk_on_device(s, 5)
     assert torch.equal(idx[:, 0], s.argmax(1)) and vals.shape == (37, 5)
+
+
+def test_persistent_attention_backward_copy_bookkeeping():
+    """attn_bwd16p_kernel (attention_bwd.hip) tracks its LDS copies per wave with s_waitcnt vmcnt(n): loads return in order, so "at most n
+    outstanding" means everything but this wave's n newest loads has landed.  A model of the issue order the kernel uses -- per step and
+    wave: record pieces (2 for waves 0-3, 1 for 4-7), then one K piece at step positions 1..4 (waves 0-6); record s+4 is issued in step s --
+    replayed against the kernel's n(t) = ops(t-1) + (t == 6 ? 0 : ops(t-2)): before the barrier of step s every wave must have its pieces
+    of record s+1 down, and at position 6 (where the next unit's K fragments are read from LDS at the end of the step) every K piece of the
+    next unit.  The constants are read from the source so that a change of ring depth or K schedule has to come through here."""
+    import re
+    src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "alpro_amd", "csrc", "attention_bwd.hip")).read()
+    body = src[src.index("void attn_bwd16p_kernel("):]
+    m = re.search(r"constexpr int NT = (\d+), NS = (\d+)", body)
+    NT, NS = int(m.group(1)), int(m.group(2))
+    assert "(t >= 1 && t <= 4) ? k_ops : 0" in body and "wait_vm(ops_at(tm1) + (t == 6 ? 0 : ops_at(tm2)))" in body
+    assert "wave < 4 ? 2 : 1" in body and "wave < 7 ? 1 : 0" in body and "t + NS - 1 < NT" in body
+    assert NT == 7 and NS - 1 <= NT            # the fill issues records 0 .. NS-2 of unit 0
+
+    for wave in range(7):                       # pair waves (the service wave drains to vmcnt(0): nothing to model)
+        rec_ops, k_ops = (2 if wave < 4 else 1), 1
+        ops_at = lambda t: rec_ops + (k_ops if 1 <= t <= 4 else 0)
+        issued = []                             # this wave's copies in issue order: ("K", unit) / ("R", record)
+        issued += [("K", 0)] * 4                # fill: 4 K parts (one piece per part for this wave), then records 0 .. NS-2
+        for x in range(NS - 1):
+            issued += [("R", x)] * rec_ops
+        units = 4
+        for s in range(units * NT):
+            t, ui = s % NT, s // NT
+            tm1 = 6 if t == 0 else t - 1
+            tm2 = 6 if tm1 == 0 else tm1 - 1
+            n = ops_at(tm1) + (0 if t == 6 else ops_at(tm2))
+            landed = issued[:max(0, len(issued) - n)]           # in-order return: all but the n newest
+            assert landed.count(("R", s + 1)) == rec_ops or s + 1 >= units * NT + NS, (wave, s)
+            assert landed.count(("R", s)) == rec_ops, (wave, s)
+            if t == 6:                                          # kf of unit ui+1 is read from LDS at the end of this step
+                assert landed.count(("K", ui + 1)) == 4, (wave, s)
+            if t == 0:                                          # ... and unit ui's K was complete when its first pair started
+                assert landed.count(("K", ui)) == 4, (wave, s)
+            # this step's copies, in the kernel's order: record pieces first, the K piece last
+            issued += [("R", s + NS - 1)] * rec_ops
+            if 1 <= t <= 4:
+                issued += [("K", ui + 1)]
+        assert n <= 6                           # the kernel's wait_vm switch covers 0..6
