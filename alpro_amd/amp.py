@@ -94,7 +94,8 @@ def initialize(models, optimizers=None, enabled=True, opt_level="O1", loss_scale
 
 
 def _grads_of(optimizer):
-    return [p.grad for g in optimizer.param_groups for p in g["params"] if p.grad is not None]
+    from alpro_amd.optim import real_grad
+    return [p.grad for g in optimizer.param_groups for p in g["params"] if real_grad(p) is not None]
 
 
 def unscale_(optimizer, scaler):
@@ -104,6 +105,13 @@ def unscale_(optimizer, scaler):
     inv = torch.reciprocal(scaler.scale).reshape(())
     flat = getattr(inner, "flat", None)
     if flat is not None:
+        if getattr(inner, "_inflight", None):
+            # the overlapped exchange launched from inside backward (FlatAdamW._on_grads_final) is still writing this buffer on RCCL's stream:
+            # finish it (remaining ranges go out, every handle is waited for, a 16-bit wire copy comes back) BEFORE scaling in place, and tell
+            # step() that the summed gradients are already here -- a driver that calls optimizer.synchronize() inside the with block (the
+            # reference's do) never gets here with handles pending
+            inner._finish_exchange()
+            inner._pre_synced = "sum"
         flat["g"].mul_(inv)
     else:
         grads = _grads_of(inner)
@@ -162,9 +170,18 @@ def _install_foreign_step_guard(opt, scaler):
 
 
 def master_params(optimizer):
+    """apex.amp.master_params: what the drivers hand to clip_grad_norm_ (run_pretrain_sparse.py:633).  FlatAdamW answers with ONE view over
+    its flat gradient buffer; placeholder gradients (alpro_amd.optim.zero_none_grad) are left out -- they are zeros and must not be scaled
+    in place (every element aliases one scalar)."""
+    from alpro_amd.optim import is_placeholder_grad
+    inner = getattr(optimizer, "_opt", optimizer)
+    if hasattr(inner, "master_params"):
+        yield from inner.master_params()
+        return
     for group in optimizer.param_groups:
         for p in group["params"]:
-            yield p
+            if not is_placeholder_grad(p.grad):
+                yield p
 
 
 def state_dict():

@@ -144,7 +144,7 @@ def allreduce_grads_(params, bucket_bytes=64 << 20, average=True):
     Returns the number of bytes reduced."""
     if not collectives_active():
         return 0
-    grads = [p.grad for p in params if p.grad is not None]
+    grads = [p.grad for p in params if p.grad is not None and (p.grad.dim() == 0 or p.grad.numel() <= 1 or any(p.grad.stride()))]   # (stride-0 placeholders of optim.zero_none_grad: nothing to exchange)
     sent = 0
     bucket, nbytes = [], 0
 

@@ -19,14 +19,14 @@ from alpro_amd.modeling.weights import param_version
 
 def grad_buffer(p, zero=False):
     """Return (p.grad, existed).  Allocates an fp32 buffer on first use."""
-    if p.grad is not None:
+    if p.grad is not None and (p.grad.numel() <= 1 or any(p.grad.stride())):   # (a stride-0 placeholder of optim.zero_none_grad is "no buffer yet")
         return p.grad, True
     p.grad = torch.zeros_like(p, memory_format=torch.contiguous_format) if zero else torch.empty_like(p, memory_format=torch.contiguous_format)
     return p.grad, False
 
 
 def add_grad(p, g):
-    if p.grad is None:
+    if p.grad is None or (p.grad.numel() > 1 and not any(p.grad.stride())):
         p.grad = g.detach().clone().reshape(p.shape).contiguous()
     else:
         p.grad.add_(g.reshape(p.shape))

@@ -21,6 +21,53 @@ from alpro_amd import config as rt
 from alpro_amd.modeling.weights import bump_param_epoch, register_flat_lp
 
 
+# ---- placeholder gradients: what the reference's `zero_none_grad` (src/utils/misc.py:28-31) stands for, without the bytes ------------------
+# The reference's drivers fill the gradient of every parameter that received none (the frozen prompter: 231 M values; the unused Kinetics
+# head) with zeros before the exchange, and assert afterwards that no trainable parameter has `grad is None` (run_pretrain_sparse.py:598,
+# 640-644).  Here such a parameter gets a stride-0 view of ONE shared zero scalar: `grad is not None` holds, its value is the zero tensor of
+# the right shape, and everything on this path that would move or update gradients (FlatAdamW's flat buffers and exchange, the hvd facade's
+# buckets, amp's unscale, master_params for clipping) skips it -- a zero gradient moves neither the Adam moments nor the parameter
+# (adamw.py:77-88 with weight_decay 0), so skipping it is what the reference computes, minus 0.93 GB of zeros on the wire per step.
+_ZERO = {}
+
+
+def placeholder_grad(p):
+    """Stride-0 zero gradient for `p` (shared storage per device / dtype); one-element parameters get a real zero (nothing to save)."""
+    if p.numel() <= 1:
+        return torch.zeros_like(p)
+    key = (p.device, p.dtype)
+    z = _ZERO.get(key)
+    if z is None:
+        z = _ZERO[key] = torch.zeros(1, dtype=p.dtype, device=p.device)
+    return z.expand(p.shape)
+
+
+def is_placeholder_grad(g):
+    return g is not None and g.dim() > 0 and g.numel() > 1 and not any(g.stride())
+
+
+def zero_none_grad(model):
+    """Drop-in for src.utils.misc.zero_none_grad (reference misc.py:28-31): afterwards no trainable parameter has `grad is None`."""
+    for p in model.parameters():
+        if p.grad is None and p.requires_grad:
+            p.grad = placeholder_grad(p)
+
+
+def real_grad(p):
+    """p.grad unless it is absent or a placeholder."""
+    g = p.grad
+    return None if (g is None or is_placeholder_grad(g)) else g
+
+
+class _FlatView:
+    """What amp.master_params() yields for a FlatAdamW whose flat buffers exist: ONE object whose .grad is the whole flat gradient buffer, so
+    the driver's `clip_grad_norm_(amp.master_params(optimizer), cfg.grad_norm)` (run_pretrain_sparse.py:633) is one norm and one scale over
+    0.94 GB instead of ~460 tensors (torch's clip only reads `.grad`)."""
+
+    def __init__(self, grad):
+        self.grad = grad
+
+
 class FlatAdamW:
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-6, weight_decay=0.0, correct_bias=True, max_grad_norm=None,
                  allreduce=True, bucket_elems=64 << 20, overlap_backward=None, wire_dtype=None):
@@ -56,7 +103,7 @@ class FlatAdamW:
     def _build(self):
         seen, live = set(), []
         for p in self.params:
-            if p.grad is not None and id(p) not in seen:
+            if real_grad(p) is not None and id(p) not in seen:
                 seen.add(id(p))
                 live.append(p)
         if not live:
@@ -102,6 +149,12 @@ class FlatAdamW:
                                "different set of trained parameters" % (len(lay), len(self.flat["live"])))
         for k in ("m", "v"):
             self.flat[k].copy_(sd[k].to(self.flat[k].device, torch.float32).reshape(-1))
+
+    def master_params(self):
+        """Objects carrying the gradients this optimizer will apply (for gradient clipping by the caller): the flat view once it exists."""
+        if self.flat is not None:
+            return [_FlatView(self.flat["g"])]
+        return [p for p in self.params if real_grad(p) is not None]
 
     @property
     def n_params(self):
@@ -211,8 +264,7 @@ class FlatAdamW:
             # first backward, run_pretrain_sparse.py:508-511)
             return None
         f, grp = self.flat, self.param_groups[0]
-        late = [p for p in self.params if p.grad is not None and p.grad.data_ptr() < f["g"].data_ptr()
-                or (p.grad is not None and p.grad.data_ptr() >= f["g"].data_ptr() + f["n"] * 4)]
+        late = [p for p in self.params if real_grad(p) is not None and (p.grad.data_ptr() < f["g"].data_ptr() or p.grad.data_ptr() >= f["g"].data_ptr() + f["n"] * 4)]
         if late:
             raise RuntimeError("%d parameters started receiving gradients after the flat buffers were built" % len(late))
         if pre is None:

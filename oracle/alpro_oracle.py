@@ -440,3 +440,47 @@ def det_state(kind, bert_cfg, num_frm, img_size=224, num_entities=1000, only=Non
         ck = canonical_name(k)
         p[k] = p[ck] if ck in p and ck != k else det_param(ck, shape)
     return p
+
+
+# ----------------------------------------------------------------------------- optimizer epilogue
+def warmup_linear(step, warmup_step, tot_step):
+    """src/optimization/sched.py:14-17."""
+    if step < warmup_step:
+        return step / warmup_step
+    return max(0, (tot_step - step) / (tot_step - warmup_step))
+
+
+def lr_sched(global_step, decay, learning_rate, num_train_steps, warmup_ratio=0.1):
+    """src/optimization/sched.py:28-49 (get_lr_sched), the 'linear' and 'constant' branches the release configs use."""
+    warmup_steps = int(warmup_ratio * num_train_steps)
+    if decay == "linear":
+        lr = learning_rate * warmup_linear(global_step, warmup_steps, num_train_steps)
+    elif decay == "constant":
+        lr = learning_rate
+    else:
+        raise ValueError(decay)
+    return lr if lr > 0 else 1e-8
+
+
+def clip_and_adamw_step(params, grads, exp_avg, exp_avg_sq, step, lr, betas=(0.9, 0.999), eps=1e-6, weight_decay=0.0, max_norm=None,
+                        correct_bias=True):
+    """One optimizer step of the reference's loop on lists of tensors, in place: torch.nn.utils.clip_grad_norm_
+    (run_pretrain_sparse.py:633: total 2-norm over all gradients, coefficient max_norm / (total + 1e-6) clamped to 1) followed by
+    AdamW.step (src/optimization/adamw.py:77-101: moments, bias-corrected step size, update, decoupled weight decay with the step's lr).
+    `step` counts from 1.  Returns the total gradient norm before clipping (what the driver logs)."""
+    total = torch.sqrt(sum((g.double() ** 2).sum() for g in grads)).to(grads[0].dtype)
+    coef = 1.0
+    if max_norm is not None and max_norm > 0:
+        coef = min(float(max_norm) / (float(total) + 1e-6), 1.0)
+    b1, b2 = betas
+    step_size = lr
+    if correct_bias:
+        step_size = lr * math.sqrt(1.0 - b2 ** step) / (1.0 - b1 ** step)
+    for p, g, m, v in zip(params, grads, exp_avg, exp_avg_sq):
+        g = g * coef
+        m.mul_(b1).add_(g, alpha=1.0 - b1)
+        v.mul_(b2).addcmul_(g, g, value=1.0 - b2)
+        p.addcdiv_(m, v.sqrt().add_(eps), value=-step_size)
+        if weight_decay > 0.0:
+            p.add_(p, alpha=-lr * weight_decay)
+    return float(total)

@@ -159,3 +159,27 @@ def det_caption_ids(B, Lt=40, seed_name="input_ids"):
         ids[b, n_valid:] = 0
     ids[0, 5] = 100  # an [UNK] inside a caption: special, never masked
     return ids
+
+
+# ---- optimizer trajectory (tests/golden/optimizer_adamw_3steps.npz: the reference's AdamW + get_lr_sched + clip_grad_norm_, three steps)
+OPT_SHAPES = [("enc.layer.0.weight", (37, 64)), ("enc.layer.0.bias", (64,)), ("enc.patch.weight", (8, 3, 4, 4)), ("temp", ()),
+              ("enc.layer.1.weight", (64, 37)), ("enc.norm.weight", (37,)), ("head.weight", (5, 63))]
+OPT_GRAD_SCALES = (2.4, 0.55, 0.11)   # global gradient norms of about 40, 9 and 1.9: above / between / below the two clip thresholds
+OPT_SCENARIOS = {
+    # run_pretrain_sparse.py:433 (setup_e2e_optimizer: lr + betas, eps 1e-6, weight_decay 0), :615-634 (lr set, clip at cfg.grad_norm, step)
+    "release": dict(lr=1e-4, betas=(0.9, 0.98), weight_decay=0.0, grad_norm=20.0, decay="linear", num_train_steps=10, warmup_ratio=0.1),
+    "decay": dict(lr=5e-4, betas=(0.9, 0.999), weight_decay=0.01, grad_norm=5.0, decay="constant", num_train_steps=10, warmup_ratio=0.1),
+}
+
+
+def opt_tensors(kind, step=0):
+    """Closed-form parameters (kind 'param') / gradients of `step` (kind 'grad') for the optimizer trajectory; shared with the tests."""
+    out = []
+    for name, shape in OPT_SHAPES:
+        n = int(np.prod(shape)) if len(shape) else 1
+        if kind == "param":
+            v = 0.05 * unit_uniform("opt/param/" + name, n)
+        else:
+            v = OPT_GRAD_SCALES[step] * unit_uniform("opt/grad/%d/%s" % (step, name), n)
+        out.append(torch.from_numpy(np.asarray(v, dtype=np.float32).reshape(shape)))
+    return out

@@ -19,7 +19,8 @@ import torch
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 
-from tests.golden.det_init import det_batch, det_caption_ids, det_prompts, det_raw_clips, fill_state_dict_, unit_uniform  # noqa: E402
+from tests.golden.det_init import (OPT_SCENARIOS, det_batch, det_caption_ids, det_prompts, det_raw_clips, fill_state_dict_, opt_tensors,  # noqa: E402
+                                    unit_uniform)
 from tests.golden import ref_harness as rh  # noqa: E402
 
 MLM_COL_STRIDE = 61
@@ -429,6 +430,37 @@ def case_input_pipeline(fname, B=4, T=2):
     np.savez_compressed(os.path.join(HERE, fname), **g)
 
 
+def case_optimizer(fname):
+    """a22 / N2 pinned to the reference: its own AdamW (src/optimization/adamw.py:40-103), get_lr_sched (src/optimization/sched.py:28) and
+    torch's clip_grad_norm_, driven in the order of run_pretrain_sparse.py:615-646 (lr of the step -> clip -> step -> zero_grad) for three
+    steps on closed-form parameters and gradients, in two scenarios (the release hyper-parameters; weight decay > 0 with a tighter clip)."""
+    import warnings
+    from torch.nn.utils import clip_grad_norm_
+    from src.optimization.adamw import AdamW
+    from src.optimization.sched import get_lr_sched
+    g = {}
+    for sc, hp in OPT_SCENARIOS.items():
+        params = [torch.nn.Parameter(t.clone()) for t in opt_tensors("param")]
+        opt = AdamW(params, lr=hp["lr"], betas=hp["betas"], weight_decay=hp["weight_decay"])
+        for step in range(3):
+            for p_, gr in zip(params, opt_tensors("grad", step)):
+                p_.grad = gr.clone()
+            lr_this_step = get_lr_sched(step + 1, hp["decay"], hp["lr"], hp["num_train_steps"], warmup_ratio=hp["warmup_ratio"])
+            for pg in opt.param_groups:
+                pg["lr"] = lr_this_step
+            total = clip_grad_norm_(params, hp["grad_norm"])
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")     # the deprecated add_(Number, Tensor) overloads of adamw.py:77-101 still run on this torch
+                opt.step()
+            opt.zero_grad()
+            g["%s/lr/%d" % (sc, step)] = np.float64(lr_this_step)
+            g["%s/grad_norm/%d" % (sc, step)] = np.float64(float(total))
+            g["%s/params/%d" % (sc, step)] = np.concatenate([npf(p_).reshape(-1) for p_ in params])
+        g[sc + "/exp_avg"] = np.concatenate([npf(opt.state[p_]["exp_avg"]).reshape(-1) for p_ in params])
+        g[sc + "/exp_avg_sq"] = np.concatenate([npf(opt.state[p_]["exp_avg_sq"]).reshape(-1) for p_ in params])
+    np.savez_compressed(os.path.join(HERE, fname), **g)
+
+
 def main():
     am, _ = rh.import_reference()
     torch.set_num_threads(8)
@@ -455,6 +487,8 @@ def main():
         case_input_pipeline("input_pipeline_B4_T2.npz")
     if want("pretrain_release"):
         case_pretrain_release(am, "pretrain_release_T4_L30_B2.npz")
+    if want("optimizer"):
+        case_optimizer("optimizer_adamw_3steps.npz")
     if len(keys) == 2:
         json.dump(keys, open(os.path.join(HERE, "state_keys.json"), "w"), indent=0, sort_keys=True)
     for f in sorted(os.listdir(HERE)):

@@ -478,6 +478,71 @@ def test_flat_adamw_behind_the_hvd_facade():
         ob.zero_grad()
 
 
+@pytest.mark.parametrize("scenario", ["release", "decay"])
+@pytest.mark.parametrize("drive", ["fused", "driver_order"])
+def test_flat_adamw_vs_the_reference_optimizer_trajectory(scenario, drive):
+    """a22 / N2 pinned to the reference: three steps of the REFERENCE's AdamW + get_lr_sched + torch clip_grad_norm_ on
+    closed-form parameters and gradients (tests/golden/optimizer_adamw_3steps.npz, written by make_golden.case_optimizer from
+    src/optimization/adamw.py / sched.py) against alpro_sumsq + alpro_adamw_step.  'fused': FlatAdamW(max_grad_norm=...) clips inside the
+    step kernel.  'driver_order': the sequence of run_pretrain_sparse.py:596-646 through the hvd / amp facades -- backward, zero_none_grad
+    (placeholder for the never-trained teacher), synchronize, lr of the step, torch's clip over amp.master_params (ONE flat view),
+    the none-grad assertion, skip_synchronize / step / zero_grad."""
+    _hip()
+    import sys
+    import numpy as np
+    import alpro_amd.compat
+    sys.path.insert(0, alpro_amd.compat.PATH)
+    from horovod import torch as hvd
+    from alpro_amd import amp, config as rt, optim
+    from tests.conftest import GOLDEN
+    from tests.golden.det_init import OPT_SCENARIOS
+    from tests.test_host_cpu import _OptToy
+    import os
+    g = np.load(os.path.join(GOLDEN, "optimizer_adamw_3steps.npz"))
+    hp = OPT_SCENARIOS[scenario]
+    model = _OptToy("cuda")
+    with rt.use_compute_dtype("fp32"):
+        if drive == "fused":
+            opt = optim.FlatAdamW(model.parameters(), lr=hp["lr"], betas=hp["betas"], weight_decay=hp["weight_decay"], max_grad_norm=hp["grad_norm"])
+        else:
+            opt = hvd.DistributedOptimizer(optim.FlatAdamW(model.parameters(), lr=hp["lr"], betas=hp["betas"], weight_decay=hp["weight_decay"]),
+                                           named_parameters=model.named_parameters(), compression=hvd.Compression.none)
+        for step in range(3):
+            lr = float(g["%s/lr/%d" % (scenario, step)])
+            loss = model.loss(step)
+            if drive == "fused":
+                loss.backward()
+                opt.param_groups[0]["lr"] = lr
+                opt.step()
+                total = math.sqrt(float(opt.last_grad_norm))
+                opt.zero_grad()
+            else:
+                with amp.scale_loss(loss, opt, delay_unscale=False) as scaled:
+                    scaled.backward()
+                    optim.zero_none_grad(model)
+                    opt.synchronize()
+                for pg in opt.param_groups:
+                    pg["lr"] = lr
+                views = list(amp.master_params(opt))
+                assert len(views) == (len(model.ps) if step == 0 else 1)      # separate tensors before the first step built the flat buffers
+                total = float(torch.nn.utils.clip_grad_norm_(views, hp["grad_norm"]))
+                assert not [n for n, p in model.named_parameters() if p.requires_grad and p.grad is None]
+                with opt.skip_synchronize():
+                    opt.step()
+                    opt.zero_grad()
+                assert optim.is_placeholder_grad(model.teacher.grad)
+            assert total == pytest.approx(float(g["%s/grad_norm/%d" % (scenario, step)]), rel=2e-6)
+            got = torch.cat([p.detach().reshape(-1) for p in model.ps]).cpu().numpy().astype(np.float64)
+            np.testing.assert_allclose(got, g["%s/params/%d" % (scenario, step)], rtol=3e-6, atol=2e-8, err_msg="%s / %s step %d" % (scenario, drive, step))
+        inner = getattr(opt, "_opt", opt)
+        assert inner.n_params == sum(p.numel() for p in model.ps) and torch.equal(model.teacher.detach().cpu(), torch.ones(300, 7))
+        lay = {i: (o, n) for i, o, n in inner._layout()}
+        m = torch.cat([inner.flat["m"][lay[i][0]:lay[i][0] + lay[i][1]] for i in range(len(model.ps))]).cpu().numpy()
+        v = torch.cat([inner.flat["v"][lay[i][0]:lay[i][0] + lay[i][1]] for i in range(len(model.ps))]).cpu().numpy()
+        np.testing.assert_allclose(m, g[scenario + "/exp_avg"], rtol=1e-5, atol=1e-9)
+        np.testing.assert_allclose(v, g[scenario + "/exp_avg_sq"], rtol=1e-5, atol=1e-12)
+
+
 @pytest.mark.parametrize("mode,tol", [("fp32", 2e-4), ("bf16", 4e-2)])
 def test_merged_temporal_projection_equals_two_linears(mode, tol):
     """Block with merge_temporal_proj (one GEMM with We = Wfc Wp, product rule in backward) vs the two Linears of

@@ -211,3 +211,25 @@ def test_retrieval_16_frames(bert_cfg):
         close(out[k], g[k], what=k)
     close(ve[:, [0, 1, 100, 196]], g["video_embeds_rows"]); close(ve.norm(dim=-1), g["video_embeds_rownorm"])
     close(inf["logits"], g["inf_logits"]); close(inf["itc_scores"], g["inf_itc_scores"])
+
+
+def test_optimizer_epilogue_trajectory():
+    """a22: the oracle's clip + AdamW + lr schedule against the trajectory the REFERENCE's AdamW / get_lr_sched / torch clip_grad_norm_
+    produced (tests/golden/optimizer_adamw_3steps.npz, make_golden.case_optimizer): parameters after each of three steps, the logged
+    gradient norms, the learning rates and the final moments, with and without weight decay, clipped and unclipped steps."""
+    from tests.golden.det_init import OPT_SCENARIOS, opt_tensors
+    g = np.load(os.path.join(GOLDEN, "optimizer_adamw_3steps.npz"))
+    for sc, hp in OPT_SCENARIOS.items():
+        params = [t.clone() for t in opt_tensors("param")]
+        m, v = [torch.zeros_like(t) for t in params], [torch.zeros_like(t) for t in params]
+        clipped = []
+        for step in range(3):
+            lr = ao.lr_sched(step + 1, hp["decay"], hp["lr"], hp["num_train_steps"], hp["warmup_ratio"])
+            assert lr == pytest.approx(float(g["%s/lr/%d" % (sc, step)]), rel=1e-12)
+            total = ao.clip_and_adamw_step(params, opt_tensors("grad", step), m, v, step + 1, lr, hp["betas"], 1e-6, hp["weight_decay"], hp["grad_norm"])
+            assert total == pytest.approx(float(g["%s/grad_norm/%d" % (sc, step)]), rel=1e-6)
+            clipped.append(total > hp["grad_norm"])
+            close(torch.cat([p.reshape(-1) for p in params]), g["%s/params/%d" % (sc, step)], rtol=1e-6, atol=1e-8, what="%s params after step %d" % (sc, step))
+        assert clipped == [True, True, False]
+        close(torch.cat([t.reshape(-1) for t in m]), g[sc + "/exp_avg"], rtol=1e-5, atol=1e-9)
+        close(torch.cat([t.reshape(-1) for t in v]), g[sc + "/exp_avg_sq"], rtol=1e-5, atol=1e-12)
