@@ -35,6 +35,52 @@ class use_compute_dtype:
         set_compute_dtype(self.prev)
 
 
+# ---- precise CLS rows (round 4).  The VTC features are projections of one row per sequence (the CLS token); in the 16-bit modes its own
+# chain of roundings (LayerNorm output -> q/k/v -> attention output -> projection -> MLP, once per block) carries most of the VTC-logit
+# error, and re-evaluating exactly those rows in fp32 costs < 1e-3 of the FLOPs (csrc/cls_precise.hip).
+# ALPRO_CLS_PRECISE = auto (default: on with fp16 operands -- the mode that then meets "VTC logits within 1e-3" on every reference fixture;
+# off with bf16, whose 8-bit mantissa stays far from the bar either way) | 1 | 0.
+_cls_precise = [os.environ.get("ALPRO_CLS_PRECISE", "auto").lower()]
+_cls_off = [0]
+
+
+def cls_precise(dt=None):
+    dt = dt if dt is not None else _compute_dtype
+    if dt == torch.float32 or _cls_off[0] > 0:
+        return False
+    if _cls_precise[0] == "auto":
+        return dt == torch.float16
+    return _cls_precise[0] in ("1", "true", "on")
+
+
+def set_cls_precise(v):
+    _cls_precise[0] = v.lower() if isinstance(v, str) else ("1" if v else "0")
+
+
+class use_cls_precise:
+    """`with use_cls_precise(False): ...` (tests, bench.py's mode table)."""
+
+    def __init__(self, v):
+        self.v = v
+
+    def __enter__(self):
+        self.prev = _cls_precise[0]
+        set_cls_precise(self.v)
+
+    def __exit__(self, *a):
+        _cls_precise[0] = self.prev
+
+
+class cls_precise_off:
+    """Passes whose CLS row feeds no VTC logit (the frozen teacher's pseudo-label pass) skip the side path."""
+
+    def __enter__(self):
+        _cls_off[0] += 1
+
+    def __exit__(self, *a):
+        _cls_off[0] -= 1
+
+
 # ---- fp16 operands: loss scaling (alpro_amd.amp).  The hand-written backward passes refuse to run on fp16 gradient operands unless the
 # loss was scaled (an unscaled fp16 backward silently flushes most activation gradients to zero); the LM head writes its logit gradient
 # at FORWARD time and therefore needs to know the scale that the coming backward will use ("armed" scaler).

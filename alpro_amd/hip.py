@@ -23,7 +23,7 @@ _CODE = {v: k for k, v in _TORCH_DTYPE.items()}
 EXPORTS = ["alpro_hip_last_error", "alpro_hip_abi_version", "alpro_hip_set_option", "alpro_gemm", "alpro_layernorm_fwd",
            "alpro_attn_temporal_fwd", "alpro_attn_fwd", "alpro_patchify", "alpro_cls_mean_residual",
            "alpro_vit_final_pool", "alpro_bert_embed_fwd", "alpro_cast_from_f32", "alpro_attn_bwd", "alpro_attn_temporal_bwd",
-           "alpro_layernorm_bwd", "alpro_transpose", "alpro_transpose_batch", "alpro_gelu_bwd", "alpro_cls_mean_bwd", "alpro_scatter_add_rows", "alpro_gather_cast", "alpro_sumsq", "alpro_adamw_step", "alpro_gemm_tn_acc", "alpro_gemm_tn_acc_ws", "alpro_gemm_tn_workspace_bytes", "alpro_colsum_acc", "alpro_softmax_xent", "alpro_vtc_loss_fwd", "alpro_vtc_loss_bwd", "alpro_prepare_clips", "alpro_loss_scale_update", "alpro_add_layernorm_fwd", "alpro_layernorm_bwd_emit", "alpro_gemm_batch", "alpro_tproj_small"]
+           "alpro_layernorm_bwd", "alpro_transpose", "alpro_transpose_batch", "alpro_gelu_bwd", "alpro_cls_mean_bwd", "alpro_scatter_add_rows", "alpro_gather_cast", "alpro_sumsq", "alpro_adamw_step", "alpro_gemm_tn_acc", "alpro_gemm_tn_acc_ws", "alpro_gemm_tn_workspace_bytes", "alpro_colsum_acc", "alpro_softmax_xent", "alpro_vtc_loss_fwd", "alpro_vtc_loss_bwd", "alpro_prepare_clips", "alpro_loss_scale_update", "alpro_add_layernorm_fwd", "alpro_layernorm_bwd_emit", "alpro_gemm_batch", "alpro_tproj_small", "alpro_attn_cls_fwd"]
 
 
 class GemmDesc(ctypes.Structure):
@@ -50,7 +50,7 @@ class TransposeJob(ctypes.Structure):
                 ("R", ctypes.c_int32), ("C", ctypes.c_int32), ("Rpad", ctypes.c_int32), ("tile0", ctypes.c_int32)]   # 48 bytes
 
 
-ABI_VERSION = 14
+ABI_VERSION = 15
 _lib = None
 
 
@@ -95,6 +95,7 @@ def load():
     lib.alpro_cls_mean_bwd.argtypes = [vp, i64, vp, i32, i32, i32, vp]
     lib.alpro_scatter_add_rows.argtypes = [vp, vp, vp, i32, i32, i32, vp]
     lib.alpro_attn_fwd.argtypes = [vp, vp, i32, i32, i32, i32, f32, vp, vp, f32, u32, vp]
+    lib.alpro_attn_cls_fwd.argtypes = [vp, i32, vp, vp, vp, i32, i32, i32, i32, f32, f32, u32, vp]
     lib.alpro_patchify.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp]
     lib.alpro_cls_mean_residual.argtypes = [vp, i64, vp, vp, i64, i32, i32, i32, vp]
     lib.alpro_vit_final_pool.argtypes = [vp, vp, vp, f32, vp, vp, i32, i32, i32, i32, i32, vp]
@@ -420,6 +421,22 @@ def attn(qkv, batch, L, H, scale, key_bias=None, want_lse=False, drop_p=0.0, dro
     kb = _dev(key_bias, torch.float32) if key_bias is not None else None
     _check(lib.alpro_attn_fwd(_ptr(qkv), _ptr(out), _CODE[qkv.dtype], batch, L, H, scale, _ptr(kb), _ptr(lse), drop_p, drop_seed, _stream()), "alpro_attn_fwd")
     return (out, lse) if want_lse else out
+
+
+def attn_cls(qkv, qkv_cls, batch, L, H, scale, group=1, key_bias=None, drop_p=0.0, drop_seed=0):
+    """fp32 attention output of the CLS query (row 0) of every (sequence, head): qkv (batch*L, 3*H*64) 16-bit as written by the qkv GEMM,
+    qkv_cls (batch / group, 3*H*64) fp32 = the CLS tokens' unrounded q | k | v -> (batch, H*64) fp32 (alpro_attn_cls_fwd)."""
+    lib = load()
+    _dev(qkv); _dev(qkv_cls, torch.float32)
+    if qkv.shape != (batch * L, 3 * H * 64) or qkv_cls.shape != (batch // group, 3 * H * 64) or batch % group:
+        raise RuntimeError("attn_cls: qkv %s / qkv_cls %s do not match batch=%d L=%d H=%d group=%d" % (tuple(qkv.shape), tuple(qkv_cls.shape), batch, L, H, group))
+    if not (qkv.is_contiguous() and qkv_cls.is_contiguous()):
+        raise RuntimeError("attn_cls: contiguous tensors only")
+    out = torch.empty((batch, H * 64), dtype=torch.float32, device=qkv.device)
+    kb = _dev(key_bias, torch.float32) if key_bias is not None else None
+    _check(lib.alpro_attn_cls_fwd(_ptr(qkv), _CODE[qkv.dtype], _ptr(qkv_cls), _ptr(kb), _ptr(out), batch, L, H, group, scale, drop_p, drop_seed, _stream()),
+           "alpro_attn_cls_fwd")
+    return out
 
 
 def patchify(img, dtype):

@@ -321,7 +321,8 @@ class Prompter(AlproBaseModel):
     def get_pseudo_labels(self, batch):
         if self.training:
             self.eval()
-        with torch.no_grad():
+        from alpro_amd import config as rt
+        with torch.no_grad(), rt.cls_precise_off():   # (soft labels, not VTC logits of the trained model: the plain 16-bit pass)
             if hasattr(self.visual_encoder, "forward_cls"):  # only the CLS feature is consumed: CLS-only tail of the last block
                 cls = self.visual_encoder.forward_cls(batch['crop_visual_inputs'].transpose(1, 2))
                 feat = F.normalize(_linear32(cls, self.vision_proj), dim=-1)

@@ -141,6 +141,23 @@ class Block(nn.Module):
         self._ops._store["t_merged"] = (ver, m)
         return m
 
+    # ---- precise CLS rows (alpro_amd.config.cls_precise; csrc/cls_precise.hip) -------------------------------------------------
+    # The CLS row of the block output, re-evaluated in fp32 from the block input's CLS row: LayerNorm -> q | k | v (vit.py:84-85 on the
+    # row that :165-167 replicates per frame: ONE row per clip) -> the CLS query's attention over the frame's tokens (K / V of the patch
+    # tokens as the 16-bit GEMM produced them) -> proj -> frame mean + residual (:184-187) -> norm2 -> Mlp -> residual (:198-212).
+    # B*T + 3*B fp32 rows per block against B*(1 + N*T) 16-bit rows; drop-path scales are the main path's.
+    def _cls_chain(self, x_cls_in, qkv_s, B, T, N, H, drop_s=None, drop_m=None):
+        f32, sa = torch.float32, self.attn
+        hc = hip.layernorm(x_cls_in, self.norm1.weight, self.norm1.bias, VIT_EPS, f32)
+        qkv_c = hip.gemm(hc, self._w("s_qkv", sa.qkv, f32), bias=sa.qkv.bias, out_dtype=f32)
+        o_c = hip.attn_cls(qkv_s, qkv_c, B * T, N + 1, H, sa.scale, group=T)
+        p_c = hip.gemm(o_c, self._w("s_proj", sa.proj, f32), bias=sa.proj.bias, out_dtype=f32, row_scale=drop_s, row_scale_group=1)
+        x_cls2 = x_cls_in + p_c.view(B, T, -1).mean(1)
+        h2c = hip.layernorm(x_cls2, self.norm2.weight, self.norm2.bias, VIT_EPS, f32)
+        f1c = hip.gemm(h2c, self._w("fc1", self.mlp.fc1, f32), bias=self.mlp.fc1.bias, act=hip.ACT_GELU, out_dtype=f32)
+        x_cls_out = hip.gemm(f1c, self._w("fc2", self.mlp.fc2, f32), bias=self.mlp.fc2.bias, out_dtype=f32, residual=x_cls2, row_scale=drop_m, row_scale_group=1)
+        return x_cls2, x_cls_out
+
     def _drop(self, rows, device):
         if not isinstance(self.drop_path, DropPath):
             return None
@@ -149,16 +166,16 @@ class Block(nn.Module):
             return pre.pop(rows)
         return self.drop_path.row_scale(rows, device)
 
-    def _forward_halves_unfused(self, x, xf, a, B, T, N, H, D, dt):
+    def _forward_halves_unfused(self, x, xf, a, B, T, N, H, D, dt, drop_t=None, drop_s=None):
         """Round-2 form of the two attention halves' tails (fp32 residual read-modify-write in the GEMM epilogue, CLS side buffer);
         kept for A/B measurements (Block.fuse_residual_ln = False) and for the unmerged temporal projection."""
         ta, sa = self.temporal_attn, self.attn
         if self.merge_temporal_proj:
             mg = self._merged_tproj(dt)
             hip.gemm(a, mg["w"], out=xf, bias=mg["b1"], bias2=self.temporal_fc.bias, out_dtype=torch.float32, residual=xf,
-                     row_scale=self._drop(B * N, x.device), row_scale_group=T, map_mode=hip.MAP_SKIP_CLS, map_p0=N * T)
+                     row_scale=drop_t, row_scale_group=T, map_mode=hip.MAP_SKIP_CLS, map_p0=N * T)
         else:
-            pr = hip.gemm(a, self._w("t_proj", ta.proj, dt), bias=ta.proj.bias, row_scale=self._drop(B * N, x.device), row_scale_group=T)
+            pr = hip.gemm(a, self._w("t_proj", ta.proj, dt), bias=ta.proj.bias, row_scale=drop_t, row_scale_group=T)
             hip.gemm(pr, self._w("t_fc", self.temporal_fc, dt), out=xf, bias=self.temporal_fc.bias, out_dtype=torch.float32,
                      residual=xf, map_mode=hip.MAP_SKIP_CLS, map_p0=N * T)
         hs = hip.layernorm(x, self.norm1.weight, self.norm1.bias, VIT_EPS, dt, rows=B * T * (N + 1),
@@ -167,7 +184,7 @@ class Block(nn.Module):
         a = hip.attn(qkv, B * T, N + 1, H, sa.scale)
         side = torch.empty((B * T, D), dtype=torch.float32, device=x.device)
         hip.gemm(a, self._w("s_proj", sa.proj, dt), out=xf, bias=sa.proj.bias, out_dtype=torch.float32, residual=xf,
-                 row_scale=self._drop(B * T, x.device), row_scale_group=N + 1,
+                 row_scale=drop_s, row_scale_group=N + 1,
                  map_mode=hip.MAP_FRAME_TOKENS, map_p0=T, map_p1=N, side=side)
         hip.cls_mean_residual(x, side, x, B, T)
 
@@ -179,6 +196,9 @@ class Block(nn.Module):
         H = self.attn.num_heads
         xf = x.view(B * S, D)
         ta, sa = self.temporal_attn, self.attn
+        drop_t, drop_s, drop_m = self._drop(B * N, x.device), self._drop(B * T, x.device), self._drop(B, x.device)
+        cp = rt.cls_precise(dt) and self.fuse_residual_ln and self.merge_temporal_proj
+        x_cls_in = x[:, 0].contiguous() if cp else None   # (the temporal half never touches the CLS row; the spatial half reads it as it is now)
         # ---- temporal (vit.py:146-162)
         h = hip.layernorm(x, self.temporal_norm1.weight, self.temporal_norm1.bias, VIT_EPS, dt, rows=B * N * T,
                           map_mode=hip.MAP_SKIP_CLS, map_p0=N * T)
@@ -188,19 +208,21 @@ class Block(nn.Module):
             # round 3: the two N = 768 projections write 16-bit deltas in plain row order; residual add + row maps + LayerNorm are one
             # streaming kernel each (alpro_add_layernorm_fwd) -- see the kernel's header comment in csrc/core.hip
             mg = self._merged_tproj(dt)
-            d_t = hip.gemm(a, mg["w"], bias=mg["b1"], row_scale=self._drop(B * N, x.device), row_scale_group=T)
+            d_t = hip.gemm(a, mg["w"], bias=mg["b1"], row_scale=drop_t, row_scale_group=T)
             hs, _ = hip.add_layernorm(x, d_t, self.norm1.weight, self.norm1.bias, VIT_EPS, mode=hip.ADD_PRE_SPATIAL, x_out=x,
                                       delta_bias=self.temporal_fc.bias, T=T, N=N)
             qkv = hip.gemm(hs, self._w("s_qkv", sa.qkv, dt), bias=sa.qkv.bias)
             a = hip.attn(qkv, B * T, N + 1, H, sa.scale)
-            d_s = hip.gemm(a, self._w("s_proj", sa.proj, dt), bias=sa.proj.bias, row_scale=self._drop(B * T, x.device), row_scale_group=N + 1)
+            d_s = hip.gemm(a, self._w("s_proj", sa.proj, dt), bias=sa.proj.bias, row_scale=drop_s, row_scale_group=N + 1)
             h2, _ = hip.add_layernorm(x, d_s, self.norm2.weight, self.norm2.bias, VIT_EPS, mode=hip.ADD_PRE_MLP, x_out=x, T=T, N=N)
         else:
-            self._forward_halves_unfused(x, xf, a, B, T, N, H, D, dt)
+            self._forward_halves_unfused(x, xf, a, B, T, N, H, D, dt, drop_t, drop_s)
             h2 = hip.layernorm(x, self.norm2.weight, self.norm2.bias, VIT_EPS, dt)
         f1 = hip.gemm(h2, self._w("fc1", self.mlp.fc1, dt), bias=self.mlp.fc1.bias, act=hip.ACT_GELU)
         hip.gemm(f1, self._w("fc2", self.mlp.fc2, dt), out=xf, bias=self.mlp.fc2.bias, out_dtype=torch.float32, residual=xf,
-                 row_scale=self._drop(B, x.device), row_scale_group=S)
+                 row_scale=drop_m, row_scale_group=S)
+        if cp:
+            x[:, 0] = self._cls_chain(x_cls_in, qkv, B, T, N, H, drop_s, drop_m)[1]
         return x
 
     # ---- training path: fresh buffers (the backward needs every LayerNorm input), explicit backward ----------
@@ -260,6 +282,12 @@ class Block(nn.Module):
         out = torch.empty_like(x)
         hip.gemm(f1, self._w("fc2", self.mlp.fc2, dt), out=out.view(B * S, D), bias=self.mlp.fc2.bias, out_dtype=torch.float32,
                  residual=x2.view(B * S, D), row_scale=sv["drop_m"], row_scale_group=S)
+        if rt.cls_precise(dt) and self.fuse_residual_ln and self.merge_temporal_proj:
+            # precise CLS rows: the block output's CLS row and the saved pre-MLP stream's CLS row (norm2's backward input) take the fp32 values;
+            # the backward differentiates the 16-bit graph as before (its CLS-row operands differ from these by one rounding)
+            x_cls2, x_cls_out = self._cls_chain(x[:, 0].contiguous(), qkv_s, B, T, N, H, sv["drop_s"], sv["drop_m"])
+            x2[:, 0] = x_cls2
+            out[:, 0] = x_cls_out
         sv.update(h=h, qkv_t=qkv_t, a_t=a_t, lse_t=lse_t, pr=pr, xt=xt, hs=hs, qkv_s=qkv_s, a_s=a_s, lse_s=lse_s, x2=x2, h2=h2, u=u, f1=f1)
         return out, sv
 

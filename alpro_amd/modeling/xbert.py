@@ -111,6 +111,35 @@ class BertLayer(nn.Module):
         return (hp, rt.next_dropout_seed() if hp > 0 else 0, rt.next_dropout_seed() if hp > 0 else 0,
                 ap, rt.next_dropout_seed() if ap > 0 else 0)
 
+    # ---- precise CLS rows (alpro_amd.config.cls_precise; csrc/cls_precise.hip): the [CLS] row of a text-mode layer (the row text_proj reads,
+    # alpro_models.py:100-103) re-evaluated in fp32 from the layer input's [CLS] row: q | k | v (xbert.py:299-316) -> the [CLS] query's attention
+    # over the caption (K / V of the other tokens as the 16-bit GEMM produced them; same key bias, same probability-dropout mask) -> dense ->
+    # residual + LayerNorm (:358-359) -> intermediate GELU (:421-423) -> dense -> residual + LayerNorm (:436-437).  B fp32 rows per layer.
+    # Hidden dropout: the main path's 16-bit outputs say which elements it dropped (a dropped element is exactly 0), the same elements
+    # are dropped here.
+    def _cls_chain(self, hc, qkv, d1, d2, key_bias, B, L, H, scale, hp, ap, seed_a):
+        f32 = torch.float32
+        sa, so = self.attention.self, self.attention.output
+        eps = self.config.layer_norm_eps
+        wqkv = tr.fused_param_view([sa.query.weight, sa.key.weight, sa.value.weight])   # a view when FlatAdamW laid them out back to back
+        if wqkv is None:
+            wqkv = self._ops.get("qkv_w32", (sa.query.weight, sa.key.weight, sa.value.weight), f32)
+        bqkv = self._ops.get("qkv_b", (sa.query.bias, sa.key.bias, sa.value.bias), f32)
+        qkv_c = hip.gemm(hc, wqkv, bias=bqkv, out_dtype=f32)
+        ctx_c = hip.attn_cls(qkv, qkv_c, B, L, H, scale, group=1, key_bias=key_bias, drop_p=ap, drop_seed=seed_a)
+        d1_c = hip.gemm(ctx_c, self._ops.get("ao_w", so.dense.weight, f32), bias=so.dense.bias, out_dtype=f32)
+        if hp > 0:
+            d1_c = torch.where(d1.view(B, L, -1)[:, 0] != 0, d1_c * (1.0 / (1.0 - hp)), torch.zeros_like(d1_c))
+        s1_c = hc + d1_c
+        a32_c = hip.layernorm(s1_c, so.LayerNorm.weight, so.LayerNorm.bias, eps, f32)
+        it_c = hip.gemm(a32_c, self._ops.get("i_w", self.intermediate.dense.weight, f32), bias=self.intermediate.dense.bias, act=hip.ACT_GELU, out_dtype=f32)
+        d2_c = hip.gemm(it_c, self._ops.get("o_w", self.output.dense.weight, f32), bias=self.output.dense.bias, out_dtype=f32)
+        if hp > 0:
+            d2_c = torch.where(d2.view(B, L, -1)[:, 0] != 0, d2_c * (1.0 / (1.0 - hp)), torch.zeros_like(d2_c))
+        s2_c = a32_c + d2_c
+        o32_c = hip.layernorm(s2_c, self.output.LayerNorm.weight, self.output.LayerNorm.bias, eps, f32)
+        return s1_c, a32_c, s2_c, o32_c
+
     def forward(self, h32, h_t, key_bias, B, L):
         """h32 (B*L, H) fp32 residual stream, h_t the same in the operand dtype; returns the next pair."""
         o32, o_t, _ = self.forward_train(h32, h_t, key_bias, B, L, save=False)
@@ -137,6 +166,16 @@ class BertLayer(nn.Module):
             it = hip.gemm(a_t, self._ops.get("i_w", self.intermediate.dense.weight, dt), bias=self.intermediate.dense.bias, act=(hip.ACT_GELU_SAVE_GRAD if (save and tr.SAVE_GELU_GRAD) else hip.ACT_GELU), pre_act=u)
             d2 = hip.gemm(it, self._ops.get("o_w", self.output.dense.weight, dt), bias=self.output.dense.bias, drop_p=hp, drop_seed=seed2)
             o_t, o32, s2 = hip.add_layernorm(a32, d2, self.output.LayerNorm.weight, self.output.LayerNorm.bias, eps, out32=True, want_x=save)
+            if rt.cls_precise(dt) and self.layer_num < int(_cfg_get(self.config, "fusion_layer", 0) or 0):
+                D = h32.shape[1]
+                s1_c, a32_c, s2_c, o32_c = self._cls_chain(h32.view(B, L, D)[:, 0].contiguous(), qkv, d1, d2, key_bias, B, L, H, scale, hp if seed1 else 0.0,
+                                                          ap, seed_a)
+                o32.view(B, L, D)[:, 0] = o32_c
+                o_t.view(B, L, D)[:, 0] = o32_c.to(dt)
+                a_t.view(B, L, D)[:, 0] = a32_c.to(dt)       # (the FFN's saved input row, for its weight gradient)
+                if save:                                     # the two LayerNorm backward inputs
+                    s1.view(B, L, D)[:, 0] = s1_c
+                    s2.view(B, L, D)[:, 0] = s2_c
         else:
             s1 = hip.gemm(ctx, self._ops.get("ao_w", so.dense.weight, dt), bias=so.dense.bias, out_dtype=torch.float32, residual=h32,
                           drop_p=hp, drop_seed=seed1)

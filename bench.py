@@ -2,9 +2,11 @@
 
     python bench.py --gpus N --steps K --warmup W [--workload pretrain_step|visual_fwd|pretrain_fwd] [--batch B] [--dtype fp16|bf16|fp32]
 
-Default operand dtype: fp16 (fp32 accumulation / residual stream / statistics, dynamic loss scaling for the backward) -- the 16-bit mode
-that meets the north star's "VTC logits within 1e-3 of the reference"; bf16 has the same MFMA rate but 8e-3.  The `parity` object of the
-JSON line is MEASURED in this process against the reference-generated fixtures under tests/golden/ (measure_parity below).
+Default mode: fp16 operands (fp32 accumulation / residual stream / statistics, dynamic loss scaling for the backward) + the CLS rows of both
+encoders re-evaluated in fp32 (alpro_amd.config.cls_precise, round 4) -- the fastest mode that meets the north star's "VTC logits within
+1e-3 of the reference" on EVERY reference fixture (plain fp16: 1.06e-3 on the worst one; bf16: 9e-3).  The `parity` object of the JSON line
+is MEASURED in this process against all four reference-generated VTC fixtures under tests/golden/ (measure_parity below): `meets_bar` is
+decided by the WORST of them.
 
 Default workload: pretrain_step -- the configuration BASELINE.json's metric ("video-text pairs/sec at 1/2/4/8 MI355X") is
 quoted on (configs[2] on one GPU, configs[3] under DP); visual_fwd is configs[1] (encoder-only isolation run).
@@ -136,6 +138,7 @@ class KernelTimer:
                 sd[0] += 1
                 sd[1] += fl
                 sd[2] += e0.elapsed_time(e1)
+        self.shapes = shapes
         if os.environ.get("ALPRO_BENCH_SHAPES"):  # per-shape GEMM table (tuning aid), to stderr
             for (name, key), (c, f, ms) in sorted(shapes.items(), key=lambda kv: -kv[1][2]):
                 sys.stderr.write("%-12s %-70s n=%3d  %8.3f ms  %6.0f TF/s\n" % (name, key, c, ms, f / ms / 1e9))
@@ -273,66 +276,82 @@ def measure_divst(dev, T, model=None, B=32, iters=5):
     return {"workload": "divided space-time attention sub-blocks of the TimeSformer forward, B=%d x %df x 224^2 (BASELINE configs[1]), %s operands" % (B, T, str(rt.compute_dtype()).replace("torch.", "")),
             "ms": round(ms, 3), "accounting": "Block entry .. end of the spatial residual add; the fused add+norm2 kernel (%.3f ms over 12 blocks) counts 5/6 here (its x read, delta read, x' write) and 1/6 as the MLP half's norm2" % tail_ms if tails else "Block entry .. alpro_cls_mean_residual",
             "encoder_forward_ms": round(t0.elapsed_time(t1) / iters, 3), "gflop_per_clip": DIVST_GFLOP_PER_CLIP_8F * (T / 8.0),
-            "achieved": round(tf, 1), "peak": MFMA_PEAK_TFLOPS["bf16"], "unit": "TFLOP/s", "frac": round(tf / MFMA_PEAK_TFLOPS["bf16"], 4), "target_frac": 0.40}
+            "achieved": round(tf, 1), "peak": MFMA_PEAK_TFLOPS["bf16"], "unit": "TFLOP/s", "frac": round(tf / MFMA_PEAK_TFLOPS["bf16"], 4), "target_frac": 0.40,
+            # the conservative figure: the whole fused add + norm2 kernel counted here (no 1/6 attribution to the MLP half)
+            "ms_end_to_end": round(ms + tail_ms / 6.0, 3), "frac_end_to_end": round(B * DIVST_GFLOP_PER_CLIP_8F * (T / 8.0) / (ms + tail_ms / 6.0) / MFMA_PEAK_TFLOPS["bf16"], 4)}
+
+
+def mode_name(dtype):
+    from alpro_amd import config as rt
+    dt = {"fp16": torch.float16, "bf16": torch.bfloat16, "fp32": torch.float32}[dtype]
+    if dtype == "fp32":
+        return "fp32 exact (fp32 MFMA)"
+    return "%s operands%s" % (dtype, " + precise CLS rows (fp32)" if rt.cls_precise(dt) else "")
 
 
 def measure_parity(dev, dtype):
-    """Parity of the benchmarked operand dtype, measured in THIS process: AlproForVideoTextRetrieval (2 frames, 3 pairs, closed-form
-    weights and inputs regenerated by tests/golden/det_init.py) against what the REFERENCE produced for the same weights and inputs
-    (tests/golden/retrieval_T2_B3.npz, retrieval_grads_T2_B3.npz, written by tests/golden/make_golden.py from /root/reference):
-    forward + 1-video-x-n-captions inference (VTC logits, ITM scores, video embeddings), then the finetune loss itm + itc backward through
-    the hand-written HIP backward (364 parameter-gradient norms).  fp16 operands go through a scaled backward like the timed steps."""
+    """Parity of the benchmarked mode, measured in THIS process against what the REFERENCE produced for the same closed-form weights and inputs
+    (tests/golden/*.npz, written by tests/golden/make_golden.py from /root/reference; weights / inputs regenerated by tests/golden/det_init.py):
+      * VTC logits on ALL FOUR reference fixtures that hold them (tests/golden/parity_cases.py: retrieval 2 / 16 frames -- 1 video x n captions
+        through forward_inference --, pretraining 8 frames and the released 4-frame x 30-token geometry); `vtc_logits_max_abs_err` is the WORST
+        of them and decides `meets_bar` (north star: within 1e-3);
+      * on the retrieval fixture also ITM scores, embeddings and 451 parameter-gradient norms of itm + itc through the hand-written HIP
+        backward (fp16 operands: a loss-scaled backward like the timed steps)."""
     import numpy as np
     from alpro_amd import amp, config as rt
-    from alpro_amd.modeling.alpro_models import AlproForVideoTextRetrieval
-    from tests.golden.det_init import det_batch, fill_state_dict_
+    from tests.golden import parity_cases as pc
+    from tests.test_host_cpu import make_cfg
     gdir = os.path.join(ROOT, "tests", "golden")
-    g, gg = np.load(os.path.join(gdir, "retrieval_T2_B3.npz")), np.load(os.path.join(gdir, "retrieval_grads_T2_B3.npz"))
-    m = AlproForVideoTextRetrieval(Cfg(BERT_CFG), dict(VENC, num_frm=2))
-    fill_state_dict_(m)
-    m.eval().to(dev)
-    batch = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in det_batch(3, 2, seed_name="retrieval_T2", with_mlm=False, with_mpm=False).items()}
     err = lambda got, ref: float(np.abs(got.detach().float().cpu().numpy().astype(np.float64) - np.asarray(ref, np.float64)).max())  # noqa: E731
     orig = torch.multinomial
     torch.multinomial = lambda w, n=1, *a, **k: w.argmax(dim=-1, keepdim=True)   # the fixtures pin the hard-negative draw the same way
     prev_armed = rt._armed[0]
+    res, per = {}, {}
     try:
         with rt.use_compute_dtype(dtype):
-            with torch.no_grad():
-                ve = m._forward_visual_embeds(batch["visual_inputs"])
-                out = m(batch)
-                inf = m.forward_inference(dict(visual_inputs=batch["visual_inputs"][:1], text_input_ids=batch["text_input_ids"],
-                                               text_input_mask=batch["text_input_mask"]))
-            res = {"vtc_logits_max_abs_err": err(inf["itc_scores"], g["inf_itc_scores"]), "itm_scores_max_abs_err": err(out["itm_scores"], g["itm_scores"]),
-                   "itm_logits_inference_max_abs_err": err(inf["logits"], g["inf_logits"]), "itc_loss_abs_err": err(out["itc_loss"], g["itc_loss"]),
-                   "video_embeds_max_abs_err": err(ve[:, [0, 1, 100, 196]], g["video_embeds_rows"])}
-            with torch.enable_grad():
-                o2 = m(batch)
-                loss = o2["itm_loss"] + o2["itc_loss"]
-                scale = 1.0
-                if amp.needs_loss_scaling():
-                    sc = amp.LossScaler(init_scale=4096.0, dynamic=False, device=dev)
-                    scale = 4096.0
-                    with rt.loss_scaling(sc):
-                        (loss * sc.scale.reshape(())).backward()
-                else:
-                    loss.backward()
-        pd = dict(m.named_parameters())
-        names = [str(n) for n in gg["grad_norm_names"]]
-        got = np.array([float(pd[n].grad.norm()) / scale for n in names])
-        ref = gg["grad_norms"]
-        rel = np.abs(got - ref) / np.maximum(ref, 1e-5)
-        rel[np.array([n.endswith("attention.self.key.bias") for n in names])] = 0.0   # exactly 0 in exact arithmetic (softmax shift invariance)
-        res.update(grad_norm_rel_err_worst=float(rel.max()), grad_norm_rel_err_median=float(np.median(rel)), grad_tensors=len(names),
-                   grad_worst_param=names[int(rel.argmax())])
+            for name in pc.CASES:
+                m, batch, ref = pc.build_case(name, BERT_CFG, VENC, make_cfg, dev)
+                per[name] = float("%.3e" % pc.vtc_logit_error(name, m, batch, ref))
+                if name == "retrieval_T2":
+                    g, gg = np.load(os.path.join(gdir, "retrieval_T2_B3.npz")), np.load(os.path.join(gdir, "retrieval_grads_T2_B3.npz"))
+                    with torch.no_grad():
+                        ve = m._forward_visual_embeds(batch["visual_inputs"])
+                        out = m(batch)
+                        inf = m.forward_inference(dict(visual_inputs=batch["visual_inputs"][:1], text_input_ids=batch["text_input_ids"],
+                                                       text_input_mask=batch["text_input_mask"]))
+                    res.update(itm_scores_max_abs_err=err(out["itm_scores"], g["itm_scores"]), itm_logits_inference_max_abs_err=err(inf["logits"], g["inf_logits"]),
+                               itc_loss_abs_err=err(out["itc_loss"], g["itc_loss"]), video_embeds_max_abs_err=err(ve[:, [0, 1, 100, 196]], g["video_embeds_rows"]))
+                    with torch.enable_grad():
+                        o2 = m(batch)
+                        loss = o2["itm_loss"] + o2["itc_loss"]
+                        scale = 1.0
+                        if amp.needs_loss_scaling():
+                            sc = amp.LossScaler(init_scale=4096.0, dynamic=False, device=dev)
+                            scale = 4096.0
+                            with rt.loss_scaling(sc):
+                                (loss * sc.scale.reshape(())).backward()
+                        else:
+                            loss.backward()
+                    pd = dict(m.named_parameters())
+                    names = [str(n) for n in gg["grad_norm_names"]]
+                    got = np.array([float(pd[n].grad.norm()) / scale for n in names])
+                    rel = np.abs(got - gg["grad_norms"]) / np.maximum(gg["grad_norms"], 1e-5)
+                    rel[np.array([n.endswith("attention.self.key.bias") for n in names])] = 0.0   # exactly 0 in exact arithmetic (softmax shift invariance)
+                    res.update(grad_norm_rel_err_worst=float(rel.max()), grad_norm_rel_err_median=float(np.median(rel)), grad_tensors=len(names),
+                               grad_worst_param=names[int(rel.argmax())])
+                del m, batch
+                torch.cuda.empty_cache()
     finally:
         torch.multinomial = orig
         rt._armed[0] = prev_armed
     res = {k: (float("%.3e" % v) if isinstance(v, float) else v) for k, v in res.items()}
-    res.update(dtype=dtype, north_star_bar="VTC logits within 1e-3 of the reference", meets_bar=bool(res["vtc_logits_max_abs_err"] <= 1e-3),
-               fixture="tests/golden/retrieval_T2_B3.npz + retrieval_grads_T2_B3.npz (outputs of the reference itself, make_golden.py); measured in this process")
-    del m
-    return res
+    worst = max(per, key=per.get)
+    out = dict(mode=mode_name(dtype), vtc_logits_max_abs_err=per[worst], vtc_logits_worst_fixture=worst, vtc_logits_max_abs_err_per_fixture=per,
+               north_star_bar="VTC logits within 1e-3 of the reference", meets_bar=bool(per[worst] <= pc.NORTH_STAR_BAR))
+    out.update(res)
+    out["fixtures"] = "tests/golden/{retrieval_T2_B3, pretrain_T8_B2, retrieval_T16_B2, pretrain_release_T4_L30_B2, retrieval_grads_T2_B3}.npz (outputs of the reference itself, make_golden.py); measured in this process"
+    out["full_size_proxy"] = "tests/test_model_parity.py::test_full_size_pretrain_forward_in_the_bench_dtype_vs_the_exact_mode (B=64 x 8f against the exact fp32 HIP mode); measured numbers: profiles/r4_parity_pareto.txt"
+    return out
 
 
 def main():
@@ -345,6 +364,8 @@ def main():
     ap.add_argument("--batch", type=int, default=None)
     ap.add_argument("--frames", type=int, default=8)
     ap.add_argument("--dtype", default="fp16", choices=["bf16", "fp16", "fp32"])
+    ap.add_argument("--cls-precise", default="auto", choices=["auto", "0", "1"],
+                    help="precise (fp32) CLS rows of both encoders: auto = on with fp16 operands (the default mode), off with bf16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-divst", action="store_true", help="skip the divST sub-block measurement pass (clean per-step rocprof traces)")
     ap.add_argument("--no-parity", action="store_true", help="skip the in-run parity measurement against tests/golden (a few seconds)")
@@ -360,6 +381,7 @@ def main():
     dev = torch.device("cuda", local)
     hip.load()
     rt.set_compute_dtype(args.dtype)
+    rt.set_cls_precise(args.cls_precise)
     T = args.frames
     torch.manual_seed(1234)
 
@@ -441,7 +463,7 @@ def main():
             for k_ in ("launches", "flops", "ms"):
                 gemm[k_] += ks["gemm_tn_acc"][k_]
         ach = gemm["flops"] / (gemm["ms"] * 1e-3) / 1e12
-        traffic, traffic_src = None, None
+        traffic, traffic_src, pm = None, None, {}
         import glob
         import re
         profs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pretrain_step_B64_pmc_traffic.json")),
@@ -450,24 +472,54 @@ def main():
         if train and B == 64 and T == 8 and args.dtype in ("bf16", "fp16") and prof:
             # HBM bytes per GEMM launch from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command
             # (tools/pmc_summary.py; FETCH_SIZE doubled per MI355X_MICROARCH.md): launch-weighted mean over the GEMM kernels
-            pm = json.load(open(prof))
+            pm = {k_.replace("alpro::", ""): v_ for k_, v_ in json.load(open(prof)).items()}
             gk = {k: v for k, v in pm.items() if k.startswith("gemm_")}
             n = sum(v["launches"] for v in gk.values())
             traffic = round(sum(v["launches"] * (v["read_bytes_corrected_per_launch"] + v["write_bytes_per_launch"]) for v in gk.values()) / n)
             traffic_src = "profiles/" + os.path.basename(prof)
         peak = MFMA_PEAK_TFLOPS[args.dtype]
+        # the single dominant kernel INSTANTIATION: NT GEMM launches grouped by the template arguments the library picks --
+        # persistent 256x256 kernel from 160 tiles up, activation, row map (gemm.hip launch_gemm_inst) -- with their own FLOPs, time and PMC bytes
+        import re as _re
+        inst = {}
+        for (name, key), (c, f, ms_) in kt.shapes.items():
+            if name != "gemm":
+                continue
+            mm = _re.match(r"M=(\d+) N=(\d+) K=(\d+) act=(\S+) res=(\d) out=(\S+) map=(\S+)", key)
+            M_, N_, K_ = int(mm.group(1)), int(mm.group(2)), int(mm.group(3))
+            big = ((N_ + 255) // 256) * ((M_ + 255) // 256) >= 160 and K_ >= 128
+            kn = "%s<%s, %s, %s%s>" % ("gemm_nt256p_kernel" if big else "gemm_nt_kernel", {"fp16": "f16_t", "bf16": "bf16_t", "fp32": "float"}[args.dtype], mm.group(4), mm.group(7), ", 1" if big else "")
+            d_ = inst.setdefault(kn, [0, 0.0, 0.0])
+            d_[0] += c
+            d_[1] += f
+            d_[2] += ms_
+        dom = max(inst, key=lambda k_: inst[k_][2]) if inst else None
+        dominant = None
+        if dom:
+            c, f, ms_ = inst[dom]
+            dominant = {"kernel": dom, "launches": c, "gflop_per_launch": round(f / c / 1e9, 2), "avg_launch_ms": round(ms_ / c, 4),
+                        "achieved": round(f / ms_ / 1e9, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(f / ms_ / 1e9 / peak, 4),
+                        "share_of_step": round(ms_ / (elapsed / args.steps * 1e3), 3), "traffic": None}
+            if traffic_src and dom in pm:
+                dominant["traffic"] = pm[dom]["read_bytes_corrected_per_launch"] + pm[dom]["write_bytes_per_launch"]
+        shapes_tab = [{"op": n_, "shape": k_, "n": c, "ms": round(ms_, 3), "tflops": round(f / ms_ / 1e9, 1)}
+                      for (n_, k_), (c, f, ms_) in sorted(kt.shapes.items(), key=lambda kv: -kv[1][2]) if f > 0][:24]
         result = {
             "metric": "video-text pairs/sec (8f x 224^2, 40-tok)", "value": round(value, 3), "unit": unit, "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype, "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2**30, 2), "data": "synthetic (randn clips, random token ids; random-init weights)",
             "config": {"workload": wl, "per_gpu_batch": B, "frames": T, "parallelism": ("dp%d (RCCL: feature all-gather + flat gradient all-reduce)" % world) if train else ("dp%d (independent clips, no data-path collective)" % world)},
+            "mode": mode_name(args.dtype),
             "world_size": world, "dist_backend": (torch.distributed.get_backend() if torch.distributed.is_initialized() else "none (single process)"),
+            "rccl_version": ".".join(str(v) for v in torch.cuda.nccl.version()) if hasattr(torch.cuda, "nccl") else None,
+            "nccl_channels": {k_: os.environ.get(k_) for k_ in ("NCCL_MAX_NCHANNELS", "NCCL_MIN_NCHANNELS", "ALPRO_OVERLAP_BACKWARD") if os.environ.get(k_) is not None},
             "model_tflops_per_gpu": round(value / world * flops_per_unit / 1e12, 2),
             "roofline": {"bound": "mfma", "kernel": "gemm_nt*/gemm_tn kernels<%s> (all %d GEMM launches of one step)" % (args.dtype, gemm["launches"]),
                          "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                          "avg_launch_ms": round(gemm["ms"] / gemm["launches"], 4),
                          "gflop_per_launch": round(gemm["flops"] / gemm["launches"] / 1e9, 2), "traffic": traffic,
-                         "traffic_unit": "HBM bytes per GEMM launch (PMC)", "traffic_source": traffic_src},
+                         "traffic_unit": "HBM bytes per GEMM launch (PMC)", "traffic_source": traffic_src,
+                         "dominant_instance": dominant, "gemm_shapes": shapes_tab},
             "kernel_ms_per_step": {k: round(v["ms"], 3) for k, v in ks.items()},
         }
         if world == 1 and args.dtype in ("bf16", "fp16") and T == 8 and not args.no_divst:  # the north-star kernel target, measured in the same process (~1 s)
@@ -481,6 +533,9 @@ def main():
                 opt = None
             torch.cuda.empty_cache()
             result["parity"] = measure_parity(dev, args.dtype)
+        else:   # (--no-parity, or N > 1 where rank 0 alone cannot run it): say where the measured numbers of this mode live
+            result["parity"] = {"mode": mode_name(args.dtype), "measured_in_this_run": False,
+                                "see": "profiles/r4_parity_pareto.txt (worst-of-four-fixture VTC-logit error and the B=64 proxy per mode); rerun with N=1 and without --no-parity to measure in-process"}
         if not args.no_cpu_baseline and world == 1:  # reported at N=1 only (rank 0 would keep its peers waiting at N>1)
             result["cpu_baseline"] = cpu_baseline_train(T) if train else cpu_baseline(T)
         print(json.dumps(result), flush=True)

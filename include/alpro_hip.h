@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define ALPRO_HIP_ABI_VERSION 14
+#define ALPRO_HIP_ABI_VERSION 15
 
 enum { ALPRO_OK = 0, ALPRO_ERR_INVALID = 1, ALPRO_ERR_LAUNCH = 2 };
 enum { ALPRO_F32 = 0, ALPRO_BF16 = 1, ALPRO_F16 = 2 };
@@ -149,6 +149,15 @@ int alpro_add_layernorm_fwd(const float* x_in, const void* delta, int dtype, con
  * T must divide 32.  softmax(q k^T * scale) v on MFMA with a block-diagonal group mask. */
 int alpro_attn_temporal_fwd(const void* qkv, void* out, int dtype, int64_t rows, int T, int H, float scale,
                             float* lse /* optional (ceil(rows/32), H, 32) row log-sum-exp for the backward */, void* stream);
+
+/* Precise CLS-query attention of the 16-bit operand modes (round 4; DESIGN.md section 2, "CLS rows precise"): for every (sequence, head) of
+ * the spatial half (vit.py:180 on (B*T, 1+N) tokens, query row 0 = the CLS token of :165-167) or of a text-mode BERT layer (xbert.py:299-341,
+ * query row 0 = [CLS]):   out[s, h*64:(h+1)*64] = softmax(q_cls K^T * scale + key_bias) V   in fp32, where q_cls and the CLS token's own
+ * k / v come UNROUNDED from qkv_cls (batch / group rows of 3*H*64 fp32: sequences s*group .. s*group+group-1 share row s -- the T frame
+ * copies of one clip; group = 1 for text) and the other tokens' K / V from the 16-bit qkv tensor (batch*L, 3*H*64) that alpro_gemm wrote.
+ * drop_p / drop_seed: attention-probability dropout with the mask alpro_attn_fwd draws for query 0 (xbert.py:331).  out (batch, H*64) fp32. */
+int alpro_attn_cls_fwd(const void* qkv, int dtype, const float* qkv_cls, const float* key_bias /* (batch, L) or NULL */, float* out, int batch,
+                       int L, int H, int group, float scale, float drop_p, uint32_t drop_seed, void* stream);
 
 /* Full (bidirectional) attention over `batch` sequences of L <= 256 tokens, head_dim 64:
  * spatial half of divided attention (vit.py:180 on (B*T, 1+N) tokens, :81-96) and the BERT

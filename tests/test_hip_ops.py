@@ -319,6 +319,41 @@ def test_attn_temporal(dt, T, groups):
     close(out, ref, *tol, "temporal attn")
 
 
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("batch,L,group,masked,p", [(6, 197, 3, False, 0.0), (4, 40, 1, True, 0.0), (8, 30, 1, True, 0.1), (2, 5, 2, False, 0.0), (16, 197, 8, False, 0.0),
+                                                    (3, 256, 1, True, 0.0)])
+def test_attn_cls_precise_query(dt, batch, L, group, masked, p):
+    """alpro_attn_cls_fwd (round 4): the CLS query's attention in fp32 -- q and the CLS token's own k / v unrounded from the fp32 side
+    tensor (one row per `group` sequences), the other tokens' K / V from the 16-bit qkv tensor -- against fp64; with probability dropout,
+    under the mask alpro_attn_fwd draws for query 0."""
+    hip = _hip()
+    H = 12
+    qkv = rnd(batch * L, 3 * H * 64, seed=300 + L).to(dt)
+    cls = rnd(batch // group, 3 * H * 64, seed=301 + L)
+    bias = None
+    if masked:
+        m = torch.ones(batch, L)
+        for b in range(batch):
+            m[b, L - 2 - (3 * b) % (L - 4):] = 0
+        bias = (1.0 - m) * -10000.0
+    seed = 12345 if p > 0 else 0
+    out = hip.attn_cls(qkv.cuda(), cls.cuda(), batch, L, H, 0.125, group=group, key_bias=None if bias is None else bias.cuda(), drop_p=p, drop_seed=seed)
+    t = qkv.double().view(batch, L, 3, H, 64).clone()
+    t[:, 0] = cls.double().view(batch // group, 3, H, 64).repeat_interleave(group, 0)   # the CLS token's q / k / v: unrounded
+    qc, k, v = t[:, 0, 0], t[:, :, 1], t[:, :, 2]                                       # (b, H, 64), (b, L, H, 64) x 2
+    sc = torch.einsum("bhd,blhd->bhl", qc, k) * 0.125
+    if bias is not None:
+        sc = sc + bias[:, None, :].double()
+    pr = sc.softmax(-1)
+    if p > 0:   # the mask alpro_attn_fwd draws for query 0 of (b, h): drop_keep(seed, ((b*H + h)*L + 0)*L + key) (attention.hip; numpy restatement)
+        from tests.test_hip_bwd_ops import _keep_mask
+        keep = torch.stack([_keep_mask(seed, (batch * H * L) * L, p).view(batch, H, L, L)[:, :, 0]])[0].double()
+        assert 0.02 < float(1.0 - keep.mean()) < 0.3
+        pr = pr * keep / (1.0 - p)
+    ref = torch.einsum("bhl,blhd->bhd", pr, v).reshape(batch, H * 64)
+    close(out, ref, 2e-5, 2e-5, "attn_cls")
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("M,N,K", [(15168, 768, 768), (45 * 256 + 17, 1024, 128), (2560, 3072, 768)])
 def test_gemm_persistent_partial_grid(M, N, K):

@@ -122,11 +122,8 @@ def test_pretrain_forward_vs_reference(bert_cfg, monkeypatch, mode, tol):
         e[k] = close(out[k], g[k], tol, what=k)
     close(out["mpm_labels"], g["mpm_labels"], tol * 1e-2, what="mpm_labels (soft)")
     e["mlm_scores"] = close(out["mlm_scores"][:, :, ::61], g["mlm_scores_cols"], tol, what="mlm_scores")
-    # fp16: 4e-4 .. 1e-3 depending on the fixture and on which roundings the kernels make (1.03e-3 on THIS fixture before the round-3
-    # fusions, 4.1e-4 after; 5.3e-4 / 7.4e-4 on retrieval_T2 / T16): 11-bit operands through the ~60 GEMM / attention layers of the ViT put
-    # the logits just inside the north star's 1e-3.  Asserted: 1e-3 here and on retrieval_T2 (>= 2x margin), 1.5e-3 on retrieval_T16 and the
-    # released geometry (7.4e-4 / 8.0e-4 measured: any change of which value gets rounded where moves these by tens of percent) -- see
-    # DESIGN.md section 2 for what that means at B = 64
+    # fp16 (since round 4: 16-bit operands + the CLS rows re-evaluated in fp32, alpro_amd.config.cls_precise): asserted at the north star's
+    # 1e-3 on ALL four reference fixtures (test_vtc_logits_meet_the_north_star_bar_on_every_fixture); plain fp16 measured 3.4e-4 .. 1.06e-3
     e["sim_v2t"] = close(vf @ tf.t() / m.temp, g["sim_v2t"], {"fp32": 1e-3, "fp16": 1e-3, "bf16": 1.6e-2}[mode], what="VTC logits")
     e["video_feat"] = close(vf, g["video_feat"], tol, what="video_feat")
     e["text_embeds"] = close(te, g["text_embeds"], tol * (1 if mode == "fp32" else 2), what="text_embeds")
@@ -486,7 +483,7 @@ def test_retrieval_16_frames_vs_reference(bert_cfg, monkeypatch, mode, tol):
         close(out[k], g[k], tol, what=k)
     assert torch.equal(out["itm_labels"].cpu(), torch.from_numpy(g["itm_labels"]).long())
     close(ve[:, [0, 1, 100, 196]], g["video_embeds_rows"], tol * (1 if mode == "fp32" else 2), what="video_embeds rows (16 frames)")
-    close(inf["itc_scores"], g["inf_itc_scores"], {"fp32": 1e-3, "fp16": 1.5e-3}.get(mode, tol), what="VTC logits (16 frames; fp16 measures 7.4e-4)")
+    close(inf["itc_scores"], g["inf_itc_scores"], {"fp32": 1e-3, "fp16": 1e-3}.get(mode, tol), what="VTC logits (16 frames): the north star's 1e-3 for fp32 and fp16")
     close(inf["logits"], g["inf_logits"], tol, what="inference ITM logits (16 frames)")
 
 
@@ -547,8 +544,8 @@ def test_pretrain_released_geometry_vs_reference(bert_cfg, monkeypatch, mode, to
     for k in ("itc_loss", "itm_loss", "mlm_loss", "mpm_loss", "itm_scores", "mpm_logits"):
         close(out[k], g[k], tol, what=k)
     close(out["mlm_scores"][:, :, ::61], g["mlm_scores_cols"], tol, what="mlm_scores")
-    close(vf @ tf.t() / m.temp, g["sim_v2t"], {"fp32": 1e-3, "fp16": 1.5e-3, "bf16": 1.6e-2}[mode],
-          what="VTC logits (released geometry; fp16 measures 8.0e-4 here -- see the note in test_pretrain_forward_vs_reference)")
+    close(vf @ tf.t() / m.temp, g["sim_v2t"], {"fp32": 1e-3, "fp16": 1e-3, "bf16": 1.6e-2}[mode],
+          what="VTC logits (released geometry): the north star's 1e-3 for fp32 and fp16 (fp16 = 16-bit operands + precise CLS rows since round 4)")
     close(te[:, [0, 1, 29]], g["text_embeds_rows"], tol * (1 if mode == "fp32" else 2), what="text_embeds rows")
     close(ve[:, [0, 1, 57, 196]], g["video_embeds_rows"], tol * (1 if mode == "fp32" else 2), what="video_embeds rows")
     assert torch.equal(out["itm_labels"].cpu(), torch.from_numpy(g["itm_labels"]).long())
@@ -566,3 +563,95 @@ def test_pretrain_released_geometry_vs_reference(bert_cfg, monkeypatch, mode, to
         print("[parity-report] released_geometry_gradients[%s] | worst grad-norm rel err | err %.3e | limit %.1e" % (mode, rel.max(), rtol))
         return
     assert rel.max() < rtol, (names[int(rel.argmax())], float(rel.max()))
+
+# ---- round 4: the bar on the worst fixture, and parity at the benchmarked size ------------------------------------
+MODES = {"fp32": ("fp32", "auto"), "fp16": ("fp16", "auto"), "fp16_plain": ("fp16", "0"), "bf16": ("bf16", "auto"), "bf16_cls": ("bf16", "1")}
+
+
+@pytest.fixture(scope="module")
+def fixture_models(bert_cfg):
+    from tests.golden import parity_cases as pc
+    built = {}
+
+    def get(name):
+        if name not in built:
+            built.clear()           # one 465 M-parameter model on the device at a time
+            torch.cuda.empty_cache()
+            built[name] = pc.build_case(name, bert_cfg, VENC, make_cfg, "cuda")
+        return built[name]
+    return get
+
+
+@pytest.mark.parametrize("case", ["retrieval_T2", "pretrain_T8", "retrieval_T16", "pretrain_release_T4_L30"])
+def test_vtc_logits_meet_the_north_star_bar_on_every_fixture(fixture_models, case):
+    """BASELINE.json: "VTC logits within 1e-3 of reference" -- on EVERY reference-generated fixture, in the exact mode and in the benchmark's
+    mode (fp16 operands + precise CLS rows).  Plain fp16 (no CLS side path: 3.4e-4 .. 1.06e-3 in round 3) and bf16 are measured beside
+    them with the limits of what they reach."""
+    from alpro_amd import config as rt
+    from tests.golden import parity_cases as pc
+    m, batch, ref = fixture_models(case)
+    errs = {}
+    for name, (dt, cls) in MODES.items():
+        with rt.use_compute_dtype(dt), rt.use_cls_precise(cls):
+            errs[name] = pc.vtc_logit_error(case, m, batch, ref)
+    print("\n[vtc-logit parity %s] " % case + "  ".join("%s %.2e" % kv for kv in errs.items()))
+    if os.environ.get("ALPRO_PARITY_REPORT"):
+        for k, v in errs.items():
+            print("[parity-report] vtc_logits[%s] | %s | err %.3e | limit %.1e" % (case, k, v, pc.NORTH_STAR_BAR if k in ("fp32", "fp16") else 2e-2))
+        return
+    assert errs["fp32"] <= 2e-5, errs
+    assert errs["fp16"] <= pc.NORTH_STAR_BAR, errs
+    assert errs["fp16_plain"] <= 2e-3 and errs["bf16"] <= 1.6e-2 and errs["bf16_cls"] <= 1.6e-2, errs
+
+
+def test_full_size_pretrain_forward_in_the_bench_dtype_vs_the_exact_mode(bert_cfg, monkeypatch):
+    """No golden vectors exist at BASELINE's size, but the exact fp32 HIP mode is pinned to the reference at <= 5e-6 on every fixture: it is
+    the oracle at full size.  AlproForPretrain, eval mode, B = 64 x 8 frames x 224^2 + 40 tokens, random-init weights: the benchmark's mode
+    (fp16 operands + precise CLS rows) against the exact mode on ALL 4096 VTC logits (max and p99.9), the ITM scores of the same hard
+    negatives, the MPM logits and every 61st MLM column."""
+    from alpro_amd import config as rt
+    from alpro_amd.modeling.alpro_models import AlproForPretrain
+    import bench
+    torch.manual_seed(4)
+    B, T = 64, 8
+    m = AlproForPretrain(make_cfg(bert_cfg), dict(VENC, num_frm=T)).eval().cuda()
+    batch = bench.synth_batch(B, T, "cuda", seed=11, full=True)
+    batch["text_input_mask"] = batch["text_input_mask"].clone()
+    batch["text_input_mask"][::3, 31:] = 0
+    monkeypatch.setattr(torch, "multinomial", argmax_multinomial)
+    negs = {}
+    orig = AlproForPretrain._sample_negatives
+
+    def record(sim_v2t, sim_t2v, bs):
+        if "n" not in negs:
+            negs["n"] = orig(sim_v2t, sim_t2v, bs)
+        return negs["n"]
+    monkeypatch.setattr(AlproForPretrain, "_sample_negatives", staticmethod(record))
+
+    def run(dt, cls):
+        with rt.use_compute_dtype(dt), rt.use_cls_precise(cls), torch.no_grad():
+            ve = m._forward_visual_embeds(batch["visual_inputs"])
+            _, tf = m._forward_text_feats(batch)
+            logits = m._video_feat(ve) @ tf.t() / m.temp
+            out = m(batch)
+        return dict(logits=logits.double().cpu(), itm=out["itm_scores"].double().cpu(), mpm=out["mpm_logits"].double().cpu(),
+                    mlm=out["mlm_scores"][:, :, ::61].double().cpu(), itc_loss=out["itc_loss"].double().cpu())
+    ref = run("fp32", "auto")        # (runs first: its hard negatives are the ones every mode scores)
+    rep = {}
+    for name, (dt, cls) in MODES.items():
+        if name == "fp32":
+            continue
+        got = run(dt, cls)
+        e = (got["logits"] - ref["logits"]).abs().flatten()
+        rep[name] = dict(max=float(e.max()), p999=float(e.kthvalue(int(0.999 * e.numel()))[0]), rms=float(e.pow(2).mean().sqrt()),
+                         itm=float((got["itm"] - ref["itm"]).abs().max()), mpm=float((got["mpm"] - ref["mpm"]).abs().max()),
+                         mlm=float((got["mlm"] - ref["mlm"]).abs().max()), itc_loss=float((got["itc_loss"] - ref["itc_loss"]).abs()))
+        print("\n[B=64 proxy %-10s] VTC logits (4096): max %.2e p99.9 %.2e rms %.2e | ITM %.2e | MPM %.2e | MLM %.2e | itc_loss %.2e" % (
+            name, rep[name]["max"], rep[name]["p999"], rep[name]["rms"], rep[name]["itm"], rep[name]["mpm"], rep[name]["mlm"], rep[name]["itc_loss"]))
+        if os.environ.get("ALPRO_PARITY_REPORT"):
+            print("[parity-report] full_size_proxy[%s] | VTC logits max / p99.9 / rms | err %.3e / %.3e / %.3e | limit 1.0e-03" % (name, rep[name]["max"], rep[name]["p999"], rep[name]["rms"]))
+    if os.environ.get("ALPRO_PARITY_REPORT"):
+        return
+    assert rep["fp16"]["p999"] <= 1e-3 and rep["fp16"]["max"] <= 1.5e-3, rep["fp16"]     # (tightened to what the first measurement shows)
+    assert rep["fp16"]["rms"] < 0.6 * rep["fp16_plain"]["rms"], rep                        # the side path must carry its weight at full size too
+    assert rep["fp16"]["itm"] <= 5e-3 and rep["fp16"]["mlm"] <= 2e-2 and rep["fp16"]["mpm"] <= 5e-3, rep["fp16"]
