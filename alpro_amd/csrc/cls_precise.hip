@@ -113,6 +113,120 @@ __global__ __launch_bounds__(256) void attn_cls_kernel(const T* __restrict__ qkv
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// alpro_gemm_rows_f32: the Linears of the precise side path -- C[M, N] = residual + row_scale * act(LN?(A)[M, K] W[N, K]^T + bias), fp32
+// throughout (v_mfma_f32_16x16x4_f32: exact fp32 products, fp32 accumulation), for a HANDFUL of rows (M = B or B*T) against a full weight
+// matrix.  alpro_gemm's 128x128 fp32 tile turns such a problem into N/128 workgroups walking the whole K serially (fc2 of the CLS rows:
+// 6 workgroups x 96 K-steps = 190 us on an otherwise idle chip); here a workgroup owns 64 rows x 16 columns, its four waves split K four
+// ways and meet in LDS (fixed summation order: bit-reproducible), so the same problem is 48 workgroups x 12 steps (~10 us).
+// Optional fused LayerNorm of the A rows (K == the row width: statistics of the 64 rows recomputed per workgroup, two-pass in registers).
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+template <int ACT, bool LN>
+__global__ __launch_bounds__(256) void gemm_rows_f32_kernel(const float* __restrict__ A, int64_t lda, const float* __restrict__ W, int64_t ldw,
+                                                            float* __restrict__ C, int64_t ldc, int M, int N, int K, const float* __restrict__ bias,
+                                                            const float* __restrict__ row_scale, const float* __restrict__ residual, int64_t ldr,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta, float eps) {
+  __shared__ float part[4][64][16];
+  __shared__ float stat[64][2];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n0 = blockIdx.x * 16, m0 = blockIdx.y * 64;
+  const int r15 = lane & 15, kg = lane >> 4;
+  if (LN) {   // mean / rstd of rows m0 + wave*16 .. +15, one row at a time: the whole row in registers (K <= 64 * 12 * 4), two passes
+    for (int r = 0; r < 16; ++r) {
+      const int row = min(m0 + wave * 16 + r, M - 1);
+      const float* a = A + (int64_t)row * lda;
+      float v[48];
+      float sum = 0.f;
+      const int nv = K >> 8;   // float4 per lane (K multiple of 256 when LN is fused: 768)
+#pragma unroll
+      for (int i = 0; i < 12; ++i) {
+        if (i < nv) {
+          const float4 t = *(const float4*)(a + (i * 64 + lane) * 4);
+          v[4 * i] = t.x; v[4 * i + 1] = t.y; v[4 * i + 2] = t.z; v[4 * i + 3] = t.w;
+          sum += (t.x + t.y) + (t.z + t.w);
+        }
+      }
+      const float mean = wave_sum(sum) / (float)K;
+      float sq = 0.f;
+#pragma unroll
+      for (int i = 0; i < 12; ++i) {
+        if (i < nv) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { const float d = v[4 * i + e] - mean; sq = fmaf(d, d, sq); }
+        }
+      }
+      const float var = wave_sum(sq) / (float)K;
+      if (lane == 0) { stat[wave * 16 + r][0] = mean; stat[wave * 16 + r][1] = rsqrtf(var + eps); }
+    }
+    __syncthreads();
+  }
+  float mu[4], rs[4];
+#pragma unroll
+  for (int f = 0; f < 4; ++f) { mu[f] = LN ? stat[f * 16 + r15][0] : 0.f; rs[f] = LN ? stat[f * 16 + r15][1] : 1.f; }
+  const int kslice = K >> 2, k0 = wave * kslice;
+  const float* ap[4];
+#pragma unroll
+  for (int f = 0; f < 4; ++f) ap[f] = A + (int64_t)min(m0 + f * 16 + r15, M - 1) * lda + k0 + kg * 4;
+  const float* wp = W + (int64_t)(n0 + r15) * ldw + k0 + kg * 4;
+  const float* gp = LN ? gamma + k0 + kg * 4 : nullptr;
+  const float* bp = LN ? beta + k0 + kg * 4 : nullptr;
+  f32x4v acc[4];
+#pragma unroll
+  for (int f = 0; f < 4; ++f) acc[f] = f32x4v{0.f, 0.f, 0.f, 0.f};
+  const int steps = kslice >> 4;
+#pragma unroll 4
+  for (int s = 0; s < steps; ++s) {
+    const float4 b4 = *(const float4*)(wp + s * 16);
+    float4 a4[4];
+#pragma unroll
+    for (int f = 0; f < 4; ++f) a4[f] = *(const float4*)(ap[f] + s * 16);
+    if (LN) {
+      const float4 g4 = *(const float4*)(gp + s * 16), o4 = *(const float4*)(bp + s * 16);
+#pragma unroll
+      for (int f = 0; f < 4; ++f) {
+        a4[f].x = fmaf((a4[f].x - mu[f]) * rs[f], g4.x, o4.x);
+        a4[f].y = fmaf((a4[f].y - mu[f]) * rs[f], g4.y, o4.y);
+        a4[f].z = fmaf((a4[f].z - mu[f]) * rs[f], g4.z, o4.z);
+        a4[f].w = fmaf((a4[f].w - mu[f]) * rs[f], g4.w, o4.w);
+      }
+    }
+    const float bb[4] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+      const float aa[4] = {a4[f].x, a4[f].y, a4[f].z, a4[f].w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[f] = __builtin_amdgcn_mfma_f32_16x16x4f32(aa[e], bb[e], acc[f], 0, 0, 0);
+    }
+  }
+  // D layout: lane holds rows kg*4 + r, column r15 of each 16x16 fragment
+#pragma unroll
+  for (int f = 0; f < 4; ++f)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) part[wave][f * 16 + kg * 4 + r][r15] = acc[f][r];
+  __syncthreads();
+  {
+    const int row = tid >> 2, c4 = (tid & 3) * 4;
+    const int m = m0 + row, n = n0 + c4;
+    if (m < M) {
+      float v[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = ((part[0][row][c4 + e] + part[1][row][c4 + e]) + part[2][row][c4 + e]) + part[3][row][c4 + e];
+      const float sc = row_scale ? row_scale[m] : 1.0f;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float x = v[e] + (bias ? bias[n + e] : 0.f);
+        if (ACT == ALPRO_ACT_GELU) x = gelu_erf(x);
+        x *= sc;
+        if (residual) x += residual[(int64_t)m * ldr + n + e];
+        v[e] = x;
+      }
+      *(float4*)(C + (int64_t)m * ldc + n) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+  }
+}
+
 }  // namespace
 }  // namespace alpro
 
@@ -132,4 +246,26 @@ extern "C" int alpro_attn_cls_fwd(const void* qkv, int dtype, const float* qkv_c
   else
     hipLaunchKernelGGL(attn_cls_kernel<f16_t>, grid, block, 0, (hipStream_t)stream, (const f16_t*)qkv, qkv_cls, key_bias, out, batch, L, H, group, scale, drop_p, drop_seed);
   return check_launch("alpro_attn_cls_fwd");
+}
+
+extern "C" int alpro_gemm_rows_f32(const float* A, int64_t lda, const float* W, int64_t ldw, float* C, int64_t ldc, int M, int N, int K,
+                                   const float* bias, int act, const float* row_scale, const float* residual, int64_t ldr,
+                                   const float* ln_gamma, const float* ln_beta, float ln_eps, void* stream) {
+  ALPRO_CHECK(A && W && C && M > 0 && N > 0 && K > 0, "alpro_gemm_rows_f32: bad args");
+  ALPRO_CHECK(N % 16 == 0 && K % 64 == 0, "alpro_gemm_rows_f32: N=%d must be a multiple of 16 and K=%d of 64", N, K);
+  ALPRO_CHECK(lda % 4 == 0 && ldw % 4 == 0 && ldc % 4 == 0 && ((uintptr_t)A % 16) == 0 && ((uintptr_t)W % 16) == 0 && ((uintptr_t)C % 16) == 0,
+              "alpro_gemm_rows_f32: rows must be 16-byte aligned");
+  ALPRO_CHECK(act == ALPRO_ACT_NONE || act == ALPRO_ACT_GELU, "alpro_gemm_rows_f32: act %d unsupported (none / gelu)", act);
+  ALPRO_CHECK(!ln_gamma == !ln_beta, "alpro_gemm_rows_f32: LayerNorm needs both gamma and beta");
+  ALPRO_CHECK(!ln_gamma || (K % 256 == 0 && K <= 3072), "alpro_gemm_rows_f32: fused LayerNorm needs K a multiple of 256, at most 3072 (got %d)", K);
+  const dim3 grid(N / 16, (M + 63) / 64), block(256);
+  hipStream_t st = (hipStream_t)stream;
+#define ALPRO_ROWS(ACT_, LN_) hipLaunchKernelGGL((gemm_rows_f32_kernel<ACT_, LN_>), grid, block, 0, st, A, lda, W, ldw, C, ldc, M, N, K, bias, row_scale, residual, ldr, ln_gamma, ln_beta, ln_eps)
+  if (ln_gamma) {
+    if (act == ALPRO_ACT_GELU) ALPRO_ROWS(ALPRO_ACT_GELU, true); else ALPRO_ROWS(ALPRO_ACT_NONE, true);
+  } else {
+    if (act == ALPRO_ACT_GELU) ALPRO_ROWS(ALPRO_ACT_GELU, false); else ALPRO_ROWS(ALPRO_ACT_NONE, false);
+  }
+#undef ALPRO_ROWS
+  return check_launch("alpro_gemm_rows_f32");
 }

@@ -218,7 +218,7 @@ __device__ __forceinline__ void attn_unit(int blk, int nblk, int H, int order, i
     h = blk - b * H;
   }
 }
-enum { OPT_GEMM_TILE = 0, OPT_GEMM_GRID = 1, OPT_GEMM_TUNE = 2, OPT_TN_SPLITS = 3, OPT_TN_KIND = 4, OPT_GEMM_TAIL = 5, OPT_ATTN_BWD = 6, OPT_ATTN_ORDER = 7, OPT_COUNT = 8 };
+enum { OPT_GEMM_TILE = 0, OPT_GEMM_GRID = 1, OPT_GEMM_TUNE = 2, OPT_TN_SPLITS = 3, OPT_TN_KIND = 4, OPT_GEMM_TAIL = 5, OPT_ATTN_BWD = 6, OPT_ATTN_ORDER = 7, OPT_GEMM_KIND = 8, OPT_COUNT = 9 };
 int get_option(int which);
 
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) must be applied once per (kernel, device): a per-instantiation bit mask

@@ -728,6 +728,251 @@ __global__ __launch_bounds__(NT2, 2) void gemm_nt256p_kernel(const alpro_gemm_de
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Round 4: the 256x256 tile as an 8-phase, two-group ("ping-pong") schedule on v_mfma_f32_16x16x32 fragments.
+//
+// What changes against gemm_nt256p_kernel (same macro tile, same 8 waves as 2 x 4, same 128x64 per wave, same LDS images and swizzle):
+//  * the two waves that share a SIMD (w and w + 4) never want the matrix pipe at the same time.  A K-tile is four PHASES, one 64x32
+//    quadrant of the wave's tile each (16 MFMAs on 8 independent accumulators: no dependent back-to-back issue); a phase is
+//        LOAD segment: this quadrant's ds_read_b128 fragment reads + the two DMA pieces of one half-tile  -> s_barrier
+//        MFMA segment: 16 MFMAs at raised priority                                                     -> s_barrier
+//    and the upper wave row (waves 4-7) runs one barrier behind the lower one, so on every SIMD one wave is in its MFMA segment while
+//    its partner issues LDS reads and copies -- the pipe sees a continuous MFMA stream instead of two identical streams colliding;
+//  * the stage buffers are eight 16 KiB half-tile slots (2 K-tile parities x {A rows 0-127, A 128-255, W 0-127, W 128-255}) refilled one
+//    slot per phase as soon as its last reader is two phases behind; ONE counted wait per K-tile (vmcnt(2) at the end of phase 4's LOAD
+//    segment: everything but the half-tile just issued has landed), placed one phase before the first read of the data it covers;
+//  * the next tile's first K-tile streams in during the current tile's last K-tile, so the K loop runs across tile boundaries without a
+//    prologue; the two groups re-align only for the epilogue (both store at the same time) and split again behind it.
+// Schedule (K-tile t of the tile, buffer parity P = t & 1; quadrant = (A rows mi*64.., W rows ni*32..) of the wave's 128 x 64):
+//    phase 1  reads B(ni 0) + A(mi 0)   copies A-half 0 of K-tile t+1 -> parity P^1     MFMA quadrant (0, 0)
+//    phase 2  reads B(ni 1)             copies A-half 1 of K-tile t+1 -> parity P^1     MFMA quadrant (0, 1)
+//    phase 3  reads A(mi 1)             copies W-half 1 of K-tile t+1 -> parity P^1     MFMA quadrant (1, 1)
+//    phase 4  --                        copies W-half 0 of K-tile t+2 -> parity P, vmcnt(2)   MFMA quadrant (1, 0)
+// Hazards (phase index k, barrier b; lower group: LOAD(k) in [b 2k-1, b 2k], MFMA(k) in [2k, 2k+1]; upper group one barrier later):
+//    RAW  a wave's wait at the end of LOAD(k) precedes barrier 2k+1 for both groups; the data is first read in LOAD(k+1), after it;
+//    WAR  a slot last read in LOAD(kr) is idle once barrier 2kr+2 has passed (the upper group's reads retire inside its MFMA(kr));
+//         its refill is issued in LOAD(kw), kw >= kr + 2, i.e. after barrier 2kw-1 >= 2kr+3.  (A-half h: kr = phase 3 of K-tile t-1, kw =
+//         phase 1 / 2 of K-tile t; W-half 1: kr = phase 2 of t-1, kw = phase 3 of t; W-half 0: kr = phase 2 of t, kw = phase 4 of t.)
+constexpr int HALF2_BYTES = 128 * ROWB;           // 16 KiB: 128 rows x 128 bytes
+constexpr int STAGE2_BYTES = 4 * HALF2_BYTES;     // one K-tile parity: A0 | A1 | W0 | W1
+
+template <typename T> struct Mma16;
+template <> struct Mma16<bf16_t> {
+  static __device__ __forceinline__ f32x4 run(const u32x4& a, const u32x4& b, const f32x4& c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+  }
+};
+template <> struct Mma16<f16_t> {
+  static __device__ __forceinline__ f32x4 run(const u32x4& a, const u32x4& b, const f32x4& c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+  }
+};
+
+template <typename T, int ACT, int MAP>
+__global__ __launch_bounds__(NT2, 2) void gemm_nt256q_kernel(const alpro_gemm_desc_t g) {
+  static_assert(sizeof(T) == 2, "16-bit operands only");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  const int ntn = (g.N + BN2 - 1) / BN2, ntm = (g.M + BM2 - 1) / BM2;
+  const int nblk = ntn * ntm;
+  const int64_t lda_b = g.lda * 2, ldw_b = g.ldw * 2;
+  const int nk = g.K >> 6;                       // K-tiles of 64 elements; even and >= 4 (launcher)
+  const int G = gridDim.x, per_xcd = (G + 7) >> 3;
+  const int slot = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+  if (slot >= nblk) return;
+  const int ntile = (nblk - slot + G - 1) / G;   // tiles slot, slot + G, ...
+  const uint32_t lds_base = lds_addr_of(smem);
+
+  // DMA sources.  Full tiles only (launcher), so nothing is clamped and everything tile-dependent is wave-uniform: a copy reads
+  //   [A + (m0 + h*128 + i*8) * lda_b + kt*128]  (SGPR pair)  +  [(r0 * lda_b + chunk*16) ^ i*64]  (one 32-bit VGPR per operand)
+  // for piece i of half-tile h, r0 = wave*16 + (lane >> 3) = the lane's row in piece 0, chunk = (lane & 7) ^ swizzle(r0); piece 1 sits 8 rows
+  // further, where the swizzle differs by 4 chunks = 64 bytes (lda_b is a multiple of 128: launcher).
+  const int r0 = wave * 16 + (lane >> 3);
+  const uint32_t sw0 = (uint32_t)(((lane & 7) ^ ((r0 >> 1) & 7)) << 4);
+  uint32_t oa[2][2], ow[2][2];   // [half-tile h][piece i]: the lane's byte offset from the tile's K-tile base
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      oa[h][i] = (uint32_t)((r0 + h * 128 + i * 8) * lda_b) + (sw0 ^ (uint32_t)(i * 64));
+      ow[h][i] = (uint32_t)((r0 + h * 128 + i * 8) * ldw_b) + (sw0 ^ (uint32_t)(i * 64));
+    }
+  struct Tile { const char* a; const char* w; };   // A + m0 * lda_b, W + n0 * ldw_b (wave-uniform)
+  auto tile_base = [&](int tile) {
+    const int tm = tile / ntn, tn = tile - tm * ntn;
+    return Tile{(const char*)g.A + (int64_t)tm * BM2 * lda_b, (const char*)g.W + (int64_t)tn * BN2 * ldw_b};
+  };
+  // half-tile `hs` (0 / 1: A rows 0-127 / 128-255, 2 / 3: W rows) from `kbase` (= tile base + kt * 128 bytes, wave-uniform) -> slot hs of parity `par`
+  auto copy_half = [&](const char* kbase, int hs, int par) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const uint32_t vo = hs < 2 ? oa[hs & 1][i] : ow[hs & 1][i];
+      const uint32_t dst = __builtin_amdgcn_readfirstlane(lds_base + par * STAGE2_BYTES + hs * HALF2_BYTES + (wave * 2 + i) * 1024);
+      asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(vo), "s"(kbase), "s"(dst) : "memory", "m0");
+    }
+  };
+  // fragment read offsets: lane l supplies row (l & 15) and the 8-element k group (l >> 4) of a 16 x 32 operand fragment; chunk index
+  // (ks * 4 + kg) ^ swizzle(row) == (ks * 64 bytes) ^ ((kg ^ swizzle) * 16 bytes)
+  const int l15 = lane & 15, kg = lane >> 4;
+  const int frag0 = l15 * ROWB + ((kg ^ ((l15 >> 1) & 7)) << 4);
+  const char* aF[2] = {smem + wr * HALF2_BYTES + frag0, smem + wr * HALF2_BYTES + (frag0 ^ 64)};
+  const char* bF[2] = {smem + (2 + (wc >> 1)) * HALF2_BYTES + (wc & 1) * 64 * ROWB + frag0,
+                       smem + (2 + (wc >> 1)) * HALF2_BYTES + (wc & 1) * 64 * ROWB + (frag0 ^ 64)};
+  float* stage = (float*)(smem + 2 * STAGE2_BYTES + wave * (16 * 64 * 4));   // 4 KiB per wave: 16 rows x 64 columns fp32
+
+  auto barrier = [] {
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  Tile cur = tile_base(slot);
+  Tile nxt = ntile > 1 ? tile_base(slot + G) : cur;   // (no next tile: the run-ahead copies re-read this tile's first K-tiles into dead slots)
+  // pipeline fill: K-tile 0 complete in parity 0, W-half 0 of K-tile 1 on its way into parity 1
+#pragma unroll
+  for (int hs = 0; hs < 4; ++hs) copy_half(hs < 2 ? cur.a : cur.w, hs, 0);
+  copy_half(cur.w + ROWB, 2, 1);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  barrier();
+
+  for (int it = 0; it < ntile; ++it) {
+    const int tile = slot + it * G;
+    const int tm0 = (tile / ntn) * BM2, tn0 = (tile - (tile / ntn) * ntn) * BN2;
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (wr == 1) barrier();   // the upper wave row drops one barrier behind
+
+    // one K-tile (parity P compile-time): four phases
+    auto ktile = [&](auto par_tag, int t) {
+      constexpr int P = decltype(par_tag)::value;
+      u32x4 fa[4][2], fb[2][2][2];
+      const bool in1 = t + 1 < nk, in2 = t + 2 < nk;          // targets inside this tile? else the next tile's K-tile 0 / 1
+      const int k1 = in1 ? t + 1 : 0, k2 = in2 ? t + 2 : t + 2 - nk;
+      const char* a1 = (in1 ? cur.a : nxt.a) + (int64_t)k1 * ROWB;   // K-tile t+1: both A halves and W half 1
+      const char* w1 = (in1 ? cur.w : nxt.w) + (int64_t)k1 * ROWB;
+      const char* w2 = (in2 ? cur.w : nxt.w) + (int64_t)k2 * ROWB;   // K-tile t+2: W half 0
+      auto load_a = [&](int mi) {
+#pragma unroll
+        for (int f = 0; f < 4; ++f)
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks) fa[f][ks] = *(const u32x4*)(aF[ks] + P * STAGE2_BYTES + (mi * 64 + f * 16) * ROWB);
+      };
+      auto load_b = [&](int ni) {
+#pragma unroll
+        for (int f = 0; f < 2; ++f)
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks) fb[ni][f][ks] = *(const u32x4*)(bF[ks] + P * STAGE2_BYTES + (ni * 32 + f * 16) * ROWB);
+      };
+      auto mma = [&](int mi, int ni) {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+          for (int f = 0; f < 4; ++f)
+#pragma unroll
+            for (int e = 0; e < 2; ++e) acc[mi * 4 + f][ni * 2 + e] = Mma16<T>::run(fa[f][ks], fb[ni][e][ks], acc[mi * 4 + f][ni * 2 + e]);
+        __builtin_amdgcn_s_setprio(0);
+      };
+      // phase 1
+      load_b(0);
+      load_a(0);
+      copy_half(a1, 0, P ^ 1);
+      barrier();
+      mma(0, 0);
+      barrier();
+      // phase 2
+      load_b(1);
+      copy_half(a1, 1, P ^ 1);
+      barrier();
+      mma(0, 1);
+      barrier();
+      // phase 3
+      load_a(1);
+      copy_half(w1, 3, P ^ 1);
+      barrier();
+      mma(1, 1);
+      barrier();
+      // phase 4
+      copy_half(w2, 2, P);
+      asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+      barrier();
+      mma(1, 0);
+      barrier();
+    };
+    for (int t = 0; t < nk; t += 2) {
+      ktile(std::integral_constant<int, 0>{}, t);
+      ktile(std::integral_constant<int, 1>{}, t + 1);
+    }
+    if (wr == 0) barrier();   // re-align: both wave rows run their epilogues at the same time
+
+    // ---- epilogue: one 16-row fragment row (16 x 64 fp32 = 4 KiB of wave-private LDS) at a time
+    {
+      const int mb = tm0 + wr * 128, nb = tn0 + wc * 64;
+      auto stage_rows = [&](int mf) {
+#pragma unroll
+        for (int nf = 0; nf < 4; ++nf)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) stage[(kg * 4 + r) * 64 + nf * 16 + l15] = acc[mf][nf][r];
+      };
+      const bool fast = epi_fast_ok(g, mb, 128, nb);
+      bool c16 = false;
+      if constexpr (MAP == ALPRO_MAP_IDENTITY) c16 = fast && g.c_dtype != ALPRO_F32 && ((g.ldc & 7) == 0) && (!g.C2 || (g.ldc2 & 7) == 0);
+      if (c16) {
+        if constexpr (MAP == ALPRO_MAP_IDENTITY) {
+          float bias8[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) bias8[e] = g.bias ? g.bias[nb + (lane & 7) * 8 + e] : 0.f;
+          constexpr bool READS_C2 = ACT == ALPRO_ACT_GELU_BWD || ACT == ALPRO_ACT_MUL_SAVED;
+          u32x4 pring[2][2];   // the saved factor rows of the NEXT fragment row are in flight while this one is finished
+          auto load_pre = [&](int mf, u32x4(&pp)[2]) {
+#pragma unroll
+            for (int p = 0; p < 2; ++p)
+              pp[p] = __builtin_nontemporal_load((const u32x4*)((const T*)g.C2 + (int64_t)(mb + mf * 16 + p * 8 + (lane >> 3)) * g.ldc2 + nb + (lane & 7) * 8));
+          };
+          if (READS_C2) load_pre(0, pring[0]);
+#pragma unroll
+          for (int mf = 0; mf < 8; ++mf) {
+            if (READS_C2 && mf + 1 < 8) load_pre(mf + 1, pring[(mf + 1) & 1]);
+            stage_rows(mf);
+            epi_rows16_c16<T, ACT, 2>(g, stage, mb + mf * 16, nb, lane, bias8, READS_C2 ? pring[mf & 1] : nullptr);
+          }
+        }
+      } else {
+        float bias[4];
+        load_bias4(g, nb + (lane & 15) * 4, bias);
+        auto run = [&](auto fast_tag) {
+          constexpr bool FAST = decltype(fast_tag)::value;
+          const bool pf = FAST && MAP != ALPRO_MAP_FRAME_TOKENS && g.residual != nullptr;
+          float4 ring[2][4];   // residual rows of the next fragment row, fetched one fragment row ahead
+          auto load_res = [&](int mf, float4(&rr)[4]) {
+            epi_prefetch_res<MAP>(g, mb + mf * 16, nb, lane, *(float4(*)[2]) & rr[0]);
+            epi_prefetch_res<MAP>(g, mb + mf * 16 + 8, nb, lane, *(float4(*)[2]) & rr[2]);
+          };
+          if (pf) load_res(0, ring[0]);
+#pragma unroll
+          for (int mf = 0; mf < 8; ++mf) {
+            if (pf && mf + 1 < 8) load_res(mf + 1, ring[(mf + 1) & 1]);
+            stage_rows(mf);
+            // (two 8-row passes of the staged fragment row: the 8-row row order of epi_rows16<.., 2> matches epi_prefetch_res)
+            epi_rows16<T, ACT, MAP, FAST, 2>(g, stage, mb + mf * 16, nb, lane, bias, pf ? &ring[mf & 1][0] : nullptr);
+            epi_rows16<T, ACT, MAP, FAST, 2>(g, stage + 8 * 64, mb + mf * 16 + 8, nb, lane, bias, pf ? &ring[mf & 1][2] : nullptr);
+          }
+        };
+        if (fast) run(std::true_type{});
+        else run(std::false_type{});
+      }
+    }
+    cur = nxt;
+    if (it + 2 < ntile) nxt = tile_base(slot + (it + 2) * G);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the run-ahead copies of the last tile must not land in LDS that already belongs to someone else
+}
+
 template <typename T, int ACT, int MAP>
 int launch_gemm_inst(const alpro_gemm_desc_t& g, hipStream_t st) {
   static DeviceOnce attr_once;
@@ -753,6 +998,22 @@ int launch_gemm_inst(const alpro_gemm_desc_t& g, hipStream_t st) {
   const int nk = (g.K * (int)sizeof(T)) / ROWB;
   // the persistent 256^2 kernel wins from ~160 tiles up (measured, tools/gemm_bert_bench.py: M=15168 N=768 = 180 tiles is 15-25 % faster than on the 128^2 kernel; M=2560 N=3072 = 120 tiles is not); its pipeline needs >= 2 K-tiles
   const bool use256 = nk >= 2 && (force ? force == 256 : big_tiles >= 160);
+  if constexpr (sizeof(T) == 2 && MAP == ALPRO_MAP_IDENTITY) {
+    // round 4: the 8-phase two-group schedule (gemm_nt256q_kernel) for the identity-map shapes; needs an even number >= 4 of 64-deep K-tiles
+    // and 32-bit operand offsets.  gemm_kind 0 = the round-3 kernel (A/B), 1 = the 8-phase kernel
+    static DeviceOnce attr_q;
+    attr_q.run([&] {
+      (void)hipFuncSetAttribute((const void*)gemm_nt256q_kernel<T, ACT, MAP>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE2_BYTES + EPI_BYTES);
+    });
+    const bool fits = (int64_t)g.M * g.lda * 2 < (int64_t)0xFFFF0000 && (int64_t)g.N * g.ldw * 2 < (int64_t)0xFFFF0000;
+    const bool full = (g.M % BM2) == 0 && (g.N % BN2) == 0 && ((g.lda * 2) % 128) == 0 && ((g.ldw * 2) % 128) == 0;
+    if (use256 && get_option(OPT_GEMM_KIND) == 1 && (g.K % 128) == 0 && g.K >= 256 && fits && full) {
+      int grid = big_tiles < 256 ? (big_tiles + 7) / 8 * 8 : 256;
+      if (const int cap = get_option(OPT_GEMM_GRID)) grid = cap < grid ? (cap + 7) / 8 * 8 : grid;
+      hipLaunchKernelGGL((gemm_nt256q_kernel<T, ACT, MAP>), dim3(grid), dim3(NT2), 2 * STAGE2_BYTES + EPI_BYTES, st, g);
+      return check_launch("alpro_gemm");
+    }
+  }
   if (use256) {
     int grid = big_tiles < 256 ? (big_tiles + 7) / 8 * 8 : 256;  // multiple of 8: the XCD-contiguous slot map must be a bijection
     if (const int cap = get_option(OPT_GEMM_GRID)) grid = cap < grid ? (cap + 7) / 8 * 8 : grid;  // tuning aid: cap the persistent grid

@@ -23,7 +23,7 @@ _CODE = {v: k for k, v in _TORCH_DTYPE.items()}
 EXPORTS = ["alpro_hip_last_error", "alpro_hip_abi_version", "alpro_hip_set_option", "alpro_gemm", "alpro_layernorm_fwd",
            "alpro_attn_temporal_fwd", "alpro_attn_fwd", "alpro_patchify", "alpro_cls_mean_residual",
            "alpro_vit_final_pool", "alpro_bert_embed_fwd", "alpro_cast_from_f32", "alpro_attn_bwd", "alpro_attn_temporal_bwd",
-           "alpro_layernorm_bwd", "alpro_transpose", "alpro_transpose_batch", "alpro_gelu_bwd", "alpro_cls_mean_bwd", "alpro_scatter_add_rows", "alpro_gather_cast", "alpro_sumsq", "alpro_adamw_step", "alpro_gemm_tn_acc", "alpro_gemm_tn_acc_ws", "alpro_gemm_tn_workspace_bytes", "alpro_colsum_acc", "alpro_softmax_xent", "alpro_vtc_loss_fwd", "alpro_vtc_loss_bwd", "alpro_prepare_clips", "alpro_loss_scale_update", "alpro_add_layernorm_fwd", "alpro_layernorm_bwd_emit", "alpro_gemm_batch", "alpro_tproj_small", "alpro_attn_cls_fwd"]
+           "alpro_layernorm_bwd", "alpro_transpose", "alpro_transpose_batch", "alpro_gelu_bwd", "alpro_cls_mean_bwd", "alpro_scatter_add_rows", "alpro_gather_cast", "alpro_sumsq", "alpro_adamw_step", "alpro_gemm_tn_acc", "alpro_gemm_tn_acc_ws", "alpro_gemm_tn_workspace_bytes", "alpro_colsum_acc", "alpro_softmax_xent", "alpro_vtc_loss_fwd", "alpro_vtc_loss_bwd", "alpro_prepare_clips", "alpro_loss_scale_update", "alpro_add_layernorm_fwd", "alpro_layernorm_bwd_emit", "alpro_gemm_batch", "alpro_tproj_small", "alpro_attn_cls_fwd", "alpro_gemm_rows_f32"]
 
 
 class GemmDesc(ctypes.Structure):
@@ -96,6 +96,7 @@ def load():
     lib.alpro_scatter_add_rows.argtypes = [vp, vp, vp, i32, i32, i32, vp]
     lib.alpro_attn_fwd.argtypes = [vp, vp, i32, i32, i32, i32, f32, vp, vp, f32, u32, vp]
     lib.alpro_attn_cls_fwd.argtypes = [vp, i32, vp, vp, vp, i32, i32, i32, i32, f32, f32, u32, vp]
+    lib.alpro_gemm_rows_f32.argtypes = [vp, i64, vp, i64, vp, i64, i32, i32, i32, vp, i32, vp, vp, i64, vp, vp, f32, vp]
     lib.alpro_patchify.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp]
     lib.alpro_cls_mean_residual.argtypes = [vp, i64, vp, vp, i64, i32, i32, i32, vp]
     lib.alpro_vit_final_pool.argtypes = [vp, vp, vp, f32, vp, vp, i32, i32, i32, i32, i32, vp]
@@ -111,7 +112,7 @@ def load():
     return lib
 
 
-_OPTION_DEFAULTS = {"gemm_tile": 0, "gemm_grid": 0, "gemm_tune": 1, "tn_splits": 0, "tn_kind": 0, "gemm_tail": 1, "attn_bwd": 1, "attn_order": 0}
+_OPTION_DEFAULTS = {"gemm_tile": 0, "gemm_grid": 0, "gemm_tune": 1, "tn_splits": 0, "tn_kind": 0, "gemm_tail": 1, "attn_bwd": 1, "attn_order": 0, "gemm_kind": 0}
 _option_values = {}
 
 
@@ -436,6 +437,31 @@ def attn_cls(qkv, qkv_cls, batch, L, H, scale, group=1, key_bias=None, drop_p=0.
     kb = _dev(key_bias, torch.float32) if key_bias is not None else None
     _check(lib.alpro_attn_cls_fwd(_ptr(qkv), _CODE[qkv.dtype], _ptr(qkv_cls), _ptr(kb), _ptr(out), batch, L, H, group, scale, drop_p, drop_seed, _stream()),
            "alpro_attn_cls_fwd")
+    return out
+
+
+def gemm_rows(a, w, bias=None, act=ACT_NONE, row_scale=None, residual=None, ln=None, out=None):
+    """fp32 Linear on a handful of rows (alpro_gemm_rows_f32): out = residual + row_scale * act(LN(a) @ w.T + bias); a (M, K), w (N, K) fp32
+    (row-strided views allowed), ln = (gamma, beta, eps) fuses the LayerNorm of a's rows."""
+    lib = load()
+    _dev(a, torch.float32); _dev(w, torch.float32)
+    M, K = a.shape
+    N = w.shape[0]
+    assert w.shape[1] == K and a.stride(1) == 1 and w.stride(1) == 1
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float32, device=a.device)
+    _dev(out, torch.float32)
+    g = b = None
+    eps = 0.0
+    if ln is not None:
+        g, b, eps = _dev(ln[0], torch.float32), _dev(ln[1], torch.float32), float(ln[2])
+    if residual is not None:
+        _dev(residual, torch.float32)
+        assert residual.shape == (M, N) and residual.stride(1) == 1
+    _check(lib.alpro_gemm_rows_f32(_ptr(a), a.stride(0), _ptr(w), w.stride(0), _ptr(out), out.stride(0), M, N, K,
+                                   _ptr(_dev(bias, torch.float32)) if bias is not None else None, act,
+                                   _ptr(_dev(row_scale, torch.float32)) if row_scale is not None else None,
+                                   _ptr(residual), residual.stride(0) if residual is not None else 0, _ptr(g), _ptr(b), eps, _stream()), "alpro_gemm_rows_f32")
     return out
 
 

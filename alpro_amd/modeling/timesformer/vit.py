@@ -147,15 +147,16 @@ class Block(nn.Module):
     # tokens as the 16-bit GEMM produced them) -> proj -> frame mean + residual (:184-187) -> norm2 -> Mlp -> residual (:198-212).
     # B*T + 3*B fp32 rows per block against B*(1 + N*T) 16-bit rows; drop-path scales are the main path's.
     def _cls_chain(self, x_cls_in, qkv_s, B, T, N, H, drop_s=None, drop_m=None):
-        f32, sa = torch.float32, self.attn
-        hc = hip.layernorm(x_cls_in, self.norm1.weight, self.norm1.bias, VIT_EPS, f32)
-        qkv_c = hip.gemm(hc, self._w("s_qkv", sa.qkv, f32), bias=sa.qkv.bias, out_dtype=f32)
+        """x_cls_in: (B, D) fp32 view of the block input's CLS rows (row-strided is fine) -> (CLS rows before the MLP, CLS rows of the block output).
+        Four alpro_gemm_rows_f32 launches (norm1 / norm2 fused into the operand loads), alpro_attn_cls_fwd, and the frame mean."""
+        sa = self.attn
+        f32 = torch.float32
+        qkv_c = hip.gemm_rows(x_cls_in, self._w("s_qkv", sa.qkv, f32), bias=sa.qkv.bias, ln=(self.norm1.weight, self.norm1.bias, VIT_EPS))
         o_c = hip.attn_cls(qkv_s, qkv_c, B * T, N + 1, H, sa.scale, group=T)
-        p_c = hip.gemm(o_c, self._w("s_proj", sa.proj, f32), bias=sa.proj.bias, out_dtype=f32, row_scale=drop_s, row_scale_group=1)
+        p_c = hip.gemm_rows(o_c, self._w("s_proj", sa.proj, f32), bias=sa.proj.bias, row_scale=drop_s)
         x_cls2 = x_cls_in + p_c.view(B, T, -1).mean(1)
-        h2c = hip.layernorm(x_cls2, self.norm2.weight, self.norm2.bias, VIT_EPS, f32)
-        f1c = hip.gemm(h2c, self._w("fc1", self.mlp.fc1, f32), bias=self.mlp.fc1.bias, act=hip.ACT_GELU, out_dtype=f32)
-        x_cls_out = hip.gemm(f1c, self._w("fc2", self.mlp.fc2, f32), bias=self.mlp.fc2.bias, out_dtype=f32, residual=x_cls2, row_scale=drop_m, row_scale_group=1)
+        f1c = hip.gemm_rows(x_cls2, self._w("fc1", self.mlp.fc1, f32), bias=self.mlp.fc1.bias, act=hip.ACT_GELU, ln=(self.norm2.weight, self.norm2.bias, VIT_EPS))
+        x_cls_out = hip.gemm_rows(f1c, self._w("fc2", self.mlp.fc2, f32), bias=self.mlp.fc2.bias, residual=x_cls2, row_scale=drop_m)
         return x_cls2, x_cls_out
 
     def _drop(self, rows, device):
@@ -198,7 +199,7 @@ class Block(nn.Module):
         ta, sa = self.temporal_attn, self.attn
         drop_t, drop_s, drop_m = self._drop(B * N, x.device), self._drop(B * T, x.device), self._drop(B, x.device)
         cp = rt.cls_precise(dt) and self.fuse_residual_ln and self.merge_temporal_proj
-        x_cls_in = x[:, 0].contiguous() if cp else None   # (the temporal half never touches the CLS row; the spatial half reads it as it is now)
+        x_cls_in = x[:, 0].clone() if cp else None   # a COPY (x is updated in place below; .contiguous() of a one-clip batch is a view); the temporal half never touches the CLS row
         # ---- temporal (vit.py:146-162)
         h = hip.layernorm(x, self.temporal_norm1.weight, self.temporal_norm1.bias, VIT_EPS, dt, rows=B * N * T,
                           map_mode=hip.MAP_SKIP_CLS, map_p0=N * T)
@@ -285,7 +286,7 @@ class Block(nn.Module):
         if rt.cls_precise(dt) and self.fuse_residual_ln and self.merge_temporal_proj:
             # precise CLS rows: the block output's CLS row and the saved pre-MLP stream's CLS row (norm2's backward input) take the fp32 values;
             # the backward differentiates the 16-bit graph as before (its CLS-row operands differ from these by one rounding)
-            x_cls2, x_cls_out = self._cls_chain(x[:, 0].contiguous(), qkv_s, B, T, N, H, sv["drop_s"], sv["drop_m"])
+            x_cls2, x_cls_out = self._cls_chain(x[:, 0], qkv_s, B, T, N, H, sv["drop_s"], sv["drop_m"])
             x2[:, 0] = x_cls2
             out[:, 0] = x_cls_out
         sv.update(h=h, qkv_t=qkv_t, a_t=a_t, lse_t=lse_t, pr=pr, xt=xt, hs=hs, qkv_s=qkv_s, a_s=a_s, lse_s=lse_s, x2=x2, h2=h2, u=u, f1=f1)

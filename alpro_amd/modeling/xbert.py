@@ -125,15 +125,15 @@ class BertLayer(nn.Module):
         if wqkv is None:
             wqkv = self._ops.get("qkv_w32", (sa.query.weight, sa.key.weight, sa.value.weight), f32)
         bqkv = self._ops.get("qkv_b", (sa.query.bias, sa.key.bias, sa.value.bias), f32)
-        qkv_c = hip.gemm(hc, wqkv, bias=bqkv, out_dtype=f32)
+        qkv_c = hip.gemm_rows(hc, wqkv, bias=bqkv)
         ctx_c = hip.attn_cls(qkv, qkv_c, B, L, H, scale, group=1, key_bias=key_bias, drop_p=ap, drop_seed=seed_a)
-        d1_c = hip.gemm(ctx_c, self._ops.get("ao_w", so.dense.weight, f32), bias=so.dense.bias, out_dtype=f32)
+        d1_c = hip.gemm_rows(ctx_c, self._ops.get("ao_w", so.dense.weight, f32), bias=so.dense.bias)
         if hp > 0:
             d1_c = torch.where(d1.view(B, L, -1)[:, 0] != 0, d1_c * (1.0 / (1.0 - hp)), torch.zeros_like(d1_c))
         s1_c = hc + d1_c
         a32_c = hip.layernorm(s1_c, so.LayerNorm.weight, so.LayerNorm.bias, eps, f32)
-        it_c = hip.gemm(a32_c, self._ops.get("i_w", self.intermediate.dense.weight, f32), bias=self.intermediate.dense.bias, act=hip.ACT_GELU, out_dtype=f32)
-        d2_c = hip.gemm(it_c, self._ops.get("o_w", self.output.dense.weight, f32), bias=self.output.dense.bias, out_dtype=f32)
+        it_c = hip.gemm_rows(a32_c, self._ops.get("i_w", self.intermediate.dense.weight, f32), bias=self.intermediate.dense.bias, act=hip.ACT_GELU)
+        d2_c = hip.gemm_rows(it_c, self._ops.get("o_w", self.output.dense.weight, f32), bias=self.output.dense.bias)
         if hp > 0:
             d2_c = torch.where(d2.view(B, L, -1)[:, 0] != 0, d2_c * (1.0 / (1.0 - hp)), torch.zeros_like(d2_c))
         s2_c = a32_c + d2_c
@@ -168,7 +168,7 @@ class BertLayer(nn.Module):
             o_t, o32, s2 = hip.add_layernorm(a32, d2, self.output.LayerNorm.weight, self.output.LayerNorm.bias, eps, out32=True, want_x=save)
             if rt.cls_precise(dt) and self.layer_num < int(_cfg_get(self.config, "fusion_layer", 0) or 0):
                 D = h32.shape[1]
-                s1_c, a32_c, s2_c, o32_c = self._cls_chain(h32.view(B, L, D)[:, 0].contiguous(), qkv, d1, d2, key_bias, B, L, H, scale, hp if seed1 else 0.0,
+                s1_c, a32_c, s2_c, o32_c = self._cls_chain(h32.view(B, L, D)[:, 0], qkv, d1, d2, key_bias, B, L, H, scale, hp if seed1 else 0.0,
                                                           ap, seed_a)
                 o32.view(B, L, D)[:, 0] = o32_c
                 o_t.view(B, L, D)[:, 0] = o32_c.to(dt)

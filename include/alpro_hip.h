@@ -159,6 +159,15 @@ int alpro_attn_temporal_fwd(const void* qkv, void* out, int dtype, int64_t rows,
 int alpro_attn_cls_fwd(const void* qkv, int dtype, const float* qkv_cls, const float* key_bias /* (batch, L) or NULL */, float* out, int batch,
                        int L, int H, int group, float scale, float drop_p, uint32_t drop_seed, void* stream);
 
+/* The Linears (and pre-LayerNorms) of the precise CLS-row side path: C[M, N] = residual + row_scale[m] * act(LN(A)[M, K] W[N, K]^T + bias), all
+ * fp32 (exact fp32 MFMA, fixed summation order), for M = B or B*T rows against a full (N, K) fp32 master weight (vit.py:84,98,59-65 / xbert.py
+ * :304-316,357,421,435 applied to the CLS rows only).  ln_gamma / ln_beta (K,) or NULL: LayerNorm of the A rows over their K elements fused
+ * into the operand load (vit.py:180 norm1, :200 norm2).  act: ALPRO_ACT_NONE / ALPRO_ACT_GELU (exact erf).  N % 16 == 0, K % 64 == 0. */
+int alpro_gemm_rows_f32(const float* A, int64_t lda, const float* W, int64_t ldw, float* C, int64_t ldc, int M, int N, int K,
+                        const float* bias /* (N) or NULL */, int act, const float* row_scale /* (M) or NULL */,
+                        const float* residual /* (M, ldr) or NULL */, int64_t ldr, const float* ln_gamma, const float* ln_beta, float ln_eps,
+                        void* stream);
+
 /* Full (bidirectional) attention over `batch` sequences of L <= 256 tokens, head_dim 64:
  * spatial half of divided attention (vit.py:180 on (B*T, 1+N) tokens, :81-96) and the BERT
  * text / fusion self-attention (xbert.py:299-341) where key_bias (batch, L) is the additive

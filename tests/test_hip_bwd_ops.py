@@ -536,9 +536,9 @@ def test_flat_adamw_vs_the_reference_optimizer_trajectory(scenario, drive):
             np.testing.assert_allclose(got, g["%s/params/%d" % (scenario, step)], rtol=3e-6, atol=2e-8, err_msg="%s / %s step %d" % (scenario, drive, step))
         inner = getattr(opt, "_opt", opt)
         assert inner.n_params == sum(p.numel() for p in model.ps) and torch.equal(model.teacher.detach().cpu(), torch.ones(300, 7))
-        lay = {i: (o, n) for i, o, n in inner._layout()}
-        m = torch.cat([inner.flat["m"][lay[i][0]:lay[i][0] + lay[i][1]] for i in range(len(model.ps))]).cpu().numpy()
-        v = torch.cat([inner.flat["v"][lay[i][0]:lay[i][0] + lay[i][1]] for i in range(len(model.ps))]).cpu().numpy()
+        where = {id(p): (o, p.numel()) for p, o in zip(inner.flat["live"], inner.flat["offs"])}     # flat offset of every trained parameter
+        m = torch.cat([inner.flat["m"][where[id(p)][0]:sum(where[id(p)])] for p in model.ps]).cpu().numpy()
+        v = torch.cat([inner.flat["v"][where[id(p)][0]:sum(where[id(p)])] for p in model.ps]).cpu().numpy()
         np.testing.assert_allclose(m, g[scenario + "/exp_avg"], rtol=1e-5, atol=1e-9)
         np.testing.assert_allclose(v, g[scenario + "/exp_avg_sq"], rtol=1e-5, atol=1e-12)
 

@@ -319,6 +319,103 @@ def test_attn_temporal(dt, T, groups):
     close(out, ref, *tol, "temporal attn")
 
 
+@pytest.mark.parametrize("M,N,K,case", [(64, 768, 3072, "res_scale"), (3, 2304, 768, "ln"), (512, 768, 768, "scale"), (64, 3072, 768, "ln_gelu"), (130, 256, 768, "plain"), (1, 768, 768, "ln")])
+def test_gemm_rows_f32(M, N, K, case):
+    """alpro_gemm_rows_f32 (round 4: the fp32 Linears of the precise CLS-row chain, a few rows against a full fp32 weight, optional fused
+    LayerNorm, exact erf GELU, row scale, residual) against fp64, with a row-strided A view and run twice (fixed summation order: bitwise equal)."""
+    hip = _hip()
+    wide = rnd(M, K + 64, seed=800 + M)
+    a, w, b = wide[:, :K], rnd(N, K, seed=801, scale=0.05), rnd(N, seed=802)
+    g, be = 1.0 + 0.1 * rnd(K, seed=803), 0.1 * rnd(K, seed=804)
+    x = a.double()
+    kw = {}
+    if case.startswith("ln"):
+        kw["ln"] = (g.cuda(), be.cuda(), 1e-6)
+        x = torch.nn.functional.layer_norm(x, (K,), g.double(), be.double(), 1e-6)
+    ref = x @ w.double().T + b.double()
+    if case == "ln_gelu":
+        kw["act"] = hip.ACT_GELU
+        ref = gelu(ref)
+    if case in ("res_scale", "scale"):
+        rs = (torch.arange(M) % 3).float() * 0.75
+        kw["row_scale"] = rs.cuda()
+        ref = ref * rs.double()[:, None]
+    if case == "res_scale":
+        res = rnd(M, N, seed=805)
+        kw["residual"] = res.cuda()
+        ref = ref + res.double()
+    A = wide.cuda()[:, :K]
+    out = hip.gemm_rows(A, w.cuda(), bias=b.cuda(), **kw)
+    close(out, ref, 2e-5, 2e-5 * math.sqrt(K / 768), "gemm_rows " + case)
+    assert torch.equal(out, hip.gemm_rows(A, w.cuda(), bias=b.cuda(), **kw))
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("M,N,K,case", [(256 * 80, 512, 768, "plain"), (256 * 54, 768, 256, "plain"), (256 * 130, 768, 768, "bias_rowscale"), (256 * 40, 1024, 3072, "f32res"),
+                                        (256 * 80, 512, 768, "gelu_save"), (256 * 80, 512, 768, "mul_saved"), (256 * 80, 512, 768, "gelu"), (256 * 44, 1024, 768, "dropout"),
+                                        (256 * 80, 512, 768, "strided")])
+def test_gemm_8phase_kernel(dt, M, N, K, case):
+    """gemm_nt256q_kernel (round 4: 8-phase two-group schedule on 16x16x32 MFMA fragments; option gemm_kind = 1) on full-tile shapes with >= 160
+    tiles -- one and several tiles per workgroup, K = 4 / 12 / 48 K-tiles, every epilogue the identity-map shapes of the model use -- against
+    fp64 of the same rounded operands, and against the round-3 kernel (gemm_kind = 0) on the same inputs."""
+    hip = _hip()
+    a, w, b = rnd(M, K, seed=700 + K), rnd(N, K, seed=701, scale=0.05), rnd(N, seed=702)
+    A, W = a.to(dt).cuda(), w.to(dt).cuda()
+    if case == "strided":       # A is a column slice of a wider activation (row stride 1.5 K elements)
+        wide = torch.zeros(M, K + K // 2, dtype=dt, device="cuda")
+        wide[:, :K] = A
+        A = wide[:, :K]
+    ref = a.to(dt).double() @ w.to(dt).double().T
+    kw, post = {}, (lambda x: x)
+    if case in ("bias_rowscale", "f32res", "gelu", "gelu_save", "mul_saved", "dropout"):
+        kw["bias"] = b.cuda()
+        ref = ref + b.double()
+    if case == "bias_rowscale":
+        rs = (torch.arange(M // 8) % 3).float() * 0.5
+        kw.update(row_scale=rs.cuda(), row_scale_group=8)
+        ref = ref * rs.double().repeat_interleave(8)[:, None]
+    if case == "f32res":
+        res = rnd(M, N, seed=703)
+        kw.update(residual=res.cuda(), out_dtype=torch.float32)
+        ref = ref + res.double()
+    saved = None
+    if case == "gelu":
+        kw["act"] = hip.ACT_GELU
+        ref = gelu(ref)
+    if case == "gelu_save":
+        saved = torch.empty(M, N, dtype=dt, device="cuda")
+        kw.update(act=hip.ACT_GELU_SAVE_GRAD, pre_act=saved)
+    if case == "mul_saved":
+        fac = rnd(M, N, seed=704).to(dt)
+        kw.update(act=hip.ACT_MUL_SAVED, pre_act=fac.cuda())
+        ref = ref * fac.double()
+    if case == "dropout":
+        kw.update(drop_p=0.1, drop_seed=4242)
+    outs = {}
+    for kind in (0, 1):
+        with hip.option("gemm_kind", kind):
+            if saved is not None:
+                saved.zero_()
+            outs[kind] = hip.gemm(A, W, **kw)
+            if saved is not None:
+                outs[("saved", kind)] = saved.clone()
+    tol = (2e-5, 2e-4 * math.sqrt(K / 768)) if case == "f32res" else OUT_TOL[dt]
+    if case == "gelu_save":
+        x = ref.clone().requires_grad_(True)
+        y = torch.nn.functional.gelu(x)
+        y.sum().backward()
+        close(outs[1], y.detach(), *tol, "gelu out")
+        close(outs[("saved", 1)], x.grad, *tol, "saved gelu'")
+        close(outs[("saved", 1)], outs[("saved", 0)].double(), *tol, "saved gelu' vs round-3 kernel")
+    elif case == "dropout":
+        kept = outs[1] != 0
+        assert torch.equal(kept, outs[0] != 0) and 0.05 < float((~kept).float().mean()) < 0.15       # same hash mask as the round-3 kernel
+        close(torch.where(kept, outs[1].float(), torch.zeros_like(outs[1], dtype=torch.float32)), torch.where(kept.cpu(), ref / 0.9, torch.zeros_like(ref)), *tol, "dropout")
+    else:
+        close(outs[1], ref, *tol, "8-phase kernel (%s)" % case)
+    close(outs[1], outs[0].double(), tol[0] * 2, tol[1] * 2, "8-phase vs round-3 kernel")
+
+
 @pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("batch,L,group,masked,p", [(6, 197, 3, False, 0.0), (4, 40, 1, True, 0.0), (8, 30, 1, True, 0.1), (2, 5, 2, False, 0.0), (16, 197, 8, False, 0.0),
                                                     (3, 256, 1, True, 0.0)])
