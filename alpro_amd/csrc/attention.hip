@@ -264,7 +264,8 @@ constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
 template <typename T, int NKT, bool HAS_BIAS>
 __global__ __launch_bounds__(256, 2) void attn_fwd16_kernel(const T* __restrict__ qkv, T* __restrict__ out, int L, int H, float scale,
                                                             const float* __restrict__ key_bias, float* __restrict__ lse, float drop_p,
-                                                            uint32_t drop_seed, int order) {
+                                                            uint32_t drop_seed, int order, const float* __restrict__ cls_q, int cls_group,
+                                                            float* __restrict__ cls_out) {
   static_assert(sizeof(T) == 2, "16-bit storage only");
   constexpr int LP = NKT * 32, RB = 128;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -434,6 +435,99 @@ __global__ __launch_bounds__(256, 2) void attn_fwd16_kernel(const T* __restrict_
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) qf[ks] = qn[ks];
   }
+  // ---- precise CLS query (round 4, alpro_amd.config.cls_precise; stand-alone form: cls_precise.hip alpro_attn_cls_fwd).  Query 0 of the
+  // sequence once more, in fp32 on the VALU: q unrounded from cls_q (one fp32 row per `cls_group` sequences), K / V from the images already in
+  // LDS, scores / online softmax / P V in fp32 -- no P rounding, no output rounding.  Thread = (key slot tid >> 3 of 32, 8-element head chunk
+  // tid & 7); the 32 slots keep independent softmax states, merged over the wave by shuffles and over the four waves through the (now idle)
+  // output staging area.  ~NKT iterations of two ds_read_b128 + 40 VALU per thread on top of a 32 x NKT-tile workgroup.
+  if (cls_q) {
+    const int gs = tid >> 3, e = tid & 7;
+    float q[8];
+    {
+      const float* cq = cls_q + (int64_t)(b / cls_group) * ldq + h * HD + e * 8;
+      const float4 a = *(const float4*)cq, c = *(const float4*)(cq + 4);
+      q[0] = a.x * sl; q[1] = a.y * sl; q[2] = a.z * sl; q[3] = a.w * sl; q[4] = c.x * sl; q[5] = c.y * sl; q[6] = c.z * sl; q[7] = c.w * sl;
+    }
+    const uint32_t th = drop_thresh24(drop_p);
+    const float ks_ = drop_seed ? 1.0f / (1.0f - drop_p) : 1.0f;
+    const uint64_t base0 = (((uint64_t)b * H + h) * L) * (uint64_t)L;
+    float m = -INFINITY, l = 0.f, acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+#pragma unroll
+    for (int it = 0; it < NKT; ++it) {
+      const int j = it * 32 + gs;
+      if (j < L) {   // (uniform over the 8 lanes of a key slot)
+        float kf[8], vf[8];
+        unpack_chunk<T>(*(const u32x4*)(Ks + j * RB + ((e ^ ((j >> 1) & 7)) << 4)), kf);
+        unpack_chunk<T>(*(const u32x4*)(Vs + j * RB + ((e ^ (((j >> 1) & 1) << 2)) << 4)), vf);
+        float d = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) d = fmaf(q[i], kf[i], d);
+        d += __shfl_xor(d, 1, 64);
+        d += __shfl_xor(d, 2, 64);
+        d += __shfl_xor(d, 4, 64);
+        d += Bs[j];
+        const float mn = fmaxf(m, d);
+        const float alpha = __builtin_amdgcn_exp2f(m - mn);
+        const float p = __builtin_amdgcn_exp2f(d - mn);
+        l = fmaf(l, alpha, p);
+        float pd = p;
+        if (drop_seed) pd = drop_keep(drop_seed, base0 + (uint64_t)j, th) ? p * ks_ : 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] = fmaf(acc[i], alpha, pd * vf[i]);
+        m = mn;
+      }
+    }
+    // merge the wave's 8 key slots (lanes with equal e) ...
+    float Mw = m;
+    Mw = fmaxf(Mw, __shfl_xor(Mw, 8, 64));
+    Mw = fmaxf(Mw, __shfl_xor(Mw, 16, 64));
+    Mw = fmaxf(Mw, __shfl_xor(Mw, 32, 64));
+    const float w0 = __builtin_amdgcn_exp2f(m - Mw);   // a slot without keys: exp2(-inf - M) = 0; a wave without keys: Mw = -inf -> NaN below is masked
+    float lw = (m == -INFINITY) ? 0.f : l * w0;
+    lw += __shfl_xor(lw, 8, 64);
+    lw += __shfl_xor(lw, 16, 64);
+    lw += __shfl_xor(lw, 32, 64);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      float a = (m == -INFINITY) ? 0.f : acc[i] * w0;
+      a += __shfl_xor(a, 8, 64);
+      a += __shfl_xor(a, 16, 64);
+      a += __shfl_xor(a, 32, 64);
+      acc[i] = a;
+    }
+    // ... and the four waves through LDS: [wave][0] = max, [1] = sum, [2 + e*8 + i] = accumulators
+    __syncthreads();   // every wave is past its last output tile: the staging area is free
+    float* sc = (float*)Os;
+    if (lane < 8) {
+      float* mine = sc + wave * 72;
+      if (lane == 0) { mine[0] = Mw; mine[1] = lw; }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) mine[2 + lane * 8 + i] = acc[i];
+    }
+    __syncthreads();
+    if (tid < 8) {
+      float M = -INFINITY;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) M = fmaxf(M, sc[w * 72]);
+      float lt = 0.f, o[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) o[i] = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {   // fixed order
+        const float mw = sc[w * 72];
+        const float f = (mw == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(mw - M);
+        lt = fmaf(sc[w * 72 + 1], f, lt);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o[i] = fmaf(sc[w * 72 + 2 + tid * 8 + i], f, o[i]);
+      }
+      const float inv = 1.0f / lt;
+      float* dst = cls_out + (int64_t)b * H * HD + h * HD + tid * 8;
+      *(float4*)dst = make_float4(o[0] * inv, o[1] * inv, o[2] * inv, o[3] * inv);
+      *(float4*)(dst + 4) = make_float4(o[4] * inv, o[5] * inv, o[6] * inv, o[7] * inv);
+    }
+  }
 }
 
 // ================================================================================================
@@ -601,24 +695,24 @@ int launch_attn(const void* qkv, void* out, int batch, int L, int H, float scale
 
 template <typename T, int NKT, bool HAS_BIAS>
 int launch_attn16(const void* qkv, void* out, int batch, int L, int H, float scale, const float* key_bias, float* lse, float drop_p,
-                  uint32_t drop_seed, hipStream_t st) {
+                  uint32_t drop_seed, const float* cls_q, int cls_group, float* cls_out, hipStream_t st) {
   const size_t lds = 2 * (size_t)NKT * 32 * 128 + 4 * (NKT == 8 ? 2048 : 4096) + (size_t)NKT * 32 * sizeof(float);
   static DeviceOnce attr_once;
   attr_once.run([&] {
     (void)hipFuncSetAttribute((const void*)attn_fwd16_kernel<T, NKT, HAS_BIAS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   });
-  hipLaunchKernelGGL((attn_fwd16_kernel<T, NKT, HAS_BIAS>), dim3(batch * H), dim3(256), lds, st, (const T*)qkv, (T*)out, L, H, scale, key_bias, lse, drop_p, drop_seed, get_option(OPT_ATTN_ORDER));
+  hipLaunchKernelGGL((attn_fwd16_kernel<T, NKT, HAS_BIAS>), dim3(batch * H), dim3(256), lds, st, (const T*)qkv, (T*)out, L, H, scale, key_bias, lse, drop_p, drop_seed, get_option(OPT_ATTN_ORDER), cls_q, cls_group, cls_out);
   return check_launch("alpro_attn_fwd");
 }
 
 template <typename T>
 int dispatch_attn(const void* qkv, void* out, int batch, int L, int H, float scale, const float* key_bias, float* lse, float dp, uint32_t ds,
-                  hipStream_t st) {
+                  const float* cls_q, int cls_group, float* cls_out, hipStream_t st) {
   const int nkt = (L + 31) / 32;
   if constexpr (sizeof(T) == 2) {
 #define ALPRO_ATTN16(N)                                                                                       \
-  return key_bias ? launch_attn16<T, N, true>(qkv, out, batch, L, H, scale, key_bias, lse, dp, ds, st)         \
-                  : launch_attn16<T, N, false>(qkv, out, batch, L, H, scale, key_bias, lse, dp, ds, st)
+  return key_bias ? launch_attn16<T, N, true>(qkv, out, batch, L, H, scale, key_bias, lse, dp, ds, cls_q, cls_group, cls_out, st)         \
+                  : launch_attn16<T, N, false>(qkv, out, batch, L, H, scale, key_bias, lse, dp, ds, cls_q, cls_group, cls_out, st)
     if (nkt <= 2) ALPRO_ATTN16(2);
     if (nkt <= 4) ALPRO_ATTN16(4);
     if (nkt <= 7) ALPRO_ATTN16(7);
@@ -637,12 +731,15 @@ int dispatch_attn(const void* qkv, void* out, int batch, int L, int H, float sca
 using namespace alpro;
 
 extern "C" int alpro_attn_fwd(const void* qkv, void* out, int dtype, int batch, int L, int H, float scale,
-                              const float* key_bias, float* lse, float drop_p, uint32_t drop_seed, void* stream) {
+                              const float* key_bias, float* lse, float drop_p, uint32_t drop_seed, const float* cls_q, int cls_group, float* cls_out,
+                              void* stream) {
+  ALPRO_CHECK(!cls_q || (cls_out && cls_group > 0 && batch % cls_group == 0 && dtype != ALPRO_F32 && ((uintptr_t)cls_q % 16) == 0 && ((uintptr_t)cls_out % 16) == 0),
+              "alpro_attn_fwd: the precise CLS query needs cls_out, a group size dividing the batch, 16-byte aligned fp32 side tensors and a 16-bit operand dtype");
   ALPRO_CHECK(qkv && out && batch > 0 && H > 0, "alpro_attn_fwd: bad args");
   ALPRO_CHECK(L > 0 && L <= 256, "alpro_attn_fwd: L=%d unsupported (1..256; the path needs 40, 197, 237)", L);
   ALPRO_CHECK(((uintptr_t)qkv % 16) == 0 && ((uintptr_t)out % 16) == 0, "alpro_attn_fwd: pointers must be 16-byte aligned");
   ALPRO_CHECK(!drop_seed || (drop_p > 0.f && drop_p < 1.f), "alpro_attn_fwd: dropout needs 0 < p < 1");
-  ALPRO_DISPATCH_DTYPE(dtype, T, return dispatch_attn<T>(qkv, out, batch, L, H, scale, key_bias, lse, drop_p, drop_seed, (hipStream_t)stream));
+  ALPRO_DISPATCH_DTYPE(dtype, T, return dispatch_attn<T>(qkv, out, batch, L, H, scale, key_bias, lse, drop_p, drop_seed, cls_q, cls_group, cls_out, (hipStream_t)stream));
   return ALPRO_OK;
 }
 

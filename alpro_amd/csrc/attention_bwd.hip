@@ -818,6 +818,7 @@ __global__ __launch_bounds__(512) void attn_bwd16k_kernel(const T* __restrict__ 
   ALPRO_TS(12);
 }
 
+#ifdef ALPRO_ABLATIONS   // measurement build only (round 4: slower than the shipped kernels on every shape measured, profiles/r3_attn_bwd_phase_stamps.txt)
 // ================================================================================================
 // Persistent variant of the key-owned backward for EXACTLY 7 key tiles, no key bias, no dropout (ViT spatial attention,
 // L = 197): one 8-wave workgroup per CU walks its units (sequence, head) and the NEXT query tiles are always in flight.
@@ -1241,6 +1242,7 @@ __global__ __launch_bounds__(512) void attn_bwd16p_kernel(const T* __restrict__ 
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the repeats issued by the last steps
 }
 
+#endif  // ALPRO_ABLATIONS (persistent key-owned backward)
 // ================================================================================================
 // 16-bit temporal-attention backward: one WAVE per (32 consecutive tokens, head) unit, everything wave-private.
 // The four 4 KiB tiles K, V, Q, dO of the unit go global -> LDS by DMA (16 copies per unit, swizzled on the source side) and
@@ -1414,6 +1416,7 @@ int launch_bwd16k(const void* qkv, const void* out, const void* dout, const floa
   return check_launch("alpro_attn_bwd");
 }
 
+#ifdef ALPRO_ABLATIONS
 template <typename T>
 int launch_bwd16p(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, int batch, int L, int H, float scale,
                   int flags, hipStream_t st) {
@@ -1427,6 +1430,7 @@ int launch_bwd16p(const void* qkv, const void* out, const void* dout, const floa
                      (const T*)dout, lse, (T*)dqkv, L, H, scale, units, flags);
   return check_launch("alpro_attn_bwd");
 }
+#endif
 
 template <typename T, int NKT, int NW, bool GROUPED>
 int launch_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, int64_t nblocks_b, int L, int H, float scale,
@@ -1462,8 +1466,10 @@ int dispatch_bwd(const void* qkv, const void* out, const void* dout, const float
     // workgroup per CU leaves its input latency uncovered); 2 key-owned wherever it applies (>= 5 key tiles); 3 / 4 the persistent
     // key-owned kernel with / without its L2 touches where IT applies (7 key tiles, no bias, no dropout), else as 2.
     const int kind = get_option(OPT_ATTN_BWD);
+#ifdef ALPRO_ABLATIONS   // (the product library refuses attn_bwd 3 / 4: core.hip option_allowed)
     if (nkt == 7 && !key_bias && !ds && kind >= 3)
       return launch_bwd16p<T>(qkv, out, dout, lse, dqkv, batch, L, H, scale, kind == 3 ? 1 : 0, st);
+#endif
     if ((nkt >= 5 && kind >= 2) || (nkt == 8 && kind == 1)) {   // every (query tile, key tile) pair once, one 8-wave workgroup per CU
 #define ALPRO_BWD16K(N)                                                                                        \
   return ds ? launch_bwd16k<T, N, true>(qkv, out, dout, lse, dqkv, batch, L, H, scale, key_bias, dp, ds, st)   \

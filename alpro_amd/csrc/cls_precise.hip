@@ -123,49 +123,46 @@ __global__ __launch_bounds__(256) void attn_cls_kernel(const T* __restrict__ qkv
 // Optional fused LayerNorm of the A rows (K == the row width: statistics of the 64 rows recomputed per workgroup, two-pass in registers).
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 
-template <int ACT, bool LN>
-__global__ __launch_bounds__(256) void gemm_rows_f32_kernel(const float* __restrict__ A, int64_t lda, const float* __restrict__ W, int64_t ldw,
-                                                            float* __restrict__ C, int64_t ldc, int M, int N, int K, const float* __restrict__ bias,
-                                                            const float* __restrict__ row_scale, const float* __restrict__ residual, int64_t ldr,
-                                                            const float* __restrict__ gamma, const float* __restrict__ beta, float eps) {
-  __shared__ float part[4][64][16];
-  __shared__ float stat[64][2];
+template <int ACT, bool LN, int NW>
+__global__ __launch_bounds__(NW * 64) void gemm_rows_f32_kernel(const float* __restrict__ A, int64_t lda, const float* __restrict__ W, int64_t ldw,
+                                                                float* __restrict__ C, int64_t ldc, int M, int N, int K, const float* __restrict__ bias,
+                                                                const float* __restrict__ row_scale, const float* __restrict__ residual, int64_t ldr,
+                                                                const float* __restrict__ gamma, const float* __restrict__ beta, float eps) {
+  extern __shared__ __attribute__((aligned(16))) float smem_f[];
+  float (*part)[64][16] = (float (*)[64][16])smem_f;          // [NW][64][16] partial sums of the K slices
+  float (*stat)[2] = (float (*)[2])(smem_f + NW * 64 * 16);   // [64][2] mean, rstd of the tile's rows (fused LayerNorm)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n0 = blockIdx.x * 16, m0 = blockIdx.y * 64;
   const int r15 = lane & 15, kg = lane >> 4;
-  if (LN) {   // mean / rstd of rows m0 + wave*16 .. +15, one row at a time: the whole row in registers (K <= 64 * 12 * 4), two passes
-    for (int r = 0; r < 16; ++r) {
-      const int row = min(m0 + wave * 16 + r, M - 1);
-      const float* a = A + (int64_t)row * lda;
-      float v[48];
+  if (LN) {   // statistics of the 64 rows: four lanes per row (a quarter of the row each, float4 loads), two passes (mean, then centred squares)
+    if (wave < 4) {
+      const int r = wave * 16 + (lane >> 2), q = lane & 3;
+      const float* a = A + (int64_t)min(m0 + r, M - 1) * lda + q * (K >> 2);
+      const int nv = K >> 4;   // float4 per lane
       float sum = 0.f;
-      const int nv = K >> 8;   // float4 per lane (K multiple of 256 when LN is fused: 768)
-#pragma unroll
-      for (int i = 0; i < 12; ++i) {
-        if (i < nv) {
-          const float4 t = *(const float4*)(a + (i * 64 + lane) * 4);
-          v[4 * i] = t.x; v[4 * i + 1] = t.y; v[4 * i + 2] = t.z; v[4 * i + 3] = t.w;
-          sum += (t.x + t.y) + (t.z + t.w);
-        }
+      for (int i = 0; i < nv; ++i) {
+        const float4 t = *(const float4*)(a + i * 4);
+        sum += (t.x + t.y) + (t.z + t.w);
       }
-      const float mean = wave_sum(sum) / (float)K;
+      sum += __shfl_xor(sum, 1, 64);
+      sum += __shfl_xor(sum, 2, 64);
+      const float mean = sum / (float)K;
       float sq = 0.f;
-#pragma unroll
-      for (int i = 0; i < 12; ++i) {
-        if (i < nv) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) { const float d = v[4 * i + e] - mean; sq = fmaf(d, d, sq); }
-        }
+      for (int i = 0; i < nv; ++i) {
+        const float4 t = *(const float4*)(a + i * 4);
+        const float d0 = t.x - mean, d1 = t.y - mean, d2 = t.z - mean, d3 = t.w - mean;
+        sq += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
       }
-      const float var = wave_sum(sq) / (float)K;
-      if (lane == 0) { stat[wave * 16 + r][0] = mean; stat[wave * 16 + r][1] = rsqrtf(var + eps); }
+      sq += __shfl_xor(sq, 1, 64);
+      sq += __shfl_xor(sq, 2, 64);
+      if (q == 0) { stat[r][0] = mean; stat[r][1] = rsqrtf(sq / (float)K + eps); }
     }
     __syncthreads();
   }
   float mu[4], rs[4];
 #pragma unroll
   for (int f = 0; f < 4; ++f) { mu[f] = LN ? stat[f * 16 + r15][0] : 0.f; rs[f] = LN ? stat[f * 16 + r15][1] : 1.f; }
-  const int kslice = K >> 2, k0 = wave * kslice;
+  const int kslice = K / NW, k0 = wave * kslice;
   const float* ap[4];
 #pragma unroll
   for (int f = 0; f < 4; ++f) ap[f] = A + (int64_t)min(m0 + f * 16 + r15, M - 1) * lda + k0 + kg * 4;
@@ -176,7 +173,7 @@ __global__ __launch_bounds__(256) void gemm_rows_f32_kernel(const float* __restr
 #pragma unroll
   for (int f = 0; f < 4; ++f) acc[f] = f32x4v{0.f, 0.f, 0.f, 0.f};
   const int steps = kslice >> 4;
-#pragma unroll 4
+#pragma unroll 3
   for (int s = 0; s < steps; ++s) {
     const float4 b4 = *(const float4*)(wp + s * 16);
     float4 a4[4];
@@ -206,13 +203,15 @@ __global__ __launch_bounds__(256) void gemm_rows_f32_kernel(const float* __restr
 #pragma unroll
     for (int r = 0; r < 4; ++r) part[wave][f * 16 + kg * 4 + r][r15] = acc[f][r];
   __syncthreads();
-  {
+  if (tid < 256) {
     const int row = tid >> 2, c4 = (tid & 3) * 4;
     const int m = m0 + row, n = n0 + c4;
     if (m < M) {
-      float v[4];
+      float v[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = ((part[0][row][c4 + e] + part[1][row][c4 + e]) + part[2][row][c4 + e]) + part[3][row][c4 + e];
+      for (int w = 0; w < NW; ++w)   // fixed order: bit-reproducible
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] += part[w][row][c4 + e];
       const float sc = row_scale ? row_scale[m] : 1.0f;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -224,6 +223,28 @@ __global__ __launch_bounds__(256) void gemm_rows_f32_kernel(const float* __restr
       }
       *(float4*)(C + (int64_t)m * ldc + n) = make_float4(v[0], v[1], v[2], v[3]);
     }
+  }
+}
+
+
+struct RowsArgs {
+  const float* A; int64_t lda; const float* W; int64_t ldw; float* C; int64_t ldc; int M, N, K;
+  const float* bias; const float* row_scale; const float* residual; int64_t ldr; const float* gamma; const float* beta; float eps;
+};
+template <int ACT, bool LN, int NW>
+void launch_rows_inst(const RowsArgs& a, hipStream_t st) {
+  constexpr int LDS = (NW * 64 * 16 + 128) * (int)sizeof(float);
+  static DeviceOnce once;
+  once.run([&] { (void)hipFuncSetAttribute((const void*)gemm_rows_f32_kernel<ACT, LN, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); });
+  hipLaunchKernelGGL((gemm_rows_f32_kernel<ACT, LN, NW>), dim3(a.N / 16, (a.M + 63) / 64), dim3(NW * 64), LDS, st, a.A, a.lda, a.W, a.ldw, a.C, a.ldc, a.M,
+                     a.N, a.K, a.bias, a.row_scale, a.residual, a.ldr, a.gamma, a.beta, a.eps);
+}
+template <int NW>
+void launch_rows_nw(const RowsArgs& a, bool ln, bool gelu, hipStream_t st) {
+  if (ln) {
+    if (gelu) launch_rows_inst<ALPRO_ACT_GELU, true, NW>(a, st); else launch_rows_inst<ALPRO_ACT_NONE, true, NW>(a, st);
+  } else {
+    if (gelu) launch_rows_inst<ALPRO_ACT_GELU, false, NW>(a, st); else launch_rows_inst<ALPRO_ACT_NONE, false, NW>(a, st);
   }
 }
 
@@ -257,15 +278,14 @@ extern "C" int alpro_gemm_rows_f32(const float* A, int64_t lda, const float* W, 
               "alpro_gemm_rows_f32: rows must be 16-byte aligned");
   ALPRO_CHECK(act == ALPRO_ACT_NONE || act == ALPRO_ACT_GELU, "alpro_gemm_rows_f32: act %d unsupported (none / gelu)", act);
   ALPRO_CHECK(!ln_gamma == !ln_beta, "alpro_gemm_rows_f32: LayerNorm needs both gamma and beta");
-  ALPRO_CHECK(!ln_gamma || (K % 256 == 0 && K <= 3072), "alpro_gemm_rows_f32: fused LayerNorm needs K a multiple of 256, at most 3072 (got %d)", K);
-  const dim3 grid(N / 16, (M + 63) / 64), block(256);
+  ALPRO_CHECK(!ln_gamma || K % 64 == 0, "alpro_gemm_rows_f32: fused LayerNorm needs K a multiple of 64 (got %d)", K);
+  // K split over the waves of a workgroup: 16 waves for the long contractions (K = 3072: 12 steps per wave), 8 below (K = 768: 6 steps)
+  const int nw = (K >= 2048 && K % 256 == 0) ? 16 : (K % 128 == 0 ? 8 : 4);
+  const RowsArgs ra{A, lda, W, ldw, C, ldc, M, N, K, bias, row_scale, residual, ldr, ln_gamma, ln_beta, ln_eps};
   hipStream_t st = (hipStream_t)stream;
-#define ALPRO_ROWS(ACT_, LN_) hipLaunchKernelGGL((gemm_rows_f32_kernel<ACT_, LN_>), grid, block, 0, st, A, lda, W, ldw, C, ldc, M, N, K, bias, row_scale, residual, ldr, ln_gamma, ln_beta, ln_eps)
-  if (ln_gamma) {
-    if (act == ALPRO_ACT_GELU) ALPRO_ROWS(ALPRO_ACT_GELU, true); else ALPRO_ROWS(ALPRO_ACT_NONE, true);
-  } else {
-    if (act == ALPRO_ACT_GELU) ALPRO_ROWS(ALPRO_ACT_GELU, false); else ALPRO_ROWS(ALPRO_ACT_NONE, false);
-  }
-#undef ALPRO_ROWS
+  const bool ln = ln_gamma != nullptr, ge = act == ALPRO_ACT_GELU;
+  if (nw == 16) launch_rows_nw<16>(ra, ln, ge, st);
+  else if (nw == 8) launch_rows_nw<8>(ra, ln, ge, st);
+  else launch_rows_nw<4>(ra, ln, ge, st);
   return check_launch("alpro_gemm_rows_f32");
 }

@@ -32,6 +32,7 @@ bool option_allowed(int which, int value) {
 #else
   if (which == OPT_GEMM_TUNE) return value >= 0 && value <= 2;
   if (which == OPT_TN_KIND) return value == 0;
+  if (which == OPT_ATTN_BWD) return value >= 0 && value <= 2;   // 3 / 4: the persistent key-owned backward, compiled into the measurement build only (round 4)
   return value >= 0;
 #endif
 }
@@ -39,7 +40,7 @@ struct OptInit {
   OptInit() {
     for (int i = 0; i < OPT_COUNT; ++i) {
       const char* e = getenv(kOptEnv[i]);
-      const int dflt = (i == OPT_GEMM_TUNE || i == OPT_GEMM_TAIL || i == OPT_ATTN_BWD) ? 1 : 0;
+      const int dflt = (i == OPT_GEMM_TUNE || i == OPT_GEMM_TAIL || i == OPT_ATTN_BWD || i == OPT_GEMM_KIND) ? 1 : 0;
       g_opts[i] = e ? atoi(e) : dflt;
       if (!option_allowed(i, g_opts[i])) {
         fprintf(stderr, "libalpro_hip: %s=%d is a result-corrupting ablation and is not part of this build (ignored)\n", kOptEnv[i], g_opts[i]);
@@ -412,7 +413,7 @@ extern "C" int alpro_hip_set_option(const char* name, int value) {
   for (int i = 0; name && i < OPT_COUNT; ++i)
     if (!strcmp(name, kOptNames[i])) {
       if (!option_allowed(i, value)) {
-        set_error("alpro_hip_set_option: %s=%d is a result-corrupting ablation, only available in the measurement build (-DALPRO_ABLATIONS)", name, value);
+        set_error("alpro_hip_set_option: %s=%d is an ablation / measurement-only variant, only available in the measurement build (-DALPRO_ABLATIONS)", name, value);
         return ALPRO_ERR_INVALID;
       }
       __atomic_store_n(&g_opts[i], value, __ATOMIC_RELAXED);

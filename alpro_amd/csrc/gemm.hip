@@ -945,26 +945,38 @@ __global__ __launch_bounds__(NT2, 2) void gemm_nt256q_kernel(const alpro_gemm_de
       } else {
         float bias[4];
         load_bias4(g, nb + (lane & 15) * 4, bias);
-        auto run = [&](auto fast_tag) {
+        auto run = [&](auto fast_tag, auto pf_tag) {
           constexpr bool FAST = decltype(fast_tag)::value;
-          const bool pf = FAST && MAP != ALPRO_MAP_FRAME_TOKENS && g.residual != nullptr;
-          float4 ring[2][4];   // residual rows of the next fragment row, fetched one fragment row ahead
-          auto load_res = [&](int mf, float4(&rr)[4]) {
-            epi_prefetch_res<MAP>(g, mb + mf * 16, nb, lane, *(float4(*)[2]) & rr[0]);
-            epi_prefetch_res<MAP>(g, mb + mf * 16 + 8, nb, lane, *(float4(*)[2]) & rr[2]);
-          };
-          if (pf) load_res(0, ring[0]);
+          constexpr bool PF = decltype(pf_tag)::value;   // residual rows fetched one fragment row ahead (compile-time: a maybe-null pointer to the
+                                                         // register array sends it through scratch)
+          float4 ra[2], rb[2], na[2], nb2[2];
+          if constexpr (PF) {
+            epi_prefetch_res<MAP>(g, mb, nb, lane, ra);
+            epi_prefetch_res<MAP>(g, mb + 8, nb, lane, rb);
+          }
 #pragma unroll
           for (int mf = 0; mf < 8; ++mf) {
-            if (pf && mf + 1 < 8) load_res(mf + 1, ring[(mf + 1) & 1]);
+            if constexpr (PF) {
+              if (mf + 1 < 8) {
+                epi_prefetch_res<MAP>(g, mb + (mf + 1) * 16, nb, lane, na);
+                epi_prefetch_res<MAP>(g, mb + (mf + 1) * 16 + 8, nb, lane, nb2);
+              }
+            }
             stage_rows(mf);
-            // (two 8-row passes of the staged fragment row: the 8-row row order of epi_rows16<.., 2> matches epi_prefetch_res)
-            epi_rows16<T, ACT, MAP, FAST, 2>(g, stage, mb + mf * 16, nb, lane, bias, pf ? &ring[mf & 1][0] : nullptr);
-            epi_rows16<T, ACT, MAP, FAST, 2>(g, stage + 8 * 64, mb + mf * 16 + 8, nb, lane, bias, pf ? &ring[mf & 1][2] : nullptr);
+            if constexpr (PF) {
+              epi_rows16<T, ACT, MAP, FAST, 2>(g, stage, mb + mf * 16, nb, lane, bias, ra);
+              epi_rows16<T, ACT, MAP, FAST, 2>(g, stage + 8 * 64, mb + mf * 16 + 8, nb, lane, bias, rb);
+#pragma unroll
+              for (int p = 0; p < 2; ++p) { ra[p] = na[p]; rb[p] = nb2[p]; }
+            } else {
+              epi_rows16<T, ACT, MAP, FAST, 2>(g, stage, mb + mf * 16, nb, lane, bias);
+              epi_rows16<T, ACT, MAP, FAST, 2>(g, stage + 8 * 64, mb + mf * 16 + 8, nb, lane, bias);
+            }
           }
         };
-        if (fast) run(std::true_type{});
-        else run(std::false_type{});
+        if (fast && MAP != ALPRO_MAP_FRAME_TOKENS && g.residual != nullptr) run(std::true_type{}, std::true_type{});
+        else if (fast) run(std::true_type{}, std::false_type{});
+        else run(std::false_type{}, std::false_type{});
       }
     }
     cur = nxt;

@@ -24,18 +24,25 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x,
   if (threadIdx.x == 0) atomicAdd(out, part[0] + part[1] + part[2] + part[3]);
 }
 
-__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
                                                     float* __restrict__ v, int64_t n, float lr, float beta1, float beta2, float eps,
                                                     float weight_decay, float step_size, const float* __restrict__ gnorm_sq,
                                                     float max_norm, float grad_scale, const float* __restrict__ dyn, int grads_scaled,
-                                                    int correct_bias) {
+                                                    int correct_bias, int zero_grad) {
   float coef = grad_scale;
   if (dyn) {
     // dynamic loss scaling (fp16 operands; apex.amp semantics, run_pretrain_sparse.py:596-634 with fp16 = 1): dyn = {loss scale S,
     // growth tracker, completed optimizer steps}.  The gradients hold S * dL/dw (unless the caller already unscaled them); a non-finite
     // squared norm means some fp16 gradient operand overflowed: the whole update is skipped -- parameters and moments untouched -- and
     // alpro_loss_scale_update halves S.  The bias correction uses the DEVICE step counter, which only counts applied updates.
-    if (!isfinite(*gnorm_sq)) return;
+    if (!isfinite(*gnorm_sq)) {   // skipped step: nothing moves -- but a caller that asked for consumed gradients still gets them zeroed
+      if (zero_grad) {
+        const int64_t stride0 = (int64_t)gridDim.x * blockDim.x * 4;
+        for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += stride0)
+          for (int k = 0; k < 4 && i + k < n; ++k) g[i + k] = 0.f;
+      }
+      return;
+    }
     if (grads_scaled) coef /= dyn[0];
     const float t = dyn[2] + 1.0f;
     step_size = correct_bias ? lr * sqrtf(1.0f - powf(beta2, t)) / (1.0f - powf(beta1, t)) : lr;
@@ -70,8 +77,9 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
       *(float4*)(p + i) = make_float4(pv[0], pv[1], pv[2], pv[3]);
       *(float4*)(m + i) = make_float4(mv[0], mv[1], mv[2], mv[3]);
       *(float4*)(v + i) = make_float4(vv[0], vv[1], vv[2], vv[3]);
+      if (zero_grad) *(float4*)(g + i) = make_float4(0.f, 0.f, 0.f, 0.f);   // optimizer.zero_grad() folded in (round 4): no separate 0.94 GB memset
     } else {
-      for (int k = 0; k < cnt; ++k) { p[i + k] = pv[k]; m[i + k] = mv[k]; v[i + k] = vv[k]; }
+      for (int k = 0; k < cnt; ++k) { p[i + k] = pv[k]; m[i + k] = mv[k]; v[i + k] = vv[k]; if (zero_grad) g[i + k] = 0.f; }
     }
   }
 }
@@ -113,15 +121,15 @@ extern "C" int alpro_sumsq(const float* x, int64_t n, float* out, void* stream) 
   return check_launch("alpro_sumsq");
 }
 
-extern "C" int alpro_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+extern "C" int alpro_adamw_step(float* p, float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
                                 float weight_decay, float step_size, const float* gnorm_sq, float max_norm, float grad_scale,
-                                const float* dyn_state, int grads_scaled, int correct_bias, void* stream) {
+                                const float* dyn_state, int grads_scaled, int correct_bias, int zero_grad, void* stream) {
   ALPRO_CHECK(p && g && m && v && n > 0, "alpro_adamw_step: bad args");
   ALPRO_CHECK(!dyn_state || gnorm_sq, "alpro_adamw_step: dynamic loss scaling needs the squared gradient norm (overflow detection)");
   ALPRO_CHECK(((uintptr_t)p % 16) == 0 && ((uintptr_t)g % 16) == 0 && ((uintptr_t)m % 16) == 0 && ((uintptr_t)v % 16) == 0,
               "alpro_adamw_step: buffers must be 16-byte aligned");
   hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1, beta2, eps, weight_decay,
-                     step_size, gnorm_sq, max_norm, grad_scale, dyn_state, grads_scaled, correct_bias);
+                     step_size, gnorm_sq, max_norm, grad_scale, dyn_state, grads_scaled, correct_bias, zero_grad);
   return check_launch("alpro_adamw_step");
 }
 

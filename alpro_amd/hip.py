@@ -89,12 +89,12 @@ def load():
     lib.alpro_gemm_tn_workspace_bytes.restype = ctypes.c_size_t
     lib.alpro_colsum_acc.argtypes = [vp, i64, vp, i32, i32, i32, vp]
     lib.alpro_transpose_batch.argtypes = [vp, i32, i32, i32, vp]
-    lib.alpro_adamw_step.argtypes = [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, f32, vp, f32, f32, vp, i32, i32, vp]
+    lib.alpro_adamw_step.argtypes = [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, f32, vp, f32, f32, vp, i32, i32, i32, vp]
     lib.alpro_loss_scale_update.argtypes = [vp, vp, f32, f32, i32, f32, f32, vp]
     lib.alpro_gather_cast.argtypes = [vp, i64, vp, i32, i32, i32, i32, i32, i32, vp, i32, f32, f32, u32, vp, vp, vp]
     lib.alpro_cls_mean_bwd.argtypes = [vp, i64, vp, i32, i32, i32, vp]
     lib.alpro_scatter_add_rows.argtypes = [vp, vp, vp, i32, i32, i32, vp]
-    lib.alpro_attn_fwd.argtypes = [vp, vp, i32, i32, i32, i32, f32, vp, vp, f32, u32, vp]
+    lib.alpro_attn_fwd.argtypes = [vp, vp, i32, i32, i32, i32, f32, vp, vp, f32, u32, vp, i32, vp, vp]
     lib.alpro_attn_cls_fwd.argtypes = [vp, i32, vp, vp, vp, i32, i32, i32, i32, f32, f32, u32, vp]
     lib.alpro_gemm_rows_f32.argtypes = [vp, i64, vp, i64, vp, i64, i32, i32, i32, vp, i32, vp, vp, i64, vp, vp, f32, vp]
     lib.alpro_patchify.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp]
@@ -112,7 +112,7 @@ def load():
     return lib
 
 
-_OPTION_DEFAULTS = {"gemm_tile": 0, "gemm_grid": 0, "gemm_tune": 1, "tn_splits": 0, "tn_kind": 0, "gemm_tail": 1, "attn_bwd": 1, "attn_order": 0, "gemm_kind": 0}
+_OPTION_DEFAULTS = {"gemm_tile": 0, "gemm_grid": 0, "gemm_tune": 1, "tn_splits": 0, "tn_kind": 0, "gemm_tail": 1, "attn_bwd": 1, "attn_order": 0, "gemm_kind": 1}
 _option_values = {}
 
 
@@ -413,15 +413,25 @@ def scatter_add_rows(src, idx, dst, idx_mod=0):
     return dst
 
 
-def attn(qkv, batch, L, H, scale, key_bias=None, want_lse=False, drop_p=0.0, drop_seed=0):
+def attn(qkv, batch, L, H, scale, key_bias=None, want_lse=False, drop_p=0.0, drop_seed=0, cls_q=None, cls_group=1):
+    """-> out [, lse] [, cls_out].  cls_q (batch / cls_group, 3*H*64) fp32: also evaluate the CLS query (row 0 of every sequence) in fp32 from
+    these unrounded q rows against the K / V staged in LDS -> cls_out (batch, H*64) fp32 (precise CLS rows, 16-bit dtypes only)."""
     lib = load()
     _dev(qkv)
     assert qkv.shape[0] == batch * L
     out = torch.empty((batch * L, H * 64), dtype=qkv.dtype, device=qkv.device)
     lse = torch.empty((batch, H, L), dtype=torch.float32, device=qkv.device) if want_lse else None
     kb = _dev(key_bias, torch.float32) if key_bias is not None else None
-    _check(lib.alpro_attn_fwd(_ptr(qkv), _ptr(out), _CODE[qkv.dtype], batch, L, H, scale, _ptr(kb), _ptr(lse), drop_p, drop_seed, _stream()), "alpro_attn_fwd")
-    return (out, lse) if want_lse else out
+    cls_out = None
+    if cls_q is not None:
+        _dev(cls_q, torch.float32)
+        if cls_q.shape != (batch // cls_group, 3 * H * 64) or batch % cls_group or not cls_q.is_contiguous():
+            raise RuntimeError("attn: cls_q %s does not match batch=%d H=%d cls_group=%d" % (tuple(cls_q.shape), batch, H, cls_group))
+        cls_out = torch.empty((batch, H * 64), dtype=torch.float32, device=qkv.device)
+    _check(lib.alpro_attn_fwd(_ptr(qkv), _ptr(out), _CODE[qkv.dtype], batch, L, H, scale, _ptr(kb), _ptr(lse), drop_p, drop_seed,
+                              _ptr(cls_q), cls_group, _ptr(cls_out), _stream()), "alpro_attn_fwd")
+    res = (out,) + ((lse,) if want_lse else ()) + ((cls_out,) if cls_q is not None else ())
+    return res if len(res) > 1 else out
 
 
 def attn_cls(qkv, qkv_cls, batch, L, H, scale, group=1, key_bias=None, drop_p=0.0, drop_seed=0):
@@ -531,7 +541,7 @@ def sumsq(x, out):
 
 
 def adamw_step(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step_size, gnorm_sq=None, max_norm=0.0, grad_scale=1.0, dyn_state=None,
-               grads_scaled=True, correct_bias=True):
+               grads_scaled=True, correct_bias=True, zero_grad=False):
     """dyn_state: (4,) fp32 device tensor {loss scale, growth tracker, applied steps, skipped steps} -- see alpro_adamw_step."""
     lib = load()
     for t in (p, g, m, v):
@@ -540,7 +550,7 @@ def adamw_step(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step_size, gnorm
         _dev(dyn_state, torch.float32)
         assert dyn_state.numel() >= 4 and gnorm_sq is not None
     _check(lib.alpro_adamw_step(_ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), lr, beta1, beta2, eps, weight_decay, step_size,
-                                _ptr(gnorm_sq), max_norm, grad_scale, _ptr(dyn_state), int(bool(grads_scaled)), int(bool(correct_bias)), _stream()),
+                                _ptr(gnorm_sq), max_norm, grad_scale, _ptr(dyn_state), int(bool(grads_scaled)), int(bool(correct_bias)), int(bool(zero_grad)), _stream()),
            "alpro_adamw_step")
 
 

@@ -146,13 +146,16 @@ class Block(nn.Module):
     # row that :165-167 replicates per frame: ONE row per clip) -> the CLS query's attention over the frame's tokens (K / V of the patch
     # tokens as the 16-bit GEMM produced them) -> proj -> frame mean + residual (:184-187) -> norm2 -> Mlp -> residual (:198-212).
     # B*T + 3*B fp32 rows per block against B*(1 + N*T) 16-bit rows; drop-path scales are the main path's.
-    def _cls_chain(self, x_cls_in, qkv_s, B, T, N, H, drop_s=None, drop_m=None):
-        """x_cls_in: (B, D) fp32 view of the block input's CLS rows (row-strided is fine) -> (CLS rows before the MLP, CLS rows of the block output).
-        Four alpro_gemm_rows_f32 launches (norm1 / norm2 fused into the operand loads), alpro_attn_cls_fwd, and the frame mean."""
+    def _cls_qkv(self, x_cls_in):
+        """(B, D) fp32 CLS rows of the block input -> their unrounded q | k | v (norm1 fused into the operand load)."""
+        sa = self.attn
+        return hip.gemm_rows(x_cls_in, self._w("s_qkv", sa.qkv, torch.float32), bias=sa.qkv.bias, ln=(self.norm1.weight, self.norm1.bias, VIT_EPS))
+
+    def _cls_chain(self, x_cls_in, o_c, B, T, drop_s=None, drop_m=None):
+        """o_c: (B*T, D) fp32 attention output of the CLS query of every frame (alpro_attn_fwd's cls_out) -> (CLS rows before the MLP, CLS rows of
+        the block output).  Three alpro_gemm_rows_f32 launches (norm2 fused into fc1's operand load) and the frame mean."""
         sa = self.attn
         f32 = torch.float32
-        qkv_c = hip.gemm_rows(x_cls_in, self._w("s_qkv", sa.qkv, f32), bias=sa.qkv.bias, ln=(self.norm1.weight, self.norm1.bias, VIT_EPS))
-        o_c = hip.attn_cls(qkv_s, qkv_c, B * T, N + 1, H, sa.scale, group=T)
         p_c = hip.gemm_rows(o_c, self._w("s_proj", sa.proj, f32), bias=sa.proj.bias, row_scale=drop_s)
         x_cls2 = x_cls_in + p_c.view(B, T, -1).mean(1)
         f1c = hip.gemm_rows(x_cls2, self._w("fc1", self.mlp.fc1, f32), bias=self.mlp.fc1.bias, act=hip.ACT_GELU, ln=(self.norm2.weight, self.norm2.bias, VIT_EPS))
@@ -213,7 +216,10 @@ class Block(nn.Module):
             hs, _ = hip.add_layernorm(x, d_t, self.norm1.weight, self.norm1.bias, VIT_EPS, mode=hip.ADD_PRE_SPATIAL, x_out=x,
                                       delta_bias=self.temporal_fc.bias, T=T, N=N)
             qkv = hip.gemm(hs, self._w("s_qkv", sa.qkv, dt), bias=sa.qkv.bias)
-            a = hip.attn(qkv, B * T, N + 1, H, sa.scale)
+            if cp:   # the CLS query of every frame once more in fp32, inside the same attention launch
+                a, o_c = hip.attn(qkv, B * T, N + 1, H, sa.scale, cls_q=self._cls_qkv(x_cls_in), cls_group=T)
+            else:
+                a = hip.attn(qkv, B * T, N + 1, H, sa.scale)
             d_s = hip.gemm(a, self._w("s_proj", sa.proj, dt), bias=sa.proj.bias, row_scale=drop_s, row_scale_group=N + 1)
             h2, _ = hip.add_layernorm(x, d_s, self.norm2.weight, self.norm2.bias, VIT_EPS, mode=hip.ADD_PRE_MLP, x_out=x, T=T, N=N)
         else:
@@ -223,7 +229,7 @@ class Block(nn.Module):
         hip.gemm(f1, self._w("fc2", self.mlp.fc2, dt), out=xf, bias=self.mlp.fc2.bias, out_dtype=torch.float32, residual=xf,
                  row_scale=drop_m, row_scale_group=S)
         if cp:
-            x[:, 0] = self._cls_chain(x_cls_in, qkv, B, T, N, H, drop_s, drop_m)[1]
+            x[:, 0] = self._cls_chain(x_cls_in, o_c, B, T, drop_s, drop_m)[1]
         return x
 
     # ---- training path: fresh buffers (the backward needs every LayerNorm input), explicit backward ----------
@@ -250,7 +256,11 @@ class Block(nn.Module):
                                        delta_bias=self.temporal_fc.bias, T=T, N=N)
             del d_t
             qkv_s = hip.gemm(hs, self._w("s_qkv", sa.qkv, dt), bias=sa.qkv.bias)
-            a_s, lse_s = hip.attn(qkv_s, B * T, N + 1, H, sa.scale, want_lse=True)
+            o_c = None
+            if rt.cls_precise(dt):
+                a_s, lse_s, o_c = hip.attn(qkv_s, B * T, N + 1, H, sa.scale, want_lse=True, cls_q=self._cls_qkv(x[:, 0]), cls_group=T)
+            else:
+                a_s, lse_s = hip.attn(qkv_s, B * T, N + 1, H, sa.scale, want_lse=True)
             d_s = hip.gemm(a_s, self._w("s_proj", sa.proj, dt), bias=sa.proj.bias, row_scale=sv["drop_s"], row_scale_group=N + 1)
             h2, x2 = hip.add_layernorm(xt, d_s, self.norm2.weight, self.norm2.bias, VIT_EPS, mode=hip.ADD_PRE_MLP, T=T, N=N)
             del d_s
@@ -286,7 +296,7 @@ class Block(nn.Module):
         if rt.cls_precise(dt) and self.fuse_residual_ln and self.merge_temporal_proj:
             # precise CLS rows: the block output's CLS row and the saved pre-MLP stream's CLS row (norm2's backward input) take the fp32 values;
             # the backward differentiates the 16-bit graph as before (its CLS-row operands differ from these by one rounding)
-            x_cls2, x_cls_out = self._cls_chain(x[:, 0], qkv_s, B, T, N, H, sv["drop_s"], sv["drop_m"])
+            x_cls2, x_cls_out = self._cls_chain(x[:, 0], o_c, B, T, sv["drop_s"], sv["drop_m"])
             x2[:, 0] = x_cls2
             out[:, 0] = x_cls_out
         sv.update(h=h, qkv_t=qkv_t, a_t=a_t, lse_t=lse_t, pr=pr, xt=xt, hs=hs, qkv_s=qkv_s, a_s=a_s, lse_s=lse_s, x2=x2, h2=h2, u=u, f1=f1)

@@ -117,16 +117,19 @@ class BertLayer(nn.Module):
     # residual + LayerNorm (:358-359) -> intermediate GELU (:421-423) -> dense -> residual + LayerNorm (:436-437).  B fp32 rows per layer.
     # Hidden dropout: the main path's 16-bit outputs say which elements it dropped (a dropped element is exactly 0), the same elements
     # are dropped here.
-    def _cls_chain(self, hc, qkv, d1, d2, key_bias, B, L, H, scale, hp, ap, seed_a):
-        f32 = torch.float32
-        sa, so = self.attention.self, self.attention.output
-        eps = self.config.layer_norm_eps
+    def _cls_qkv(self, hc):
+        """(B, D) fp32 [CLS] rows of the layer input -> their unrounded q | k | v."""
+        sa = self.attention.self
         wqkv = tr.fused_param_view([sa.query.weight, sa.key.weight, sa.value.weight])   # a view when FlatAdamW laid them out back to back
         if wqkv is None:
-            wqkv = self._ops.get("qkv_w32", (sa.query.weight, sa.key.weight, sa.value.weight), f32)
-        bqkv = self._ops.get("qkv_b", (sa.query.bias, sa.key.bias, sa.value.bias), f32)
-        qkv_c = hip.gemm_rows(hc, wqkv, bias=bqkv)
-        ctx_c = hip.attn_cls(qkv, qkv_c, B, L, H, scale, group=1, key_bias=key_bias, drop_p=ap, drop_seed=seed_a)
+            wqkv = self._ops.get("qkv_w32", (sa.query.weight, sa.key.weight, sa.value.weight), torch.float32)
+        return hip.gemm_rows(hc, wqkv, bias=self._ops.get("qkv_b", (sa.query.bias, sa.key.bias, sa.value.bias), torch.float32))
+
+    def _cls_chain(self, hc, ctx_c, d1, d2, B, L, hp):
+        """ctx_c: (B, D) fp32 attention output of the [CLS] query (alpro_attn_fwd's cls_out)."""
+        f32 = torch.float32
+        so = self.attention.output
+        eps = self.config.layer_norm_eps
         d1_c = hip.gemm_rows(ctx_c, self._ops.get("ao_w", so.dense.weight, f32), bias=so.dense.bias)
         if hp > 0:
             d1_c = torch.where(d1.view(B, L, -1)[:, 0] != 0, d1_c * (1.0 / (1.0 - hp)), torch.zeros_like(d1_c))
@@ -156,7 +159,12 @@ class BertLayer(nn.Module):
         wqkv = self._ops.get("qkv_w", (sa.query.weight, sa.key.weight, sa.value.weight), dt)
         bqkv = self._ops.get("qkv_b", (sa.query.bias, sa.key.bias, sa.value.bias), torch.float32)
         qkv = hip.gemm(h_t, wqkv, bias=bqkv)
-        ctx, lse = hip.attn(qkv, B, L, H, scale, key_bias, want_lse=True, drop_p=ap, drop_seed=seed_a)
+        cp = rt.cls_precise(dt) and self.fuse_residual_ln and self.layer_num < int(_cfg_get(self.config, "fusion_layer", 0) or 0)
+        if cp:   # the [CLS] query once more in fp32, inside the same attention launch
+            hc = h32.view(B, L, -1)[:, 0]
+            ctx, lse, ctx_c = hip.attn(qkv, B, L, H, scale, key_bias, want_lse=True, drop_p=ap, drop_seed=seed_a, cls_q=self._cls_qkv(hc), cls_group=1)
+        else:
+            ctx, lse = hip.attn(qkv, B, L, H, scale, key_bias, want_lse=True, drop_p=ap, drop_seed=seed_a)
         u = torch.empty((h_t.shape[0], self.intermediate.dense.out_features), dtype=dt, device=h_t.device) if save else None
         if self.fuse_residual_ln:
             # the two dense Linears write their (dropped-out) 16-bit output only; residual add + post-LayerNorm are one streaming kernel
@@ -166,10 +174,9 @@ class BertLayer(nn.Module):
             it = hip.gemm(a_t, self._ops.get("i_w", self.intermediate.dense.weight, dt), bias=self.intermediate.dense.bias, act=(hip.ACT_GELU_SAVE_GRAD if (save and tr.SAVE_GELU_GRAD) else hip.ACT_GELU), pre_act=u)
             d2 = hip.gemm(it, self._ops.get("o_w", self.output.dense.weight, dt), bias=self.output.dense.bias, drop_p=hp, drop_seed=seed2)
             o_t, o32, s2 = hip.add_layernorm(a32, d2, self.output.LayerNorm.weight, self.output.LayerNorm.bias, eps, out32=True, want_x=save)
-            if rt.cls_precise(dt) and self.layer_num < int(_cfg_get(self.config, "fusion_layer", 0) or 0):
+            if cp:
                 D = h32.shape[1]
-                s1_c, a32_c, s2_c, o32_c = self._cls_chain(h32.view(B, L, D)[:, 0], qkv, d1, d2, key_bias, B, L, H, scale, hp if seed1 else 0.0,
-                                                          ap, seed_a)
+                s1_c, a32_c, s2_c, o32_c = self._cls_chain(hc, ctx_c, d1, d2, B, L, hp if seed1 else 0.0)
                 o32.view(B, L, D)[:, 0] = o32_c
                 o_t.view(B, L, D)[:, 0] = o32_c.to(dt)
                 a_t.view(B, L, D)[:, 0] = a32_c.to(dt)       # (the FFN's saved input row, for its weight gradient)

@@ -70,7 +70,7 @@ class _FlatView:
 
 class FlatAdamW:
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-6, weight_decay=0.0, correct_bias=True, max_grad_norm=None,
-                 allreduce=True, bucket_elems=64 << 20, overlap_backward=None, wire_dtype=None):
+                 allreduce=True, bucket_elems=64 << 20, overlap_backward=None, wire_dtype=None, fused_zero_grad=True):
         self.params = [p for p in params if p.requires_grad]
         self.param_groups = [dict(params=self.params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, correct_bias=correct_bias)]
         self.max_grad_norm = max_grad_norm
@@ -86,6 +86,11 @@ class FlatAdamW:
         self.overlap_backward = overlap_backward
         self.wire_dtype = wire_dtype
         self._inflight, self._reduced = [], []     # async handles (+ staging tensors) and element ranges already on the wire
+        # fused_zero_grad: step() hands the flat gradient buffer back ZEROED (alpro_adamw_step clears it on the way: the gradients are consumed
+        # by the update, as the reference's `optimizer.step(); optimizer.zero_grad()` pair leaves them, run_pretrain_sparse.py:646-648), and the
+        # zero_grad() that follows is free instead of a second 0.94 GB pass
+        self.fused_zero_grad = fused_zero_grad
+        self._g_clean = False
         self.step_count = 0
         self._pending_state = None  # load_state_dict() before the flat buffers exist: applied by _build()
         self.flat = None  # built at the first step(), when we know which parameters actually receive gradients
@@ -167,6 +172,8 @@ class FlatAdamW:
         if self.flat is None:
             for p in self.params:
                 p.grad = None
+        elif self._g_clean:
+            self._g_clean = False      # step() already cleared the buffer (fused_zero_grad)
         else:
             self.flat["g"].zero_()
 
@@ -246,6 +253,10 @@ class FlatAdamW:
         return n * 4
 
     def backward(self, loss):
+        self._g_clean = False
+        return self._backward(loss)
+
+    def _backward(self, loss):
         """loss.backward() for this optimizer's parameters; with fp16 operands the loss is first multiplied by the (device-resident) loss
         scale and step() divides it out again inside the AdamW kernel -- the fused form of apex's
         `with amp.scale_loss(loss, optimizer, delay_unscale=True) as s: s.backward()` (run_pretrain_sparse.py:596-599)."""
@@ -292,7 +303,8 @@ class FlatAdamW:
             self.last_grad_norm = norm  # squared norm of the SUMMED (and, after a scaled backward, loss-scaled) gradient, device tensor (no host sync)
         hip.adamw_step(f["p"], f["g"], f["m"], f["v"], lr, b1, b2, grp["eps"], grp["weight_decay"], step_size, norm,
                        float(self.max_grad_norm or 0.0), 1.0 / world, dyn_state=sc.state if sc is not None else None,
-                       grads_scaled=self._grads_scaled, correct_bias=grp["correct_bias"])
+                       grads_scaled=self._grads_scaled, correct_bias=grp["correct_bias"], zero_grad=self.fused_zero_grad)
+        self._g_clean = self.fused_zero_grad
         if sc is not None:  # overflow -> the kernel skipped the update; the schedule halves / grows the scale on the device
             dyn = sc.dynamic
             hip.loss_scale_update(sc.state, norm, sc.growth if dyn else 1.0, sc.backoff if dyn else 1.0, sc.window, sc.min_scale, sc.max_scale)

@@ -174,7 +174,10 @@ int alpro_gemm_rows_f32(const float* A, int64_t lda, const float* W, int64_t ldw
  * (1 - mask) * -10000 of xbert.py:936-937 (NULL = no mask).  K/V of one (sequence, head) stay
  * resident in LDS; QK^T and PV run on MFMA; softmax in fp32 registers.  lse (batch, H, L) optional. */
 int alpro_attn_fwd(const void* qkv, void* out, int dtype, int batch, int L, int H, float scale,
-                   const float* key_bias, float* lse, float drop_p, uint32_t drop_seed, void* stream);
+                   const float* key_bias, float* lse, float drop_p, uint32_t drop_seed,
+                   /* round 4, precise CLS query fused into the same launch (NULL = off; semantics of alpro_attn_cls_fwd with K / V taken from the
+                    * images already staged in LDS): cls_q (batch / cls_group, 3*H*64) fp32, cls_out (batch, H*64) fp32; 16-bit dtypes only */
+                   const float* cls_q, int cls_group, float* cls_out, void* stream);
 /* drop_p > 0: dropout on the attention probabilities (xbert.py:331), mask = hash(seed, ((b*H+h)*L+q)*L+key). */
 
 /* out[(b*T+t)*N + n, c*256 + i*16 + j] = img[b, t, c, ph*16 + i, pw*16 + j], n = ph*(W/16) + pw:
@@ -341,9 +344,10 @@ int alpro_sumsq(const float* x, int64_t n, float* out, void* stream);
  * when *gnorm_sq is not finite (an fp16 overflow somewhere in the backward), (ii) divides the gradients by S when grads_scaled != 0,
  * (iii) takes the bias-correction step count from dyn_state[2] (applied steps only; `step_size` is then ignored, correct_bias selects
  * the formula).  gnorm_sq is required with dyn_state. */
-int alpro_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+int alpro_adamw_step(float* p, float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
                      float eps, float weight_decay, float step_size, const float* gnorm_sq, float max_norm,
-                     float grad_scale, const float* dyn_state, int grads_scaled, int correct_bias, void* stream);
+                     float grad_scale, const float* dyn_state, int grads_scaled, int correct_bias,
+                     int zero_grad /* round 4: also clear g (optimizer.zero_grad(), run_pretrain_sparse.py:648, folded in) */, void* stream);
 
 /* After alpro_adamw_step on the same stream: *gnorm_sq not finite -> S = max(S * backoff, min_scale), tracker = 0, skipped += 1;
  * else applied += 1, tracker += 1 and after `window` clean steps S = min(S * growth, max_scale).  apex defaults: growth 2, backoff 0.5,

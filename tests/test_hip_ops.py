@@ -406,23 +406,24 @@ def test_gemm_8phase_kernel(dt, M, N, K, case):
         y.sum().backward()
         close(outs[1], y.detach(), *tol, "gelu out")
         close(outs[("saved", 1)], x.grad, *tol, "saved gelu'")
-        close(outs[("saved", 1)], outs[("saved", 0)].double(), *tol, "saved gelu' vs round-3 kernel")
+        close(outs[("saved", 1)], outs[("saved", 0)].double().cpu(), *tol, "saved gelu' vs round-3 kernel")
     elif case == "dropout":
         kept = outs[1] != 0
         assert torch.equal(kept, outs[0] != 0) and 0.05 < float((~kept).float().mean()) < 0.15       # same hash mask as the round-3 kernel
         close(torch.where(kept, outs[1].float(), torch.zeros_like(outs[1], dtype=torch.float32)), torch.where(kept.cpu(), ref / 0.9, torch.zeros_like(ref)), *tol, "dropout")
     else:
         close(outs[1], ref, *tol, "8-phase kernel (%s)" % case)
-    close(outs[1], outs[0].double(), tol[0] * 2, tol[1] * 2, "8-phase vs round-3 kernel")
+    close(outs[1], outs[0].double().cpu(), tol[0] * 2, tol[1] * 2, "8-phase vs round-3 kernel")
 
 
 @pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("batch,L,group,masked,p", [(6, 197, 3, False, 0.0), (4, 40, 1, True, 0.0), (8, 30, 1, True, 0.1), (2, 5, 2, False, 0.0), (16, 197, 8, False, 0.0),
                                                     (3, 256, 1, True, 0.0)])
 def test_attn_cls_precise_query(dt, batch, L, group, masked, p):
-    """alpro_attn_cls_fwd (round 4): the CLS query's attention in fp32 -- q and the CLS token's own k / v unrounded from the fp32 side
-    tensor (one row per `group` sequences), the other tokens' K / V from the 16-bit qkv tensor -- against fp64; with probability dropout,
-    under the mask alpro_attn_fwd draws for query 0."""
+    """The CLS query's attention in fp32 (round 4) against fp64, in both forms: alpro_attn_cls_fwd (stand-alone: q and the CLS token's own
+    k / v unrounded from the fp32 side tensor, one row per `group` sequences; the other tokens' K / V from the 16-bit qkv tensor) and the
+    cls_q / cls_out side path of alpro_attn_fwd (same launch as the full attention; every K / V row, the CLS token's included, from the 16-bit
+    images in LDS).  With probability dropout: under the mask alpro_attn_fwd draws for query 0.  The regular output must not move."""
     hip = _hip()
     H = 12
     qkv = rnd(batch * L, 3 * H * 64, seed=300 + L).to(dt)
@@ -434,21 +435,31 @@ def test_attn_cls_precise_query(dt, batch, L, group, masked, p):
             m[b, L - 2 - (3 * b) % (L - 4):] = 0
         bias = (1.0 - m) * -10000.0
     seed = 12345 if p > 0 else 0
-    out = hip.attn_cls(qkv.cuda(), cls.cuda(), batch, L, H, 0.125, group=group, key_bias=None if bias is None else bias.cuda(), drop_p=p, drop_seed=seed)
-    t = qkv.double().view(batch, L, 3, H, 64).clone()
-    t[:, 0] = cls.double().view(batch // group, 3, H, 64).repeat_interleave(group, 0)   # the CLS token's q / k / v: unrounded
-    qc, k, v = t[:, 0, 0], t[:, :, 1], t[:, :, 2]                                       # (b, H, 64), (b, L, H, 64) x 2
-    sc = torch.einsum("bhd,blhd->bhl", qc, k) * 0.125
-    if bias is not None:
-        sc = sc + bias[:, None, :].double()
-    pr = sc.softmax(-1)
+    kb = None if bias is None else bias.cuda()
+    out = hip.attn_cls(qkv.cuda(), cls.cuda(), batch, L, H, 0.125, group=group, key_bias=kb, drop_p=p, drop_seed=seed)
+    plain = hip.attn(qkv.cuda(), batch, L, H, 0.125, kb, drop_p=p, drop_seed=seed)
+    full, fused = hip.attn(qkv.cuda(), batch, L, H, 0.125, kb, drop_p=p, drop_seed=seed, cls_q=cls.cuda(), cls_group=group)
+    assert torch.equal(full, plain)
+    keep = None
     if p > 0:   # the mask alpro_attn_fwd draws for query 0 of (b, h): drop_keep(seed, ((b*H + h)*L + 0)*L + key) (attention.hip; numpy restatement)
         from tests.test_hip_bwd_ops import _keep_mask
-        keep = torch.stack([_keep_mask(seed, (batch * H * L) * L, p).view(batch, H, L, L)[:, :, 0]])[0].double()
+        keep = _keep_mask(seed, (batch * H * L) * L, p).view(batch, H, L, L)[:, :, 0].double()
         assert 0.02 < float(1.0 - keep.mean()) < 0.3
-        pr = pr * keep / (1.0 - p)
-    ref = torch.einsum("bhl,blhd->bhd", pr, v).reshape(batch, H * 64)
-    close(out, ref, 2e-5, 2e-5, "attn_cls")
+    for name, got, own_kv in (("stand-alone", out, True), ("fused", fused, False)):
+        t = qkv.double().view(batch, L, 3, H, 64).clone()
+        c = cls.double().view(batch // group, 3, H, 64).repeat_interleave(group, 0)
+        qc = c[:, 0]
+        if own_kv:
+            t[:, 0] = c                                     # the CLS token's own k / v: unrounded too
+        k, v = t[:, :, 1], t[:, :, 2]                        # (b, L, H, 64)
+        sc = torch.einsum("bhd,blhd->bhl", qc, k) * 0.125
+        if bias is not None:
+            sc = sc + bias[:, None, :].double()
+        pr = sc.softmax(-1)
+        if keep is not None:
+            pr = pr * keep / (1.0 - p)
+        ref = torch.einsum("bhl,blhd->bhd", pr, v).reshape(batch, H * 64)
+        close(got, ref, 2e-5, 2e-5, "attn_cls " + name)
 
 
 @pytest.mark.gpu

@@ -86,17 +86,17 @@ def test_transpose_job_layout_and_wgrad_workspace_plan():
 def test_product_library_refuses_result_corrupting_knobs():
     """the ablations (gemm_tune 3/4/10/11/12, tn_kind 1) are compiled only into the measurement build."""
     from alpro_amd import hip
-    for name, bad in (("gemm_tune", 3), ("gemm_tune", 4), ("gemm_tune", 10), ("gemm_tune", 11), ("gemm_tune", 12), ("tn_kind", 1)):
+    for name, bad in (("gemm_tune", 3), ("gemm_tune", 4), ("gemm_tune", 10), ("gemm_tune", 11), ("gemm_tune", 12), ("tn_kind", 1), ("attn_bwd", 3), ("attn_bwd", 4)):
         with pytest.raises(RuntimeError, match="ablation"):
             hip.set_option(name, bad)
     hip.set_option("gemm_tune", 2)
     hip.set_option("gemm_tune", 1)
     assert hip._DETERMINISTIC_WGRAD[0] is True        # bit-reproducible weight gradients are the default, atomics the opt-in
     # every knob the binding knows is a knob of the library (names resolved by alpro_hip_set_option), and its built-in default is accepted;
-    # attn_bwd (round 3): 0 two-phase .. 4 persistent without touches, all result-preserving, so none of them is an ablation
+    # attn_bwd: 0 two-phase, 1 best per shape, 2 key-owned; 3 / 4 (persistent key-owned, round 3) moved to the measurement build in round 4
     for name, dflt in hip._OPTION_DEFAULTS.items():
         hip.set_option(name, dflt)
-    for kind in (0, 2, 3, 4, 1):
+    for kind in (0, 2, 1):
         hip.set_option("attn_bwd", kind)
     with pytest.raises(RuntimeError):
         hip.set_option("no_such_knob", 1)
@@ -864,9 +864,11 @@ def test_reference_driver_optimizer_lines_run_unchanged_on_the_fused_optimizer(m
     from src.utils.misc import NoOp, zero_none_grad
     assert get_lr_sched.__code__.co_filename.startswith(ref) and setup_e2e_optimizer.__code__.co_filename.startswith(ROOT) and zero_none_grad is optim.zero_none_grad
 
-    def fake_adamw(p, g, m, v, lr, b1, b2, eps, wd, step_size, gnorm_sq=None, max_norm=0.0, grad_scale=1.0, dyn_state=None, grads_scaled=True, correct_bias=True):
+    def fake_adamw(p, g, m, v, lr, b1, b2, eps, wd, step_size, gnorm_sq=None, max_norm=0.0, grad_scale=1.0, dyn_state=None, grads_scaled=True, correct_bias=True, zero_grad=False):
         assert gnorm_sq is None and max_norm == 0.0 and grad_scale == 1.0   # the driver clipped; the facade averaged
         ao.clip_and_adamw_step([p], [g], [m], [v], fake_adamw.t, lr, (b1, b2), eps, wd, None, correct_bias)   # (fake_adamw.t: step counter kept by the test)
+        if zero_grad:
+            g.zero_()
     fake_adamw.t = 0
     monkeypatch.setattr(hip, "adamw_step", fake_adamw)
     hp = OPT_SCENARIOS["release"]
