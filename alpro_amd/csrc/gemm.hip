@@ -1020,14 +1020,16 @@ int launch_gemm_inst(const alpro_gemm_desc_t& g, hipStream_t st) {
     const bool fits = (int64_t)g.M * g.lda * 2 < (int64_t)0xFFFF0000 && (int64_t)g.N * g.ldw * 2 < (int64_t)0xFFFF0000;
     const bool full = (g.M % BM2) == 0 && (g.N % BN2) == 0 && ((g.lda * 2) % 128) == 0 && ((g.ldw * 2) % 128) == 0;
     if (use256 && get_option(OPT_GEMM_KIND) == 1 && (g.K % 128) == 0 && g.K >= 256 && fits && full) {
-      int grid = big_tiles < 256 ? (big_tiles + 7) / 8 * 8 : 256;
+      const int cus = cu_budget();
+      int grid = big_tiles < cus ? (big_tiles + 7) / 8 * 8 : cus;
       if (const int cap = get_option(OPT_GEMM_GRID)) grid = cap < grid ? (cap + 7) / 8 * 8 : grid;
       hipLaunchKernelGGL((gemm_nt256q_kernel<T, ACT, MAP>), dim3(grid), dim3(NT2), 2 * STAGE2_BYTES + EPI_BYTES, st, g);
       return check_launch("alpro_gemm");
     }
   }
   if (use256) {
-    int grid = big_tiles < 256 ? (big_tiles + 7) / 8 * 8 : 256;  // multiple of 8: the XCD-contiguous slot map must be a bijection
+    const int cus = cu_budget();
+    int grid = big_tiles < cus ? (big_tiles + 7) / 8 * 8 : cus;  // multiple of 8: the XCD-contiguous slot map must be a bijection
     if (const int cap = get_option(OPT_GEMM_GRID)) grid = cap < grid ? (cap + 7) / 8 * 8 : grid;  // tuning aid: cap the persistent grid
     const int tune = get_option(OPT_GEMM_TUNE);
     const int tail = get_option(OPT_GEMM_TAIL);

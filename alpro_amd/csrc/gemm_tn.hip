@@ -359,10 +359,11 @@ TnPlan tn_plan(int M, int N, int K, bool ws) {
   } else {
     const double set_us = (ws ? 0.4e-6 : 1.14e-6) * 4.0 * (double)N * (double)K;
     double best_t = 1e30;
+    const int cus = cu_budget();   // 256, or fewer while a collective's kernels hold CUs: one workgroup per CU, so rounds are counted over these
     for (int r = 1; r <= 256; ++r) {
       const int per_try = (p.total_steps + r - 1) / r;
       if (per_try < 4 && r > 1) break;
-      const double t = (double)(((long)p.tiles * r + 255) / 256) * (26.0 + 1.15 * per_try) + set_us * r + (ws && r > 1 ? 6.0 : 0.0);
+      const double t = (double)(((long)p.tiles * r + cus - 1) / cus) * (26.0 + 1.15 * per_try) + set_us * r + (ws && r > 1 ? 6.0 : 0.0);
       if (t < best_t * 0.98) { best_t = t; p.ranges = r; }
     }
   }

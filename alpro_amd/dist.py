@@ -28,10 +28,22 @@ def collectives_active():
     return is_initialized() and (td.get_world_size() > 1 or _FORCE[0])
 
 
+def rccl_cu_reserve():
+    """Compute units set aside for the collective library's kernels while the gradient exchange overlaps with backward (round 4, measured
+    policy: profiles/r4_overlap_cu_contention.txt).  The persistent GEMMs run one workgroup per CU with 128-160 KiB of LDS: a CU that holds an
+    RCCL channel's kernel cannot take one, and a 256-workgroup launch then needs a second round for the displaced workgroups -- worse than
+    giving the CUs up in the first place.  So (i) RCCL is capped at this many channels (NCCL_MAX_NCHANNELS, unless the user set it) and (ii)
+    while async all-reduces are in flight the library sizes its persistent grids for 256 - reserve CUs (option "cu_budget").
+    ALPRO_RCCL_CU_RESERVE overrides (0 = no reservation)."""
+    return max(0, min(64, int(os.environ.get("ALPRO_RCCL_CU_RESERVE", "16"))))
+
+
 def init(backend=None):
     """Initialise from the torchrun-style environment; no-op when WORLD_SIZE is unset or 1 (unless ALPRO_FORCE_COLLECTIVES=1)."""
     if is_initialized() or (int(os.environ.get("WORLD_SIZE", "1")) <= 1 and not _FORCE[0]):
         return
+    if rccl_cu_reserve() > 0 and os.environ.get("ALPRO_OVERLAP_BACKWARD", "1") != "0":
+        os.environ.setdefault("NCCL_MAX_NCHANNELS", str(rccl_cu_reserve()))   # one channel = one resident workgroup = one CU
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29500")
     os.environ.setdefault("RANK", "0")

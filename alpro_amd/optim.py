@@ -91,6 +91,7 @@ class FlatAdamW:
         # zero_grad() that follows is free instead of a second 0.94 GB pass
         self.fused_zero_grad = fused_zero_grad
         self._g_clean = False
+        self._cus_reserved = False
         self.step_count = 0
         self._pending_state = None  # load_state_dict() before the flat buffers exist: applied by _build()
         self.flat = None  # built at the first step(), when we know which parameters actually receive gradients
@@ -169,6 +170,7 @@ class FlatAdamW:
         for h, _, _ in self._inflight:  # a driver that skips step() (e.g. on a NaN loss) must not zero under a running all-reduce
             h.wait()
         self._inflight, self._reduced = [], []
+        self._reserve_cus(False)
         if self.flat is None:
             for p in self.params:
                 p.grad = None
@@ -196,7 +198,17 @@ class FlatAdamW:
             spans = [v for k, v in self._span.items() if k not in skip]
         return self._merge(spans)
 
+    def _reserve_cus(self, on):
+        """While all-reduces launched from inside backward are in flight, the persistent GEMM grids / the weight-gradient range plan leave
+        dist.rccl_cu_reserve() CUs to RCCL's kernels (library option "cu_budget")."""
+        r = dist.rccl_cu_reserve()
+        if r > 0 and on != self._cus_reserved:
+            hip.set_option("cu_budget", 256 - r if on else 0)
+            self._cus_reserved = on
+
     def _launch(self, s, e):
+        if self.overlap_backward:
+            self._reserve_cus(True)
         g = self.flat["g"][s:e]
         if self.wire_dtype is not None and self.wire_dtype != torch.float32:
             w = g.to(self.wire_dtype)
@@ -233,6 +245,7 @@ class FlatAdamW:
             if w is not None:
                 g.copy_(w)
         self._inflight, self._reduced = [], []
+        self._reserve_cus(False)
 
     def synchronize(self, average=False):
         """Sum gradients across ranks; step() folds the 1/world averaging into the AdamW kernel's grad_scale.

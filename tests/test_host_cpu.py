@@ -896,3 +896,28 @@ def test_reference_driver_optimizer_lines_run_unchanged_on_the_fused_optimizer(m
     assert inner.n_params == sum(p.numel() for p in model.ps) and torch.equal(model.teacher.detach(), torch.ones(300, 7))
     assert model.teacher.grad.untyped_storage().nbytes() == 4            # one shared zero scalar, not 300 x 7 of them
     assert len(list(amp.master_params(ns["optimizer"]))) == 1            # the driver's clip sees ONE flat gradient view
+
+
+def test_overlapped_exchange_reserves_cus_for_the_collective_library(monkeypatch):
+    """while FlatAdamW's async all-reduces are in flight the persistent GEMM grids are sized for 256 - reserve CUs (library
+    option cu_budget), and back to all of them when the exchange has been waited for; dist.init caps RCCL at the same number of channels."""
+    from alpro_amd import dist, hip, optim
+    calls = []
+    monkeypatch.setattr(hip, "set_option", lambda name, value: calls.append((name, value)))
+    opt = optim.FlatAdamW([torch.nn.Parameter(torch.zeros(8))], overlap_backward=True)
+    assert dist.rccl_cu_reserve() == 16
+    opt._reserve_cus(True)
+    opt._reserve_cus(True)            # idempotent while the exchange is running
+    opt._reserve_cus(False)
+    assert calls == [("cu_budget", 240), ("cu_budget", 0)]
+    monkeypatch.setenv("ALPRO_RCCL_CU_RESERVE", "0")
+    opt._reserve_cus(True)
+    assert len(calls) == 2            # reservation switched off: nothing is touched
+    monkeypatch.setenv("ALPRO_RCCL_CU_RESERVE", "24")
+    monkeypatch.delenv("NCCL_MAX_NCHANNELS", raising=False)
+    monkeypatch.setenv("WORLD_SIZE", "2")
+    seen = {}
+    monkeypatch.setattr(dist.td, "init_process_group", lambda **k: seen.update(k, channels=os.environ.get("NCCL_MAX_NCHANNELS")))
+    monkeypatch.setattr(dist, "is_initialized", lambda: False)
+    dist.init(backend="gloo")
+    assert seen["channels"] == "24" and seen["world_size"] == 2
