@@ -31,7 +31,7 @@ bool option_allowed(int which, int value) {
   return true;
 #else
   if (which == OPT_GEMM_TUNE) return value >= 0 && value <= 2;
-  if (which == OPT_TN_KIND) return value == 0;
+  if (which == OPT_TN_KIND) return value == 0 || value == 2;   // 1: no epilogue (timing only, measurement build); 2: two-group schedule
   if (which == OPT_ATTN_BWD) return value >= 0 && value <= 2;   // 3 / 4: the persistent key-owned backward, compiled into the measurement build only (round 4)
   return value >= 0;
 #endif

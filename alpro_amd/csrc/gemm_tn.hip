@@ -53,7 +53,7 @@ __device__ __forceinline__ u32x4 frag8(const char* img, int ks, int col0, int la
   return mk4(ax, ay, bx, by);
 }
 
-template <typename T>
+template <typename T, int PP = 0>
 __global__ __launch_bounds__(NT3, 1) void gemm_tn_kernel(const T* __restrict__ A, int64_t lda, const T* __restrict__ B, int64_t ldb,
                                                          float* __restrict__ C, int64_t ldc, int M, int N, int K, int per,
                                                          int tiles, int units, int tn_cnt, float* __restrict__ colsum, float* __restrict__ part,
@@ -132,17 +132,30 @@ __global__ __launch_bounds__(NT3, 1) void gemm_tn_kernel(const T* __restrict__ A
   // (out-of-range stages read the zero page), which is what makes the vmcnt arithmetic exact.
   // A copy stalls its wave for ~60-150 issue cycles (the CU's address unit takes 1 KiB per ~16 clk): the two waves
   // that share a SIMD (w, w+4) use alternating slots so that the partner's MFMAs cover it.
+  if constexpr (PP == 0) {
 #pragma unroll
-  for (int p = 0; p < 3; ++p) {
+    for (int p = 0; p < 3; ++p) {
 #pragma unroll
-    for (int d = 0; d < 4; ++d) copy(d, p);
+      for (int d = 0; d < 4; ++d) copy(d, p);
+      advance(0);
+      advance(1);
+    }
+    copy(0, 3);
+    copy(1, 3);  // piece 0 of stage s0+3; piece 1 follows in the first half of step s0
     advance(0);
-    advance(1);
+  } else {   // two-group schedule: stages s0, s0+1 complete and piece 0 of stage s0+2; the loop issues one piece pair per phase from there on
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+#pragma unroll
+      for (int d = 0; d < 4; ++d) copy(d, p);
+      advance(0);
+      advance(1);
+    }
+    copy(0, 2);
+    copy(1, 2);
+    advance(0);
   }
-  copy(0, 3);
-  copy(1, 3);  // piece 0 of stage s0+3; piece 1 follows in the first half of step s0
-  advance(0);
-  const int pos = wave >> 2;
+  [[maybe_unused]] const int pos = wave >> 2;
   auto load_frags = [&](u32x4* fa, u32x4* fb, const char* cA, const char* cB, int ks) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) fb[j] = frag8(cB, ks, wc * 64 + j * 32, lane);
@@ -170,42 +183,88 @@ __global__ __launch_bounds__(NT3, 1) void gemm_tn_kernel(const T* __restrict__ A
         cs += ((f[0] + f[1]) + (f[2] + f[3])) + ((f[4] + f[5]) + (f[6] + f[7]));
       }
   };
-  u32x4 fa0[4], fb0[2], fa1[4], fb1[2];
-  asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  asm volatile("" ::: "memory");
-  load_frags(fa0, fb0, smem, smem + IMG_BYTES, 0);
-  for (int st = s0; st < s1; ++st) {
-    const int cur = (st - s0) & (NSTAGE - 1);
-    const int b3 = (cur + 3) & (NSTAGE - 1), b1 = (cur + 1) & (NSTAGE - 1);
-    const char* cA = smem + cur * 2 * IMG_BYTES;
-    load_frags(fa1, fb1, cA, cA + IMG_BYTES, 1);
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        mma_chunk<T>(acc[i][j], fa0[i], fb0[j]);
-        if (j == 1 && (i & 1) == pos) copy(2 + (i >> 1), b3);  // piece 1 (A, B) of stage st+3
-      }
-    const bool cs_now = do_cs && cs_turn == tk;
-    cs_turn = cs_turn + 1 == tk_cnt ? 0 : cs_turn + 1;
-    if (cs_now) add_cols(fa0);
-    advance(1);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  if constexpr (PP == 0) {
+    u32x4 fa0[4], fb0[2], fa1[4], fb1[2];
+    asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    const char* nA = smem + b1 * 2 * IMG_BYTES;
-    load_frags(fa0, fb0, nA, nA + IMG_BYTES, 0);
+    load_frags(fa0, fb0, smem, smem + IMG_BYTES, 0);
+    for (int st = s0; st < s1; ++st) {
+      const int cur = (st - s0) & (NSTAGE - 1);
+      const int b3 = (cur + 3) & (NSTAGE - 1), b1 = (cur + 1) & (NSTAGE - 1);
+      const char* cA = smem + cur * 2 * IMG_BYTES;
+      load_frags(fa1, fb1, cA, cA + IMG_BYTES, 1);
+  #pragma unroll
+      for (int i = 0; i < 4; ++i)
+  #pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          mma_chunk<T>(acc[i][j], fa0[i], fb0[j]);
+          if (j == 1 && (i & 1) == pos) copy(2 + (i >> 1), b3);  // piece 1 (A, B) of stage st+3
+        }
+      const bool cs_now = do_cs && cs_turn == tk;
+      cs_turn = cs_turn + 1 == tk_cnt ? 0 : cs_turn + 1;
+      if (cs_now) add_cols(fa0);
+      advance(1);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      const char* nA = smem + b1 * 2 * IMG_BYTES;
+      load_frags(fa0, fb0, nA, nA + IMG_BYTES, 0);
+  #pragma unroll
+      for (int i = 0; i < 4; ++i)
+  #pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          mma_chunk<T>(acc[i][j], fa1[i], fb1[j]);
+          if (j == 1 && (i & 1) == pos) copy(i >> 1, cur);  // piece 0 (A, B) of stage st+4
+        }
+      if (cs_now) add_cols(fa1);
+      advance(0);
+    }
+  } else {
+    // Two-group ("ping-pong") schedule (round 4; the NT kernel's structure, gemm.hip gemm_nt256q_kernel, on this kernel's operands).  A stage
+    // is two PHASES (token halves ks = 0 / 1): LOAD segment = the phase's six 8-token fragments (24 ds_read_b64_tr_b16) + one piece pair of a
+    // later stage -> s_barrier -> MFMA segment = 8 MFMAs on 8 different accumulators at raised priority -> s_barrier.  The upper wave row
+    // runs one barrier behind, so each SIMD always has one wave on the matrix pipe and one on LDS / copies.  Phase k = 2j + ks of stage j:
+    //   copies: piece (k-1) & 1 of stage ((k-1) >> 1) + 3, i.e. phase 2j -> piece 1 of stage j+2, phase 2j+1 -> piece 0 of stage j+3, into the
+    //           buffer last read in LOAD(2j-1) / LOAD(2j+1 - 2): two phases after its last reader (WAR, see gemm.hip);
+    //   wait:   vmcnt(6) at the end of every LOAD segment: all but the last three phases' copies have landed, so the stage first read in
+    //           the NEXT phase is complete before the barrier that separates the two (RAW).
+    u32x4 fa[4], fb[2];
+    auto pbar = [] {
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // stage s0 landed (10 copies issued: stage s0+1 and piece 0 of s0+2 stay in flight)
+    pbar();
+    if (wr == 1) pbar();   // the upper wave row drops one barrier behind
+    for (int st = s0; st < s1; ++st) {
+      const int j = st - s0;
+      const int cur = j & (NSTAGE - 1);
+      const char* cA = smem + cur * 2 * IMG_BYTES;
+      const bool cs_now = do_cs && cs_turn == tk;
+      cs_turn = cs_turn + 1 == tk_cnt ? 0 : cs_turn + 1;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+      for (int ks = 0; ks < 2; ++ks) {
+        load_frags(fa, fb, cA, cA + IMG_BYTES, ks);
+        const int buf = (j + 2 + ks) & (NSTAGE - 1);
+        copy(2 * (1 - ks), buf);          // phase 2j: piece 1 (A, B) of stage j+2; phase 2j+1: piece 0 (A, B) of stage j+3
+        copy(2 * (1 - ks) + 1, buf);
+        advance(1 - ks);
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        pbar();
+        __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        mma_chunk<T>(acc[i][j], fa1[i], fb1[j]);
-        if (j == 1 && (i & 1) == pos) copy(i >> 1, cur);  // piece 0 (A, B) of stage st+4
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int jj = 0; jj < 2; ++jj) mma_chunk<T>(acc[i][jj], fa[i], fb[jj]);
+        __builtin_amdgcn_s_setprio(0);
+        if (cs_now) add_cols(fa);
+        pbar();
       }
-    if (cs_now) add_cols(fa1);
-    advance(0);
+    }
+    if (wr == 0) pbar();   // equal barrier counts for both wave rows
   }
   if (do_cs) {
     const float t = cs + __shfl_xor(cs, 32, 64);  // the two token halves of the fragment
@@ -402,8 +461,10 @@ extern "C" int alpro_gemm_tn_acc_ws(const void* A, int64_t lda, const void* B, i
     part = p.ranges > 1 ? (float*)workspace : nullptr;
     part_cs = colsum ? (float*)workspace + p.part_floats : nullptr;
   }
+  const int kind_opt = get_option(OPT_TN_KIND);
+  const bool pp = kind_opt == 2;             // 2: the two-group schedule (round 4), result-preserving
 #ifdef ALPRO_ABLATIONS
-  const int kind = get_option(OPT_TN_KIND);
+  const int kind = kind_opt == 1 ? 1 : 0;    // 1: no epilogue (timing only; measurement build)
 #else
   const int kind = 0;
 #endif
@@ -412,12 +473,20 @@ extern "C" int alpro_gemm_tn_acc_ws(const void* A, int64_t lda, const void* B, i
   hipStream_t st = (hipStream_t)stream;
   if (dtype == ALPRO_BF16) {
     static DeviceOnce once;
-    once.run([&] { (void)hipFuncSetAttribute((const void*)gemm_tn_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); });
-    hipLaunchKernelGGL(gemm_tn_kernel<bf16_t>, dim3(grid), dim3(NT3), lds, st, (const bf16_t*)A, lda, (const bf16_t*)B, ldb, C, ldc, M, N, K, p.per, p.tiles, p.units, p.tn, colsum, part, part_cs, kind);
+    once.run([&] {
+      (void)hipFuncSetAttribute((const void*)gemm_tn_kernel<bf16_t, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      (void)hipFuncSetAttribute((const void*)gemm_tn_kernel<bf16_t, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    });
+    if (pp) hipLaunchKernelGGL((gemm_tn_kernel<bf16_t, 1>), dim3(grid), dim3(NT3), lds, st, (const bf16_t*)A, lda, (const bf16_t*)B, ldb, C, ldc, M, N, K, p.per, p.tiles, p.units, p.tn, colsum, part, part_cs, kind);
+    else hipLaunchKernelGGL((gemm_tn_kernel<bf16_t, 0>), dim3(grid), dim3(NT3), lds, st, (const bf16_t*)A, lda, (const bf16_t*)B, ldb, C, ldc, M, N, K, p.per, p.tiles, p.units, p.tn, colsum, part, part_cs, kind);
   } else {
     static DeviceOnce once;
-    once.run([&] { (void)hipFuncSetAttribute((const void*)gemm_tn_kernel<f16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); });
-    hipLaunchKernelGGL(gemm_tn_kernel<f16_t>, dim3(grid), dim3(NT3), lds, st, (const f16_t*)A, lda, (const f16_t*)B, ldb, C, ldc, M, N, K, p.per, p.tiles, p.units, p.tn, colsum, part, part_cs, kind);
+    once.run([&] {
+      (void)hipFuncSetAttribute((const void*)gemm_tn_kernel<f16_t, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      (void)hipFuncSetAttribute((const void*)gemm_tn_kernel<f16_t, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    });
+    if (pp) hipLaunchKernelGGL((gemm_tn_kernel<f16_t, 1>), dim3(grid), dim3(NT3), lds, st, (const f16_t*)A, lda, (const f16_t*)B, ldb, C, ldc, M, N, K, p.per, p.tiles, p.units, p.tn, colsum, part, part_cs, kind);
+    else hipLaunchKernelGGL((gemm_tn_kernel<f16_t, 0>), dim3(grid), dim3(NT3), lds, st, (const f16_t*)A, lda, (const f16_t*)B, ldb, C, ldc, M, N, K, p.per, p.tiles, p.units, p.tn, colsum, part, part_cs, kind);
   }
   if ((part || part_cs) && kind != 1)
     hipLaunchKernelGGL(tn_reduce_kernel, dim3((part ? p.tiles * 64 : 0) + (part_cs ? p.tn * (TW / 32) : 0)), dim3(256), 0, st, part, part_cs, C, ldc, colsum, N, K, p.tiles, p.ranges, p.tn);

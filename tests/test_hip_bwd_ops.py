@@ -181,13 +181,15 @@ def test_flat_adamw_matches_reference_update():
         assert all(float(p.grad.abs().sum()) == 0 for p in params)
 
 
+@pytest.mark.parametrize("tn_kind", [0, 2])
 @pytest.mark.parametrize("atomic", [False, True])
 @pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("M,N,K", [(3138, 768, 768), (1000, 2304, 768), (6400, 768, 3072), (130, 30522, 768), (64, 8, 8), (4001, 520, 264)])
-def test_gemm_tn_acc(dt, M, N, K, atomic):
+@pytest.mark.parametrize("M,N,K", [(3138, 768, 768), (1000, 2304, 768), (6400, 768, 3072), (130, 30522, 768), (64, 8, 8), (4001, 520, 264), (50176, 768, 768)])
+def test_gemm_tn_acc(dt, M, N, K, atomic, tn_kind):
     """Weight-gradient GEMM on natural layouts (tr-read operands, split over token ranges; partial tiles combined through the
-    workspace + fixed-order reduce, or by fp32 atomics)."""
+    workspace + fixed-order reduce, or by fp32 atomics); tn_kind 2 = the two-group schedule of round 4 (same operands, same epilogue)."""
     hip = _hip()
+    hip.set_option("tn_kind", tn_kind)
     ldn = (N + 7) // 8 * 8
     a = torch.zeros(M, ldn)
     a[:, :N] = rnd(M, N, seed=120) * 0.5
@@ -196,6 +198,7 @@ def test_gemm_tn_acc(dt, M, N, K, atomic):
     c = c0.clone().cuda()
     bg = torch.full((ldn,), 2.0).cuda()
     hip.gemm_tn_acc(a.to(dt).cuda()[:, :N], b.to(dt).cuda(), c, colsum=bg, atomic=atomic)
+    hip.set_option("tn_kind", 0)
     ref = c0.double() + a[:, :N].to(dt).double().T @ b.to(dt).double()
     close(c, ref, 2e-5, 2e-3 * math.sqrt(M / 1000.0), "gemm_tn_acc")
     close(bg[:N], 2 + a[:, :N].to(dt).double().sum(0), 1e-5, 1e-3, "gemm_tn_acc fused bias gradient")
