@@ -919,10 +919,7 @@ __global__ __launch_bounds__(NT2, 2) void gemm_nt256q_kernel(const alpro_gemm_de
 #pragma unroll
           for (int r = 0; r < 4; ++r) stage[(kg * 4 + r) * 64 + nf * 16 + l15] = acc[mf][nf][r];
       };
-      const bool fast = epi_fast_ok(g, mb, 128, nb);
-      bool c16 = false;
-      if constexpr (MAP == ALPRO_MAP_IDENTITY) c16 = fast && g.c_dtype != ALPRO_F32 && ((g.ldc & 7) == 0) && (!g.C2 || (g.ldc2 & 7) == 0);
-      if (c16) {
+      {
         if constexpr (MAP == ALPRO_MAP_IDENTITY) {
           float bias8[8];
 #pragma unroll
@@ -942,42 +939,8 @@ __global__ __launch_bounds__(NT2, 2) void gemm_nt256q_kernel(const alpro_gemm_de
             epi_rows16_c16<T, ACT, 2>(g, stage, mb + mf * 16, nb, lane, bias8, READS_C2 ? pring[mf & 1] : nullptr);
           }
         }
-      } else {
-        float bias[4];
-        load_bias4(g, nb + (lane & 15) * 4, bias);
-        auto run = [&](auto fast_tag, auto pf_tag) {
-          constexpr bool FAST = decltype(fast_tag)::value;
-          constexpr bool PF = decltype(pf_tag)::value;   // residual rows fetched one fragment row ahead (compile-time: a maybe-null pointer to the
-                                                         // register array sends it through scratch)
-          float4 ra[2], rb[2], na[2], nb2[2];
-          if constexpr (PF) {
-            epi_prefetch_res<MAP>(g, mb, nb, lane, ra);
-            epi_prefetch_res<MAP>(g, mb + 8, nb, lane, rb);
-          }
-#pragma unroll
-          for (int mf = 0; mf < 8; ++mf) {
-            if constexpr (PF) {
-              if (mf + 1 < 8) {
-                epi_prefetch_res<MAP>(g, mb + (mf + 1) * 16, nb, lane, na);
-                epi_prefetch_res<MAP>(g, mb + (mf + 1) * 16 + 8, nb, lane, nb2);
-              }
-            }
-            stage_rows(mf);
-            if constexpr (PF) {
-              epi_rows16<T, ACT, MAP, FAST, 2>(g, stage, mb + mf * 16, nb, lane, bias, ra);
-              epi_rows16<T, ACT, MAP, FAST, 2>(g, stage + 8 * 64, mb + mf * 16 + 8, nb, lane, bias, rb);
-#pragma unroll
-              for (int p = 0; p < 2; ++p) { ra[p] = na[p]; rb[p] = nb2[p]; }
-            } else {
-              epi_rows16<T, ACT, MAP, FAST, 2>(g, stage, mb + mf * 16, nb, lane, bias);
-              epi_rows16<T, ACT, MAP, FAST, 2>(g, stage + 8 * 64, mb + mf * 16 + 8, nb, lane, bias);
-            }
-          }
-        };
-        if (fast && MAP != ALPRO_MAP_FRAME_TOKENS && g.residual != nullptr) run(std::true_type{}, std::true_type{});
-        else if (fast) run(std::true_type{}, std::false_type{});
-        else run(std::false_type{}, std::false_type{});
       }
+      // (no other epilogue: the launcher hands this kernel 16-bit outputs on full tiles only; fp32 outputs / row maps stay on gemm_nt256p_kernel)
     }
     cur = nxt;
     if (it + 2 < ntile) nxt = tile_base(slot + (it + 2) * G);
@@ -1017,13 +980,32 @@ int launch_gemm_inst(const alpro_gemm_desc_t& g, hipStream_t st) {
     attr_q.run([&] {
       (void)hipFuncSetAttribute((const void*)gemm_nt256q_kernel<T, ACT, MAP>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE2_BYTES + EPI_BYTES);
     });
-    const bool fits = (int64_t)g.M * g.lda * 2 < (int64_t)0xFFFF0000 && (int64_t)g.N * g.ldw * 2 < (int64_t)0xFFFF0000;
-    const bool full = (g.M % BM2) == 0 && (g.N % BN2) == 0 && ((g.lda * 2) % 128) == 0 && ((g.ldw * 2) % 128) == 0;
-    if (use256 && get_option(OPT_GEMM_KIND) == 1 && (g.K % 128) == 0 && g.K >= 256 && fits && full) {
+    // eligible: 16-bit output through the 16-byte-store epilogue, whole 256-column tiles, 128-byte-aligned operand rows, an even number >= 4 of
+    // K-tiles; a ragged M (the ViT's B * 1569 token rows: M % 256 = 64) is split -- whole tiles here, the remaining rows on the 128 x 128 kernel
+    // in a second launch -- when the epilogue does not index by absolute row (row scale, dropout)
+    const int m_full = g.M / BM2 * BM2, m_rem = g.M - m_full;
+    const bool c16 = g.c_dtype != ALPRO_F32 && (g.ldc & 7) == 0 && (!g.C2 || (g.ldc2 & 7) == 0) && (!g.residual || (g.ldr & 3) == 0) && ((uintptr_t)g.C % 16) == 0;
+    const bool shape = (g.N % BN2) == 0 && ((g.lda * 2) % 128) == 0 && ((g.ldw * 2) % 128) == 0 && (g.K % 128) == 0 && g.K >= 256 &&
+                       (int64_t)g.M * g.lda * 2 < (int64_t)0xFFFF0000 && (int64_t)g.N * g.ldw * 2 < (int64_t)0xFFFF0000;
+    const bool split_ok = m_rem == 0 || (!g.row_scale && !g.drop_seed);
+    const int full_tiles = (g.N / BN2) * (m_full / BM2);
+    if (get_option(OPT_GEMM_KIND) == 1 && c16 && shape && split_ok && (force ? force == 256 : full_tiles >= 160)) {
+      alpro_gemm_desc_t gq = g;
+      gq.M = m_full;
       const int cus = cu_budget();
-      int grid = big_tiles < cus ? (big_tiles + 7) / 8 * 8 : cus;
+      int grid = full_tiles < cus ? (full_tiles + 7) / 8 * 8 : cus;
       if (const int cap = get_option(OPT_GEMM_GRID)) grid = cap < grid ? (cap + 7) / 8 * 8 : grid;
-      hipLaunchKernelGGL((gemm_nt256q_kernel<T, ACT, MAP>), dim3(grid), dim3(NT2), 2 * STAGE2_BYTES + EPI_BYTES, st, g);
+      hipLaunchKernelGGL((gemm_nt256q_kernel<T, ACT, MAP>), dim3(grid), dim3(NT2), 2 * STAGE2_BYTES + EPI_BYTES, st, gq);
+      if (m_rem) {
+        alpro_gemm_desc_t gr = g;
+        gr.M = m_rem;
+        gr.A = (const char*)g.A + (int64_t)m_full * g.lda * 2;
+        gr.C = (char*)g.C + (int64_t)m_full * g.ldc * 2;
+        if (g.C2) gr.C2 = (char*)g.C2 + (int64_t)m_full * g.ldc2 * 2;
+        if (g.residual) gr.residual = g.residual + (int64_t)m_full * g.ldr;
+        const int ntn = (gr.N + BN - 1) / BN, ntm = (gr.M + BM - 1) / BM;
+        hipLaunchKernelGGL((gemm_nt_kernel<T, ACT, MAP>), dim3(ntn * ntm), dim3(NT), 4 * TILE_BYTES, st, gr);
+      }
       return check_launch("alpro_gemm");
     }
   }

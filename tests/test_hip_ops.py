@@ -353,11 +353,13 @@ def test_gemm_rows_f32(M, N, K, case):
 @pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("M,N,K,case", [(256 * 80, 512, 768, "plain"), (256 * 54, 768, 256, "plain"), (256 * 130, 768, 768, "bias_rowscale"), (256 * 40, 1024, 3072, "f32res"),
                                         (256 * 80, 512, 768, "gelu_save"), (256 * 80, 512, 768, "mul_saved"), (256 * 80, 512, 768, "gelu"), (256 * 44, 1024, 768, "dropout"),
-                                        (256 * 80, 512, 768, "strided")])
+                                        (256 * 80, 512, 768, "strided"), (256 * 80 + 64, 512, 768, "plain"), (256 * 80 + 64, 512, 768, "gelu_save"), (256 * 392 + 64, 768, 3072, "mul_saved")])
 def test_gemm_8phase_kernel(dt, M, N, K, case):
     """gemm_nt256q_kernel (round 4: 8-phase two-group schedule on 16x16x32 MFMA fragments; option gemm_kind = 1) on full-tile shapes with >= 160
     tiles -- one and several tiles per workgroup, K = 4 / 12 / 48 K-tiles, every epilogue the identity-map shapes of the model use -- against
-    fp64 of the same rounded operands, and against the round-3 kernel (gemm_kind = 0) on the same inputs."""
+    fp64 of the same rounded operands, and against the round-3 kernel (gemm_kind = 0) on the same inputs.  Ragged M (the ViT's B * 1569 rows:
+    M % 256 = 64) is split by the launcher: whole tiles on the 8-phase kernel, the last 64 rows on the 128 x 128 kernel.  (fp32 outputs and
+    row-scaled ragged shapes stay on the round-3 kernel: those cases check the routing.)"""
     hip = _hip()
     a, w, b = rnd(M, K, seed=700 + K), rnd(N, K, seed=701, scale=0.05), rnd(N, seed=702)
     A, W = a.to(dt).cuda(), w.to(dt).cuda()
