@@ -261,7 +261,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qkv
 __device__ u32x4 g_attn_zero[4];
 constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
 
-template <typename T, int NKT, bool HAS_BIAS>
+template <typename T, int NKT, bool HAS_BIAS, bool CLS = false>
 __global__ __launch_bounds__(256, 2) void attn_fwd16_kernel(const T* __restrict__ qkv, T* __restrict__ out, int L, int H, float scale,
                                                             const float* __restrict__ key_bias, float* __restrict__ lse, float drop_p,
                                                             uint32_t drop_seed, int order, const float* __restrict__ cls_q, int cls_group,
@@ -440,7 +440,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd16_kernel(const T* __restrict_
   // LDS, scores / online softmax / P V in fp32 -- no P rounding, no output rounding.  Thread = (key slot tid >> 3 of 32, 8-element head chunk
   // tid & 7); the 32 slots keep independent softmax states, merged over the wave by shuffles and over the four waves through the (now idle)
   // output staging area.  ~NKT iterations of two ds_read_b128 + 40 VALU per thread on top of a 32 x NKT-tile workgroup.
-  if (cls_q) {
+  // (CLS is a template parameter: the instantiations without the side path must keep the register allocation they had -- with the extra code
+  // compiled in, <8 key tiles, bias> went to 256 VGPRs + 112 bytes of scratch and produced wrong rows at B = 64, profiles/r4_fusion_diag.txt)
+  if constexpr (CLS) {
     const int gs = tid >> 3, e = tid & 7;
     float q[8];
     {
@@ -699,9 +701,13 @@ int launch_attn16(const void* qkv, void* out, int batch, int L, int H, float sca
   const size_t lds = 2 * (size_t)NKT * 32 * 128 + 4 * (NKT == 8 ? 2048 : 4096) + (size_t)NKT * 32 * sizeof(float);
   static DeviceOnce attr_once;
   attr_once.run([&] {
-    (void)hipFuncSetAttribute((const void*)attn_fwd16_kernel<T, NKT, HAS_BIAS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)attn_fwd16_kernel<T, NKT, HAS_BIAS, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)attn_fwd16_kernel<T, NKT, HAS_BIAS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   });
-  hipLaunchKernelGGL((attn_fwd16_kernel<T, NKT, HAS_BIAS>), dim3(batch * H), dim3(256), lds, st, (const T*)qkv, (T*)out, L, H, scale, key_bias, lse, drop_p, drop_seed, get_option(OPT_ATTN_ORDER), cls_q, cls_group, cls_out);
+  if (cls_q)
+    hipLaunchKernelGGL((attn_fwd16_kernel<T, NKT, HAS_BIAS, true>), dim3(batch * H), dim3(256), lds, st, (const T*)qkv, (T*)out, L, H, scale, key_bias, lse, drop_p, drop_seed, get_option(OPT_ATTN_ORDER), cls_q, cls_group, cls_out);
+  else
+    hipLaunchKernelGGL((attn_fwd16_kernel<T, NKT, HAS_BIAS, false>), dim3(batch * H), dim3(256), lds, st, (const T*)qkv, (T*)out, L, H, scale, key_bias, lse, drop_p, drop_seed, get_option(OPT_ATTN_ORDER), cls_q, cls_group, cls_out);
   return check_launch("alpro_attn_fwd");
 }
 

@@ -123,7 +123,7 @@ __device__ __forceinline__ void epi_rows16(const alpro_gemm_desc_t& g, const flo
     const float4 a = *(const float4*)(stage + row * 64 + c4);
     float v[4] = {a.x, a.y, a.z, a.w};
     const float res[4] = {rr[p].x, rr[p].y, rr[p].z, rr[p].w};
-    const float rs = g.row_scale ? g.row_scale[(m_base + row) / g.row_scale_group] : 1.0f;
+    const float rs = g.row_scale ? g.row_scale[(g.m_off + m_base + row) / g.row_scale_group] : 1.0f;
 #pragma unroll
     for (int e = 0; e < 4; ++e) v[e] = g.alpha * v[e] + bias[e];
     if ((ACT == ALPRO_ACT_GELU || ACT == ALPRO_ACT_RELU) && g.C2) {  // pre-activation copy (host guarantees vector alignment for C2)
@@ -176,7 +176,7 @@ __device__ __forceinline__ void epi_rows16(const alpro_gemm_desc_t& g, const flo
     if (MAP == ALPRO_MAP_IDENTITY && g.drop_seed) {
       const uint32_t th = drop_thresh24(g.drop_p);
       const float ks = 1.0f / (1.0f - g.drop_p);
-      const uint64_t i0 = (uint64_t)(m_base + row) * (uint64_t)g.N + (uint64_t)n;
+      const uint64_t i0 = (uint64_t)(g.m_off + m_base + row) * (uint64_t)g.N + (uint64_t)n;
 #pragma unroll
       for (int e = 0; e < 4; ++e) v[e] = drop_keep(g.drop_seed, i0 + e, th) ? v[e] * ks : 0.f;
     }
@@ -241,7 +241,7 @@ __device__ __forceinline__ void epi_rows16_c16(const alpro_gemm_desc_t& g, const
     const int64_t m = m_base + row;
     const float4 a0 = *(const float4*)(stage + row * 64 + c8), a1 = *(const float4*)(stage + row * 64 + c8 + 4);
     float v[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
-    const float rs = g.row_scale ? g.row_scale[m / g.row_scale_group] : 1.0f;
+    const float rs = g.row_scale ? g.row_scale[(g.m_off + m) / g.row_scale_group] : 1.0f;
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] = g.alpha * v[e] + bias[e];
     if ((ACT == ALPRO_ACT_GELU || ACT == ALPRO_ACT_RELU) && g.C2) __builtin_nontemporal_store(pack_chunk<T>(v), (u32x4*)((T*)g.C2 + m * g.ldc2 + n));
@@ -262,7 +262,7 @@ __device__ __forceinline__ void epi_rows16_c16(const alpro_gemm_desc_t& g, const
     if (g.drop_seed) {
       const uint32_t th = drop_thresh24(g.drop_p);
       const float ks = 1.0f / (1.0f - g.drop_p);
-      const uint64_t i0 = (uint64_t)m * (uint64_t)g.N + (uint64_t)n;
+      const uint64_t i0 = (uint64_t)(g.m_off + m) * (uint64_t)g.N + (uint64_t)n;
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] = drop_keep(g.drop_seed, i0 + e, th) ? v[e] * ks : 0.f;
     }
@@ -919,7 +919,7 @@ __global__ __launch_bounds__(NT2, 2) void gemm_nt256q_kernel(const alpro_gemm_de
 #pragma unroll
           for (int r = 0; r < 4; ++r) stage[(kg * 4 + r) * 64 + nf * 16 + l15] = acc[mf][nf][r];
       };
-      {
+      if (g.c_dtype != ALPRO_F32) {
         if constexpr (MAP == ALPRO_MAP_IDENTITY) {
           float bias8[8];
 #pragma unroll
@@ -940,7 +940,40 @@ __global__ __launch_bounds__(NT2, 2) void gemm_nt256q_kernel(const alpro_gemm_de
           }
         }
       }
-      // (no other epilogue: the launcher hands this kernel 16-bit outputs on full tiles only; fp32 outputs / row maps stay on gemm_nt256p_kernel)
+      // fp32 output (launcher: ACT none, identity map, no C2 / dropout): C = residual + row_scale * (alpha * acc + bias) -- the MLP's fc2 with its
+      // fp32 residual (vit.py:212).  A staged fragment row is 16 rows x 16 float4; lane l finishes pieces l, l+64, l+128, l+192 = rows
+      // (l >> 4) + 4j, columns 4 (l & 15) .. +3: whole 256-byte row segments per 16 lanes, the residual pieces of the NEXT fragment row in flight.
+      if constexpr (MAP == ALPRO_MAP_IDENTITY && ACT == ALPRO_ACT_NONE) {
+        if (g.c_dtype == ALPRO_F32) {
+          const int c4 = (lane & 15) * 4, r0e = lane >> 4;
+          float bias4[4];
+          load_bias4(g, nb + c4, bias4);
+          float* Cf = (float*)g.C;
+          f32x4 rn[4], rc[4];
+          auto load_res = [&](int mf, f32x4(&rr)[4]) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) rr[j] = __builtin_nontemporal_load((const f32x4*)(g.residual + (int64_t)(mb + mf * 16 + r0e + 4 * j) * g.ldr + nb + c4));
+          };
+          if (g.residual) load_res(0, rc);
+#pragma unroll
+          for (int mf = 0; mf < 8; ++mf) {
+            if (g.residual && mf + 1 < 8) load_res(mf + 1, rn);
+            stage_rows(mf);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const int row = r0e + 4 * j;
+              const int64_t m = mb + mf * 16 + row;
+              const float4 a = *(const float4*)(stage + row * 64 + c4);
+              const float rs = g.row_scale ? g.row_scale[(g.m_off + m) / g.row_scale_group] : 1.0f;
+              f32x4 v = {(g.alpha * a.x + bias4[0]) * rs, (g.alpha * a.y + bias4[1]) * rs, (g.alpha * a.z + bias4[2]) * rs, (g.alpha * a.w + bias4[3]) * rs};
+              if (g.residual) v += rc[j];
+              __builtin_nontemporal_store(v, (f32x4*)(Cf + m * g.ldc + nb + c4));
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) rc[j] = rn[j];
+          }
+        }
+      }
     }
     cur = nxt;
     if (it + 2 < ntile) nxt = tile_base(slot + (it + 2) * G);
@@ -985,11 +1018,13 @@ int launch_gemm_inst(const alpro_gemm_desc_t& g, hipStream_t st) {
     // in a second launch -- when the epilogue does not index by absolute row (row scale, dropout)
     const int m_full = g.M / BM2 * BM2, m_rem = g.M - m_full;
     const bool c16 = g.c_dtype != ALPRO_F32 && (g.ldc & 7) == 0 && (!g.C2 || (g.ldc2 & 7) == 0) && (!g.residual || (g.ldr & 3) == 0) && ((uintptr_t)g.C % 16) == 0;
+    const bool c32 = g.c_dtype == ALPRO_F32 && ACT == ALPRO_ACT_NONE && !g.C2 && !g.drop_seed && (g.ldc & 3) == 0 && (!g.residual || ((g.ldr & 3) == 0 && ((uintptr_t)g.residual % 16) == 0)) &&
+                     ((uintptr_t)g.C % 16) == 0;
     const bool shape = (g.N % BN2) == 0 && ((g.lda * 2) % 128) == 0 && ((g.ldw * 2) % 128) == 0 && (g.K % 128) == 0 && g.K >= 256 &&
                        (int64_t)g.M * g.lda * 2 < (int64_t)0xFFFF0000 && (int64_t)g.N * g.ldw * 2 < (int64_t)0xFFFF0000;
-    const bool split_ok = m_rem == 0 || (!g.row_scale && !g.drop_seed);
+    const bool split_ok = true;   // (row scale / dropout index by absolute row: the remainder launch carries m_off)
     const int full_tiles = (g.N / BN2) * (m_full / BM2);
-    if (get_option(OPT_GEMM_KIND) == 1 && c16 && shape && split_ok && (force ? force == 256 : full_tiles >= 160)) {
+    if (get_option(OPT_GEMM_KIND) == 1 && (c16 || c32) && shape && split_ok && (force ? force == 256 : full_tiles >= 160)) {
       alpro_gemm_desc_t gq = g;
       gq.M = m_full;
       const int cus = cu_budget();
@@ -1000,7 +1035,8 @@ int launch_gemm_inst(const alpro_gemm_desc_t& g, hipStream_t st) {
         alpro_gemm_desc_t gr = g;
         gr.M = m_rem;
         gr.A = (const char*)g.A + (int64_t)m_full * g.lda * 2;
-        gr.C = (char*)g.C + (int64_t)m_full * g.ldc * 2;
+        gr.C = (char*)g.C + (int64_t)m_full * g.ldc * (g.c_dtype == ALPRO_F32 ? 4 : 2);
+        gr.m_off = g.m_off + m_full;
         if (g.C2) gr.C2 = (char*)g.C2 + (int64_t)m_full * g.ldc2 * 2;
         if (g.residual) gr.residual = g.residual + (int64_t)m_full * g.ldr;
         const int ntn = (gr.N + BN - 1) / BN, ntm = (gr.M + BM - 1) / BM;

@@ -37,7 +37,7 @@ class GemmDesc(ctypes.Structure):
                 ("map_mode", ctypes.c_int), ("map_p0", ctypes.c_int), ("map_p1", ctypes.c_int),
                 ("side", ctypes.c_void_p), ("ld_side", ctypes.c_int64),
                 ("C2", ctypes.c_void_p), ("ldc2", ctypes.c_int64),
-                ("drop_p", ctypes.c_float), ("drop_seed", ctypes.c_uint32), ("bias2", ctypes.c_void_p)]
+                ("drop_p", ctypes.c_float), ("drop_seed", ctypes.c_uint32), ("bias2", ctypes.c_void_p), ("m_off", ctypes.c_int64)]
 
 
 class TprojJob(ctypes.Structure):

@@ -94,6 +94,9 @@ typedef struct {
   const float* bias2;     /* optional (N) fp32 added AFTER the row scale: C = residual + row_scale*act(..) + bias2.  SKIP_CLS map
                              only: the merged temporal projection W_fc*W_proj of vit.py:157-162, where drop_path scales the
                              proj output but not temporal_fc's own bias. */
+  int64_t m_off;          /* round 4: absolute index of row 0 for what the epilogue indexes by row -- row_scale[(m_off + m) / group] and the
+                             dropout hash (m_off + m) * N + n.  0 for callers; the library sets it on the second launch when it splits a
+                             ragged M into whole 256-row tiles + a remainder. */
 } alpro_gemm_desc_t;
 
 int alpro_gemm(const alpro_gemm_desc_t* d, void* stream);

@@ -353,13 +353,13 @@ def test_gemm_rows_f32(M, N, K, case):
 @pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("M,N,K,case", [(256 * 80, 512, 768, "plain"), (256 * 54, 768, 256, "plain"), (256 * 130, 768, 768, "bias_rowscale"), (256 * 40, 1024, 3072, "f32res"),
                                         (256 * 80, 512, 768, "gelu_save"), (256 * 80, 512, 768, "mul_saved"), (256 * 80, 512, 768, "gelu"), (256 * 44, 1024, 768, "dropout"),
-                                        (256 * 80, 512, 768, "strided"), (256 * 80 + 64, 512, 768, "plain"), (256 * 80 + 64, 512, 768, "gelu_save"), (256 * 392 + 64, 768, 3072, "mul_saved")])
+                                        (256 * 80, 512, 768, "strided"), (256 * 80 + 64, 512, 768, "plain"), (256 * 80 + 64, 512, 768, "gelu_save"), (256 * 392 + 64, 768, 3072, "mul_saved"), (64 * 1569, 768, 3072, "f32res_rowscale"), (16 * 1569 * 4, 768, 256, "f32res_rowscale")])
 def test_gemm_8phase_kernel(dt, M, N, K, case):
     """gemm_nt256q_kernel (round 4: 8-phase two-group schedule on 16x16x32 MFMA fragments; option gemm_kind = 1) on full-tile shapes with >= 160
     tiles -- one and several tiles per workgroup, K = 4 / 12 / 48 K-tiles, every epilogue the identity-map shapes of the model use -- against
     fp64 of the same rounded operands, and against the round-3 kernel (gemm_kind = 0) on the same inputs.  Ragged M (the ViT's B * 1569 rows:
-    M % 256 = 64) is split by the launcher: whole tiles on the 8-phase kernel, the last 64 rows on the 128 x 128 kernel.  (fp32 outputs and
-    row-scaled ragged shapes stay on the round-3 kernel: those cases check the routing.)"""
+    M % 256 = 64) is split by the launcher: whole tiles on the 8-phase kernel, the last 64 rows on the 128 x 128 kernel (which indexes the
+    row scale by absolute row through the descriptor's m_off)."""
     hip = _hip()
     a, w, b = rnd(M, K, seed=700 + K), rnd(N, K, seed=701, scale=0.05), rnd(N, seed=702)
     A, W = a.to(dt).cuda(), w.to(dt).cuda()
@@ -376,7 +376,12 @@ def test_gemm_8phase_kernel(dt, M, N, K, case):
         rs = (torch.arange(M // 8) % 3).float() * 0.5
         kw.update(row_scale=rs.cuda(), row_scale_group=8)
         ref = ref * rs.double().repeat_interleave(8)[:, None]
-    if case == "f32res":
+    if case == "f32res_rowscale":     # the ViT's fc2 in training: fp32 residual stream, drop-path scale per clip of 1569 token rows, ragged M
+        kw["bias"] = b.cuda()
+        rs = ((torch.arange(M // 1569) % 4) != 1).float() / 0.75
+        kw.update(row_scale=rs.cuda(), row_scale_group=1569)
+        ref = (ref + b.double()) * rs.double().repeat_interleave(1569)[:, None]
+    if case in ("f32res", "f32res_rowscale"):
         res = rnd(M, N, seed=703)
         kw.update(residual=res.cuda(), out_dtype=torch.float32)
         ref = ref + res.double()
@@ -401,7 +406,7 @@ def test_gemm_8phase_kernel(dt, M, N, K, case):
             outs[kind] = hip.gemm(A, W, **kw)
             if saved is not None:
                 outs[("saved", kind)] = saved.clone()
-    tol = (2e-5, 2e-4 * math.sqrt(K / 768)) if case == "f32res" else OUT_TOL[dt]
+    tol = (2e-5, 2e-4 * math.sqrt(K / 768)) if case.startswith("f32res") else OUT_TOL[dt]
     if case == "gelu_save":
         x = ref.clone().requires_grad_(True)
         y = torch.nn.functional.gelu(x)

@@ -54,7 +54,7 @@ def test_gemm_desc_matches_header_layout():
         for part in decl.split(","):
             names.append(part.replace("*", " ").split()[-1])
     assert names == [f[0] for f in hip.GemmDesc._fields_]
-    assert ctypes.sizeof(hip.GemmDesc) == 184
+    assert ctypes.sizeof(hip.GemmDesc) == 192
 
 
 def test_transpose_job_layout_and_wgrad_workspace_plan():
