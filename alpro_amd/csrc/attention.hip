@@ -412,6 +412,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd16_kernel(const T* __restrict_
         const int qq = qt * 32 + row;
         if (qq < L) store16_sc1(out + ((int64_t)b * L + qq) * H * HD + h * HD + slot * 8, v);
       }
+      asm volatile("" ::: "memory");  // (compiler order only) these reads stay ahead of the next query tile's writes into Ow
     } else {  // the two 32-wide d halves one after the other, as 64-byte row pieces
 #pragma unroll
       for (int dt = 0; dt < 2; ++dt) {

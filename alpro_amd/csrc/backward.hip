@@ -2,6 +2,7 @@
 // (with the row maps of the forward gather turned into scatters), CLS-mean / final-pool / BERT-embedding
 // backward, and the GELU-gradient multiply.  All HBM-bound; 16-byte accesses wherever rows are contiguous.
 #include "common.hpp"
+#include <algorithm>
 
 namespace alpro {
 namespace {
@@ -58,6 +59,7 @@ __global__ __launch_bounds__(256) void transpose_batch_kernel(const alpro_transp
 
 // ---- LayerNorm backward, D = 768, one wave per row ------------------------------------------------------
 constexpr int LN_D = 768;
+constexpr int LN_PART_BYTES = 3 * LN_D * (int)sizeof(float);  // one workgroup's column sums in the reduction workspace: dgamma | dbeta | colsum_pre
 
 __device__ __forceinline__ void ld12(const float* row, int lane, float (&v)[12]) {
 #pragma unroll
@@ -190,7 +192,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
                                                             const float* __restrict__ x, int64_t ldx, const float* __restrict__ gamma, float eps,
                                                             float* __restrict__ dx, int64_t ld_dx, int accumulate, float* __restrict__ dgamma,
                                                             float* __restrict__ dbeta, int64_t rows, int mode, int p0, int p1, float drop_p,
-                                                            uint32_t drop_seed, const EmitArgs em) {
+                                                            uint32_t drop_seed, const EmitArgs em, float* __restrict__ part) {
   __shared__ float red[2][4][LN_D];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int64_t wave = (int64_t)blockIdx.x * 4 + w;
@@ -199,17 +201,10 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
   ld12(gamma, lane, g);
 #pragma unroll
   for (int i = 0; i < 12; ++i) ag[i] = ab[i] = cp[i] = 0.f;
-  for (int64_t m = wave; m < rows + em.extra_cls; m += nwaves) {
-    if (m >= rows) {  // cast-only rows: the CLS rows a SKIP_CLS-mapped LayerNorm does not touch (their gradient is already final)
-      const int64_t r = (m - rows) * (1 + (int64_t)em.p1 * em.p0);
-      float v[12];
-      ld12_nt(dx + r * ld_dx, lane, v);
-      emit_row<TE>(em, r, lane, v, cp);
-      continue;
-    }
-    const SrcRow src = ln_src_row(mode, p0, p1, m);
+  // one row: loads, statistics, dgamma / dbeta terms; fin = its input-gradient row (not stored here)
+  auto row_grad = [&](int64_t m, int64_t srow, float (&fin)[12]) {
     float xv[12], d[12];
-    ld12_nt(x + src.row * ldx, lane, xv);
+    ld12_nt(x + srow * ldx, lane, xv);
     ld12_t<T>(dy + m * ld_dy, lane, d);
     if (dy2) {  // second gradient stream on the same LN output (fp32 copy consumed as a residual)
       float d2[12];
@@ -246,30 +241,50 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
     }
     s1 = wave_sum(s1) * (1.0f / LN_D);
     s2 = wave_sum(s2) * (1.0f / LN_D);
+#pragma unroll
+    for (int i = 0; i < 12; ++i) fin[i] = rstd * (d[i] - s1 - xv[i] * s2);
+  };
+  for (int64_t m = wave; m < rows + em.extra_cls; m += nwaves) {
+    if (m >= rows) {  // cast-only rows: the CLS rows a SKIP_CLS-mapped LayerNorm does not touch (their gradient is already final)
+      const int64_t r = (m - rows) * (1 + (int64_t)em.p1 * em.p0);
+      float v[12];
+      ld12_nt(dx + r * ld_dx, lane, v);
+      emit_row<TE>(em, r, lane, v, cp);
+      continue;
+    }
+    const SrcRow src = ln_src_row(mode, p0, p1, m);
+    // FRAME_TOKENS: the clip's CLS row receives one term per frame.  The wave that draws frame 0 computes all T of them and adds them in
+    // frame order -- one writer per row, fixed order (rounds 1-3 let T waves race with fp32 atomics: run-to-run differences in the last bit)
+    int reps = 1;
+    if (src.shared) {
+      if ((m / (p1 + 1)) % p0 != 0) continue;
+      reps = p0;
+    }
+    float fin[12];  // the finished gradient row
+#pragma unroll
+    for (int i = 0; i < 12; ++i) fin[i] = 0.f;
+#pragma unroll 1
+    for (int rep = 0; rep < reps; ++rep) {
+      float one[12];
+      row_grad(m + (int64_t)rep * (p1 + 1), src.row, one);
+#pragma unroll
+      for (int i = 0; i < 12; ++i) fin[i] += one[i];
+    }
     float* o = dx + src.row * ld_dx;
-    float fin[12];  // the finished gradient row (for the emit)
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-      float4 r;
-      r.x = rstd * (d[4 * i] - s1 - xv[4 * i] * s2);
-      r.y = rstd * (d[4 * i + 1] - s1 - xv[4 * i + 1] * s2);
-      r.z = rstd * (d[4 * i + 2] - s1 - xv[4 * i + 2] * s2);
-      r.w = rstd * (d[4 * i + 3] - s1 - xv[4 * i + 3] * s2);
       float* p = o + i * 256 + lane * 4;
-      if (src.shared) {
-        atomicAdd(p, r.x); atomicAdd(p + 1, r.y); atomicAdd(p + 2, r.z); atomicAdd(p + 3, r.w);
-      } else if (accumulate) {
+      if (accumulate || src.shared) {
         const float4 c = *(const float4*)p;
-        r.x += c.x; r.y += c.y; r.z += c.z; r.w += c.w;
-        __builtin_nontemporal_store(f32x4{r.x, r.y, r.z, r.w}, (f32x4*)p);
-      } else {
-        __builtin_nontemporal_store(f32x4{r.x, r.y, r.z, r.w}, (f32x4*)p);
+        fin[4 * i] += c.x; fin[4 * i + 1] += c.y; fin[4 * i + 2] += c.z; fin[4 * i + 3] += c.w;
       }
-      fin[4 * i] = r.x; fin[4 * i + 1] = r.y; fin[4 * i + 2] = r.z; fin[4 * i + 3] = r.w;
+      __builtin_nontemporal_store(f32x4{fin[4 * i], fin[4 * i + 1], fin[4 * i + 2], fin[4 * i + 3]}, (f32x4*)p);
     }
     if (em.mode != ALPRO_EMIT_NONE && !src.shared) emit_row<TE>(em, src.row, lane, fin, cp);
   }
-  // block reduction of dgamma / dbeta, then one atomic per column per block
+  // block reduction of dgamma / dbeta (and the emit's column sums).  part != nullptr: this workgroup's sums go to its slot of the caller's
+  // workspace -- part[block][3][768] -- and colsum_reduce_kernel adds the slots in a fixed order (bit-reproducible, the default since
+  // round 4); part == nullptr: one fp32 atomic per column per workgroup straight into the gradients (no workspace, order varies)
 #pragma unroll
   for (int i = 0; i < 3; ++i)
 #pragma unroll
@@ -278,9 +293,12 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
       red[1][w][i * 256 + lane * 4 + e] = ab[4 * i + e];
     }
   __syncthreads();
+  float* slot = part ? part + (int64_t)blockIdx.x * (3 * LN_D) : nullptr;
   for (int c = threadIdx.x; c < LN_D; c += 256) {
-    atomicAdd(dgamma + c, red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c]);
-    atomicAdd(dbeta + c, red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c]);
+    const float sg = red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c];
+    const float sb = red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c];
+    if (slot) { slot[c] = sg; slot[LN_D + c] = sb; }
+    else { atomicAdd(dgamma + c, sg); atomicAdd(dbeta + c, sb); }
   }
   if (em.colsum_pre) {  // bias gradient of the Linear whose output gradient the emitted rows are (before the row scale)
     __syncthreads();
@@ -289,7 +307,37 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
 #pragma unroll
       for (int e = 0; e < 4; ++e) red[0][w][i * 256 + lane * 4 + e] = cp[4 * i + e];
     __syncthreads();
-    for (int c = threadIdx.x; c < LN_D; c += 256) atomicAdd(em.colsum_pre + c, red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c]);
+    for (int c = threadIdx.x; c < LN_D; c += 256) {
+      const float sc = red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c];
+      if (slot) slot[2 * LN_D + c] = sc;
+      else atomicAdd(em.colsum_pre + c, sc);
+    }
+  }
+}
+
+// dst_k[c] += sum over workgroup slots p of part[p][nslots][768] for the column sums k = 0 .. gridDim.y-1: ONE workgroup per (64 columns, k)
+// -- 16 float4 column lanes x 64 slices of slots, slice s adds slots s, s + 64, ... in ascending order, then lane 0's slice adds the 64
+// slice sums in ascending order: a single writer per output and an order that depends on nothing but the slot count.
+__global__ __launch_bounds__(1024) void colsum_reduce_kernel(const float* __restrict__ part, int nparts, int nslots, float* __restrict__ d0,
+                                                             float* __restrict__ d1, float* __restrict__ d2) {
+  __shared__ float4 red[64][16];
+  const int k = blockIdx.y, c4 = threadIdx.x & 15, sl = threadIdx.x >> 4;
+  float* dst = k == 0 ? d0 : (k == 1 ? d1 : d2);
+  if (!dst) return;
+  const int col = blockIdx.x * 64 + c4 * 4;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int p = sl; p < nparts; p += 64) {
+    const float4 v = *(const float4*)(part + ((int64_t)p * nslots + k) * LN_D + col);
+    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+  }
+  red[sl][c4] = s;
+  __syncthreads();
+  if (sl == 0) {
+    float4 t = red[0][c4];
+    for (int i = 1; i < 64; ++i) { const float4 v = red[i][c4]; t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w; }
+    float4* o = (float4*)(dst + col);
+    const float4 c = *o;
+    *o = make_float4(c.x + t.x, c.y + t.y, c.z + t.z, c.w + t.w);
   }
 }
 
@@ -299,7 +347,7 @@ template <typename T, int NW>
 __global__ __launch_bounds__(NW * 64) void gather_cast_kernel(const float* __restrict__ src, int64_t ld, T* __restrict__ out, int64_t rows, int mode,
                                                           int p0, int p1, const float* __restrict__ row_scale, int group, float cls_scale,
                                                           float drop_p, uint32_t drop_seed, float* __restrict__ colsum,
-                                                          float* __restrict__ colsum_pre) {
+                                                          float* __restrict__ colsum_pre, float* __restrict__ part) {
   __shared__ float red[NW][LN_D];
   const int lane = threadIdx.x & 63;
   const int64_t wave = (int64_t)blockIdx.x * NW + (threadIdx.x >> 6);
@@ -364,9 +412,9 @@ __global__ __launch_bounds__(NW * 64) void gather_cast_kernel(const float* __res
     emit(m, v, sc);
     if (has2) emit(m2, v2, sc2);
   }
-  // bias gradients of the Linears these rows are the dY of (after / before the row scale): 4-wave LDS fold, one atomic per
-  // column per workgroup
-  auto flush = [&](const float (&acc)[12], float* dst) {
+  // bias gradients of the Linears these rows are the dY of (after / before the row scale): LDS fold over the waves, then this workgroup's
+  // sums go to its workspace slot part[block][2][768] for colsum_reduce_kernel (fixed order), or -- part == nullptr -- one atomic per column
+  auto flush = [&](const float (&acc)[12], float* dst, int k) {
     const int w = threadIdx.x >> 6;
     __syncthreads();
 #pragma unroll
@@ -377,12 +425,13 @@ __global__ __launch_bounds__(NW * 64) void gather_cast_kernel(const float* __res
     for (int c = threadIdx.x; c < LN_D; c += NW * 64) {
       float t = 0.f;
 #pragma unroll
-      for (int k = 0; k < NW; ++k) t += red[k][c];
-      unsafeAtomicAdd(dst + c, t);
+      for (int j = 0; j < NW; ++j) t += red[j][c];
+      if (part) part[((int64_t)blockIdx.x * 2 + k) * LN_D + c] = t;
+      else unsafeAtomicAdd(dst + c, t);
     }
   };
-  if (colsum) flush(cs, colsum);
-  if (colsum_pre) flush(cp, colsum_pre);
+  if (colsum) flush(cs, colsum, 0);
+  if (colsum_pre) flush(cp, colsum_pre, 1);
 }
 
 // ---- du = dh * gelu'(u) (erf GELU), elementwise over 16-byte chunks ---------------------------------------
@@ -416,12 +465,15 @@ __global__ void cls_mean_bwd_kernel(const float* __restrict__ dx_out, int64_t ld
 }
 
 // ---- dst[idx[i], :] += src[i, :] (word / position embedding gradients), D = 768 ---------------------------
+// Rows whose index equals skip_idx contribute nothing: nn.Embedding(padding_idx=...) keeps the pad row's gradient at zero (xbert.py:171).
+// fp32 atomics: the order of the duplicates' additions varies run to run (the bit-reproducible caller sorts instead, see hip.py).
 __global__ __launch_bounds__(256) void scatter_add_rows_kernel(const float* __restrict__ src, const int64_t* __restrict__ idx, float* __restrict__ dst,
-                                                               int rows, int idx_mod) {
+                                                               int rows, int idx_mod, int64_t skip_idx) {
   const int lane = threadIdx.x & 63;
   const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (m >= rows) return;
   const int64_t r = idx ? idx[m] : (m % idx_mod);
+  if (r == skip_idx) return;
   const float* s = src + (int64_t)m * LN_D;
   float* d = dst + r * LN_D;
 #pragma unroll
@@ -429,6 +481,30 @@ __global__ __launch_bounds__(256) void scatter_add_rows_kernel(const float* __re
     const float4 f = *(const float4*)(s + i * 256 + lane * 4);
     float* p = d + i * 256 + lane * 4;
     atomicAdd(p, f.x); atomicAdd(p + 1, f.y); atomicAdd(p + 2, f.z); atomicAdd(p + 3, f.w);
+  }
+}
+
+// idx == nullptr (destination row = m % idx_mod, the position table): one wave per DESTINATION row adds its rows m = r, r + idx_mod, ...
+// in ascending order -- single writer, fixed order, no atomics.
+__global__ __launch_bounds__(256) void scatter_add_mod_kernel(const float* __restrict__ src, float* __restrict__ dst, int rows, int idx_mod) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= idx_mod || r >= rows) return;
+  float acc[12];
+#pragma unroll
+  for (int i = 0; i < 12; ++i) acc[i] = 0.f;
+  for (int m = r; m < rows; m += idx_mod) {
+    float v[12];
+    ld12_nt(src + (int64_t)m * LN_D, lane, v);
+#pragma unroll
+    for (int i = 0; i < 12; ++i) acc[i] += v[i];
+  }
+  float* d = dst + (int64_t)r * LN_D;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    float4* p = (float4*)(d + i * 256 + lane * 4);
+    const float4 c = *p;
+    *p = make_float4(c.x + acc[4 * i], c.y + acc[4 * i + 1], c.z + acc[4 * i + 2], c.w + acc[4 * i + 3]);
   }
 }
 
@@ -512,8 +588,10 @@ extern "C" int alpro_layernorm_bwd_emit(const void* dy, int dy_dtype, int64_t ld
                                         const float* gamma, float eps, float* dx, int64_t ld_dx, int accumulate, float* dgamma, float* dbeta,
                                         int rows, int D, int map_mode, int map_p0, int map_p1, float drop_p, uint32_t drop_seed, void* emit_out,
                                         int emit_dtype, int emit_mode, int emit_p0, int emit_p1, const float* emit_scale, int emit_scale_group, float emit_drop_p,
-                                        uint32_t emit_drop_seed, float* emit_colsum_pre, int emit_extra_cls, void* stream) {
+                                        uint32_t emit_drop_seed, float* emit_colsum_pre, int emit_extra_cls, void* workspace, size_t workspace_bytes,
+                                        void* stream) {
   ALPRO_CHECK(dy && x && gamma && dx && dgamma && dbeta && rows > 0, "alpro_layernorm_bwd: bad args");
+  ALPRO_CHECK(!workspace || (((uintptr_t)workspace % 16) == 0 && workspace_bytes >= LN_PART_BYTES), "alpro_layernorm_bwd: the workspace must be 16-byte aligned and hold at least one workgroup's sums (%d bytes)", LN_PART_BYTES);
   ALPRO_CHECK(D == LN_D, "alpro_layernorm_bwd: D=%d unsupported", D);
   ALPRO_CHECK(map_mode >= 0 && map_mode <= ALPRO_MAP_FRAME_TOKENS, "alpro_layernorm_bwd: bad map_mode %d", map_mode);
   ALPRO_CHECK(map_mode != ALPRO_MAP_FRAME_TOKENS || accumulate, "alpro_layernorm_bwd: the FRAME_TOKENS scatter needs accumulate=1 (CLS rows are shared)");
@@ -530,9 +608,14 @@ extern "C" int alpro_layernorm_bwd_emit(const void* dy, int dy_dtype, int64_t ld
   em.out = emit_out; em.mode = emit_mode; em.p0 = emit_p0; em.p1 = emit_p1; em.scale = emit_scale; em.group = emit_scale_group;
   em.drop_p = emit_drop_p; em.drop_seed = emit_drop_seed; em.colsum_pre = emit_colsum_pre; em.extra_cls = emit_extra_cls;
   ALPRO_CHECK(emit_mode == ALPRO_EMIT_NONE || emit_dtype == dy_dtype || dy_dtype == ALPRO_F32, "alpro_layernorm_bwd_emit: emit_dtype must be dy's dtype, or any dtype when dy is the fp32 stream");
-  const dim3 grid(grid_for(rows, 4 * 8, 256 * 8)), blk(256);
+  // workspace given: the column sums (dgamma, dbeta, colsum_pre) leave as per-workgroup partials and are added in a fixed order by a second
+  // small kernel -- bit-reproducible; the grid is capped to the slots the workspace holds.  NULL: fp32 atomics (no workspace, order varies).
+  int nblk = grid_for(rows, 4 * 8, 256 * 8);
+  if (workspace) nblk = (int)std::min<size_t>((size_t)nblk, workspace_bytes / LN_PART_BYTES);
+  const dim3 grid(nblk), blk(256);
+  float* part = (float*)workspace;
   hipStream_t st = (hipStream_t)stream;
-#define ALPRO_LNB(T, TE) hipLaunchKernelGGL((layernorm_bwd_kernel<T, TE>), grid, blk, 0, st, (const T*)dy, ld_dy, dy2, x, ldx, gamma, eps, dx, ld_dx, accumulate, dgamma, dbeta, (int64_t)rows, map_mode, map_p0, map_p1, drop_p, drop_seed, em)
+#define ALPRO_LNB(T, TE) hipLaunchKernelGGL((layernorm_bwd_kernel<T, TE>), grid, blk, 0, st, (const T*)dy, ld_dy, dy2, x, ldx, gamma, eps, dx, ld_dx, accumulate, dgamma, dbeta, (int64_t)rows, map_mode, map_p0, map_p1, drop_p, drop_seed, em, part)
   if (dy_dtype == ALPRO_F32 && emit_mode != ALPRO_EMIT_NONE && emit_dtype == ALPRO_BF16) ALPRO_LNB(float, bf16_t);
   else if (dy_dtype == ALPRO_F32 && emit_mode != ALPRO_EMIT_NONE && emit_dtype == ALPRO_F16) ALPRO_LNB(float, f16_t);
   else if (dy_dtype == ALPRO_F32) ALPRO_LNB(float, float);
@@ -540,29 +623,37 @@ extern "C" int alpro_layernorm_bwd_emit(const void* dy, int dy_dtype, int64_t ld
   else if (dy_dtype == ALPRO_F16) ALPRO_LNB(f16_t, f16_t);
   else { set_error("alpro_layernorm_bwd: bad dtype %d", dy_dtype); return ALPRO_ERR_INVALID; }
 #undef ALPRO_LNB
+  if (part) hipLaunchKernelGGL(colsum_reduce_kernel, dim3(LN_D / 64, emit_colsum_pre ? 3 : 2), dim3(1024), 0, st, part, nblk, 3, dgamma, dbeta, emit_colsum_pre);
   return check_launch("alpro_layernorm_bwd");
 }
 
 extern "C" int alpro_layernorm_bwd(const void* dy, int dy_dtype, int64_t ld_dy, const float* dy2, const float* x, int64_t ldx,
                                    const float* gamma, float eps, float* dx, int64_t ld_dx, int accumulate, float* dgamma, float* dbeta,
-                                   int rows, int D, int map_mode, int map_p0, int map_p1, float drop_p, uint32_t drop_seed, void* stream) {
+                                   int rows, int D, int map_mode, int map_p0, int map_p1, float drop_p, uint32_t drop_seed, void* workspace,
+                                   size_t workspace_bytes, void* stream) {
   return alpro_layernorm_bwd_emit(dy, dy_dtype, ld_dy, dy2, x, ldx, gamma, eps, dx, ld_dx, accumulate, dgamma, dbeta, rows, D, map_mode, map_p0, map_p1,
-                                  drop_p, drop_seed, nullptr, dy_dtype, ALPRO_EMIT_NONE, 0, 0, nullptr, 1, 0.f, 0u, nullptr, 0, stream);
+                                  drop_p, drop_seed, nullptr, dy_dtype, ALPRO_EMIT_NONE, 0, 0, nullptr, 1, 0.f, 0u, nullptr, 0, workspace, workspace_bytes, stream);
 }
 
 extern "C" int alpro_gather_cast(const float* src, int64_t ld, void* out, int dtype, int rows, int D, int map_mode, int map_p0, int map_p1,
                                  const float* row_scale, int row_scale_group, float cls_scale, float drop_p, uint32_t drop_seed, float* colsum,
-                                 float* colsum_pre, void* stream) {
+                                 float* colsum_pre, void* workspace, size_t workspace_bytes, void* stream) {
   ALPRO_CHECK(src && out && rows > 0, "alpro_gather_cast: bad args");
+  ALPRO_CHECK(!workspace || (((uintptr_t)workspace % 16) == 0 && workspace_bytes >= 2 * LN_D * sizeof(float)), "alpro_gather_cast: the workspace must be 16-byte aligned and hold at least one workgroup's sums");
   ALPRO_CHECK(D == LN_D, "alpro_gather_cast: D=%d unsupported", D);
   ALPRO_CHECK(map_mode >= 0 && map_mode <= ALPRO_MAP_PATCH_EMBED, "alpro_gather_cast: bad map_mode %d", map_mode);
   ALPRO_CHECK(!row_scale || row_scale_group > 0, "alpro_gather_cast: row_scale_group must be > 0");
   // with a colsum target: few, fat workgroups (16 waves) -- every workgroup ends with 768 same-address atomics, and those
   // serialise at the memory side (3072 workgroups cost 2x the whole cast); plain casts use many small workgroups
   if (colsum || colsum_pre) {
-    ALPRO_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((gather_cast_kernel<T, 16>), dim3(grid_for(rows, 32, 512)), dim3(1024), 0, (hipStream_t)stream, src, ld, (T*)out, (int64_t)rows, map_mode, map_p0, map_p1, row_scale, row_scale_group, cls_scale, drop_p, drop_seed, colsum, colsum_pre));
+    // workspace given: per-workgroup partial sums + the fixed-order colsum_reduce_kernel (bit-reproducible); NULL: fp32 atomics
+    float* part = (float*)workspace;
+    int nblk = grid_for(rows, 32, 512);
+    if (part) nblk = (int)std::min<size_t>((size_t)nblk, workspace_bytes / (2 * LN_D * sizeof(float)));
+    ALPRO_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((gather_cast_kernel<T, 16>), dim3(nblk), dim3(1024), 0, (hipStream_t)stream, src, ld, (T*)out, (int64_t)rows, map_mode, map_p0, map_p1, row_scale, row_scale_group, cls_scale, drop_p, drop_seed, colsum, colsum_pre, part));
+    if (part) hipLaunchKernelGGL(colsum_reduce_kernel, dim3(LN_D / 64, 2), dim3(1024), 0, (hipStream_t)stream, part, nblk, 2, colsum, colsum_pre, (float*)nullptr);
   } else {
-    ALPRO_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((gather_cast_kernel<T, 4>), dim3(grid_for(rows, 8, 256 * 32)), dim3(256), 0, (hipStream_t)stream, src, ld, (T*)out, (int64_t)rows, map_mode, map_p0, map_p1, row_scale, row_scale_group, cls_scale, drop_p, drop_seed, colsum, colsum_pre));
+    ALPRO_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((gather_cast_kernel<T, 4>), dim3(grid_for(rows, 8, 256 * 32)), dim3(256), 0, (hipStream_t)stream, src, ld, (T*)out, (int64_t)rows, map_mode, map_p0, map_p1, row_scale, row_scale_group, cls_scale, drop_p, drop_seed, colsum, colsum_pre, (float*)nullptr));
   }
   return check_launch("alpro_gather_cast");
 }
@@ -588,9 +679,13 @@ extern "C" int alpro_cls_mean_bwd(const float* dx_out, int64_t ld_batch, float* 
   return check_launch("alpro_cls_mean_bwd");
 }
 
-extern "C" int alpro_scatter_add_rows(const float* src, const int64_t* idx, float* dst, int rows, int idx_mod, int D, void* stream) {
+extern "C" int alpro_scatter_add_rows(const float* src, const int64_t* idx, float* dst, int rows, int idx_mod, int D, int64_t skip_idx, void* stream) {
   ALPRO_CHECK(src && dst && rows > 0 && (idx || idx_mod > 0), "alpro_scatter_add_rows: bad args");
   ALPRO_CHECK(D == LN_D, "alpro_scatter_add_rows: D=%d unsupported", D);
-  hipLaunchKernelGGL(scatter_add_rows_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, src, idx, dst, rows, idx_mod);
+  if (!idx && skip_idx < 0) {  // destination = row % idx_mod: one wave per destination row, ascending order (bit-reproducible)
+    hipLaunchKernelGGL(scatter_add_mod_kernel, dim3((idx_mod + 3) / 4), dim3(256), 0, (hipStream_t)stream, src, dst, rows, idx_mod);
+    return check_launch("alpro_scatter_add_rows");
+  }
+  hipLaunchKernelGGL(scatter_add_rows_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, src, idx, dst, rows, idx_mod, skip_idx);
   return check_launch("alpro_scatter_add_rows");
 }

@@ -72,6 +72,13 @@ __device__ __forceinline__ void wave_lds_sync() {
   __builtin_amdgcn_wave_barrier();
 }
 
+// The same hand-off without the wait: pins the COMPILER's issue order only (no instruction).  The compiler reasons per lane -- when it can
+// prove that a lane's own staging writes and its own reads never overlap, it may move the read above a write that ANOTHER lane's read depends
+// on.  Round 4 hit exactly that: the fp32-output epilogue of the 8-phase kernel read its first staged row before the last ds_write2 of the
+// fragment row had been issued (256 stale elements per tile, tests/test_hip_ops.py::test_gemm_8phase_kernel[f32res]); the other staging
+// epilogues had been in source order by luck.  Every stage write block is now bracketed by this.
+__device__ __forceinline__ void wave_lds_order() { asm volatile("" ::: "memory"); }
+
 template <typename T, int ACT> __device__ __forceinline__ float apply_act(float x) {
   if (ACT == ALPRO_ACT_GELU) return gelu_fast<T>(x);   // (GELU_SAVE_GRAD computes gelu together with gelu' before this point)
   if (ACT == ALPRO_ACT_RELU) return fmaxf(x, 0.f);
@@ -646,15 +653,17 @@ __global__ __launch_bounds__(NT2, 2) void gemm_nt256p_kernel(const alpro_gemm_de
       load_bias4(g, nb + (lane & 15) * 4, bias);
       wait_vm0();
       // 8-row chunks through two alternating 2 KiB staging buffers per wave: the ds_writes of chunk c+1 are independent
-      // of the ds_reads of chunk c, so LDS latency and the global stores of consecutive chunks overlap.  No explicit
-      // wave sync is needed: DS operations of one wave execute in order and the compiler keeps the may-alias order.
+      // of the ds_reads of chunk c, so LDS latency and the global stores of consecutive chunks overlap.  No hardware
+      // wait is needed (DS operations of one wave execute in order); the compiler's order is pinned by wave_lds_order().
       auto stage_chunk = [&](float* st, const f32x16& a0, const f32x16& a1, int q) {
+        wave_lds_order();
 #pragma unroll
         for (int r4 = 0; r4 < 4; ++r4) {
           const int row = r4 + 4 * (lane >> 5);
           st[row * 64 + (lane & 31)] = a0[4 * q + r4];
           st[row * 64 + 32 + (lane & 31)] = a1[4 * q + r4];
         }
+        wave_lds_order();
       };
       auto run_epilogue = [&](auto fast_tag) {
         constexpr bool FAST = decltype(fast_tag)::value;
@@ -914,10 +923,12 @@ __global__ __launch_bounds__(NT2, 2) void gemm_nt256q_kernel(const alpro_gemm_de
     {
       const int mb = tm0 + wr * 128, nb = tn0 + wc * 64;
       auto stage_rows = [&](int mf) {
+        wave_lds_order();   // the other lanes' reads of the previous fragment row are issued before these writes ...
 #pragma unroll
         for (int nf = 0; nf < 4; ++nf)
 #pragma unroll
           for (int r = 0; r < 4; ++r) stage[(kg * 4 + r) * 64 + nf * 16 + l15] = acc[mf][nf][r];
+        wave_lds_order();   // ... and every write of this one before the reads that follow
       };
       if (g.c_dtype != ALPRO_F32) {
         if constexpr (MAP == ALPRO_MAP_IDENTITY) {

@@ -74,11 +74,9 @@ constexpr int VTC_MAX_E = 1024;
 
 __global__ __launch_bounds__(256) void vtc_fwd_kernel(const float* __restrict__ v, const float* __restrict__ t, const float* __restrict__ gv,
                                                       const float* __restrict__ gt, const float* __restrict__ temp, int B, int G, int E, int col0,
-                                                      float* __restrict__ sim_v2t, float* __restrict__ sim_t2v, float* __restrict__ lse,
-                                                      float* __restrict__ loss) {
+                                                      float* __restrict__ sim_v2t, float* __restrict__ sim_t2v, float* __restrict__ lse) {
   __shared__ float q[VTC_MAX_E];
   __shared__ float sh[4];
-  __shared__ float pos;
   const int dir = blockIdx.x / B, i = blockIdx.x - dir * B;
   const float* qrow = (dir == 0 ? v : t) + (int64_t)i * E;
   const float* keys = dir == 0 ? gt : gv;
@@ -96,17 +94,44 @@ __global__ __launch_bounds__(256) void vtc_fwd_kernel(const float* __restrict__ 
     }
     acc *= inv_temp;
     sim[j] = acc;
-    if (j == col0 + i) pos = acc;  // the positive pair's logit, handed to thread 0 through LDS
     mx = fmaxf(mx, acc);
   }
   mx = block_reduce(mx, sh, true);
   float s = 0.f;
   for (int j = threadIdx.x; j < G; j += 256) s += expf(sim[j] - mx);  // own writes: visible to the writing thread
   s = block_reduce(s, sh, false);
+  if (threadIdx.x == 0) lse[blockIdx.x] = mx + logf(s);   // the loss itself: vtc_loss_finish_kernel (fixed summation order)
+}
+
+// loss = sum over (direction, row) of (lse - positive logit) / (2B): one workgroup, thread k adds rows k, k + 256, ... in ascending order, then
+// a fixed tree -- rounds 1-3 added the 2B terms with one fp32 atomic each, in whatever order the workgroups finished.
+__global__ __launch_bounds__(256) void vtc_loss_finish_kernel(const float* __restrict__ sim_v2t, const float* __restrict__ sim_t2v,
+                                                              const float* __restrict__ lse, int B, int G, int col0, float* __restrict__ loss) {
+  __shared__ float sh[4];
+  float s = 0.f;
+  for (int k = threadIdx.x; k < 2 * B; k += 256) {
+    const int dir = k / B, i = k - dir * B;
+    s += lse[k] - (dir == 0 ? sim_v2t : sim_t2v)[(int64_t)i * G + col0 + i];
+  }
+  s = block_reduce(s, sh, false);
+  if (threadIdx.x == 0) *loss = s * (0.5f / B);
+}
+
+// d(temp) = -sum over both directions of ds[i][j] * sim[i][j] / temp, same fixed order (the rows kernel used to add its row's share atomically)
+__global__ __launch_bounds__(1024) void vtc_dtemp_kernel(const float* __restrict__ temp, const float* __restrict__ sim_v2t, const float* __restrict__ sim_t2v,
+                                                         const float* __restrict__ ds_v2t, const float* __restrict__ ds_t2v, int64_t n,
+                                                         float* __restrict__ dtemp) {
+  __shared__ float sh[16];
+  float s = 0.f;
+  for (int64_t k = threadIdx.x; k < n; k += 1024) s += ds_v2t[k] * sim_v2t[k];
+  for (int64_t k = threadIdx.x; k < n; k += 1024) s += ds_t2v[k] * sim_t2v[k];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+  __syncthreads();
   if (threadIdx.x == 0) {
-    const float l = mx + logf(s);
-    lse[blockIdx.x] = l;
-    atomicAdd(loss, (l - pos) * (0.5f / B));
+    float t = 0.f;
+    for (int w = 0; w < 16; ++w) t += sh[w];
+    *dtemp = -t / fminf(fmaxf(*temp, 0.001f), 0.5f);
   }
 }
 
@@ -116,9 +141,8 @@ __global__ __launch_bounds__(256) void vtc_bwd_rows_kernel(const float* __restri
                                                            int B, int G, int E, int col0, const float* __restrict__ sim_v2t,
                                                            const float* __restrict__ sim_t2v, const float* __restrict__ lse,
                                                            const float* __restrict__ dloss, float* __restrict__ ds_v2t, float* __restrict__ ds_t2v,
-                                                           float* __restrict__ dv, float* __restrict__ dt, float* __restrict__ dtemp) {
+                                                           float* __restrict__ dv, float* __restrict__ dt) {
   extern __shared__ float dsrow[];  // G floats
-  __shared__ float sh[4];
   const int dir = blockIdx.x / B, i = blockIdx.x - dir * B;
   const float* keys = dir == 0 ? gt : gv;
   const float* sim = (dir == 0 ? sim_v2t : sim_t2v) + (int64_t)i * G;
@@ -126,16 +150,12 @@ __global__ __launch_bounds__(256) void vtc_bwd_rows_kernel(const float* __restri
   const float tc = fminf(fmaxf(*temp, 0.001f), 0.5f);
   const float inv_temp = 1.0f / tc;
   const float scale = *dloss * (0.5f / B), l = lse[blockIdx.x];
-  float tacc = 0.f;
   for (int j = threadIdx.x; j < G; j += 256) {
-    const float sj = sim[j];
-    const float d = (expf(sj - l) - (j == col0 + i ? 1.f : 0.f)) * scale;
+    const float d = (expf(sim[j] - l) - (j == col0 + i ? 1.f : 0.f)) * scale;
     dsrow[j] = d;
     ds[j] = d;
-    tacc += d * sj;
   }
-  tacc = block_reduce(tacc, sh, false);  // (also the barrier that publishes dsrow)
-  if (threadIdx.x == 0 && dtemp) atomicAdd(dtemp, -tacc * inv_temp);
+  __syncthreads();  // publishes dsrow
   float* dq = (dir == 0 ? dv : dt) + (int64_t)i * E;
   for (int e = threadIdx.x; e < E; e += 256) {
     float acc = 0.f;
@@ -168,8 +188,8 @@ extern "C" int alpro_vtc_loss_fwd(const float* v, const float* t, const float* g
                                   int col0, float* sim_v2t, float* sim_t2v, float* lse, float* loss, void* stream) {
   ALPRO_CHECK(v && t && gv && gt && temp && sim_v2t && sim_t2v && lse && loss, "alpro_vtc_loss_fwd: null argument");
   ALPRO_CHECK(B > 0 && G >= B && E > 0 && E % 4 == 0 && E <= VTC_MAX_E && col0 >= 0 && col0 + B <= G, "alpro_vtc_loss_fwd: bad shape B=%d G=%d E=%d col0=%d", B, G, E, col0);
-  (void)hipMemsetAsync(loss, 0, sizeof(float), (hipStream_t)stream);
-  hipLaunchKernelGGL(vtc_fwd_kernel, dim3(2 * B), dim3(256), 0, (hipStream_t)stream, v, t, gv, gt, temp, B, G, E, col0, sim_v2t, sim_t2v, lse, loss);
+  hipLaunchKernelGGL(vtc_fwd_kernel, dim3(2 * B), dim3(256), 0, (hipStream_t)stream, v, t, gv, gt, temp, B, G, E, col0, sim_v2t, sim_t2v, lse);
+  hipLaunchKernelGGL(vtc_loss_finish_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, sim_v2t, sim_t2v, lse, B, G, col0, loss);
   return check_launch("alpro_vtc_loss_fwd");
 }
 
@@ -179,9 +199,9 @@ extern "C" int alpro_vtc_loss_bwd(const float* v, const float* t, const float* g
   ALPRO_CHECK(v && t && gv && gt && temp && sim_v2t && sim_t2v && lse && dloss && ds_v2t && ds_t2v && dv && dt && dgv && dgt, "alpro_vtc_loss_bwd: null argument");
   ALPRO_CHECK(B > 0 && G >= B && E > 0 && E % 4 == 0 && E <= VTC_MAX_E && G <= 8192, "alpro_vtc_loss_bwd: bad shape B=%d G=%d E=%d", B, G, E);
   hipStream_t st = (hipStream_t)stream;
-  if (dtemp) (void)hipMemsetAsync(dtemp, 0, sizeof(float), st);
   hipLaunchKernelGGL(vtc_bwd_rows_kernel, dim3(2 * B), dim3(256), G * sizeof(float), st, gv, gt, temp, B, G, E, col0, sim_v2t, sim_t2v, lse, dloss, ds_v2t,
-                     ds_t2v, dv, dt, dtemp);
+                     ds_t2v, dv, dt);
+  if (dtemp) hipLaunchKernelGGL(vtc_dtemp_kernel, dim3(1), dim3(1024), 0, st, temp, sim_v2t, sim_t2v, ds_v2t, ds_t2v, (int64_t)B * G, dtemp);
   hipLaunchKernelGGL(vtc_bwd_cols_kernel, dim3(2 * G), dim3(256), 0, st, v, t, temp, B, G, E, ds_v2t, ds_t2v, dgv, dgt);
   return check_launch("alpro_vtc_loss_bwd");
 }

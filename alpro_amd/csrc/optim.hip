@@ -2,11 +2,15 @@
 // reference's HF-style AdamW (src/optimization/adamw.py:40-103) with the clip_grad_norm_ coefficient
 // (run_pretrain_sparse.py:633) folded in.  One pass over (param, grad, m, v): 16 B/param read + 12 B/param written.
 #include "common.hpp"
+#include <algorithm>
 
 namespace alpro {
 namespace {
 
-__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x, int64_t n, float* __restrict__ out) {
+// part == nullptr: out += sum(x^2) through one fp32 atomic per workgroup (order varies run to run).  part given: workgroup b leaves its sum in
+// part[b] and sumsq_finish_kernel adds the slots in a fixed order -- the squared norm feeds the clip coefficient of EVERY parameter, so a
+// last-bit difference here would make two identical steps differ everywhere.
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x, int64_t n, float* __restrict__ out, float* __restrict__ part) {
   float s = 0.f;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x * 4;
   for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += stride) {
@@ -18,10 +22,25 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x,
     }
   }
   s = wave_sum(s);
-  __shared__ float part[4];
-  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+  __shared__ float sh[4];
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
   __syncthreads();
-  if (threadIdx.x == 0) atomicAdd(out, part[0] + part[1] + part[2] + part[3]);
+  if (threadIdx.x == 0) {
+    const float t = sh[0] + sh[1] + sh[2] + sh[3];
+    if (part) part[blockIdx.x] = t;
+    else atomicAdd(out, t);
+  }
+}
+
+// out += sum of part[0 .. n): one workgroup, thread t adds slots t, t + 256, ... in ascending order, then a fixed tree.
+__global__ __launch_bounds__(256) void sumsq_finish_kernel(const float* __restrict__ part, int n, float* __restrict__ out) {
+  float s = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) s += part[i];
+  s = wave_sum(s);
+  __shared__ float sh[4];
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) *out += (sh[0] + sh[1]) + (sh[2] + sh[3]);
 }
 
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
@@ -114,10 +133,15 @@ inline int grid_for(int64_t n) {
 
 using namespace alpro;
 
-extern "C" int alpro_sumsq(const float* x, int64_t n, float* out, void* stream) {
+extern "C" int alpro_sumsq(const float* x, int64_t n, float* out, void* workspace, size_t workspace_bytes, void* stream) {
   ALPRO_CHECK(x && out && n > 0, "alpro_sumsq: bad args");
   ALPRO_CHECK(((uintptr_t)x % 16) == 0, "alpro_sumsq: x must be 16-byte aligned");
-  hipLaunchKernelGGL(sumsq_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, x, n, out);
+  ALPRO_CHECK(!workspace || (((uintptr_t)workspace % 4) == 0 && workspace_bytes >= sizeof(float)), "alpro_sumsq: bad workspace");
+  int grid = grid_for(n);
+  float* part = (float*)workspace;
+  if (part) grid = (int)std::min<size_t>((size_t)grid, workspace_bytes / sizeof(float));
+  hipLaunchKernelGGL(sumsq_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, n, out, part);
+  if (part) hipLaunchKernelGGL(sumsq_finish_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, part, grid, out);
   return check_launch("alpro_sumsq");
 }
 

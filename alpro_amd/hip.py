@@ -50,7 +50,7 @@ class TransposeJob(ctypes.Structure):
                 ("R", ctypes.c_int32), ("C", ctypes.c_int32), ("Rpad", ctypes.c_int32), ("tile0", ctypes.c_int32)]   # 48 bytes
 
 
-ABI_VERSION = 15
+ABI_VERSION = 16
 _lib = None
 
 
@@ -76,12 +76,12 @@ def load():
     u32 = ctypes.c_uint32
     lib.alpro_attn_bwd.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, vp, f32, u32, vp]
     lib.alpro_attn_temporal_bwd.argtypes = [vp, vp, vp, vp, vp, i32, i64, i32, i32, f32, vp]
-    lib.alpro_layernorm_bwd.argtypes = [vp, i32, i64, vp, vp, i64, vp, f32, vp, i64, i32, vp, vp, i32, i32, i32, i32, i32, f32, u32, vp]
+    lib.alpro_layernorm_bwd.argtypes = [vp, i32, i64, vp, vp, i64, vp, f32, vp, i64, i32, vp, vp, i32, i32, i32, i32, i32, f32, u32, vp, ctypes.c_size_t, vp]
     lib.alpro_layernorm_bwd_emit.argtypes = [vp, i32, i64, vp, vp, i64, vp, f32, vp, i64, i32, vp, vp, i32, i32, i32, i32, i32, f32, u32,
-                                             vp, i32, i32, i32, i32, vp, i32, f32, u32, vp, i32, vp]
+                                             vp, i32, i32, i32, i32, vp, i32, f32, u32, vp, i32, vp, ctypes.c_size_t, vp]
     lib.alpro_transpose.argtypes = [vp, i32, i64, vp, i32, i64, i32, i32, i32, vp, vp]
     lib.alpro_gelu_bwd.argtypes = [vp, vp, vp, i32, i64, vp]
-    lib.alpro_sumsq.argtypes = [vp, i64, vp, vp]
+    lib.alpro_sumsq.argtypes = [vp, i64, vp, vp, ctypes.c_size_t, vp]
     lib.alpro_softmax_xent.argtypes = [vp, i64, vp, i32, vp, vp, i32, i64, vp, i32, i32, i32, vp]
     lib.alpro_gemm_tn_acc.argtypes = [vp, i64, vp, i64, vp, i64, i32, i32, i32, i32, vp, vp]
     lib.alpro_gemm_tn_acc_ws.argtypes = [vp, i64, vp, i64, vp, i64, i32, i32, i32, i32, vp, vp, ctypes.c_size_t, vp]
@@ -91,9 +91,9 @@ def load():
     lib.alpro_transpose_batch.argtypes = [vp, i32, i32, i32, vp]
     lib.alpro_adamw_step.argtypes = [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, f32, vp, f32, f32, vp, i32, i32, i32, vp]
     lib.alpro_loss_scale_update.argtypes = [vp, vp, f32, f32, i32, f32, f32, vp]
-    lib.alpro_gather_cast.argtypes = [vp, i64, vp, i32, i32, i32, i32, i32, i32, vp, i32, f32, f32, u32, vp, vp, vp]
+    lib.alpro_gather_cast.argtypes = [vp, i64, vp, i32, i32, i32, i32, i32, i32, vp, i32, f32, f32, u32, vp, vp, vp, ctypes.c_size_t, vp]
     lib.alpro_cls_mean_bwd.argtypes = [vp, i64, vp, i32, i32, i32, vp]
-    lib.alpro_scatter_add_rows.argtypes = [vp, vp, vp, i32, i32, i32, vp]
+    lib.alpro_scatter_add_rows.argtypes = [vp, vp, vp, i32, i32, i32, i64, vp]
     lib.alpro_attn_fwd.argtypes = [vp, vp, i32, i32, i32, i32, f32, vp, vp, f32, u32, vp, i32, vp, vp]
     lib.alpro_attn_cls_fwd.argtypes = [vp, i32, vp, vp, vp, i32, i32, i32, i32, f32, f32, u32, vp]
     lib.alpro_gemm_rows_f32.argtypes = [vp, i64, vp, i64, vp, i64, i32, i32, i32, vp, i32, vp, vp, i64, vp, vp, f32, vp]
@@ -347,15 +347,16 @@ def layernorm_bwd(dy, x, gamma, eps, dx, dgamma, dbeta, rows=None, dy2=None, acc
     common = (_ptr(dy), _CODE[dy.dtype], D, _ptr(_dev(dy2, torch.float32)) if dy2 is not None else None, _ptr(x), D,
               _ptr(_dev(gamma, torch.float32)), eps, _ptr(dx), D, 1 if accumulate else 0, _ptr(dgamma), _ptr(dbeta), rows, D,
               map_mode, map_p0, map_p1, drop_p, drop_seed)
+    ws, wsb = _reduce_ws(dy.device)
     if emit is None:
-        _check(lib.alpro_layernorm_bwd(*common, _stream()), "alpro_layernorm_bwd")
+        _check(lib.alpro_layernorm_bwd(*common, ws, wsb, _stream()), "alpro_layernorm_bwd")
         return dx
     out = torch.empty((emit["rows"], D), dtype=emit.get("dtype", dy.dtype), device=dy.device)
     sc, cp = emit.get("scale"), emit.get("colsum_pre")
     _check(lib.alpro_layernorm_bwd_emit(*common, _ptr(out), _CODE[out.dtype], emit["mode"], emit.get("T", 0), emit.get("N", 0),
                                         _ptr(_dev(sc, torch.float32)) if sc is not None else None, emit.get("group", 1), emit.get("drop_p", 0.0),
                                         emit.get("drop_seed", 0), _ptr(_dev(cp, torch.float32)) if cp is not None else None, emit.get("extra_cls", 0),
-                                        _stream()), "alpro_layernorm_bwd_emit")
+                                        ws, wsb, _stream()), "alpro_layernorm_bwd_emit")
     return dx, out
 
 
@@ -367,6 +368,9 @@ def transpose(x, out_dtype=None, pad_to=64, colsum=None):
     out_dtype = out_dtype or x.dtype
     Rpad = (R + pad_to - 1) // pad_to * pad_to
     out = torch.empty((C, Rpad), dtype=out_dtype, device=x.device)
+    if colsum is not None and _DETERMINISTIC[0]:   # the fused column sums are one fp32 atomic per 64-row tile (order varies); fp32 exact mode only
+        _dev(colsum, torch.float32)[:C].add_(x.sum(0, dtype=torch.float32))
+        colsum = None
     _check(lib.alpro_transpose(_ptr(x), _CODE[x.dtype], x.stride(0), _ptr(out), _CODE[out_dtype], Rpad, R, C, Rpad,
                                _ptr(_dev(colsum, torch.float32)) if colsum is not None else None, _stream()), "alpro_transpose")
     return out
@@ -380,10 +384,11 @@ def gather_cast(src, dtype, rows=None, map_mode=MAP_IDENTITY, map_p0=0, map_p1=0
     D = src.shape[-1]
     rows = rows if rows is not None else src.numel() // D
     out = torch.empty((rows, D), dtype=dtype, device=src.device)
+    ws, wsb = _reduce_ws(src.device) if (colsum is not None or colsum_pre is not None) else (None, 0)
     _check(lib.alpro_gather_cast(_ptr(src), D, _ptr(out), _CODE[dtype], rows, D, map_mode, map_p0, map_p1,
                                  _ptr(_dev(row_scale, torch.float32)) if row_scale is not None else None, row_scale_group, cls_scale, drop_p, drop_seed,
                                  _ptr(_dev(colsum, torch.float32)) if colsum is not None else None,
-                                 _ptr(_dev(colsum_pre, torch.float32)) if colsum_pre is not None else None, _stream()),
+                                 _ptr(_dev(colsum_pre, torch.float32)) if colsum_pre is not None else None, ws, wsb, _stream()),
            "alpro_gather_cast")
     return out
 
@@ -405,11 +410,20 @@ def cls_mean_bwd(dx_out, B, T):
     return dside
 
 
-def scatter_add_rows(src, idx, dst, idx_mod=0):
+def scatter_add_rows(src, idx, dst, idx_mod=0, skip_idx=-1):
+    """dst[idx[i]] += src[i] (idx None: row i % idx_mod); rows whose index is skip_idx contribute nothing (nn.Embedding's padding_idx).
+    Reproducible mode (the default, see set_deterministic): the position form runs the one-writer-per-row kernel; the indexed form goes
+    through a sort (torch's index_put_ with accumulate: duplicates are added in a fixed order) after the skipped rows have been zeroed --
+    the atomic kernel's order of additions to a duplicated row (every [CLS], [SEP], [MASK] ...) varies run to run."""
     lib = load()
     _dev(src, torch.float32); _dev(dst, torch.float32)
+    if idx is not None and _DETERMINISTIC[0]:
+        idx = _dev(idx, torch.int64).view(-1)
+        rows = src if skip_idx < 0 else src * (idx != skip_idx).unsqueeze(1).to(src.dtype)
+        dst.index_put_((idx,), rows, accumulate=True)
+        return dst
     _check(lib.alpro_scatter_add_rows(_ptr(src), _ptr(_dev(idx, torch.int64)) if idx is not None else None, _ptr(dst), src.shape[0], idx_mod,
-                                      src.shape[1], _stream()), "alpro_scatter_add_rows")
+                                      src.shape[1], int(skip_idx), _stream()), "alpro_scatter_add_rows")
     return dst
 
 
@@ -536,7 +550,8 @@ def sumsq(x, out):
     """out (1,) fp32 += sum(x^2)."""
     lib = load()
     _dev(x, torch.float32); _dev(out, torch.float32)
-    _check(lib.alpro_sumsq(_ptr(x), x.numel(), _ptr(out), _stream()), "alpro_sumsq")
+    ws, wsb = _reduce_ws(x.device)
+    _check(lib.alpro_sumsq(_ptr(x), x.numel(), _ptr(out), ws, min(wsb, 1 << 16), _stream()), "alpro_sumsq")
     return out
 
 
@@ -571,6 +586,7 @@ def _tn_workspace(device, nbytes):
 
 
 _DETERMINISTIC_WGRAD = [os.environ.get("ALPRO_ATOMIC_WGRAD", "0") != "1"]
+_DETERMINISTIC = [os.environ.get("ALPRO_DETERMINISTIC", "1") != "0"]
 
 
 def set_deterministic_wgrad(on=True):
@@ -578,6 +594,29 @@ def set_deterministic_wgrad(on=True):
     are bit-reproducible run to run; costs ~0.3 % of the training step.  False (opt-in, also ALPRO_ATOMIC_WGRAD=1): the faster of the
     two plans per shape, fp32 atomics above 65536 tokens -- see gemm_tn_acc."""
     _DETERMINISTIC_WGRAD[0] = bool(on)
+
+
+def set_deterministic(on=True):
+    """True (the default since round 4; ALPRO_DETERMINISTIC=0 turns it off): every remaining reduction of the training step is summed in a
+    fixed order -- the LayerNorm backward's dgamma / dbeta / bias column sums and the gather-cast's (per-workgroup partials in the reduction
+    workspace + a fixed-order second kernel), the squared gradient norm, the embedding-table scatters; the CLS-row gradient and the VTC
+    loss / temperature gradient are single-writer in the kernels themselves.  Two runs of the same step are then bitwise equal
+    (tests/test_model_parity.py::test_two_identical_training_steps_are_bitwise_equal).  False: the kernels' fp32-atomic forms (no workspace)."""
+    _DETERMINISTIC[0] = bool(on)
+
+
+def deterministic():
+    return _DETERMINISTIC[0]
+
+
+def _reduce_ws(device):
+    """(pointer, bytes) of the reduction workspace handed to alpro_layernorm_bwd / _gather_cast / _sumsq: the head of the per-device grow-only
+    buffer the weight-gradient GEMM also uses (all of them run on one stream, each finishes with its own reduce kernel) -- or (None, 0)
+    when reproducibility is switched off."""
+    if not _DETERMINISTIC[0]:
+        return None, 0
+    ws = _tn_workspace(device, 2048 * 3 * 768 * 4)
+    return _ptr(ws), 2048 * 3 * 768 * 4
 
 
 def gemm_tn_acc(a, b, c, colsum=None, atomic=None):

@@ -719,9 +719,9 @@ class VisionTransformer(nn.Module):
         pidx, tidx = self._embed_index(N, T, Wg) if Wg is not None else (None, None)
         dpos, dtime = dtable.sum(1), dtable.sum(0)
         if pidx is not None:  # resampled tables: scatter the gradients back onto the slots they were read from
-            dpos = torch.zeros((self.pos_embed.size(1) - 1, D), dtype=dpos.dtype, device=dpos.device).index_add_(0, pidx, dpos)
+            dpos = torch.zeros((self.pos_embed.size(1) - 1, D), dtype=dpos.dtype, device=dpos.device).index_put_((pidx,), dpos, accumulate=True)   # (sorted accumulate: fixed order, unlike index_add_'s atomics)
         if tidx is not None:
-            dtime = torch.zeros((self.time_embed.size(1), D), dtype=dtime.dtype, device=dtime.device).index_add_(0, tidx, dtime)
+            dtime = torch.zeros((self.time_embed.size(1), D), dtype=dtime.dtype, device=dtime.device).index_put_((tidx,), dtime, accumulate=True)
         tr.add_grad(self.pos_embed, torch.cat([dcls[None], dpos], 0))
         tr.add_grad(self.time_embed, dtime)
 

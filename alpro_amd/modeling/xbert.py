@@ -470,7 +470,8 @@ class _BertRun:
         hip.layernorm_bwd(d_t, pre, emb.LayerNorm.weight, cfg.layer_norm_eps, de, g, b_, dy2=d32, accumulate=False,
                           drop_p=self.emb_drop[0], drop_seed=self.emb_drop[1])
         gw = tr.grad_buffer(emb.word_embeddings.weight, zero=True)[0] if emb.word_embeddings.weight.grad is None else emb.word_embeddings.weight.grad
-        hip.scatter_add_rows(de, self.ids.view(-1), gw)
+        pad = emb.word_embeddings.padding_idx   # nn.Embedding(padding_idx): the pad row's lookup gradient stays zero (xbert.py:171)
+        hip.scatter_add_rows(de, self.ids.view(-1), gw, skip_idx=-1 if pad is None else int(pad))
         gp = tr.grad_buffer(emb.position_embeddings.weight, zero=True)[0] if emb.position_embeddings.weight.grad is None else emb.position_embeddings.weight.grad
         hip.scatter_add_rows(de, None, gp, idx_mod=L)
         gt = tr.grad_buffer(emb.token_type_embeddings.weight, zero=True)[0] if emb.token_type_embeddings.weight.grad is None else emb.token_type_embeddings.weight.grad

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define ALPRO_HIP_ABI_VERSION 15
+#define ALPRO_HIP_ABI_VERSION 16
 
 enum { ALPRO_OK = 0, ALPRO_ERR_INVALID = 1, ALPRO_ERR_LAUNCH = 2 };
 enum { ALPRO_F32 = 0, ALPRO_BF16 = 1, ALPRO_F16 = 2 };
@@ -227,12 +227,17 @@ int alpro_attn_temporal_bwd(const void* qkv, const void* out, const void* dout, 
                             int64_t rows, int T, int H, float scale, void* stream);
 
 /* LayerNorm backward over D == 768: dx[map(m)] (+)= dLN(dy[m] (+ dy2[m]), x[map(m)]); dgamma/dbeta are ACCUMULATED
- * (atomics) into fp32 buffers.  The forward gather map becomes a scatter; rows gathered more than once (the CLS
- * row under FRAME_TOKENS) are accumulated atomically, so that map requires accumulate = 1. */
+ * into fp32 buffers.  The forward gather map becomes a scatter; a row gathered more than once (the clip's CLS row under
+ * FRAME_TOKENS, once per frame) is owned by ONE wave that adds the T terms in frame order -- that map requires accumulate = 1.
+ * Column sums (dgamma, dbeta, the emit's colsum_pre) -- REDUCTION WORKSPACE (ABI 16), the same contract in alpro_gather_cast / alpro_sumsq:
+ *   workspace != NULL (16-byte aligned, >= 9216 bytes; 2048 * 9216 bytes never caps the grid): every workgroup writes its partial sums
+ *   to its own slot and a second small kernel adds the slots in a fixed order -> results are bit-reproducible run to run;
+ *   workspace == NULL: one fp32 atomic per column per workgroup (no extra memory; the last bits vary with the arrival order).
+ *   The buffer is scratch: used in stream order, contents meaningless afterwards, may be shared by every call on one stream. */
 int alpro_layernorm_bwd(const void* dy, int dy_dtype, int64_t ld_dy, const float* dy2, const float* x, int64_t ldx,
                         const float* gamma, float eps, float* dx, int64_t ld_dx, int accumulate, float* dgamma,
                         float* dbeta, int rows, int D, int map_mode, int map_p0, int map_p1, float drop_p,
-                        uint32_t drop_seed, void* stream);
+                        uint32_t drop_seed, void* workspace, size_t workspace_bytes, void* stream);
 /* drop_p > 0: the incoming gradient dy (+dy2) is first multiplied by the dropout mask hash(seed, m*D+n)/(1-p) that the
  * forward applied to this LayerNorm's OUTPUT (embedding dropout). */
 
@@ -252,7 +257,8 @@ int alpro_layernorm_bwd_emit(const void* dy, int dy_dtype, int64_t ld_dy, const 
                              const float* gamma, float eps, float* dx, int64_t ld_dx, int accumulate, float* dgamma, float* dbeta,
                              int rows, int D, int map_mode, int map_p0, int map_p1, float drop_p, uint32_t drop_seed, void* emit_out,
                              int emit_dtype /* dy_dtype, or any dtype when dy is fp32 */, int emit_mode, int emit_p0, int emit_p1, const float* emit_scale, int emit_scale_group, float emit_drop_p,
-                             uint32_t emit_drop_seed, float* emit_colsum_pre, int emit_extra_cls, void* stream);
+                             uint32_t emit_drop_seed, float* emit_colsum_pre, int emit_extra_cls, void* workspace, size_t workspace_bytes,
+                             void* stream);
 
 /* out[c, r] = in[r, c] (r < R), 0 for R <= r < Rpad: puts the token dimension last so that dgrad / wgrad run on
  * the NT GEMM (dX = dY (W^T)^T, dW = dY^T (X^T)^T).  `in` is fp32 or out_dtype.  colsum (C) fp32, optional:
@@ -276,8 +282,9 @@ int alpro_transpose_batch(const alpro_transpose_job_t* jobs, int njobs, int tota
  * FRAME_TOKENS the j == 0 rows read the clip's CLS row times cls_scale (= 1/T, the frame mean of vit.py:187). */
 int alpro_gather_cast(const float* src, int64_t ld, void* out, int dtype, int rows, int D, int map_mode, int map_p0,
                       int map_p1, const float* row_scale, int row_scale_group, float cls_scale, float drop_p,
-                      uint32_t drop_seed, float* colsum, float* colsum_pre, void* stream);
-/* drop_p > 0: additionally re-applies the GEMM-epilogue dropout mask hash(seed, m*D+n)/(1-p) (backward of alpro_gemm's drop_p).
+                      uint32_t drop_seed, float* colsum, float* colsum_pre, void* workspace, size_t workspace_bytes, void* stream);
+/* workspace: reduction workspace for colsum / colsum_pre (see alpro_layernorm_bwd; >= 6144 bytes, 512 * 6144 never caps the grid), NULL = atomics.
+ * drop_p > 0: additionally re-applies the GEMM-epilogue dropout mask hash(seed, m*D+n)/(1-p) (backward of alpro_gemm's drop_p).
  * colsum (optional, (D) fp32): colsum[n] += sum_m out[m, n] -- the bias gradient of the Linear these rows are the dY of;
  * colsum_pre (optional): the same column sums taken BEFORE the row scale (bias gradient of a Linear that sits after the
  * drop-path scale, e.g. temporal_fc under the merged temporal projection). */
@@ -288,8 +295,11 @@ int alpro_gelu_bwd(const void* dh, const void* u, void* du, int dtype, int64_t n
 /* dside[b*T+t, :] = dx_out[b, 0, :] / T  (backward of alpro_cls_mean_residual w.r.t. the parked CLS rows). */
 int alpro_cls_mean_bwd(const float* dx_out, int64_t ld_batch, float* dside, int B, int T, int D, void* stream);
 
-/* dst[idx[i], :] += src[i, :] (idx NULL: row i % idx_mod): embedding-table gradients (xbert.py:203-210 backward). */
-int alpro_scatter_add_rows(const float* src, const int64_t* idx, float* dst, int rows, int idx_mod, int D, void* stream);
+/* dst[idx[i], :] += src[i, :] (idx NULL: row i % idx_mod): embedding-table gradients (xbert.py:203-210 backward).  Rows whose index equals
+ * skip_idx (>= 0) are dropped: nn.Embedding(padding_idx = pad_token_id) keeps the pad row's gradient at zero (xbert.py:171); -1 = none.
+ * idx == NULL and skip_idx < 0 (the position table): one wave per destination row adds its rows in ascending order -- bit-reproducible.
+ * With idx: fp32 atomics, the duplicates' order varies run to run (the reproducible caller sorts: alpro_amd/hip.py scatter_add_rows). */
+int alpro_scatter_add_rows(const float* src, const int64_t* idx, float* dst, int rows, int idx_mod, int D, int64_t skip_idx, void* stream);
 
 /* Weight gradient without transposed copies: C[N, K] (fp32, ATOMICALLY accumulated) += A[M, N]^T B[M, K], A = dY and
  * B = X row-major in a 16-bit dtype, contraction over tokens split across the grid (gemm_tn.hip).  C must be
@@ -326,7 +336,8 @@ int alpro_softmax_xent(const float* logits, int64_t ld, const int64_t* labels, i
  * col0 + i (col0 = local_rank * B, :121-123), temp the learnable temperature (clamped to [0.001, 0.5] like :80-81):
  *   sim_v2t = v gt^T / temp, sim_t2v = t gv^T / temp   (B, G) fp32, written out (hard-negative mining :287-306 reads them)
  *   *loss   = (mean_i CE(sim_v2t[i], col0 + i) + mean_i CE(sim_t2v[i], col0 + i)) / 2;  lse (2B): row log-sum-exps for the backward.
- * _bwd: gradients w.r.t. v, t (B, E), gv, gt (G, E) and temp (*dtemp, optional) for upstream *dloss; ds_* are (B, G) scratch. */
+ * _bwd: gradients w.r.t. v, t (B, E), gv, gt (G, E) and temp (*dtemp, optional) for upstream *dloss; ds_* are (B, G) scratch.
+ * *loss and *dtemp are summed in a fixed order by one finishing workgroup each (ABI 16; before: one fp32 atomic per row) -- bit-reproducible. */
 int alpro_vtc_loss_fwd(const float* v, const float* t, const float* gv, const float* gt, const float* temp, int B, int G, int E, int col0,
                        float* sim_v2t, float* sim_t2v, float* lse, float* loss, void* stream);
 int alpro_vtc_loss_bwd(const float* v, const float* t, const float* gv, const float* gt, const float* temp, int B, int G, int E, int col0,
@@ -335,8 +346,9 @@ int alpro_vtc_loss_bwd(const float* v, const float* t, const float* gv, const fl
 
 /* ---- step epilogue on flat fp32 buffers (run_pretrain_sparse.py:633-648, src/optimization/adamw.py:40-103) ---- */
 
-/* *out += sum(x[i]^2): global gradient norm for clip_grad_norm_. */
-int alpro_sumsq(const float* x, int64_t n, float* out, void* stream);
+/* *out += sum(x[i]^2): global gradient norm for clip_grad_norm_.  workspace: reduction workspace (see alpro_layernorm_bwd; one float per
+ * workgroup, 8192 bytes never cap the grid) -> fixed summation order; NULL = one fp32 atomic per workgroup. */
+int alpro_sumsq(const float* x, int64_t n, float* out, void* workspace, size_t workspace_bytes, void* stream);
 
 /* HF-style AdamW over n contiguous parameters: g' = g * grad_scale * min(1, max_norm / (sqrt(*gnorm_sq)*grad_scale + 1e-6));
  * m = b1 m + (1-b1) g'; v = b2 v + (1-b2) g'^2; p -= step_size * m / (sqrt(v) + eps); p -= lr * wd * p.

@@ -61,9 +61,10 @@ def test_one_rank_nccl_runs_every_collective(tmp_path, wire, tol):
     sends the training step through every collective branch the 8-GPU run takes -- broadcast_parameters, the differentiable feature
     all-gather (all_gather_into_tensor forward, reduce_scatter_tensor backward), FlatAdamW's async all_reduce handles on RCCL's
     stream launched from inside backward (grads_final) and `_finish_exchange`'s h.wait() stream hand-over, fp32 and bf16 wire -- and
-    must reproduce the plain single-process step (same loss; gradients to fp32 reduction noise: the CLS token's gradient is accumulated
-    from its T frame copies by fp32 atomics in alpro_layernorm_bwd, and the LayerNorm dgamma / dbeta likewise, so two runs of the SAME
-    single-process step already differ by ~1e-6 relative downstream of the first spatial LayerNorm backward -- not bitwise)."""
+    must reproduce the plain single-process step.  Since round 4 every reduction of the step has a fixed order (the CLS-row gradient is
+    owned by one wave, dgamma / dbeta / bias column sums go through the reduction workspace, the squared norm and the embedding scatters
+    likewise: alpro_amd.hip.set_deterministic), so with the fp32 wire the forced-collective step must be BITWISE equal to the plain one
+    (one-rank all-gather / reduce-scatter / all-reduce are copies); the bf16 wire rounds the gradients once on the way."""
     B = 2
     forced = _run(1, str(tmp_path / "nccl1"), B, wire, backend="nccl", force=True)[0]
     plain = _run(1, str(tmp_path / "plain"), B, "fp32")[0]
@@ -79,3 +80,20 @@ def test_one_rank_nccl_runs_every_collective(tmp_path, wire, tol):
     for n, g in plain["grads"].items():
         err = float((forced["grads"][n] - g).abs().max())
         assert err <= tol * max(float(g.abs().max()), 1e-6) + 1e-9, (n, err, float(g.abs().max()))
+    if wire == "fp32":
+        assert forced["loss"] == plain["loss"]
+        assert torch.equal(forced["norms"], plain["norms"]), [n for i, n in enumerate(plain["names"]) if forced["norms"][i] != plain["norms"][i]][:8]
+        for n, g in plain["grads"].items():
+            assert torch.equal(forced["grads"][n], g), n
+
+
+def test_two_runs_of_the_same_step_are_bitwise_equal(tmp_path):
+    """two processes run the same two training steps (forward, hand-written backward, clip + AdamW) from the same
+    seed; the loss, every parameter-gradient norm and the kept gradients must agree bit for bit -- the default path has no
+    order-dependent fp32 reduction left."""
+    a = _run(1, str(tmp_path / "a"), 2, "fp32")[0]
+    b = _run(1, str(tmp_path / "b"), 2, "fp32")[0]
+    assert a["loss"] == b["loss"]
+    assert torch.equal(a["norms"], b["norms"]), [n for i, n in enumerate(a["names"]) if a["norms"][i] != b["norms"][i]][:8]
+    for n, g in a["grads"].items():
+        assert torch.equal(b["grads"][n], g), n

@@ -114,6 +114,10 @@ def test_transpose_gelu_misc(dt):
     assert t.shape == (200, 320)
     assert torch.equal(t[:, :300].cpu(), x.t().contiguous()) and float(t[:, 300:].abs().sum()) == 0
     close(cs, 1 + x.double().sum(0), 1e-5, 1e-4, "colsum")
+    with _determinism(hip, False):   # the kernel's fused column sums (fp32 atomics per 64-row tile) instead of the fixed-order default
+        cs = torch.ones(200).cuda()
+        hip.transpose(x.cuda(), colsum=cs)
+        close(cs, 1 + x.double().sum(0), 1e-5, 1e-4, "colsum (fused)")
     w = rnd(100, 768, seed=101)
     t2 = hip.transpose(w.cuda(), out_dtype=dt, pad_to=64)
     assert torch.equal(t2[:, :100].cpu(), w.to(dt).t().contiguous())
@@ -911,3 +915,129 @@ def test_transpose_batch_and_operand_refresh():
         for a, b, c in zip(got, want, before):
             assert torch.equal(a, b) and not torch.equal(a, c)
     assert len(tr._WT_REGISTRY) >= 2 and tr.refresh_transposed_operands() >= 2
+
+
+def _determinism(hip, on):
+    import contextlib
+
+    @contextlib.contextmanager
+    def cm():
+        prev = hip.deterministic()
+        hip.set_deterministic(on)
+        try:
+            yield
+        finally:
+            hip.set_deterministic(prev)
+    return cm()
+
+
+def test_reductions_run_to_run_reproducibility():
+    """Round 4: the remaining fp32 atomics of the training step have a fixed-order form, and it is the default.
+      * alpro_layernorm_bwd at the benchmark's ViT shape under the FRAME_TOKENS scatter: the clip's CLS row (one term per frame, single
+        owner wave) and dgamma / dbeta / colsum_pre (per-workgroup partials in the reduction workspace + colsum_reduce_kernel);
+      * alpro_gather_cast's colsum / colsum_pre, alpro_sumsq, the position form of alpro_scatter_add_rows, the sorted index form;
+      * alpro_vtc_loss_fwd / _bwd (loss and d temp finished by one workgroup).
+    Each runs three times on the same inputs: bitwise equal.  The atomic forms (set_deterministic(False), NULL workspace) stay available
+    and agree with the fixed-order results to fp32 re-association."""
+    hip = _hip()
+    B, T, N, D = 16, 8, 196, 768
+    S = 1 + N * T
+    g = torch.Generator(device="cuda").manual_seed(5)
+    x = torch.randn(B, S, D, device="cuda", generator=g) * 2 + 0.3
+    gam = 1 + 0.1 * torch.randn(D, device="cuda", generator=g)
+    rows = B * T * (N + 1)
+    dy = (torch.randn(rows, D, device="cuda", generator=g) * 0.1).to(torch.float16)
+    res = torch.randn(B, S, D, device="cuda", generator=g)
+    drop_t = (torch.rand(B * N, device="cuda", generator=g) > 0.1).float() / 0.9
+
+    def ln(emit):
+        dx, dg, db, cp = res.clone(), torch.zeros(D, device="cuda"), torch.zeros(D, device="cuda"), torch.zeros(D, device="cuda")
+        kw = dict(rows=rows, map_mode=hip.MAP_FRAME_TOKENS, map_p0=T, map_p1=N)
+        if emit:   # norm1's backward as vit.py issues it: the same scatter + the SKIP_CLS emit with the temporal_fc bias column sums
+            kw["emit"] = dict(mode=hip.EMIT_SKIP_CLS, rows=B * N * T, T=T, N=N, scale=drop_t, group=T, colsum_pre=cp)
+            out = hip.layernorm_bwd(dy, x, gam, 1e-6, dx, dg, db, **kw)
+            return dx, dg, db, cp, out[1]
+        hip.layernorm_bwd(dy, x, gam, 1e-6, dx, dg, db, **kw)
+        return dx, dg, db
+    for emit in (False, True):
+        runs = [ln(emit) for _ in range(3)]
+        for r in runs[1:]:
+            for a, b in zip(r, runs[0]):
+                assert torch.equal(a, b), "layernorm_bwd (emit=%s) is not bit-reproducible" % emit
+        with _determinism(hip, False):
+            at = ln(emit)
+        for a, b in zip(at, runs[0]):
+            assert float((a.float() - b.float()).abs().max()) <= 2e-5 * max(float(b.float().abs().max()), 1.0)
+    # the CLS rows really carry T terms each: against fp64 on a slice
+    x64 = x[:2].double().cpu().requires_grad_(True)
+    lnr = torch.nn.functional.layer_norm(x64, (D,), gam.double().cpu(), torch.zeros(D, dtype=torch.float64), 1e-6)
+    xs = lnr[:, 1:].reshape(2, N, T, D).permute(0, 2, 1, 3)
+    y = torch.cat([lnr[:, :1].unsqueeze(1).expand(2, T, 1, D), xs], 2).reshape(-1, D)
+    (y * dy[:2 * T * (N + 1)].double().cpu()).sum().backward()
+    close(ln(False)[0][:2, 0], res[:2, 0].double().cpu() + x64.grad[:, 0], 1e-4, 5e-4, "CLS-row gradient (owner wave)")
+
+    src = torch.randn(B * S, D, device="cuda", generator=g)
+    rs = torch.rand(B, device="cuda", generator=g)
+
+    def gc():
+        cs, cp = torch.zeros(D, device="cuda"), torch.zeros(D, device="cuda")
+        out = hip.gather_cast(src, torch.float16, row_scale=rs, row_scale_group=S, colsum=cs, colsum_pre=cp)
+        return out, cs, cp
+    runs = [gc() for _ in range(3)]
+    for r in runs[1:]:
+        assert all(torch.equal(a, b) for a, b in zip(r, runs[0]))
+    close(runs[0][2], src.double().sum(0).cpu(), 1e-4, 2e-3, "gather_cast colsum_pre (workspace)")
+    with _determinism(hip, False):
+        at = gc()
+    close(at[1], runs[0][1].double().cpu(), 1e-4, 2e-3, "gather_cast colsum atomic vs workspace")
+
+    flat = torch.randn(50_000_003, device="cuda", generator=g)[4:]          # (16-byte aligned, length not a multiple of 4)
+    outs = []
+    for _ in range(3):
+        o = torch.zeros(1, device="cuda")
+        hip.sumsq(flat, o)
+        outs.append(o)
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    assert abs(float(outs[0]) - float(flat.double().pow(2).sum())) <= 1e-5 * float(outs[0])
+    with _determinism(hip, False):
+        o = torch.zeros(1, device="cuda")
+        hip.sumsq(flat, o)
+    assert abs(float(o) - float(outs[0])) <= 1e-5 * float(outs[0])
+
+    # embedding tables: 5120 token rows, heavy duplicates ([CLS] / [SEP] / [MASK] / pad), pad row skipped
+    L, V = 40, 3000
+    ids = torch.randint(4, V, (128 * L,), device="cuda", generator=g)
+    ids[::L] = 1
+    ids[7::L] = 2
+    ids[torch.rand(128 * L, device="cuda", generator=g) < 0.15] = 3
+    ids[torch.rand(128 * L, device="cuda", generator=g) < 0.2] = 0          # pad
+    de = torch.randn(128 * L, D, device="cuda", generator=g)
+    ref = torch.zeros(V, D, dtype=torch.float64).index_add_(0, ids.cpu(), (de * (ids != 0).unsqueeze(1)).double().cpu())
+
+    def emb():
+        gw, gp = torch.zeros(V, D, device="cuda"), torch.zeros(512, D, device="cuda")
+        hip.scatter_add_rows(de, ids, gw, skip_idx=0)
+        hip.scatter_add_rows(de, None, gp, idx_mod=L)
+        return gw, gp
+    runs = [emb() for _ in range(3)]
+    for r in runs[1:]:
+        assert torch.equal(r[0], runs[0][0]) and torch.equal(r[1], runs[0][1])
+    close(runs[0][0], ref, 1e-5, 1e-4, "word-embedding scatter (sorted)")
+    assert float(runs[0][0][0].abs().max()) == 0.0                             # the pad row's lookup gradient stays zero
+    close(runs[0][1][:L], de.double().cpu().view(128, L, D).sum(0), 1e-5, 1e-4, "position scatter (owner wave)")
+    with _determinism(hip, False):
+        at = emb()
+    close(at[0], ref, 1e-5, 1e-4, "word-embedding scatter (atomic, skip_idx)")
+    assert float(at[0][0].abs().max()) == 0.0
+
+    Bv, E = 64, 256
+    v, t = [torch.nn.functional.normalize(torch.randn(Bv, E, device="cuda", generator=g), dim=-1) for _ in range(2)]
+    temp = torch.tensor([0.07], device="cuda")
+
+    def vtc():
+        loss, s1, s2, lse = hip.vtc_loss_fwd(v, t, v, t, temp, 0)
+        grads = hip.vtc_loss_bwd(v, t, v, t, temp, 0, s1, s2, lse, torch.ones(1, device="cuda"))
+        return (loss,) + tuple(grads)
+    runs = [vtc() for _ in range(3)]
+    for r in runs[1:]:
+        assert all(torch.equal(a, b) for a, b in zip(r, runs[0]))
