@@ -50,7 +50,7 @@ class LossScaler:
         return float(self.state[0].item())       # host sync: logging / checkpoints only
 
     def state_dict(self):
-        s = self.state.tolist() if self.state is not None else [self._init, 0.0, 0.0, 0.0]
+        s = self.state.tolist() if self.state is not None else (getattr(self, "_pending", None) or [self._init, 0.0, 0.0, 0.0])
         return {"loss_scale": s[0], "unskipped": int(s[1]), "applied_steps": int(s[2]), "skipped_steps": int(s[3])}
 
     def load_state_dict(self, sd):

@@ -40,8 +40,11 @@ def _install_optimizer_hook():
     try:
         from torch.optim.optimizer import register_optimizer_step_post_hook
         register_optimizer_step_post_hook(lambda opt, args, kwargs: notify_params_updated())
-    except Exception:  # noqa: BLE001 -- very old torch: the facade / the driver must call notify_params_updated()
-        pass
+    except Exception as e:  # noqa: BLE001 -- very old torch: the facade / the driver must call notify_params_updated()
+        import warnings
+        warnings.warn("alpro_amd: torch.optim's global post-step hook is unavailable (%r): after every in-place parameter update outside "
+                      "alpro_amd.optim.FlatAdamW call alpro_amd.modeling.weights.notify_params_updated(), or the 16-bit operand copies of the "
+                      "weights go stale without an error (INTEGRATION.md, 'Manual parameter updates')" % (e,))
 
 
 _install_optimizer_hook()

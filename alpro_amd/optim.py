@@ -337,18 +337,27 @@ class FlatAdamW:
         meaning (parameter index in the constructor's list, offset, numel).  Savers may move / narrow the tensors
         (E2E_TrainingRestorer stores fp16 on the CPU, load_save.py:181-196); load_state_dict widens them again."""
         groups = [{k: v for k, v in g.items() if k != "params"} for g in self.param_groups]
+        # under loss scaling the bias correction runs on the scaler's DEVICE counter of APPLIED steps (overflow-skipped steps do not count,
+        # the host `step` does): the scaler state travels with the optimizer so that a resumed run continues bit for bit (ADVICE r3)
+        extra = dict(loss_scaler=self.scaler.state_dict()) if self.scaler is not None else {}
         if self.flat is None:
             if self._pending_state is not None:
-                return dict(self._pending_state, step=self.step_count, param_groups=groups)
-            return dict(step=self.step_count, param_groups=groups, layout=[], m=None, v=None)
-        return dict(step=self.step_count, param_groups=groups, layout=self._layout(), m=self.flat["m"], v=self.flat["v"])
+                return dict(self._pending_state, step=self.step_count, param_groups=groups, **extra)
+            return dict(step=self.step_count, param_groups=groups, layout=[], m=None, v=None, **extra)
+        return dict(step=self.step_count, param_groups=groups, layout=self._layout(), m=self.flat["m"], v=self.flat["v"], **extra)
 
     def load_state_dict(self, sd):
         """Restore the step counter, hyper-parameters and moments written by state_dict().  The flat buffers only exist after the
         first backward + step(): before that the moments are parked and applied by the first step(), which checks that the same set
         of parameters is being trained (the layout is a pure function of which parameters receive gradients)."""
         self.step_count = int(sd["step"])
-        self._scaler_steps_synced = None   # re-seed the device step counter from the restored host counter at the next step()
+        self._scaler_steps_synced = None   # re-seed the device step counter from the restored host counter at the next step() ...
+        if sd.get("loss_scaler") is not None:   # ... unless the checkpoint carries the scaler itself: then its applied-step count is authoritative
+            from alpro_amd import amp
+            sc = amp.scaler_for(self, create=amp.needs_loss_scaling())
+            if sc is not None:
+                sc.load_state_dict(sd["loss_scaler"])
+                self._scaler_steps_synced = sc
         for g, saved in zip(self.param_groups, sd.get("param_groups", [])):
             for k, v in saved.items():
                 g[k] = tuple(v) if k == "betas" else v

@@ -213,14 +213,21 @@ class _RestorerBase:
         except Exception:  # noqa: BLE001 -- a torn restore.pt falls back to the previous one
             return torch.load(self.backup_path, map_location="cpu")
 
+    def _amp_active(self):
+        """Loss-scaler state belongs in the checkpoint whenever a scaler exists -- `fp16: 1` in the config like the reference
+        (load_save.py:238,262), OR fp16 operands chosen by the launcher (`--dtype fp16`, the default; every release config says fp16: 0):
+        without it a resumed run restarts at 2^16 and skips steps until the scale has re-adapted."""
+        from alpro_amd import amp
+        return bool(self.amp) or amp.needs_loss_scaling() or bool(amp._SCALERS)
+
     def _write(self, checkpoint):
         """Two generations on disk, and a failed / interrupted save never costs one of them: the new checkpoint is written to
         `restore.pt.tmp` and fsync'ed FIRST; only then does the current restore.pt become the backup and the new file take its
         name (both os.replace, atomic on POSIX).  The reference renames before it saves (load_save.py:255-258, 316-319), so a torn
         save followed by its own retry renames the torn file over the only good backup."""
         import os
-        if self.amp:
-            from apex import amp
+        if self._amp_active():
+            from alpro_amd import amp
             checkpoint["amp_state_dict"] = amp.state_dict()
         tmp = self.save_path + ".tmp"
         with open(tmp, "wb") as f:
@@ -256,8 +263,8 @@ class TrainingRestorer(_RestorerBase):
         ck = self._read()
         for k, holder in self.ckpt_dict.items():
             holder.load_state_dict(_to_device(ck[k]))
-        if self.amp:
-            from apex import amp
+        if self._amp_active() and ck.get("amp_state_dict") is not None:
+            from alpro_amd import amp
             amp.load_state_dict(ck["amp_state_dict"])
         self.global_step = ck["global_step"]
         LOGGER.info("resume training from step %d", self.global_step)
@@ -287,8 +294,8 @@ class E2E_TrainingRestorer(_RestorerBase):
         ck = self._read()
         self.model.load_state_dict(_to_device(ck["model_state_dict"]))
         self.optimizer.load_state_dict(_to_device(ck["optim_state_dict"]))
-        if self.amp:
-            from apex import amp
+        if self._amp_active() and ck.get("amp_state_dict") is not None:
+            from alpro_amd import amp
             amp.load_state_dict(ck["amp_state_dict"])
         self.global_step = ck["global_step"]
         LOGGER.info("resume training from step %d", self.global_step)

@@ -93,7 +93,44 @@ def _worker(rank, world, port, out):
     assert float(lin.weight[0, 0]) == 7.0
     dist.barrier()
     _hvd_facade_checks(rank, world)
+    _amp_without_synchronize_checks(rank, world)
     out.put((rank, "ok"))
+
+
+def _amp_without_synchronize_checks(rank, world):
+    """`with amp.scale_loss(loss, opt) as s: s.backward()` on a bare FlatAdamW -- no optimizer.synchronize() inside the
+    block, the usage config.check_backward_precision's message advertises.  The all-reduces launched from inside backward (grads_final) are
+    still writing the flat gradient buffer when the block exits; unscale_ must finish the exchange (remaining ranges out, handles waited
+    for, the 16-bit wire copy back) BEFORE it multiplies by 1/S, and tell step() that the sums are already there.  Before the fix the early
+    range came out scaled-then-overwritten (wire copy) or raced, the late range unscaled-then-summed: both wrong by a factor S."""
+    from alpro_amd import amp, config as rt, dist, hip
+    from alpro_amd.optim import FlatAdamW
+    hip.set_option = lambda *a, **k: None          # (the CU reservation talks to the GPU library)
+    prev = rt.compute_dtype()
+    rt.set_compute_dtype("fp16")
+    try:
+        for wire in (None, torch.bfloat16):
+            ps = [torch.nn.Parameter(torch.zeros(64, 33)), torch.nn.Parameter(torch.zeros(130))]
+            opt = FlatAdamW(ps, lr=0.0, overlap_backward=True, wire_dtype=wire)
+            for p in ps:
+                p.grad = torch.zeros_like(p)
+            assert opt._build()
+            S = amp.scaler_for(opt).to("cpu").loss_scale()      # (attached by the constructor under fp16 operands: 2^16)
+            assert S == 65536.0
+            loss = torch.zeros((), requires_grad=True)
+            with amp.scale_loss(loss, opt) as scaled:
+                assert float(scaled) == 0.0 and opt._grads_scaled
+                with torch.no_grad():               # what a hand-written backward leaves behind: S * dL/dw in the flat views ...
+                    ps[0].grad.fill_(S * (rank + 1))
+                    ps[1].grad.fill_(S * 10 * (rank + 1))
+                dist.grads_final(params=[ps[0]])    # ... and the first parameter's range already on the wire
+                assert len(opt._inflight) >= 1 and len(opt._reduced) >= 1
+            assert not opt._inflight and not opt._reduced and opt._pre_synced == "sum" and opt._grads_scaled is False
+            tot = sum(r + 1 for r in range(world))
+            assert torch.equal(ps[0].grad, torch.full((64, 33), float(tot))), (wire, ps[0].grad.flatten()[:3])
+            assert torch.equal(ps[1].grad, torch.full((130,), 10.0 * tot)), (wire, ps[1].grad[:3])
+    finally:
+        rt.set_compute_dtype(prev)
 
 
 def _hvd_facade_checks(rank, world):

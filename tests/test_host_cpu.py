@@ -921,3 +921,29 @@ def test_overlapped_exchange_reserves_cus_for_the_collective_library(monkeypatch
     monkeypatch.setattr(dist, "is_initialized", lambda: False)
     dist.init(backend="gloo")
     assert seen["channels"] == "24" and seen["world_size"] == 2
+
+
+def test_flat_adamw_state_dict_carries_the_loss_scaler():
+    """under loss scaling Adam's bias correction runs on the scaler's device counter of APPLIED steps; the host step counter
+    also counts overflow-skipped steps.  The optimizer's state_dict therefore carries the scaler, and loading it must NOT re-seed the applied
+    count from the host counter (a resumed run would jump by the number of skipped steps)."""
+    from alpro_amd import config as rt, optim
+    prev = rt.compute_dtype()
+    rt.set_compute_dtype("fp16")
+    try:
+        a = optim.FlatAdamW([torch.nn.Parameter(torch.zeros(8))])
+        a.scaler.to("cpu").state.copy_(torch.tensor([4096.0, 17.0, 5.0, 2.0]))   # scale, growth tracker, 5 applied + 2 skipped steps
+        a.step_count = 7
+        sd = a.state_dict()
+        assert sd["loss_scaler"] == dict(loss_scale=4096.0, unskipped=17, applied_steps=5, skipped_steps=2)
+        b = optim.FlatAdamW([torch.nn.Parameter(torch.zeros(8))])
+        b.load_state_dict(sd)
+        assert b.step_count == 7 and b.scaler.state_dict() == sd["loss_scaler"]
+        assert b._scaler_steps_synced is b.scaler          # step() will not overwrite applied_steps with the host count
+        b.scaler.to("cpu")
+        assert b.scaler.state.tolist() == [4096.0, 17.0, 5.0, 2.0]
+        c = optim.FlatAdamW([torch.nn.Parameter(torch.zeros(8))])
+        c.load_state_dict({k: v for k, v in sd.items() if k != "loss_scaler"})   # an older checkpoint: the host counter seeds the device one, as before
+        assert c._scaler_steps_synced is None
+    finally:
+        rt.set_compute_dtype(prev)
