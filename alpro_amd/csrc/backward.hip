@@ -610,7 +610,9 @@ extern "C" int alpro_layernorm_bwd_emit(const void* dy, int dy_dtype, int64_t ld
   ALPRO_CHECK(emit_mode == ALPRO_EMIT_NONE || emit_dtype == dy_dtype || dy_dtype == ALPRO_F32, "alpro_layernorm_bwd_emit: emit_dtype must be dy's dtype, or any dtype when dy is the fp32 stream");
   // workspace given: the column sums (dgamma, dbeta, colsum_pre) leave as per-workgroup partials and are added in a fixed order by a second
   // small kernel -- bit-reproducible; the grid is capped to the slots the workspace holds.  NULL: fp32 atomics (no workspace, order varies).
-  int nblk = grid_for(rows, 4 * 8, 256 * 8);
+  // (185 VGPRs: two 4-wave workgroups per CU are resident at a time, so 512 workgroups are one full round -- with a workspace the grid stops
+  // there: a quarter of the partial sums to write and to reduce, measured neutral on the kernel itself)
+  int nblk = grid_for(rows, 4 * 8, workspace ? 512 : 256 * 8);
   if (workspace) nblk = (int)std::min<size_t>((size_t)nblk, workspace_bytes / LN_PART_BYTES);
   const dim3 grid(nblk), blk(256);
   float* part = (float*)workspace;

@@ -794,30 +794,40 @@ __global__ __launch_bounds__(NT2, 2) void gemm_nt256q_kernel(const alpro_gemm_de
   const int ntile = (nblk - slot + G - 1) / G;   // tiles slot, slot + G, ...
   const uint32_t lds_base = lds_addr_of(smem);
 
-  // DMA sources.  Full tiles only (launcher), so nothing is clamped and everything tile-dependent is wave-uniform: a copy reads
-  //   [A + (m0 + h*128 + i*8) * lda_b + kt*128]  (SGPR pair)  +  [(r0 * lda_b + chunk*16) ^ i*64]  (one 32-bit VGPR per operand)
+  // DMA sources.  Nothing is clamped per lane and everything tile-dependent is wave-uniform: a copy reads
+  //   [A + (m0 + h*128) * lda_b + kt*128]  (SGPR pair)  +  [((r0 + i*8) * lda_b + chunk*16) ^ i*64]  (one 32-bit VGPR per piece)
   // for piece i of half-tile h, r0 = wave*16 + (lane >> 3) = the lane's row in piece 0, chunk = (lane & 7) ^ swizzle(r0); piece 1 sits 8 rows
   // further, where the swizzle differs by 4 chunks = 64 bytes (lda_b is a multiple of 128: launcher).
   const int r0 = wave * 16 + (lane >> 3);
   const uint32_t sw0 = (uint32_t)(((lane & 7) ^ ((r0 >> 1) & 7)) << 4);
-  uint32_t oa[2][2], ow[2][2];   // [half-tile h][piece i]: the lane's byte offset from the tile's K-tile base
+  uint32_t oa[2], ow[2][2];   // A: [piece i] (the half-tile's 128 rows sit in its base pointer); W: [half-tile h][piece i]: the lane's byte offset
 #pragma unroll
-  for (int h = 0; h < 2; ++h)
+  for (int i = 0; i < 2; ++i) {
+    oa[i] = (uint32_t)((r0 + i * 8) * lda_b) + (sw0 ^ (uint32_t)(i * 64));
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      oa[h][i] = (uint32_t)((r0 + h * 128 + i * 8) * lda_b) + (sw0 ^ (uint32_t)(i * 64));
-      ow[h][i] = (uint32_t)((r0 + h * 128 + i * 8) * ldw_b) + (sw0 ^ (uint32_t)(i * 64));
-    }
-  struct Tile { const char* a; const char* w; };   // A + m0 * lda_b, W + n0 * ldw_b (wave-uniform)
+    for (int h = 0; h < 2; ++h) ow[h][i] = (uint32_t)((r0 + h * 128 + i * 8) * ldw_b) + (sw0 ^ (uint32_t)(i * 64));
+  }
+  // Tile bases (wave-uniform).  a[h] = where THIS WAVE's 16 rows of A half-tile h start, minus the wave's own row offset (which oa carries):
+  // normally A + (m0 + h * 128) * lda_b.  Ragged last tile row (M % 256 = vr valid rows, a multiple of 16: launcher): a wave's two copy
+  // instructions per half-tile move rows [h * 128 + wave * 16, + 16) -- valid or not as a whole -- and an invalid group re-reads rows 0-15 of
+  // the tile instead (base moved back by wave * 16 rows): finite values that only reach accumulator rows the epilogue never stores.  All of it
+  // is folded into the per-tile base: the copies in the K loop cost what they cost on a full tile.
+  struct Tile { const char* a[2]; const char* w; };
   auto tile_base = [&](int tile) {
     const int tm = tile / ntn, tn = tile - tm * ntn;
-    return Tile{(const char*)g.A + (int64_t)tm * BM2 * lda_b, (const char*)g.W + (int64_t)tn * BN2 * ldw_b};
+    const int vr = g.M - tm * BM2;   // (>= 256 on full tiles)
+    const char* a0 = (const char*)g.A + (int64_t)tm * BM2 * lda_b;
+    Tile t;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) t.a[h] = a0 + (int64_t)((h * 128 + wave * 16 < vr) ? h * 128 : -(wave * 16)) * lda_b;
+    t.w = (const char*)g.W + (int64_t)tn * BN2 * ldw_b;
+    return t;
   };
-  // half-tile `hs` (0 / 1: A rows 0-127 / 128-255, 2 / 3: W rows) from `kbase` (= tile base + kt * 128 bytes, wave-uniform) -> slot hs of parity `par`
+  // half-tile `hs` (0 / 1: A rows 0-127 / 128-255, 2 / 3: W rows) from `kbase` (= that half's tile base + kt * 128 bytes, wave-uniform) -> slot hs of parity `par`
   auto copy_half = [&](const char* kbase, int hs, int par) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      const uint32_t vo = hs < 2 ? oa[hs & 1][i] : ow[hs & 1][i];
+      const uint32_t vo = hs < 2 ? oa[i] : ow[hs & 1][i];
       const uint32_t dst = __builtin_amdgcn_readfirstlane(lds_base + par * STAGE2_BYTES + hs * HALF2_BYTES + (wave * 2 + i) * 1024);
       asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(vo), "s"(kbase), "s"(dst) : "memory", "m0");
     }
@@ -841,7 +851,7 @@ __global__ __launch_bounds__(NT2, 2) void gemm_nt256q_kernel(const alpro_gemm_de
   Tile nxt = ntile > 1 ? tile_base(slot + G) : cur;   // (no next tile: the run-ahead copies re-read this tile's first K-tiles into dead slots)
   // pipeline fill: K-tile 0 complete in parity 0, W-half 0 of K-tile 1 on its way into parity 1
 #pragma unroll
-  for (int hs = 0; hs < 4; ++hs) copy_half(hs < 2 ? cur.a : cur.w, hs, 0);
+  for (int hs = 0; hs < 4; ++hs) copy_half(hs < 2 ? cur.a[hs] : cur.w, hs, 0);
   copy_half(cur.w + ROWB, 2, 1);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   barrier();
@@ -862,7 +872,8 @@ __global__ __launch_bounds__(NT2, 2) void gemm_nt256q_kernel(const alpro_gemm_de
       u32x4 fa[4][2], fb[2][2][2];
       const bool in1 = t + 1 < nk, in2 = t + 2 < nk;          // targets inside this tile? else the next tile's K-tile 0 / 1
       const int k1 = in1 ? t + 1 : 0, k2 = in2 ? t + 2 : t + 2 - nk;
-      const char* a1 = (in1 ? cur.a : nxt.a) + (int64_t)k1 * ROWB;   // K-tile t+1: both A halves and W half 1
+      const char* a10 = (in1 ? cur.a[0] : nxt.a[0]) + (int64_t)k1 * ROWB;   // K-tile t+1: both A halves and W half 1
+      const char* a11 = (in1 ? cur.a[1] : nxt.a[1]) + (int64_t)k1 * ROWB;
       const char* w1 = (in1 ? cur.w : nxt.w) + (int64_t)k1 * ROWB;
       const char* w2 = (in2 ? cur.w : nxt.w) + (int64_t)k2 * ROWB;   // K-tile t+2: W half 0
       auto load_a = [&](int mi) {
@@ -890,13 +901,13 @@ __global__ __launch_bounds__(NT2, 2) void gemm_nt256q_kernel(const alpro_gemm_de
       // phase 1
       load_b(0);
       load_a(0);
-      copy_half(a1, 0, P ^ 1);
+      copy_half(a10, 0, P ^ 1);
       barrier();
       mma(0, 0);
       barrier();
       // phase 2
       load_b(1);
-      copy_half(a1, 1, P ^ 1);
+      copy_half(a11, 1, P ^ 1);
       barrier();
       mma(0, 1);
       barrier();
@@ -922,6 +933,7 @@ __global__ __launch_bounds__(NT2, 2) void gemm_nt256q_kernel(const alpro_gemm_de
     // ---- epilogue: one 16-row fragment row (16 x 64 fp32 = 4 KiB of wave-private LDS) at a time
     {
       const int mb = tm0 + wr * 128, nb = tn0 + wc * 64;
+      auto rows_ok = [&](int mf) { return mb + mf * 16 < g.M; };   // (wave-uniform)
       auto stage_rows = [&](int mf) {
         wave_lds_order();   // the other lanes' reads of the previous fragment row are issued before these writes ...
 #pragma unroll
@@ -942,10 +954,11 @@ __global__ __launch_bounds__(NT2, 2) void gemm_nt256q_kernel(const alpro_gemm_de
             for (int p = 0; p < 2; ++p)
               pp[p] = __builtin_nontemporal_load((const u32x4*)((const T*)g.C2 + (int64_t)(mb + mf * 16 + p * 8 + (lane >> 3)) * g.ldc2 + nb + (lane & 7) * 8));
           };
-          if (READS_C2) load_pre(0, pring[0]);
+          if (READS_C2 && rows_ok(0)) load_pre(0, pring[0]);
 #pragma unroll
           for (int mf = 0; mf < 8; ++mf) {
-            if (READS_C2 && mf + 1 < 8) load_pre(mf + 1, pring[(mf + 1) & 1]);
+            if (!rows_ok(mf)) break;   // ragged last tile row: fragment rows at or beyond M are not stored (M % 16 == 0: launcher)
+            if (READS_C2 && mf + 1 < 8 && rows_ok(mf + 1)) load_pre(mf + 1, pring[(mf + 1) & 1]);
             stage_rows(mf);
             epi_rows16_c16<T, ACT, 2>(g, stage, mb + mf * 16, nb, lane, bias8, READS_C2 ? pring[mf & 1] : nullptr);
           }
@@ -965,10 +978,11 @@ __global__ __launch_bounds__(NT2, 2) void gemm_nt256q_kernel(const alpro_gemm_de
 #pragma unroll
             for (int j = 0; j < 4; ++j) rr[j] = __builtin_nontemporal_load((const f32x4*)(g.residual + (int64_t)(mb + mf * 16 + r0e + 4 * j) * g.ldr + nb + c4));
           };
-          if (g.residual) load_res(0, rc);
+          if (g.residual && rows_ok(0)) load_res(0, rc);
 #pragma unroll
           for (int mf = 0; mf < 8; ++mf) {
-            if (g.residual && mf + 1 < 8) load_res(mf + 1, rn);
+            if (!rows_ok(mf)) break;
+            if (g.residual && mf + 1 < 8 && rows_ok(mf + 1)) load_res(mf + 1, rn);
             stage_rows(mf);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -1033,16 +1047,21 @@ int launch_gemm_inst(const alpro_gemm_desc_t& g, hipStream_t st) {
                      ((uintptr_t)g.C % 16) == 0;
     const bool shape = (g.N % BN2) == 0 && ((g.lda * 2) % 128) == 0 && ((g.ldw * 2) % 128) == 0 && (g.K % 128) == 0 && g.K >= 256 &&
                        (int64_t)g.M * g.lda * 2 < (int64_t)0xFFFF0000 && (int64_t)g.N * g.ldw * 2 < (int64_t)0xFFFF0000;
-    const bool split_ok = true;   // (row scale / dropout index by absolute row: the remainder launch carries m_off)
+    // ragged M: when the remainder is a multiple of 16 rows the kernel takes the partial tile row itself (invalid copy pieces re-read valid rows,
+    // the epilogue skips fragment rows beyond M) -- ONE launch; the round-4 first form ran the remainder as a second launch on the 128 x 128
+    // kernel: 46 launches of ~46 us per training step at B = 64 (M = 100416 = 392 * 256 + 64), serialised behind the main kernel.  Other
+    // remainders still take that split (the remainder launch carries m_off: row scale / dropout index by absolute row).
+    const bool ragged_in_kernel = m_rem > 0 && (m_rem % 16) == 0;
     const int full_tiles = (g.N / BN2) * (m_full / BM2);
-    if (get_option(OPT_GEMM_KIND) == 1 && (c16 || c32) && shape && split_ok && (force ? force == 256 : full_tiles >= 160)) {
+    if (get_option(OPT_GEMM_KIND) == 1 && (c16 || c32) && shape && (force ? force == 256 : full_tiles >= 160)) {
       alpro_gemm_desc_t gq = g;
-      gq.M = m_full;
+      if (!ragged_in_kernel) gq.M = m_full;
+      const int tiles = (g.N / BN2) * ((gq.M + BM2 - 1) / BM2);
       const int cus = cu_budget();
-      int grid = full_tiles < cus ? (full_tiles + 7) / 8 * 8 : cus;
+      int grid = tiles < cus ? (tiles + 7) / 8 * 8 : cus;
       if (const int cap = get_option(OPT_GEMM_GRID)) grid = cap < grid ? (cap + 7) / 8 * 8 : grid;
       hipLaunchKernelGGL((gemm_nt256q_kernel<T, ACT, MAP>), dim3(grid), dim3(NT2), 2 * STAGE2_BYTES + EPI_BYTES, st, gq);
-      if (m_rem) {
+      if (m_rem && !ragged_in_kernel) {
         alpro_gemm_desc_t gr = g;
         gr.M = m_rem;
         gr.A = (const char*)g.A + (int64_t)m_full * g.lda * 2;

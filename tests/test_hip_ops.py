@@ -353,13 +353,16 @@ def test_gemm_rows_f32(M, N, K, case):
 @pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("M,N,K,case", [(256 * 80, 512, 768, "plain"), (256 * 54, 768, 256, "plain"), (256 * 130, 768, 768, "bias_rowscale"), (256 * 40, 1024, 3072, "f32res"),
                                         (256 * 80, 512, 768, "gelu_save"), (256 * 80, 512, 768, "mul_saved"), (256 * 80, 512, 768, "gelu"), (256 * 44, 1024, 768, "dropout"),
-                                        (256 * 80, 512, 768, "strided"), (256 * 80 + 64, 512, 768, "plain"), (256 * 80 + 64, 512, 768, "gelu_save"), (256 * 392 + 64, 768, 3072, "mul_saved"), (64 * 1569, 768, 3072, "f32res_rowscale"), (16 * 1569 * 4, 768, 256, "f32res_rowscale")])
+                                        (256 * 80, 512, 768, "strided"), (256 * 80 + 64, 512, 768, "plain"), (256 * 80 + 64, 512, 768, "gelu_save"), (256 * 392 + 64, 768, 3072, "mul_saved"), (64 * 1569, 768, 3072, "f32res_rowscale"), (16 * 1569 * 4, 768, 256, "f32res_rowscale"),
+                                        (256 * 80 + 16, 512, 768, "bias_rowscale"), (256 * 80 + 240, 512, 768, "mul_saved"), (256 * 80 + 144, 1024, 256, "f32res"), (256 * 80 + 8, 512, 768, "plain")])
 def test_gemm_8phase_kernel(dt, M, N, K, case):
     """gemm_nt256q_kernel (round 4: 8-phase two-group schedule on 16x16x32 MFMA fragments; option gemm_kind = 1) on full-tile shapes with >= 160
     tiles -- one and several tiles per workgroup, K = 4 / 12 / 48 K-tiles, every epilogue the identity-map shapes of the model use -- against
     fp64 of the same rounded operands, and against the round-3 kernel (gemm_kind = 0) on the same inputs.  Ragged M (the ViT's B * 1569 rows:
-    M % 256 = 64) is split by the launcher: whole tiles on the 8-phase kernel, the last 64 rows on the 128 x 128 kernel (which indexes the
-    row scale by absolute row through the descriptor's m_off)."""
+    M % 256 = 64): a remainder that is a multiple of 16 rows (16 / 64 / 144 / 240 here) is one more tile row of the SAME launch (invalid copy
+    pieces re-read valid rows, fragment rows beyond M are not stored -- the rows behind M must stay untouched: checked through a guard band);
+    any other remainder (+8) is split by the launcher: whole tiles on the 8-phase kernel, the rest on the 128 x 128 kernel (which indexes
+    the row scale by absolute row through the descriptor's m_off)."""
     hip = _hip()
     a, w, b = rnd(M, K, seed=700 + K), rnd(N, K, seed=701, scale=0.05), rnd(N, seed=702)
     A, W = a.to(dt).cuda(), w.to(dt).cuda()
@@ -403,7 +406,9 @@ def test_gemm_8phase_kernel(dt, M, N, K, case):
         with hip.option("gemm_kind", kind):
             if saved is not None:
                 saved.zero_()
-            outs[kind] = hip.gemm(A, W, **kw)
+            guard = torch.full((M + 256, N), 7.0, dtype=kw.get("out_dtype", dt), device="cuda")
+            outs[kind] = hip.gemm(A, W, out=guard[:M], **kw)
+            assert bool((guard[M:] == 7.0).all()), "kind %d wrote rows behind M" % kind
             if saved is not None:
                 outs[("saved", kind)] = saved.clone()
     tol = (2e-5, 2e-4 * math.sqrt(K / 768)) if case.startswith("f32res") else OUT_TOL[dt]
