@@ -611,7 +611,7 @@ extern "C" int alpro_layernorm_bwd_emit(const void* dy, int dy_dtype, int64_t ld
   // workspace given: the column sums (dgamma, dbeta, colsum_pre) leave as per-workgroup partials and are added in a fixed order by a second
   // small kernel -- bit-reproducible; the grid is capped to the slots the workspace holds.  NULL: fp32 atomics (no workspace, order varies).
   // (185 VGPRs: two 4-wave workgroups per CU are resident at a time, so 512 workgroups are one full round -- with a workspace the grid stops
-  // there: a quarter of the partial sums to write and to reduce, measured neutral on the kernel itself)
+  // there: a quarter of the partial sums to write and to reduce)
   int nblk = grid_for(rows, 4 * 8, workspace ? 512 : 256 * 8);
   if (workspace) nblk = (int)std::min<size_t>((size_t)nblk, workspace_bytes / LN_PART_BYTES);
   const dim3 grid(nblk), blk(256);

@@ -118,10 +118,17 @@ _option_values = {}
 
 def set_option(name, value):
     """Measurement knob of the library (alpro_hip_set_option): 'attn_bwd' (16-bit attention backward with 5-8 key tiles: 0 two-phase,
-    1 = default, best per shape, 2 key-owned, 3 / 4 persistent key-owned with / without L2 touches), 'gemm_tile', 'gemm_grid', 'gemm_tune', 'tn_splits' (token ranges of the
-    weight-gradient GEMM), 'tn_kind' (1 = no wgrad epilogue, timing only)."""
+    1 = default, best per shape, 2 key-owned; 3 / 4, the persistent key-owned variants, only in the --ablations build), 'gemm_tile', 'gemm_grid',
+    'gemm_tune', 'gemm_kind' (identity-map 16-bit shapes: 0 = round-3 persistent kernel, 1 = 8-phase two-group kernel, the default), 'tn_splits'
+    (token ranges of the weight-gradient GEMM), 'tn_kind' (0, 2 = two-group schedule; 1 = no wgrad epilogue, --ablations build only), 'cu_budget'
+    (CUs the persistent grids are sized for; 0 = all)."""
     _check(load().alpro_hip_set_option(name.encode(), int(value)), "alpro_hip_set_option")
     _option_values[name] = int(value)
+
+
+def get_option(name):
+    """The value last set through set_option (the library's default otherwise)."""
+    return _option_values.get(name, _OPTION_DEFAULTS[name])
 
 
 class option:

@@ -488,7 +488,15 @@ def main():
             mm = _re.match(r"M=(\d+) N=(\d+) K=(\d+) act=(\S+) res=(\d) out=(\S+) map=(\S+)", key)
             M_, N_, K_ = int(mm.group(1)), int(mm.group(2)), int(mm.group(3))
             big = ((N_ + 255) // 256) * ((M_ + 255) // 256) >= 160 and K_ >= 128
-            kn = "%s<%s, %s, %s%s>" % ("gemm_nt256p_kernel" if big else "gemm_nt_kernel", {"fp16": "f16_t", "bf16": "bf16_t", "fp32": "float"}[args.dtype], mm.group(4), mm.group(7), ", 1" if big else "")
+            tname = {"fp16": "f16_t", "bf16": "bf16_t", "fp32": "float"}[args.dtype]
+            # round 4: identity-map 16-bit shapes with whole 256-column tiles and an even number >= 4 of K-tiles run on the 8-phase kernel --
+            # 16-bit outputs with any epilogue, fp32 outputs with the plain (bias / row scale / residual) one; a ragged last tile row included
+            q_ok = (args.dtype != "fp32" and mm.group(7) == "0" and N_ % 256 == 0 and K_ % 128 == 0 and K_ >= 256 and (N_ // 256) * (M_ // 256) >= 160
+                    and (mm.group(6) != "float32" or mm.group(4) == "0") and hip.get_option("gemm_kind") == 1)
+            if q_ok:
+                kn = "gemm_nt256q_kernel<%s, %s, 0>" % (tname, mm.group(4))
+            else:
+                kn = "%s<%s, %s, %s%s>" % ("gemm_nt256p_kernel" if big else "gemm_nt_kernel", tname, mm.group(4), mm.group(7), ", 1" if big else "")
             d_ = inst.setdefault(kn, [0, 0.0, 0.0])
             d_[0] += c
             d_[1] += f
@@ -509,7 +517,7 @@ def main():
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype, "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2**30, 2), "data": "synthetic (randn clips, random token ids; random-init weights)",
             "config": {"workload": wl, "per_gpu_batch": B, "frames": T, "parallelism": ("dp%d (RCCL: feature all-gather + flat gradient all-reduce)" % world) if train else ("dp%d (independent clips, no data-path collective)" % world)},
-            "mode": mode_name(args.dtype),
+            "mode": mode_name(args.dtype), "deterministic_reductions": bool(hip.deterministic()),
             "world_size": world, "dist_backend": (torch.distributed.get_backend() if torch.distributed.is_initialized() else "none (single process)"),
             "rccl_version": ".".join(str(v) for v in torch.cuda.nccl.version()) if hasattr(torch.cuda, "nccl") else None,
             "nccl_channels": {k_: os.environ.get(k_) for k_ in ("NCCL_MAX_NCHANNELS", "NCCL_MIN_NCHANNELS", "ALPRO_OVERLAP_BACKWARD") if os.environ.get(k_) is not None},

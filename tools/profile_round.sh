@@ -1,6 +1,6 @@
 #!/bin/bash
 # One round's profile evidence (run on the GPU box through gpurun):  bash tools/profile_round.sh <tag, e.g. r2>
-#   - default bench line (pretrain_step B=64) and visual_fwd B=32 bench line, with the per-shape GEMM table
+#   - (last, so that they can cite this round's PMC bytes) default bench line (pretrain_step B=64) and visual_fwd B=32 bench line, with the per-shape GEMM table
 #   - rocprofv3 --kernel-trace --stats of both commands -> per-kernel stats CSV
 #   - separate --pmc passes (never combined with traces): FETCH_SIZE, WRITE_SIZE (HBM traffic) and the MFMA-utilisation counters
 # Everything lands in gpurun_out/<tag>/; copy what should be judged into profiles/.
@@ -10,8 +10,6 @@ R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/$TAG
 mkdir -p $O
 cd $R
-ALPRO_BENCH_SHAPES=1 python bench.py --steps 10 --warmup 3 > $O/bench_pretrain_step_B64.json 2> $O/gemm_shapes_pretrain_step_B64.txt
-ALPRO_BENCH_SHAPES=1 python bench.py --workload visual_fwd --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_visual_fwd_B32.json 2> $O/gemm_shapes_visual_fwd_B32.txt
 cd /tmp
 for wl in pretrain_step visual_fwd; do
   # clean, step-delimited traces: no divST pass, no parity model, no CPU baseline inside the traced process -> every per-step
@@ -28,6 +26,12 @@ for wl in pretrain_step visual_fwd; do
   rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE -d $O/pmc_${wl}_mfma -o mfma --output-format csv -- python $R/bench.py $ARGS > $O/pmc_${wl}_mfma.log 2>&1
   python $R/tools/mfma_summary.py $(find $O/pmc_${wl}_mfma -name '*counter_collection.csv' | head -1) > $O/${wl}_${B}_mfma_util.txt 2>&1
 done
+# the bench lines LAST: bench.py reads the PMC bytes per GEMM launch from the latest profiles/r*_pretrain_step_B64_pmc_traffic.json, i.e. from
+# the passes above (copied into profiles/ here on the box; the same file comes home through gpurun_out/ and is committed under that name)
+cd $R
+cp $O/pretrain_step_B64_pmc_traffic.json profiles/${TAG}_pretrain_step_B64_pmc_traffic.json 2>/dev/null
+ALPRO_BENCH_SHAPES=1 python bench.py --steps 10 --warmup 3 > $O/bench_pretrain_step_B64.json 2> $O/gemm_shapes_pretrain_step_B64.txt
+ALPRO_BENCH_SHAPES=1 python bench.py --workload visual_fwd --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_visual_fwd_B32.json 2> $O/gemm_shapes_visual_fwd_B32.txt
 find $O -name '*.csv' -size +1500k -delete
 find $O -name '*.db' -delete
 du -sh $O; ls $O
