@@ -192,7 +192,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
                                                             const float* __restrict__ x, int64_t ldx, const float* __restrict__ gamma, float eps,
                                                             float* __restrict__ dx, int64_t ld_dx, int accumulate, float* __restrict__ dgamma,
                                                             float* __restrict__ dbeta, int64_t rows, int mode, int p0, int p1, float drop_p,
-                                                            uint32_t drop_seed, const EmitArgs em, float* __restrict__ part) {
+                                                            uint32_t drop_seed, const EmitArgs em, float* __restrict__ part, float* __restrict__ cls_ws) {
   __shared__ float red[2][4][LN_D];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int64_t wave = (int64_t)blockIdx.x * 4 + w;
@@ -253,34 +253,34 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
       continue;
     }
     const SrcRow src = ln_src_row(mode, p0, p1, m);
-    // FRAME_TOKENS: the clip's CLS row receives one term per frame.  The wave that draws frame 0 computes all T of them and adds them in
-    // frame order -- one writer per row, fixed order (rounds 1-3 let T waves race with fp32 atomics: run-to-run differences in the last bit)
-    int reps = 1;
-    if (src.shared) {
-      if ((m / (p1 + 1)) % p0 != 0) continue;
-      reps = p0;
-    }
     float fin[12];  // the finished gradient row
+    row_grad(m, src.row, fin);
+    if (src.shared) {
+      // FRAME_TOKENS: the clip's CLS row receives one term per frame.  With a workspace the term of frame copy m / (N + 1) = b * T + t is
+      // parked in cls_ws[b * T + t] and cls_rows_reduce_kernel adds the T terms of a clip in frame order (one writer per row, fixed order);
+      // without one, fp32 atomics straight into the row (rounds 1-3: run-to-run differences in the last bit)
+      if (cls_ws) {
+        float* o = cls_ws + (m / (p1 + 1)) * LN_D;
 #pragma unroll
-    for (int i = 0; i < 12; ++i) fin[i] = 0.f;
-#pragma unroll 1
-    for (int rep = 0; rep < reps; ++rep) {
-      float one[12];
-      row_grad(m + (int64_t)rep * (p1 + 1), src.row, one);
+        for (int i = 0; i < 3; ++i) *(float4*)(o + i * 256 + lane * 4) = make_float4(fin[4 * i], fin[4 * i + 1], fin[4 * i + 2], fin[4 * i + 3]);
+      } else {
+        float* o = dx + src.row * ld_dx;
 #pragma unroll
-      for (int i = 0; i < 12; ++i) fin[i] += one[i];
+        for (int i = 0; i < 12; ++i) atomicAdd(o + (i >> 2) * 256 + lane * 4 + (i & 3), fin[i]);
+      }
+      continue;
     }
     float* o = dx + src.row * ld_dx;
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
       float* p = o + i * 256 + lane * 4;
-      if (accumulate || src.shared) {
+      if (accumulate) {
         const float4 c = *(const float4*)p;
         fin[4 * i] += c.x; fin[4 * i + 1] += c.y; fin[4 * i + 2] += c.z; fin[4 * i + 3] += c.w;
       }
       __builtin_nontemporal_store(f32x4{fin[4 * i], fin[4 * i + 1], fin[4 * i + 2], fin[4 * i + 3]}, (f32x4*)p);
     }
-    if (em.mode != ALPRO_EMIT_NONE && !src.shared) emit_row<TE>(em, src.row, lane, fin, cp);
+    if (em.mode != ALPRO_EMIT_NONE) emit_row<TE>(em, src.row, lane, fin, cp);
   }
   // block reduction of dgamma / dbeta (and the emit's column sums).  part != nullptr: this workgroup's sums go to its slot of the caller's
   // workspace -- part[block][3][768] -- and colsum_reduce_kernel adds the slots in a fixed order (bit-reproducible, the default since
@@ -339,6 +339,20 @@ __global__ __launch_bounds__(1024) void colsum_reduce_kernel(const float* __rest
     const float4 c = *o;
     *o = make_float4(c.x + t.x, c.y + t.y, c.z + t.z, c.w + t.w);
   }
+}
+
+// dx[clip b's CLS row] += sum over the T frame terms parked in cls_ws[b * T + t] by layernorm_bwd_kernel, t ascending: one workgroup of 192
+// lanes (float4 each) per clip.
+__global__ __launch_bounds__(192) void cls_rows_reduce_kernel(const float* __restrict__ cls_ws, float* __restrict__ dx, int64_t ld_dx, int T, int N) {
+  const int b = blockIdx.x, c = threadIdx.x * 4;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int t = 0; t < T; ++t) {
+    const float4 v = *(const float4*)(cls_ws + ((int64_t)b * T + t) * LN_D + c);
+    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+  }
+  float4* o = (float4*)(dx + (int64_t)b * (1 + (int64_t)N * T) * ld_dx + c);
+  const float4 cur = *o;
+  *o = make_float4(cur.x + s.x, cur.y + s.y, cur.z + s.z, cur.w + s.w);
 }
 
 // ---- out[m, :] = (T)(scale(m) * src[row(m), :]): gathers fp32 token-gradient rows into a GEMM operand ---------------
@@ -609,15 +623,21 @@ extern "C" int alpro_layernorm_bwd_emit(const void* dy, int dy_dtype, int64_t ld
   em.drop_p = emit_drop_p; em.drop_seed = emit_drop_seed; em.colsum_pre = emit_colsum_pre; em.extra_cls = emit_extra_cls;
   ALPRO_CHECK(emit_mode == ALPRO_EMIT_NONE || emit_dtype == dy_dtype || dy_dtype == ALPRO_F32, "alpro_layernorm_bwd_emit: emit_dtype must be dy's dtype, or any dtype when dy is the fp32 stream");
   // workspace given: the column sums (dgamma, dbeta, colsum_pre) leave as per-workgroup partials and are added in a fixed order by a second
-  // small kernel -- bit-reproducible; the grid is capped to the slots the workspace holds.  NULL: fp32 atomics (no workspace, order varies).
-  // (185 VGPRs: two 4-wave workgroups per CU are resident at a time, so 512 workgroups are one full round -- with a workspace the grid stops
-  // there: a quarter of the partial sums to write and to reduce)
-  int nblk = grid_for(rows, 4 * 8, workspace ? 512 : 256 * 8);
-  if (workspace) nblk = (int)std::min<size_t>((size_t)nblk, workspace_bytes / LN_PART_BYTES);
+  // small kernel, and the T frame terms of every clip's CLS row (FRAME_TOKENS) are parked behind them for cls_rows_reduce_kernel --
+  // bit-reproducible.  Layout: [workgroups][3][768] floats, then [B * T][768] floats; the grid is capped to what fits.  NULL: fp32 atomics.
+  const bool frame = map_mode == ALPRO_MAP_FRAME_TOKENS;
+  const size_t cls_bytes = frame ? (size_t)(rows / (map_p1 + 1)) * LN_D * sizeof(float) : 0;
+  ALPRO_CHECK(!workspace || workspace_bytes >= cls_bytes + LN_PART_BYTES, "alpro_layernorm_bwd: the workspace must hold the CLS frame terms (%zu bytes) and at least one workgroup's sums", cls_bytes);
+  // workgroup count: 8 rows per wave at least, 2048 workgroups at most -- two 4-wave workgroups per CU are resident at a time (185 VGPRs), so
+  // that is 4 rounds; fewer, fatter workgroups measured slower (tools/ln_bwd_bench.py: 1024: +14 %, 512: +5 %; `ln_grid` overrides the cap)
+  const int cap = get_option(OPT_LN_GRID);
+  int nblk = grid_for(rows, 4 * 8, cap > 0 ? cap : 256 * 8);
+  if (workspace) nblk = (int)std::min<size_t>((size_t)nblk, (workspace_bytes - cls_bytes) / LN_PART_BYTES);
   const dim3 grid(nblk), blk(256);
   float* part = (float*)workspace;
+  float* cls_ws = (workspace && frame) ? part + (size_t)nblk * 3 * LN_D : nullptr;
   hipStream_t st = (hipStream_t)stream;
-#define ALPRO_LNB(T, TE) hipLaunchKernelGGL((layernorm_bwd_kernel<T, TE>), grid, blk, 0, st, (const T*)dy, ld_dy, dy2, x, ldx, gamma, eps, dx, ld_dx, accumulate, dgamma, dbeta, (int64_t)rows, map_mode, map_p0, map_p1, drop_p, drop_seed, em, part)
+#define ALPRO_LNB(T, TE) hipLaunchKernelGGL((layernorm_bwd_kernel<T, TE>), grid, blk, 0, st, (const T*)dy, ld_dy, dy2, x, ldx, gamma, eps, dx, ld_dx, accumulate, dgamma, dbeta, (int64_t)rows, map_mode, map_p0, map_p1, drop_p, drop_seed, em, part, cls_ws)
   if (dy_dtype == ALPRO_F32 && emit_mode != ALPRO_EMIT_NONE && emit_dtype == ALPRO_BF16) ALPRO_LNB(float, bf16_t);
   else if (dy_dtype == ALPRO_F32 && emit_mode != ALPRO_EMIT_NONE && emit_dtype == ALPRO_F16) ALPRO_LNB(float, f16_t);
   else if (dy_dtype == ALPRO_F32) ALPRO_LNB(float, float);
@@ -626,6 +646,7 @@ extern "C" int alpro_layernorm_bwd_emit(const void* dy, int dy_dtype, int64_t ld
   else { set_error("alpro_layernorm_bwd: bad dtype %d", dy_dtype); return ALPRO_ERR_INVALID; }
 #undef ALPRO_LNB
   if (part) hipLaunchKernelGGL(colsum_reduce_kernel, dim3(LN_D / 64, emit_colsum_pre ? 3 : 2), dim3(1024), 0, st, part, nblk, 3, dgamma, dbeta, emit_colsum_pre);
+  if (cls_ws) hipLaunchKernelGGL(cls_rows_reduce_kernel, dim3(rows / (map_p1 + 1) / map_p0), dim3(192), 0, st, cls_ws, dx, ld_dx, map_p0, map_p1);
   return check_launch("alpro_layernorm_bwd");
 }
 

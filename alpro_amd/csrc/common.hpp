@@ -218,7 +218,7 @@ __device__ __forceinline__ void attn_unit(int blk, int nblk, int H, int order, i
     h = blk - b * H;
   }
 }
-enum { OPT_GEMM_TILE = 0, OPT_GEMM_GRID = 1, OPT_GEMM_TUNE = 2, OPT_TN_SPLITS = 3, OPT_TN_KIND = 4, OPT_GEMM_TAIL = 5, OPT_ATTN_BWD = 6, OPT_ATTN_ORDER = 7, OPT_GEMM_KIND = 8, OPT_CU_BUDGET = 9, OPT_COUNT = 10 };
+enum { OPT_GEMM_TILE = 0, OPT_GEMM_GRID = 1, OPT_GEMM_TUNE = 2, OPT_TN_SPLITS = 3, OPT_TN_KIND = 4, OPT_GEMM_TAIL = 5, OPT_ATTN_BWD = 6, OPT_ATTN_ORDER = 7, OPT_GEMM_KIND = 8, OPT_CU_BUDGET = 9, OPT_LN_GRID = 10, OPT_COUNT = 11 };
 int get_option(int which);
 // Compute units the persistent GEMM grids and the weight-gradient range plan may count on (round 4): 256, or less while a collective's kernels
 // hold CUs (alpro_amd.dist sets "cu_budget" while the overlapped gradient exchange is in flight: a persistent one-workgroup-per-CU launch that

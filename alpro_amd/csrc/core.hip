@@ -19,8 +19,8 @@ void set_error(const char* fmt, ...) {
 }
 
 namespace {
-const char* const kOptNames[OPT_COUNT] = {"gemm_tile", "gemm_grid", "gemm_tune", "tn_splits", "tn_kind", "gemm_tail", "attn_bwd", "attn_order", "gemm_kind", "cu_budget"};
-const char* const kOptEnv[OPT_COUNT] = {"ALPRO_GEMM_TILE", "ALPRO_GEMM_GRID", "ALPRO_GEMM_TUNE", "ALPRO_TN_SPLITS", "ALPRO_TN_KIND", "ALPRO_GEMM_TAIL", "ALPRO_ATTN_BWD", "ALPRO_ATTN_ORDER", "ALPRO_GEMM_KIND", "ALPRO_CU_BUDGET"};
+const char* const kOptNames[OPT_COUNT] = {"gemm_tile", "gemm_grid", "gemm_tune", "tn_splits", "tn_kind", "gemm_tail", "attn_bwd", "attn_order", "gemm_kind", "cu_budget", "ln_grid"};
+const char* const kOptEnv[OPT_COUNT] = {"ALPRO_GEMM_TILE", "ALPRO_GEMM_GRID", "ALPRO_GEMM_TUNE", "ALPRO_TN_SPLITS", "ALPRO_TN_KIND", "ALPRO_GEMM_TAIL", "ALPRO_ATTN_BWD", "ALPRO_ATTN_ORDER", "ALPRO_GEMM_KIND", "ALPRO_CU_BUDGET", "ALPRO_LN_GRID"};
 int g_opts[OPT_COUNT];
 // Values that change RESULTS (gemm_tune 3 / 4 / 10 / 11 / 12: epilogue / synchronisation ablations; tn_kind 1: weight gradient without
 // its epilogue) exist only in the measurement build (-DALPRO_ABLATIONS, `python -m alpro_amd.build --ablations`, used by tools/); the

@@ -112,7 +112,7 @@ def load():
     return lib
 
 
-_OPTION_DEFAULTS = {"gemm_tile": 0, "gemm_grid": 0, "gemm_tune": 1, "tn_splits": 0, "tn_kind": 0, "gemm_tail": 1, "attn_bwd": 1, "attn_order": 0, "gemm_kind": 1, "cu_budget": 0}
+_OPTION_DEFAULTS = {"gemm_tile": 0, "gemm_grid": 0, "gemm_tune": 1, "tn_splits": 0, "tn_kind": 0, "gemm_tail": 1, "attn_bwd": 1, "attn_order": 0, "gemm_kind": 1, "cu_budget": 0, "ln_grid": 0}
 _option_values = {}
 
 
@@ -121,7 +121,7 @@ def set_option(name, value):
     1 = default, best per shape, 2 key-owned; 3 / 4, the persistent key-owned variants, only in the --ablations build), 'gemm_tile', 'gemm_grid',
     'gemm_tune', 'gemm_kind' (identity-map 16-bit shapes: 0 = round-3 persistent kernel, 1 = 8-phase two-group kernel, the default), 'tn_splits'
     (token ranges of the weight-gradient GEMM), 'tn_kind' (0, 2 = two-group schedule; 1 = no wgrad epilogue, --ablations build only), 'cu_budget'
-    (CUs the persistent grids are sized for; 0 = all)."""
+    (CUs the persistent grids are sized for; 0 = all), 'ln_grid' (cap on the LayerNorm backward's workgroup count; 0 = the default plan)."""
     _check(load().alpro_hip_set_option(name.encode(), int(value)), "alpro_hip_set_option")
     _option_values[name] = int(value)
 
@@ -616,14 +616,17 @@ def deterministic():
     return _DETERMINISTIC[0]
 
 
+_REDUCE_WS_BYTES = 8192 * 3 * 768 * 4 + 4096 * 768 * 4   # up to 8192 workgroups' column sums (the default plan uses 2048) + the CLS frame terms of up to 4096 frames (B * T)
+
+
 def _reduce_ws(device):
     """(pointer, bytes) of the reduction workspace handed to alpro_layernorm_bwd / _gather_cast / _sumsq: the head of the per-device grow-only
     buffer the weight-gradient GEMM also uses (all of them run on one stream, each finishes with its own reduce kernel) -- or (None, 0)
     when reproducibility is switched off."""
     if not _DETERMINISTIC[0]:
         return None, 0
-    ws = _tn_workspace(device, 2048 * 3 * 768 * 4)
-    return _ptr(ws), 2048 * 3 * 768 * 4
+    ws = _tn_workspace(device, _REDUCE_WS_BYTES)
+    return _ptr(ws), _REDUCE_WS_BYTES
 
 
 def gemm_tn_acc(a, b, c, colsum=None, atomic=None):

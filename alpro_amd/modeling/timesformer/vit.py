@@ -151,16 +151,17 @@ class Block(nn.Module):
         sa = self.attn
         return hip.gemm_rows(x_cls_in, self._w("s_qkv", sa.qkv, torch.float32), bias=sa.qkv.bias, ln=(self.norm1.weight, self.norm1.bias, VIT_EPS))
 
-    def _cls_chain(self, x_cls_in, o_c, B, T, drop_s=None, drop_m=None):
-        """o_c: (B*T, D) fp32 attention output of the CLS query of every frame (alpro_attn_fwd's cls_out) -> (CLS rows before the MLP, CLS rows of
-        the block output).  Three alpro_gemm_rows_f32 launches (norm2 fused into fc1's operand load) and the frame mean."""
+    def _cls_chain(self, x_cls_in, o_c, B, T, drop_s, drop_m, x2_out, out_out):
+        """x_cls_in: (B, D) fp32 CLS rows of the block input (a row-strided view is fine); o_c: (B*T, D) fp32 attention output of the CLS query of
+        every frame (alpro_attn_fwd's cls_out).  Writes the CLS rows before the MLP into x2_out and the CLS rows of the block output into
+        out_out (both (B, D), row-strided views of the token tensors are fine): three alpro_gemm_rows_f32 launches (norm2 fused into fc1's
+        operand load) and alpro_cls_mean_residual for the frame mean -- no torch glue in between."""
         sa = self.attn
         f32 = torch.float32
         p_c = hip.gemm_rows(o_c, self._w("s_proj", sa.proj, f32), bias=sa.proj.bias, row_scale=drop_s)
-        x_cls2 = x_cls_in + p_c.view(B, T, -1).mean(1)
-        f1c = hip.gemm_rows(x_cls2, self._w("fc1", self.mlp.fc1, f32), bias=self.mlp.fc1.bias, act=hip.ACT_GELU, ln=(self.norm2.weight, self.norm2.bias, VIT_EPS))
-        x_cls_out = hip.gemm_rows(f1c, self._w("fc2", self.mlp.fc2, f32), bias=self.mlp.fc2.bias, residual=x_cls2, row_scale=drop_m)
-        return x_cls2, x_cls_out
+        hip.cls_mean_residual(x_cls_in, p_c, x2_out, B, T)
+        f1c = hip.gemm_rows(x2_out, self._w("fc1", self.mlp.fc1, f32), bias=self.mlp.fc1.bias, act=hip.ACT_GELU, ln=(self.norm2.weight, self.norm2.bias, VIT_EPS))
+        hip.gemm_rows(f1c, self._w("fc2", self.mlp.fc2, f32), bias=self.mlp.fc2.bias, residual=x2_out, row_scale=drop_m, out=out_out)
 
     def _drop(self, rows, device):
         if not isinstance(self.drop_path, DropPath):
@@ -229,7 +230,7 @@ class Block(nn.Module):
         hip.gemm(f1, self._w("fc2", self.mlp.fc2, dt), out=xf, bias=self.mlp.fc2.bias, out_dtype=torch.float32, residual=xf,
                  row_scale=drop_m, row_scale_group=S)
         if cp:
-            x[:, 0] = self._cls_chain(x_cls_in, o_c, B, T, drop_s, drop_m)[1]
+            self._cls_chain(x_cls_in, o_c, B, T, drop_s, drop_m, torch.empty_like(x_cls_in), x[:, 0])
         return x
 
     # ---- training path: fresh buffers (the backward needs every LayerNorm input), explicit backward ----------
@@ -296,9 +297,7 @@ class Block(nn.Module):
         if rt.cls_precise(dt) and self.fuse_residual_ln and self.merge_temporal_proj:
             # precise CLS rows: the block output's CLS row and the saved pre-MLP stream's CLS row (norm2's backward input) take the fp32 values;
             # the backward differentiates the 16-bit graph as before (its CLS-row operands differ from these by one rounding)
-            x_cls2, x_cls_out = self._cls_chain(x[:, 0], o_c, B, T, sv["drop_s"], sv["drop_m"])
-            x2[:, 0] = x_cls2
-            out[:, 0] = x_cls_out
+            self._cls_chain(x[:, 0], o_c, B, T, sv["drop_s"], sv["drop_m"], x2[:, 0], out[:, 0])
         sv.update(h=h, qkv_t=qkv_t, a_t=a_t, lse_t=lse_t, pr=pr, xt=xt, hs=hs, qkv_s=qkv_s, a_s=a_s, lse_s=lse_s, x2=x2, h2=h2, u=u, f1=f1)
         return out, sv
 

@@ -130,16 +130,17 @@ class BertLayer(nn.Module):
         f32 = torch.float32
         so = self.attention.output
         eps = self.config.layer_norm_eps
-        d1_c = hip.gemm_rows(ctx_c, self._ops.get("ao_w", so.dense.weight, f32), bias=so.dense.bias)
-        if hp > 0:
-            d1_c = torch.where(d1.view(B, L, -1)[:, 0] != 0, d1_c * (1.0 / (1.0 - hp)), torch.zeros_like(d1_c))
-        s1_c = hc + d1_c
+        # dense -> hidden dropout (the main path's mask, read back from its zeros) -> residual: fused into the GEMM's residual input when no
+        # dropout is active, one addcmul otherwise
+        def dense_res(a, w, bias, res, d_main):
+            if hp <= 0:
+                return hip.gemm_rows(a, w, bias=bias, residual=res)
+            keep = (d_main.view(B, L, -1)[:, 0] != 0).to(f32).mul_(1.0 / (1.0 - hp))
+            return torch.addcmul(res, hip.gemm_rows(a, w, bias=bias), keep)
+        s1_c = dense_res(ctx_c, self._ops.get("ao_w", so.dense.weight, f32), so.dense.bias, hc, d1)
         a32_c = hip.layernorm(s1_c, so.LayerNorm.weight, so.LayerNorm.bias, eps, f32)
         it_c = hip.gemm_rows(a32_c, self._ops.get("i_w", self.intermediate.dense.weight, f32), bias=self.intermediate.dense.bias, act=hip.ACT_GELU)
-        d2_c = hip.gemm_rows(it_c, self._ops.get("o_w", self.output.dense.weight, f32), bias=self.output.dense.bias)
-        if hp > 0:
-            d2_c = torch.where(d2.view(B, L, -1)[:, 0] != 0, d2_c * (1.0 / (1.0 - hp)), torch.zeros_like(d2_c))
-        s2_c = a32_c + d2_c
+        s2_c = dense_res(it_c, self._ops.get("o_w", self.output.dense.weight, f32), self.output.dense.bias, a32_c, d2)
         o32_c = hip.layernorm(s2_c, self.output.LayerNorm.weight, self.output.LayerNorm.bias, eps, f32)
         return s1_c, a32_c, s2_c, o32_c
 
@@ -178,8 +179,8 @@ class BertLayer(nn.Module):
                 D = h32.shape[1]
                 s1_c, a32_c, s2_c, o32_c = self._cls_chain(hc, ctx_c, d1, d2, B, L, hp if seed1 else 0.0)
                 o32.view(B, L, D)[:, 0] = o32_c
-                o_t.view(B, L, D)[:, 0] = o32_c.to(dt)
-                a_t.view(B, L, D)[:, 0] = a32_c.to(dt)       # (the FFN's saved input row, for its weight gradient)
+                o_t.view(B, L, D)[:, 0].copy_(o32_c)          # (copy_ converts: one launch instead of .to() + copy)
+                a_t.view(B, L, D)[:, 0].copy_(a32_c)          # (the FFN's saved input row, for its weight gradient)
                 if save:                                     # the two LayerNorm backward inputs
                     s1.view(B, L, D)[:, 0] = s1_c
                     s2.view(B, L, D)[:, 0] = s2_c
@@ -559,29 +560,37 @@ class _LMHeadRun:
         t = hd.transform
         M, V = self.x.shape[0], hd.decoder.weight.shape[0]
         Vp = (V + 63) // 64 * 64
+        up = None
         if self.labels is not None:
             dl = self.dl                       # (softmax - onehot) / n_valid, already in the operand dtype
             if dloss is not None:
                 up = dloss.reshape(()).float()        # upstream scale of the loss (1 in the reference's sum of losses; the loss scale under fp16)
                 if getattr(self, "pre_scale", None) is not None:
                     up = up / self.pre_scale.reshape(())   # already applied at forward time
-                dl = dl * up                           # fp32 scalar, one rounding
             if dlogits is not None:            # someone also differentiated through mlm_scores
-                dl = dl.clone()
+                dl = (dl * up) if up is not None else dl.clone()
+                up = None
                 dl[:, :V] += dlogits.reshape(M, V).to(dt)
+            # otherwise `up` (a device scalar, == 1 in the usual sum of losses) is NOT multiplied into the (M, vocab) tensor -- a 0.3 GB pass for a
+            # factor of one -- but into the three small things that are linear in dl: the decoder dgrad's (M, H) result, the (M, H) operand of
+            # the tied weight's gradient, and the bias column sums
         else:
             dl = torch.zeros((M, Vp), dtype=dt, device=dlogits.device)
             dl[:, :V] = dlogits.reshape(M, V)
         dn = tr.dgrad(dl, tr.transposed_operand(hd._ops, "dec_w^T", hd.decoder.weight, dt))
+        n_op = self.n
+        if up is not None:
+            dn = dn * up
+            n_op = n_op * up
         # decoder weight is the (tied) word-embedding table: dW (V, H) += dl^T n ; bias += colsum(dl)
         gw = tr.grad_buffer(hd.decoder.weight, zero=True)[0]
         cs = torch.zeros(Vp, dtype=torch.float32, device=dl.device)
         if dt != torch.float32:
-            hip.gemm_tn_acc(dl[:, :V], self.n, gw, colsum=cs)
+            hip.gemm_tn_acc(dl[:, :V], n_op, gw, colsum=cs)
         else:
             dlT = hip.transpose(dl, colsum=cs)
-            hip.gemm(dlT[:V], hip.transpose(self.n), out=gw, out_dtype=torch.float32, residual=gw)
-        tr.add_grad(hd.bias, cs[:V])
+            hip.gemm(dlT[:V], hip.transpose(n_op), out=gw, out_dtype=torch.float32, residual=gw)
+        tr.add_grad(hd.bias, cs[:V] if up is None else cs[:V] * up)
         dg = torch.empty_like(self.g)
         gw, gb = tr.grad_buffer(t.LayerNorm.weight, zero=True)[0], tr.grad_buffer(t.LayerNorm.bias, zero=True)[0]
         hip.layernorm_bwd(dn, self.g, t.LayerNorm.weight, hd.config.layer_norm_eps, dg, gw, gb, accumulate=False)

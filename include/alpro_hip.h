@@ -228,11 +228,14 @@ int alpro_attn_temporal_bwd(const void* qkv, const void* out, const void* dout, 
 
 /* LayerNorm backward over D == 768: dx[map(m)] (+)= dLN(dy[m] (+ dy2[m]), x[map(m)]); dgamma/dbeta are ACCUMULATED
  * into fp32 buffers.  The forward gather map becomes a scatter; a row gathered more than once (the clip's CLS row under
- * FRAME_TOKENS, once per frame) is owned by ONE wave that adds the T terms in frame order -- that map requires accumulate = 1.
- * Column sums (dgamma, dbeta, the emit's colsum_pre) -- REDUCTION WORKSPACE (ABI 16), the same contract in alpro_gather_cast / alpro_sumsq:
- *   workspace != NULL (16-byte aligned, >= 9216 bytes; 2048 * 9216 bytes never caps the grid): every workgroup writes its partial sums
- *   to its own slot and a second small kernel adds the slots in a fixed order -> results are bit-reproducible run to run;
- *   workspace == NULL: one fp32 atomic per column per workgroup (no extra memory; the last bits vary with the arrival order).
+ * FRAME_TOKENS, once per frame) receives T terms -- that map requires accumulate = 1.
+ * Column sums (dgamma, dbeta, the emit's colsum_pre) and those T terms -- REDUCTION WORKSPACE (ABI 16), the same contract in
+ * alpro_gather_cast / alpro_sumsq:
+ *   workspace != NULL (16-byte aligned; >= 9216 bytes, plus rows / (N + 1) * 3072 bytes under FRAME_TOKENS; 2048 * 9216 bytes + that
+ *   never cap the grid): every workgroup writes its partial sums to its own slot, every frame's CLS term is parked in its own row, and
+ *   two small kernels add slots / terms in a fixed order -> results are bit-reproducible run to run;
+ *   workspace == NULL: fp32 atomics (one per column per workgroup; the CLS terms straight into the row): no extra memory, the last bits
+ *   vary with the arrival order.
  *   The buffer is scratch: used in stream order, contents meaningless afterwards, may be shared by every call on one stream. */
 int alpro_layernorm_bwd(const void* dy, int dy_dtype, int64_t ld_dy, const float* dy2, const float* x, int64_t ldx,
                         const float* gamma, float eps, float* dx, int64_t ld_dx, int accumulate, float* dgamma,

@@ -11,7 +11,7 @@ from alpro_amd.optim import FlatAdamW
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 hip.load()
-rt.set_compute_dtype("bf16")
+rt.set_compute_dtype(os.environ.get("ALPRO_BENCH_DTYPE", "fp16"))
 dev = torch.device("cuda", 0)
 torch.manual_seed(1234)
 model = AlproForPretrain(bench.Cfg(bench.BERT_CFG), dict(bench.VENC, num_frm=8)).to(dev).train()
@@ -21,7 +21,7 @@ batch = bench.synth_batch(B, 8, dev, seed=0, full=True)
 
 def step():
     out = model(batch)
-    (out["mlm_loss"] + out["itm_loss"] + out["itc_loss"] + out["mpm_loss"]).backward()
+    opt.backward(out["mlm_loss"] + out["itm_loss"] + out["itc_loss"] + out["mpm_loss"])   # (scaled under fp16 operands)
     opt.step()
     opt.zero_grad()
 
@@ -30,7 +30,11 @@ for _ in range(3):
     step()
 torch.cuda.synchronize()
 from torch.profiler import ProfilerActivity, profile
-with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
+try:
+    xcfg = dict(experimental_config=torch._C._profiler._ExperimentalConfig(verbose=True))   # (newer torch: python stacks need it)
+except Exception:  # noqa: BLE001
+    xcfg = {}
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True, **xcfg) as prof:
     step()
     torch.cuda.synchronize()
 ev = prof.events()
@@ -43,8 +47,8 @@ for e in ev:
         continue
     src = "?"
     for fr in e.stack:
-        if "alpro_amd/" in fr or "bench.py" in fr or "tools/aten_tail" in fr:
-            src = fr.split("/root/repo/")[-1] if "/root/repo/" in fr else fr[-90:]
+        if ("alpro_amd/" in fr or "bench.py" in fr or "tools/aten_tail" in fr) and "alpro_amd/hip.py" not in fr:
+            src = fr[fr.index("alpro_amd/"):] if "alpro_amd/" in fr else fr[-90:]
             break
     a = agg[(e.name, src)]
     a[0] += 1
