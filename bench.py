@@ -237,9 +237,10 @@ def measure_divst(dev, T, model=None, B=32, iters=5):
 
     def cls(*a, **k):      # round-2 form (Block.fuse_residual_ln = False): the sub-blocks end with alpro_cls_mean_residual
         out = orig_cls(*a, **k)
-        e1 = torch.cuda.Event(enable_timing=True)
-        e1.record()
-        marks[-1][1] = e1
+        if marks[-1][1] is None:   # (the precise-CLS chain calls the same kernel AFTER the MLP half, round 4: only the first end mark of a block counts)
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record()
+            marks[-1][1] = e1
         return out
 
     def add_ln(*a, **k):   # round-3 form: they end inside the PRE_MLP add-LayerNorm kernel (see the accounting note below)
