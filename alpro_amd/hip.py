@@ -606,9 +606,9 @@ def set_deterministic_wgrad(on=True):
 def set_deterministic(on=True):
     """True (the default since round 4; ALPRO_DETERMINISTIC=0 turns it off): every remaining reduction of the training step is summed in a
     fixed order -- the LayerNorm backward's dgamma / dbeta / bias column sums and the gather-cast's (per-workgroup partials in the reduction
-    workspace + a fixed-order second kernel), the squared gradient norm, the embedding-table scatters; the CLS-row gradient and the VTC
-    loss / temperature gradient are single-writer in the kernels themselves.  Two runs of the same step are then bitwise equal
-    (tests/test_model_parity.py::test_two_identical_training_steps_are_bitwise_equal).  False: the kernels' fp32-atomic forms (no workspace)."""
+    workspace + a fixed-order second kernel; the CLS row's T frame terms under the FRAME_TOKENS scatter go the same way), the squared gradient
+    norm, the embedding-table scatters; the VTC loss / temperature gradient are single-writer in the kernels themselves.  Two runs of the same step are then bitwise equal
+    (tests/test_dist_gpu.py::test_two_runs_of_the_same_step_are_bitwise_equal).  False: the kernels' fp32-atomic forms (no workspace)."""
     _DETERMINISTIC[0] = bool(on)
 
 

@@ -61,8 +61,8 @@ def test_one_rank_nccl_runs_every_collective(tmp_path, wire, tol):
     sends the training step through every collective branch the 8-GPU run takes -- broadcast_parameters, the differentiable feature
     all-gather (all_gather_into_tensor forward, reduce_scatter_tensor backward), FlatAdamW's async all_reduce handles on RCCL's
     stream launched from inside backward (grads_final) and `_finish_exchange`'s h.wait() stream hand-over, fp32 and bf16 wire -- and
-    must reproduce the plain single-process step.  Since round 4 every reduction of the step has a fixed order (the CLS-row gradient is
-    owned by one wave, dgamma / dbeta / bias column sums go through the reduction workspace, the squared norm and the embedding scatters
+    must reproduce the plain single-process step.  Since round 4 every reduction of the step has a fixed order (the CLS-row gradient's
+    frame terms, dgamma / dbeta / bias column sums go through the reduction workspace, the squared norm and the embedding scatters
     likewise: alpro_amd.hip.set_deterministic), so with the fp32 wire the forced-collective step must be BITWISE equal to the plain one
     (one-rank all-gather / reduce-scatter / all-reduce are copies); the bf16 wire rounds the gradients once on the way."""
     B = 2

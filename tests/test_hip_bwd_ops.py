@@ -933,8 +933,8 @@ def _determinism(hip, on):
 
 def test_reductions_run_to_run_reproducibility():
     """Round 4: the remaining fp32 atomics of the training step have a fixed-order form, and it is the default.
-      * alpro_layernorm_bwd at the benchmark's ViT shape under the FRAME_TOKENS scatter: the clip's CLS row (one term per frame, single
-        owner wave) and dgamma / dbeta / colsum_pre (per-workgroup partials in the reduction workspace + colsum_reduce_kernel);
+      * alpro_layernorm_bwd at the benchmark's ViT shape under the FRAME_TOKENS scatter: the clip's CLS row (one term per frame, parked in the
+        workspace and added in frame order by cls_rows_reduce_kernel) and dgamma / dbeta / colsum_pre (per-workgroup partials in the reduction workspace + colsum_reduce_kernel);
       * alpro_gather_cast's colsum / colsum_pre, alpro_sumsq, the position form of alpro_scatter_add_rows, the sorted index form;
       * alpro_vtc_loss_fwd / _bwd (loss and d temp finished by one workgroup).
     Each runs three times on the same inputs: bitwise equal.  The atomic forms (set_deterministic(False), NULL workspace) stay available
@@ -974,7 +974,7 @@ def test_reductions_run_to_run_reproducibility():
     xs = lnr[:, 1:].reshape(2, N, T, D).permute(0, 2, 1, 3)
     y = torch.cat([lnr[:, :1].unsqueeze(1).expand(2, T, 1, D), xs], 2).reshape(-1, D)
     (y * dy[:2 * T * (N + 1)].double().cpu()).sum().backward()
-    close(ln(False)[0][:2, 0], res[:2, 0].double().cpu() + x64.grad[:, 0], 1e-4, 5e-4, "CLS-row gradient (owner wave)")
+    close(ln(False)[0][:2, 0], res[:2, 0].double().cpu() + x64.grad[:, 0], 1e-4, 5e-4, "CLS-row gradient (frame terms through the workspace)")
 
     src = torch.randn(B * S, D, device="cuda", generator=g)
     rs = torch.rand(B, device="cuda", generator=g)
