@@ -315,26 +315,38 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
   }
 }
 
-// dst_k[c] += sum over workgroup slots p of part[p][nslots][768] for the column sums k = 0 .. gridDim.y-1: ONE workgroup per (64 columns, k)
-// -- 16 float4 column lanes x 64 slices of slots, slice s adds slots s, s + 64, ... in ascending order, then lane 0's slice adds the 64
-// slice sums in ascending order: a single writer per output and an order that depends on nothing but the slot count.
+// dst_k[c] += sum over workgroup slots p of part[p][nslots][768] for the column sums k = 0 .. gridDim.y-1: ONE workgroup per (32 columns, k)
+// -- 8 float4 column lanes x 128 slices of slots.  Slice s adds slots s, s + 128, ... in ascending order; then 8 x 8 lanes add 16 slice sums
+// each (ascending) and one lane per column group adds those 8: a single writer per output and an order that depends on nothing but the slot
+// count -- bit-reproducible.  (72 workgroups; the first form -- 36 workgroups of 64 columns, one lane walking all 64 slice sums -- took 13 us
+// for 2048 slots.)
 __global__ __launch_bounds__(1024) void colsum_reduce_kernel(const float* __restrict__ part, int nparts, int nslots, float* __restrict__ d0,
                                                              float* __restrict__ d1, float* __restrict__ d2) {
-  __shared__ float4 red[64][16];
-  const int k = blockIdx.y, c4 = threadIdx.x & 15, sl = threadIdx.x >> 4;
+  __shared__ float4 red[128][8];
+  __shared__ float4 red2[8][8];
+  const int k = blockIdx.y, c4 = threadIdx.x & 7, sl = threadIdx.x >> 3;
   float* dst = k == 0 ? d0 : (k == 1 ? d1 : d2);
   if (!dst) return;
-  const int col = blockIdx.x * 64 + c4 * 4;
+  const int col = blockIdx.x * 32 + c4 * 4;
   float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int p = sl; p < nparts; p += 64) {
+#pragma unroll 4
+  for (int p = sl; p < nparts; p += 128) {
     const float4 v = *(const float4*)(part + ((int64_t)p * nslots + k) * LN_D + col);
     s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
   }
   red[sl][c4] = s;
   __syncthreads();
+  if (sl < 8) {
+    float4 t = red[sl * 16][c4];
+#pragma unroll
+    for (int i = 1; i < 16; ++i) { const float4 v = red[sl * 16 + i][c4]; t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w; }
+    red2[sl][c4] = t;
+  }
+  __syncthreads();
   if (sl == 0) {
-    float4 t = red[0][c4];
-    for (int i = 1; i < 64; ++i) { const float4 v = red[i][c4]; t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w; }
+    float4 t = red2[0][c4];
+#pragma unroll
+    for (int i = 1; i < 8; ++i) { const float4 v = red2[i][c4]; t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w; }
     float4* o = (float4*)(dst + col);
     const float4 c = *o;
     *o = make_float4(c.x + t.x, c.y + t.y, c.z + t.z, c.w + t.w);
@@ -645,7 +657,7 @@ extern "C" int alpro_layernorm_bwd_emit(const void* dy, int dy_dtype, int64_t ld
   else if (dy_dtype == ALPRO_F16) ALPRO_LNB(f16_t, f16_t);
   else { set_error("alpro_layernorm_bwd: bad dtype %d", dy_dtype); return ALPRO_ERR_INVALID; }
 #undef ALPRO_LNB
-  if (part) hipLaunchKernelGGL(colsum_reduce_kernel, dim3(LN_D / 64, emit_colsum_pre ? 3 : 2), dim3(1024), 0, st, part, nblk, 3, dgamma, dbeta, emit_colsum_pre);
+  if (part) hipLaunchKernelGGL(colsum_reduce_kernel, dim3(LN_D / 32, emit_colsum_pre ? 3 : 2), dim3(1024), 0, st, part, nblk, 3, dgamma, dbeta, emit_colsum_pre);
   if (cls_ws) hipLaunchKernelGGL(cls_rows_reduce_kernel, dim3(rows / (map_p1 + 1) / map_p0), dim3(192), 0, st, cls_ws, dx, ld_dx, map_p0, map_p1);
   return check_launch("alpro_layernorm_bwd");
 }
@@ -674,7 +686,7 @@ extern "C" int alpro_gather_cast(const float* src, int64_t ld, void* out, int dt
     int nblk = grid_for(rows, 32, 512);
     if (part) nblk = (int)std::min<size_t>((size_t)nblk, workspace_bytes / (2 * LN_D * sizeof(float)));
     ALPRO_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((gather_cast_kernel<T, 16>), dim3(nblk), dim3(1024), 0, (hipStream_t)stream, src, ld, (T*)out, (int64_t)rows, map_mode, map_p0, map_p1, row_scale, row_scale_group, cls_scale, drop_p, drop_seed, colsum, colsum_pre, part));
-    if (part) hipLaunchKernelGGL(colsum_reduce_kernel, dim3(LN_D / 64, 2), dim3(1024), 0, (hipStream_t)stream, part, nblk, 2, colsum, colsum_pre, (float*)nullptr);
+    if (part) hipLaunchKernelGGL(colsum_reduce_kernel, dim3(LN_D / 32, 2), dim3(1024), 0, (hipStream_t)stream, part, nblk, 2, colsum, colsum_pre, (float*)nullptr);
   } else {
     ALPRO_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((gather_cast_kernel<T, 4>), dim3(grid_for(rows, 8, 256 * 32)), dim3(256), 0, (hipStream_t)stream, src, ld, (T*)out, (int64_t)rows, map_mode, map_p0, map_p1, row_scale, row_scale_group, cls_scale, drop_p, drop_seed, colsum, colsum_pre, (float*)nullptr));
   }

@@ -1,5 +1,6 @@
 #!/bin/bash
+# focused check of the LayerNorm-backward / reduction kernels: micro-benchmark + their tests (seconds on the GPU box)
 export TMPDIR=/tmp
 O=gpurun_out/r4k; mkdir -p $O
-timeout 900 python -m pytest tests/test_model_parity.py tests/test_amp_gpu.py tests/test_dist_gpu.py -m gpu -q -p no:cacheprovider -x > $O/t_model.txt 2>&1; tail -3 $O/t_model.txt
-timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-parity --no-divst > $O/bench_default2.json 2> $O/bench_default2.err; python -c "import json;d=json.load(open('$O/bench_default2.json'));print(d['ms_per_step'], d['roofline']['frac'], d['kernel_ms_per_step'])"
+timeout 300 python tools/ln_bwd_bench.py > $O/ln_bwd_bench3.txt 2>&1; grep -v "amdgpu.ids" $O/ln_bwd_bench3.txt
+timeout 600 python -m pytest tests/test_hip_bwd_ops.py -m gpu -q -p no:cacheprovider -k "reproducibility or layernorm or gather_cast or emit" > $O/t_ln.txt 2>&1; tail -2 $O/t_ln.txt
