@@ -947,3 +947,44 @@ def test_flat_adamw_state_dict_carries_the_loss_scaler():
         assert c._scaler_steps_synced is None
     finally:
         rt.set_compute_dtype(prev)
+
+
+def test_8phase_gemm_k_loop_is_exactly_what_its_counted_waits_assume(tmp_path):
+    """The 8-phase GEMM counts its own vector-memory operations: ONE `s_waitcnt vmcnt(2)` per K-tile stands for "everything but the half-tile
+    just issued has landed".  That is only true while the K loop contains NO vector-memory operation the source did not write -- a register
+    spill (scratch_load / scratch_store, or v_readlane / v_writelane traffic for spilled SGPRs next to them) between the copies would shift
+    the count and let MFMAs read half-landed tiles, silently, on some shapes.  This test disassembles the built object and checks, for every
+    instantiation of gemm_nt256q_kernel, the span from its first to its last MFMA (the two unrolled K-tiles minus the first phase's LOAD segment
+    and the last phase's trailing barrier): 128 MFMAs, 14 of the 16 LDS-DMA copies, both counted waits (vmcnt(2)), 14 of the 16 barriers, and
+    nothing else that touches vmcnt or spills -- the check that was done by hand on the ISA in round 4."""
+    import re
+    import shutil
+    import subprocess
+    llvm = "/opt/rocm/lib/llvm/bin"
+    obj = os.path.join(ROOT, "alpro_amd", "lib", "obj", "gemm.o")
+    if not (os.path.exists(obj) and os.path.exists(os.path.join(llvm, "llvm-objdump"))):
+        pytest.skip("needs the built gemm.o (python -m alpro_amd.build) and llvm-objdump")
+    work = tmp_path / "gemm.o"
+    shutil.copy(obj, work)
+    subprocess.run([os.path.join(llvm, "llvm-objdump"), "--offloading", str(work)], check=True, capture_output=True, cwd=tmp_path)
+    dev = [f for f in os.listdir(tmp_path) if "gfx950" in f]
+    assert len(dev) == 1, os.listdir(tmp_path)
+    dis = subprocess.run([os.path.join(llvm, "llvm-objdump"), "-d", str(tmp_path / dev[0])], check=True, capture_output=True, text=True).stdout
+    funcs = re.split(r"\n(?=[0-9a-f]{16} <)", dis)
+    seen = 0
+    for fn in funcs:
+        head = fn.split("\n", 1)[0]
+        if "gemm_nt256q_kernel" not in head:
+            continue
+        seen += 1
+        lines = fn.split("\n")[1:]
+        mf = [i for i, l in enumerate(lines) if "v_mfma" in l]
+        assert len(mf) == 128, (head, len(mf))
+        span = lines[mf[0]:mf[-1] + 1]
+        count = lambda pat: sum(1 for l in span if re.search(pat, l))   # noqa: E731
+        assert count(r"\bglobal_load_lds_dwordx4\b") == 14, (head, count(r"global_load_lds"))
+        assert count(r"s_waitcnt vmcnt\(2\)") == 2 and count(r"s_waitcnt.*vmcnt") == 2, head
+        assert count(r"\bs_barrier\b") == 14, (head, count(r"\bs_barrier\b"))
+        for bad in (r"\bscratch_", r"\bbuffer_", r"\bflat_", r"\bglobal_(load|store)_(?!lds)", r"\bv_readlane", r"\bv_writelane"):
+            assert count(bad) == 0, (head, bad, [l for l in span if re.search(bad, l)][:3])
+    assert seen == 12, seen   # {bf16, f16} x 6 activations, identity map
