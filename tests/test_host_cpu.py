@@ -988,3 +988,24 @@ def test_8phase_gemm_k_loop_is_exactly_what_its_counted_waits_assume(tmp_path):
         for bad in (r"\bscratch_", r"\bbuffer_", r"\bflat_", r"\bglobal_(load|store)_(?!lds)", r"\bv_readlane", r"\bv_writelane"):
             assert count(bad) == 0, (head, bad, [l for l in span if re.search(bad, l)][:3])
     assert seen == 12, seen   # {bf16, f16} x 6 activations, identity map
+    # the weight-gradient kernel counts its ring of copies the same way (one counted wait per 32-token stage): no foreign vector-memory traffic
+    obj = os.path.join(ROOT, "alpro_amd", "lib", "obj", "gemm_tn.o")
+    if os.path.exists(obj):
+        work = tmp_path / "gemm_tn.o"
+        shutil.copy(obj, work)
+        subprocess.run([os.path.join(llvm, "llvm-objdump"), "--offloading", str(work)], check=True, capture_output=True, cwd=tmp_path)
+        dev = [f for f in os.listdir(tmp_path) if "gfx950" in f and f.startswith("gemm_tn")]
+        dis = subprocess.run([os.path.join(llvm, "llvm-objdump"), "-d", str(tmp_path / dev[0])], check=True, capture_output=True, text=True).stdout
+        seen = 0
+        for fn in re.split(r"\n(?=[0-9a-f]{16} <)", dis):
+            head = fn.split("\n", 1)[0]
+            if "gemm_tn_kernel" not in head:
+                continue
+            seen += 1
+            lines = fn.split("\n")[1:]
+            mf = [i for i, l in enumerate(lines) if "v_mfma" in l]
+            span = lines[mf[0]:mf[-1] + 1]
+            for bad in (r"\bscratch_", r"\bbuffer_", r"\bflat_", r"\bglobal_(load|store)_(?!lds)", r"\bv_readlane", r"\bv_writelane"):
+                assert not [l for l in span if re.search(bad, l)], (head, bad)
+            assert sum(1 for l in span if re.search(r"s_waitcnt.*vmcnt", l)) == 1, head
+        assert seen == 4, seen   # {bf16, f16} x {round-3 schedule, two-group schedule}
