@@ -949,7 +949,7 @@ def test_flat_adamw_state_dict_carries_the_loss_scaler():
         rt.set_compute_dtype(prev)
 
 
-def test_8phase_gemm_k_loop_is_exactly_what_its_counted_waits_assume(tmp_path):
+def test_8phase_gemm_isa_keeps_the_orders_the_source_relies_on(tmp_path):
     """The 8-phase GEMM counts its own vector-memory operations: ONE `s_waitcnt vmcnt(2)` per K-tile stands for "everything but the half-tile
     just issued has landed".  That is only true while the K loop contains NO vector-memory operation the source did not write -- a register
     spill (scratch_load / scratch_store, or v_readlane / v_writelane traffic for spilled SGPRs next to them) between the copies would shift
@@ -987,6 +987,15 @@ def test_8phase_gemm_k_loop_is_exactly_what_its_counted_waits_assume(tmp_path):
         assert count(r"\bs_barrier\b") == 14, (head, count(r"\bs_barrier\b"))
         for bad in (r"\bscratch_", r"\bbuffer_", r"\bflat_", r"\bglobal_(load|store)_(?!lds)", r"\bv_readlane", r"\bv_writelane"):
             assert count(bad) == 0, (head, bad, [l for l in span if re.search(bad, l)][:3])
+        # epilogue: a fragment row is staged by 8 ds_write2_b32 per lane and read back by OTHER lanes with ds_read_b128 -- no read may be issued
+        # inside a group of 8 writes (the round-4 bug: the compiler, reasoning per lane, had hoisted one above the last write; wave_lds_order())
+        writes = 0
+        for l in lines[mf[-1] + 1:]:
+            if re.search(r"\bds_write2_b32\b", l):
+                writes += 1
+            elif re.search(r"\bds_read_b128\b", l):
+                assert writes % 8 == 0, (head, "ds_read_b128 issued after %d of 8 staging writes" % (writes % 8))
+        assert writes in (64, 128), (head, writes)   # 8 fragment rows x 8 writes per epilogue form compiled into this instantiation
     assert seen == 12, seen   # {bf16, f16} x 6 activations, identity map
     # the weight-gradient kernel counts its ring of copies the same way (one counted wait per 32-token stage): no foreign vector-memory traffic
     obj = os.path.join(ROOT, "alpro_amd", "lib", "obj", "gemm_tn.o")
