@@ -28,6 +28,7 @@ D, H, HD = 768, 12, 64
 # fp32 accumulator row of the CLS query (16-bit q / k / v / P as usual, output row NOT rounded) -> proj -> MLP unrounded; "projmlp" = the rounded
 # attention output row -> proj -> MLP unrounded; "mlp" = MLP only
 CLS_VARIANT = ["full"]
+CLS_W16 = [False]   # --cls-w16: the precise rows see the 16-bit ROUNDED weights (activations still unrounded): the cost question of DESIGN.md section 8
 VIT_EPS, BERT_EPS = 1e-6, 1e-12
 
 
@@ -62,7 +63,7 @@ def lin(r, site, x, w, b, out_round=True, rows32=None):
         y = r(site + ".out", y)
     if rows32 is not None and rows32.any():
         y = y.clone()
-        y[rows32] = F.linear(x[rows32], w, b)
+        y[rows32] = F.linear(x[rows32], r(site + ".w", w) if CLS_W16[0] else w, b)
     return y
 
 
@@ -185,9 +186,11 @@ def main():
     ap.add_argument("--seed-name", default="precision_model")
     ap.add_argument("--only", default="")
     ap.add_argument("--cls-variant", default="full", choices=["full", "osave", "projmlp", "mlp"])
+    ap.add_argument("--cls-w16", type=int, default=0)
     args = ap.parse_args()
     torch.set_num_threads(os.cpu_count())
     CLS_VARIANT[0] = args.cls_variant
+    CLS_W16[0] = bool(args.cls_w16)
     dt = {"fp16": torch.float16, "bf16": torch.bfloat16}[args.dtype]
     batch = det_batch(args.B, args.T, Lt=args.Lt, seed_name=args.seed_name, with_mlm=False, with_mpm=False)
     all12, all6 = tuple(range(12)), tuple(range(6))
