@@ -132,6 +132,8 @@ def scale_loss(loss, optimizers, delay_unscale=False, **unused):
         getattr(o, "_opt", o).scaler = scaler
     for o in opts:
         getattr(o, "_opt", o)._grads_scaled = True
+        if hasattr(getattr(o, "_opt", o), "_g_clean"):
+            getattr(o, "_opt", o)._g_clean = False   # gradients are about to be written by the caller's own scaled_loss.backward()
     with rt.loss_scaling(scaler):
         yield loss * scaler.scale.reshape(())
     if not delay_unscale:

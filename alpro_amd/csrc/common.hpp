@@ -218,13 +218,29 @@ __device__ __forceinline__ void attn_unit(int blk, int nblk, int H, int order, i
     h = blk - b * H;
   }
 }
-enum { OPT_GEMM_TILE = 0, OPT_GEMM_GRID = 1, OPT_GEMM_TUNE = 2, OPT_TN_SPLITS = 3, OPT_TN_KIND = 4, OPT_GEMM_TAIL = 5, OPT_ATTN_BWD = 6, OPT_ATTN_ORDER = 7, OPT_GEMM_KIND = 8, OPT_CU_BUDGET = 9, OPT_LN_GRID = 10, OPT_COUNT = 11 };
+enum { OPT_GEMM_TILE = 0, OPT_GEMM_GRID = 1, OPT_GEMM_TUNE = 2, OPT_TN_SPLITS = 3, OPT_TN_KIND = 4, OPT_GEMM_TAIL = 5, OPT_ATTN_BWD = 6, OPT_ATTN_ORDER = 7, OPT_GEMM_KIND = 8, OPT_CU_BUDGET = 9, OPT_LN_GRID = 10, OPT_GEMM_SCHED = 11, OPT_COUNT = 12 };
 int get_option(int which);
+// Per-stream override of an option (round 5: alpro_hip_set_stream_option).  cu_budget is the one knob that describes the SITUATION a launch
+// runs in (a collective's kernels holding CUs next to this stream's work) rather than the library: the optimizer sets it on the stream its
+// backward runs on, other streams / other models in the same process keep the process-wide value.  -1 = no override for this stream.
+int get_stream_option(int which, hipStream_t st);
+
+// ---- dynamic tile scheduler of the persistent GEMM grids (round 5) ------------------------------------------------------------------
+// One 64-byte block of device memory per launch: [0..7] per-XCD ticket counters, [8] workgroups finished.  Blocks come from a per-device
+// ring (lazily allocated, zero-filled once); the last workgroup of a launch hands its block back zeroed, so a block is clean again long
+// before the ring wraps (RING launches later, same device; launches on one stream are ordered anyway).
+struct TileSched {
+  uint32_t* blk;       // nullptr = static walk (option gemm_sched 0)
+  uint32_t magic_ntn;  // ceil(2^32 / ntn): tile / ntn == umulhi(tile, magic_ntn) (ntn > 1)
+};
+uint32_t* sched_block_next();   // nullptr on allocation failure (the caller falls back to the static walk)
+inline uint32_t magic_u32(uint32_t d) { return (uint32_t)(((1ull << 32) + d - 1) / d); }
 // Compute units the persistent GEMM grids and the weight-gradient range plan may count on (round 4): 256, or less while a collective's kernels
 // hold CUs (alpro_amd.dist sets "cu_budget" while the overlapped gradient exchange is in flight: a persistent one-workgroup-per-CU launch that
 // finds a CU taken needs a second round for the displaced workgroup).  Rounded down to a multiple of 8 (XCD-contiguous slot maps).
-inline int cu_budget() {
-  const int v = get_option(OPT_CU_BUDGET);
+inline int cu_budget(hipStream_t st) {
+  int v = get_stream_option(OPT_CU_BUDGET, st);
+  if (v < 0) v = get_option(OPT_CU_BUDGET);
   return (v >= 64 && v < 256) ? (v / 8 * 8) : 256;
 }
 

@@ -19,8 +19,8 @@ void set_error(const char* fmt, ...) {
 }
 
 namespace {
-const char* const kOptNames[OPT_COUNT] = {"gemm_tile", "gemm_grid", "gemm_tune", "tn_splits", "tn_kind", "gemm_tail", "attn_bwd", "attn_order", "gemm_kind", "cu_budget", "ln_grid"};
-const char* const kOptEnv[OPT_COUNT] = {"ALPRO_GEMM_TILE", "ALPRO_GEMM_GRID", "ALPRO_GEMM_TUNE", "ALPRO_TN_SPLITS", "ALPRO_TN_KIND", "ALPRO_GEMM_TAIL", "ALPRO_ATTN_BWD", "ALPRO_ATTN_ORDER", "ALPRO_GEMM_KIND", "ALPRO_CU_BUDGET", "ALPRO_LN_GRID"};
+const char* const kOptNames[OPT_COUNT] = {"gemm_tile", "gemm_grid", "gemm_tune", "tn_splits", "tn_kind", "gemm_tail", "attn_bwd", "attn_order", "gemm_kind", "cu_budget", "ln_grid", "gemm_sched"};
+const char* const kOptEnv[OPT_COUNT] = {"ALPRO_GEMM_TILE", "ALPRO_GEMM_GRID", "ALPRO_GEMM_TUNE", "ALPRO_TN_SPLITS", "ALPRO_TN_KIND", "ALPRO_GEMM_TAIL", "ALPRO_ATTN_BWD", "ALPRO_ATTN_ORDER", "ALPRO_GEMM_KIND", "ALPRO_CU_BUDGET", "ALPRO_LN_GRID", "ALPRO_GEMM_SCHED"};
 int g_opts[OPT_COUNT];
 // Values that change RESULTS (gemm_tune 3 / 4 / 10 / 11 / 12: epilogue / synchronisation ablations; tn_kind 1: weight gradient without
 // its epilogue) exist only in the measurement build (-DALPRO_ABLATIONS, `python -m alpro_amd.build --ablations`, used by tools/); the
@@ -40,7 +40,7 @@ struct OptInit {
   OptInit() {
     for (int i = 0; i < OPT_COUNT; ++i) {
       const char* e = getenv(kOptEnv[i]);
-      const int dflt = (i == OPT_GEMM_TUNE || i == OPT_GEMM_TAIL || i == OPT_ATTN_BWD || i == OPT_GEMM_KIND) ? 1 : 0;
+      const int dflt = (i == OPT_GEMM_TUNE || i == OPT_GEMM_TAIL || i == OPT_ATTN_BWD || i == OPT_GEMM_KIND || i == OPT_GEMM_SCHED) ? 1 : 0;
       g_opts[i] = e ? atoi(e) : dflt;
       if (!option_allowed(i, g_opts[i])) {
         fprintf(stderr, "libalpro_hip: %s=%d is a result-corrupting ablation and is not part of this build (ignored)\n", kOptEnv[i], g_opts[i]);
@@ -52,6 +52,62 @@ struct OptInit {
 }  // namespace
 
 int get_option(int which) { return __atomic_load_n(&g_opts[which], __ATOMIC_RELAXED); }
+
+// ---- per-stream option overrides (round 5) ---------------------------------------------------------------------------------------
+// A handful of (stream, option) -> value entries behind a spin lock: set by the owner of a stream (alpro_amd.optim while its gradient
+// exchange is in flight), read once per launch that consults the option.  An empty table (the normal case) costs one relaxed load.
+namespace {
+struct StreamOpt { hipStream_t st; int which, value; };
+constexpr int kMaxStreamOpts = 32;
+StreamOpt g_sopts[kMaxStreamOpts];
+int g_nsopts = 0;
+int g_sopt_lock = 0;
+struct SpinGuard {
+  SpinGuard() { while (__atomic_exchange_n(&g_sopt_lock, 1, __ATOMIC_ACQUIRE)) {} }
+  ~SpinGuard() { __atomic_store_n(&g_sopt_lock, 0, __ATOMIC_RELEASE); }
+};
+}  // namespace
+
+int get_stream_option(int which, hipStream_t st) {
+  if (__atomic_load_n(&g_nsopts, __ATOMIC_RELAXED) == 0) return -1;
+  SpinGuard g;
+  for (int i = 0; i < g_nsopts; ++i)
+    if (g_sopts[i].st == st && g_sopts[i].which == which) return g_sopts[i].value;
+  return -1;
+}
+
+// ---- tile-scheduler blocks (common.hpp) ---------------------------------------------------------------------------------------------
+namespace {
+constexpr int kSchedRing = 1024, kSchedBlockU32 = 16;   // 64 KiB per device
+uint32_t* g_sched_ring[64];
+unsigned g_sched_pos[64];
+int g_sched_lock = 0;
+}  // namespace
+
+uint32_t* sched_block_next() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  dev &= 63;
+  uint32_t* ring = __atomic_load_n(&g_sched_ring[dev], __ATOMIC_ACQUIRE);
+  if (!ring) {
+    while (__atomic_exchange_n(&g_sched_lock, 1, __ATOMIC_ACQUIRE)) {}
+    ring = g_sched_ring[dev];
+    if (!ring) {   // first persistent launch on this device: the one allocation this library makes (64 KiB, never freed)
+      void* p = nullptr;
+      if (hipMalloc(&p, (size_t)kSchedRing * kSchedBlockU32 * sizeof(uint32_t)) == hipSuccess &&
+          hipMemset(p, 0, (size_t)kSchedRing * kSchedBlockU32 * sizeof(uint32_t)) == hipSuccess && hipDeviceSynchronize() == hipSuccess) {
+        ring = (uint32_t*)p;
+        __atomic_store_n(&g_sched_ring[dev], ring, __ATOMIC_RELEASE);
+      } else {
+        (void)hipGetLastError();
+      }
+    }
+    __atomic_store_n(&g_sched_lock, 0, __ATOMIC_RELEASE);
+    if (!ring) return nullptr;
+  }
+  const unsigned pos = __atomic_fetch_add(&g_sched_pos[dev], 1u, __ATOMIC_RELAXED) % kSchedRing;
+  return ring + (size_t)pos * kSchedBlockU32;
+}
 
 int check_launch(const char* what) {
   hipError_t e = hipGetLastError();
@@ -421,6 +477,45 @@ extern "C" int alpro_hip_set_option(const char* name, int value) {
     }
   set_error("alpro_hip_set_option: unknown option '%s'", name ? name : "(null)");
   return ALPRO_ERR_INVALID;
+}
+
+extern "C" int alpro_hip_set_stream_option(void* stream, const char* name, int value) {
+  using namespace alpro;
+  int which = -1;
+  for (int i = 0; name && i < OPT_COUNT; ++i)
+    if (!strcmp(name, kOptNames[i])) which = i;
+  if (which < 0) {
+    set_error("alpro_hip_set_stream_option: unknown option '%s'", name ? name : "(null)");
+    return ALPRO_ERR_INVALID;
+  }
+  if (value >= 0 && !option_allowed(which, value)) {
+    set_error("alpro_hip_set_stream_option: %s=%d is an ablation / measurement-only variant, only available in the measurement build (-DALPRO_ABLATIONS)", name, value);
+    return ALPRO_ERR_INVALID;
+  }
+  SpinGuard g;
+  int at = -1;
+  for (int i = 0; i < g_nsopts; ++i)
+    if (g_sopts[i].st == (hipStream_t)stream && g_sopts[i].which == which) at = i;
+  if (value < 0) {   // clear the override
+    if (at >= 0) {
+      g_sopts[at] = g_sopts[g_nsopts - 1];
+      __atomic_store_n(&g_nsopts, g_nsopts - 1, __ATOMIC_RELAXED);
+    }
+    return ALPRO_OK;
+  }
+  if (at < 0) {
+    if (g_nsopts == kMaxStreamOpts) {
+      set_error("alpro_hip_set_stream_option: more than %d (stream, option) overrides", kMaxStreamOpts);
+      return ALPRO_ERR_INVALID;
+    }
+    at = g_nsopts;
+    g_sopts[at].st = (hipStream_t)stream;
+    g_sopts[at].which = which;
+    g_sopts[at].value = value;
+    __atomic_store_n(&g_nsopts, g_nsopts + 1, __ATOMIC_RELAXED);
+  }
+  g_sopts[at].value = value;
+  return ALPRO_OK;
 }
 
 extern "C" int alpro_cast_from_f32(const float* src, void* dst, int dtype, int64_t n, void* stream) {

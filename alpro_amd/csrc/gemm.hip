@@ -779,7 +779,7 @@ template <> struct Mma16<f16_t> {
 };
 
 template <typename T, int ACT, int MAP>
-__global__ __launch_bounds__(NT2, 2) void gemm_nt256q_kernel(const alpro_gemm_desc_t g) {
+__global__ __launch_bounds__(NT2, 2) void gemm_nt256q_kernel(const alpro_gemm_desc_t g, const TileSched sc) {
   static_assert(sizeof(T) == 2, "16-bit operands only");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -788,11 +788,83 @@ __global__ __launch_bounds__(NT2, 2) void gemm_nt256q_kernel(const alpro_gemm_de
   const int nblk = ntn * ntm;
   const int64_t lda_b = g.lda * 2, ldw_b = g.ldw * 2;
   const int nk = g.K >> 6;                       // K-tiles of 64 elements; even and >= 4 (launcher)
-  const int G = gridDim.x, per_xcd = (G + 7) >> 3;
-  const int slot = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
-  if (slot >= nblk) return;
-  const int ntile = (nblk - slot + G - 1) / G;   // tiles slot, slot + G, ...
   const uint32_t lds_base = lds_addr_of(smem);
+
+  // ---- which tiles (round 5) ----------------------------------------------------------------------------------------------------
+  // Tiles are numbered row-panel-major (tile = tm * ntn + tn) and dealt to the 8 XCDs in chunks of 32: XCD y's LIST is
+  //     j -> tile (j / 32) * 256 + y * 32 + (j % 32),        j = 0, 1, 2, ...  while that is < nblk,
+  // i.e. the tiles the round-4 static walk (workgroup slot s of 256 takes s, s + 256, ...) gave to the XCD's 32 workgroups, in the order
+  // it visited them: at any moment an XCD works on a contiguous run of tiles, so the tn tiles of an A row panel meet in ONE L2.
+  //   gemm_sched 0 (sc.blk == nullptr): workgroup idx of the XCD takes j = idx, idx + p, ... (p = gridDim.x / 8) -- with 256 workgroups
+  //     exactly that static walk.
+  //   gemm_sched 1: j comes from the XCD's ticket counter: one agent-scope atomic per tile, issued by wave 0 behind an epilogue TWO tiles
+  //     ahead of the tile it pays for and read back behind the next K loop -- nothing is added to the K loop, nobody waits for it.
+  //     A workgroup that cannot be resident -- another kernel holds its CU: RCCL's channels during the overlapped gradient exchange, a
+  //     side stream -- simply draws no tickets; the others finish its share one tile at a time instead of the launch waiting a whole
+  //     extra round for it (profiles/r4_overlap_cu_contention.txt: +42 % with 8 of 256 CUs taken).  When a list runs dry the workgroup
+  //     moves on to the next XCD's counter (steals), so the last partial round spreads over all XCDs.
+  // Results do not depend on who computes a tile: bitwise identical under either walk.
+  auto list_tile = [&](int y, uint32_t j) -> int {
+    const uint32_t t = ((j >> 5) << 8) + ((uint32_t)y << 5) + (j & 31u);
+    return (j < 0x100000u && t < (uint32_t)nblk) ? (int)t : -1;
+  };
+  // Mailbox wave 0 -> everybody: two dwords at the start of the A-half-1 slot of parity 1.  That slot's last reader is phase 3 of a tile's
+  // last K-tile and its next writer the copy of phase 2 of the following tile's first K-tile (two barriers into that tile): dead in between.
+  volatile int* mbox = (volatile int*)(smem + STAGE2_BYTES + HALF2_BYTES);
+  // walk state (wave 0's copy is the one that counts).  Dynamic: how many XCD lists have run dry for this workgroup (tickets are drawn from
+  // XCD (own + wstate) % 8).  Static: the workgroup's next list position.
+  uint32_t wstate = sc.blk ? 0u : (uint32_t)(blockIdx.x >> 3);
+  // One ticket of the current list's counter, lane 0 of wave 0 only (`on`; otherwise the instruction runs with an empty EXEC mask).  The
+  // value lands in `r` when the memory system answers: whoever reads it waits first (s_waitcnt vmcnt), like for the copies.  "+v": `r` is ONE
+  // register from here to its reader -- a compiler-inserted copy in between would copy the old contents (a CPU test checks the built ISA).
+  auto ticket_issue = [&](uint32_t& r, bool on) {
+    uint64_t sv;
+    const uint32_t m = (uint32_t)__builtin_amdgcn_readfirstlane(on ? 1 : 0);
+    asm volatile("s_mov_b64 %1, exec\n\ts_mov_b32 exec_lo, %5\n\ts_mov_b32 exec_hi, 0\n\tglobal_atomic_add %0, %2, %3, %4 sc0\n\ts_mov_b64 exec, %1"
+                 : "+v"(r), "=&s"(sv) : "v"(((blockIdx.x + wstate) & 7u) * 4u), "v"(1u), "s"(sc.blk), "s"(m) : "memory");
+  };
+  // ticket -> tile of the list tickets are currently drawn from; a dry list moves the workgroup on to the next XCD's
+  auto ticket_tile = [&](uint32_t k) -> int {
+    int t;
+    if (sc.blk) {
+      t = list_tile((int)((blockIdx.x + wstate) & 7u), k);
+      if (t < 0) ++wstate;
+    } else {
+      t = list_tile((int)(blockIdx.x & 7u), wstate);
+      wstate += gridDim.x >> 3;
+    }
+    return t;
+  };
+  // Blocking form, start of the workgroup and after a list ran dry: wave 0 draws TWO tiles (own list first, then the other XCDs' in turn)
+  // and posts them (-1: nothing left anywhere); one barrier.  Every wave calls it; no copy may be in flight (the caller drained vmcnt).
+  auto acquire2 = [&](int& t0, int& t1) {
+    if (wave == 0) {
+      int a = -1, b = -1;
+      if (!sc.blk) {
+        a = ticket_tile(0);
+        b = a >= 0 ? ticket_tile(0) : -1;
+      } else {
+        while (b < 0 && wstate < 8) {
+          uint32_t k0 = 0, k1 = 0;
+          ticket_issue(k0, true);
+          if (a < 0) ticket_issue(k1, true);
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          const bool two = a < 0;
+          const int u0 = list_tile((int)((blockIdx.x + wstate) & 7u), __builtin_amdgcn_readfirstlane(k0));
+          const int u1 = two ? list_tile((int)((blockIdx.x + wstate) & 7u), __builtin_amdgcn_readfirstlane(k1)) : -1;
+          if (two) { a = u0; b = u1; } else { b = u0; }
+          if (b < 0) ++wstate;   // (tickets of one list come back in increasing order: u1 valid implies u0 valid)
+        }
+      }
+      mbox[0] = a;
+      mbox[1] = b;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    t0 = __builtin_amdgcn_readfirstlane(mbox[0]);
+    t1 = __builtin_amdgcn_readfirstlane(mbox[1]);
+  };
 
   // DMA sources.  Nothing is clamped per lane and everything tile-dependent is wave-uniform: a copy reads
   //   [A + (m0 + h*128) * lda_b + kt*128]  (SGPR pair)  +  [((r0 + i*8) * lda_b + chunk*16) ^ i*64]  (one 32-bit VGPR per piece)
@@ -814,7 +886,7 @@ __global__ __launch_bounds__(NT2, 2) void gemm_nt256q_kernel(const alpro_gemm_de
   // is folded into the per-tile base: the copies in the K loop cost what they cost on a full tile.
   struct Tile { const char* a[2]; const char* w; };
   auto tile_base = [&](int tile) {
-    const int tm = tile / ntn, tn = tile - tm * ntn;
+    const int tm = ntn == 1 ? tile : (int)__umulhi((uint32_t)tile, sc.magic_ntn), tn = tile - tm * ntn;
     const int vr = g.M - tm * BM2;   // (>= 256 on full tiles)
     const char* a0 = (const char*)g.A + (int64_t)tm * BM2 * lda_b;
     Tile t;
@@ -847,18 +919,24 @@ __global__ __launch_bounds__(NT2, 2) void gemm_nt256q_kernel(const alpro_gemm_de
     __builtin_amdgcn_sched_barrier(0);
   };
 
-  Tile cur = tile_base(slot);
-  Tile nxt = ntile > 1 ? tile_base(slot + G) : cur;   // (no next tile: the run-ahead copies re-read this tile's first K-tiles into dead slots)
+  uint32_t tk = 0;   // the ticket in flight (lane 0 of wave 0): drawn behind tile i - 1's epilogue for tile i + 2, read back behind tile i's K loop
+  while (true) {
+  int cur_t, nxt_t;
+  acquire2(cur_t, nxt_t);
+  if (cur_t < 0) break;
+  Tile cur = tile_base(cur_t);
+  Tile nxt = tile_base(nxt_t >= 0 ? nxt_t : cur_t);   // (no next tile: the run-ahead copies re-read this tile's first K-tiles into dead slots)
   // pipeline fill: K-tile 0 complete in parity 0, W-half 0 of K-tile 1 on its way into parity 1
 #pragma unroll
   for (int hs = 0; hs < 4; ++hs) copy_half(hs < 2 ? cur.a[hs] : cur.w, hs, 0);
   copy_half(cur.w + ROWB, 2, 1);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   barrier();
+  ticket_issue(tk, wave == 0 && sc.blk && nxt_t >= 0);   // for the tile after next
 
-  for (int it = 0; it < ntile; ++it) {
-    const int tile = slot + it * G;
-    const int tm0 = (tile / ntn) * BM2, tn0 = (tile - (tile / ntn) * ntn) * BN2;
+  while (true) {
+    const int tile = cur_t;
+    const int tm0 = (ntn == 1 ? tile : (int)__umulhi((uint32_t)tile, sc.magic_ntn)) * BM2, tn0 = (tile - (tm0 >> 8) * ntn) * BN2;
     f32x4 acc[8][4];
 #pragma unroll
     for (int i = 0; i < 8; ++i)
@@ -928,10 +1006,20 @@ __global__ __launch_bounds__(NT2, 2) void gemm_nt256q_kernel(const alpro_gemm_de
       ktile(std::integral_constant<int, 0>{}, t);
       ktile(std::integral_constant<int, 1>{}, t + 1);
     }
+    if (wave == 0) {   // the tile after next: the ticket drawn a tile ago has landed (every counted wait of this K loop was issued behind it)
+      mbox[0] = nxt_t >= 0 ? ticket_tile(__builtin_amdgcn_readfirstlane(tk)) : -1;   // (a dry list: -1, and the blocking form behind the next tile starts at the next XCD's)
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
     if (wr == 0) barrier();   // re-align: both wave rows run their epilogues at the same time
 
     // ---- epilogue: one 16-row fragment row (16 x 64 fp32 = 4 KiB of wave-private LDS) at a time
     {
+      // The epilogue's own copy of the lane id, opaque to the optimiser: everything lane-derived below (staging offsets, row / column pieces,
+      // output pointers) is then computed HERE, where the 64 fragment registers are free -- hoisted over the K loop as tile-loop invariants
+      // they were spilled at kernel start and reloaded per fragment row (a scratch load returns behind every store issued before it).
+      int le = lane;
+      asm volatile("" : "+v"(le));
+      const int l15 = le & 15, kg = le >> 4;
       const int mb = tm0 + wr * 128, nb = tn0 + wc * 64;
       auto rows_ok = [&](int mf) { return mb + mf * 16 < g.M; };   // (wave-uniform)
       auto stage_rows = [&](int mf) {
@@ -946,13 +1034,13 @@ __global__ __launch_bounds__(NT2, 2) void gemm_nt256q_kernel(const alpro_gemm_de
         if constexpr (MAP == ALPRO_MAP_IDENTITY) {
           float bias8[8];
 #pragma unroll
-          for (int e = 0; e < 8; ++e) bias8[e] = g.bias ? g.bias[nb + (lane & 7) * 8 + e] : 0.f;
+          for (int e = 0; e < 8; ++e) bias8[e] = g.bias ? g.bias[nb + (le & 7) * 8 + e] : 0.f;
           constexpr bool READS_C2 = ACT == ALPRO_ACT_GELU_BWD || ACT == ALPRO_ACT_MUL_SAVED;
           u32x4 pring[2][2];   // the saved factor rows of the NEXT fragment row are in flight while this one is finished
           auto load_pre = [&](int mf, u32x4(&pp)[2]) {
 #pragma unroll
             for (int p = 0; p < 2; ++p)
-              pp[p] = __builtin_nontemporal_load((const u32x4*)((const T*)g.C2 + (int64_t)(mb + mf * 16 + p * 8 + (lane >> 3)) * g.ldc2 + nb + (lane & 7) * 8));
+              pp[p] = __builtin_nontemporal_load((const u32x4*)((const T*)g.C2 + (int64_t)(mb + mf * 16 + p * 8 + (le >> 3)) * g.ldc2 + nb + (le & 7) * 8));
           };
           if (READS_C2 && rows_ok(0)) load_pre(0, pring[0]);
 #pragma unroll
@@ -960,16 +1048,16 @@ __global__ __launch_bounds__(NT2, 2) void gemm_nt256q_kernel(const alpro_gemm_de
             if (!rows_ok(mf)) break;   // ragged last tile row: fragment rows at or beyond M are not stored (M % 16 == 0: launcher)
             if (READS_C2 && mf + 1 < 8 && rows_ok(mf + 1)) load_pre(mf + 1, pring[(mf + 1) & 1]);
             stage_rows(mf);
-            epi_rows16_c16<T, ACT, 2>(g, stage, mb + mf * 16, nb, lane, bias8, READS_C2 ? pring[mf & 1] : nullptr);
+            epi_rows16_c16<T, ACT, 2>(g, stage, mb + mf * 16, nb, le, bias8, READS_C2 ? pring[mf & 1] : nullptr);
           }
         }
       }
       // fp32 output (launcher: ACT none, identity map, no C2 / dropout): C = residual + row_scale * (alpha * acc + bias) -- the MLP's fc2 with its
-      // fp32 residual (vit.py:212).  A staged fragment row is 16 rows x 16 float4; lane l finishes pieces l, l+64, l+128, l+192 = rows
+      // fp32 residual (vit.py:212).  A staged fragment row is 16 rows x 16 float4; le l finishes pieces l, l+64, l+128, l+192 = rows
       // (l >> 4) + 4j, columns 4 (l & 15) .. +3: whole 256-byte row segments per 16 lanes, the residual pieces of the NEXT fragment row in flight.
       if constexpr (MAP == ALPRO_MAP_IDENTITY && ACT == ALPRO_ACT_NONE) {
         if (g.c_dtype == ALPRO_F32) {
-          const int c4 = (lane & 15) * 4, r0e = lane >> 4;
+          const int c4 = (le & 15) * 4, r0e = le >> 4;
           float bias4[4];
           load_bias4(g, nb + c4, bias4);
           float* Cf = (float*)g.C;
@@ -1000,10 +1088,24 @@ __global__ __launch_bounds__(NT2, 2) void gemm_nt256q_kernel(const alpro_gemm_de
         }
       }
     }
+    if (nxt_t < 0) break;
     cur = nxt;
-    if (it + 2 < ntile) nxt = tile_base(slot + (it + 2) * G);
+    cur_t = nxt_t;
+    nxt_t = __builtin_amdgcn_readfirstlane(mbox[0]);
+    nxt = tile_base(nxt_t >= 0 ? nxt_t : cur_t);
+    ticket_issue(tk, wave == 0 && sc.blk && nxt_t >= 0);
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the run-ahead copies of the last tile must not land in LDS that already belongs to someone else
+  // this list is dry: the run-ahead copies went into dead slots and must have landed before the stage buffers are filled again (or, at
+  // the end, before the LDS belongs to someone else); acquire2() tries the other XCDs' lists next
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  if (sc.blk && threadIdx.x == 0) {   // last workgroup out hands the scheduler block back zeroed (every workgroup's last ticket has returned by now)
+    const uint32_t d = __hip_atomic_fetch_add(sc.blk + 8, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (d == gridDim.x - 1) {
+#pragma unroll
+      for (int i = 0; i < 9; ++i) __hip_atomic_store(sc.blk + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
 }
 
 template <typename T, int ACT, int MAP>
@@ -1057,10 +1159,15 @@ int launch_gemm_inst(const alpro_gemm_desc_t& g, hipStream_t st) {
       alpro_gemm_desc_t gq = g;
       if (!ragged_in_kernel) gq.M = m_full;
       const int tiles = (g.N / BN2) * ((gq.M + BM2 - 1) / BM2);
-      const int cus = cu_budget();
-      int grid = tiles < cus ? (tiles + 7) / 8 * 8 : cus;
+      (void)tiles;
+      // one workgroup per CU the launch may count on, whatever the tile count: the per-XCD lists are chunks of 32 tiles, and a workgroup
+      // whose list (and, dynamic walk, every other list) is empty returns at once
+      int grid = cu_budget(st);
       if (const int cap = get_option(OPT_GEMM_GRID)) grid = cap < grid ? (cap + 7) / 8 * 8 : grid;
-      hipLaunchKernelGGL((gemm_nt256q_kernel<T, ACT, MAP>), dim3(grid), dim3(NT2), 2 * STAGE2_BYTES + EPI_BYTES, st, gq);
+      TileSched sc;
+      sc.blk = get_option(OPT_GEMM_SCHED) == 1 ? sched_block_next() : nullptr;
+      sc.magic_ntn = magic_u32((uint32_t)(g.N / BN2));
+      hipLaunchKernelGGL((gemm_nt256q_kernel<T, ACT, MAP>), dim3(grid), dim3(NT2), 2 * STAGE2_BYTES + EPI_BYTES, st, gq, sc);
       if (m_rem && !ragged_in_kernel) {
         alpro_gemm_desc_t gr = g;
         gr.M = m_rem;
@@ -1076,7 +1183,7 @@ int launch_gemm_inst(const alpro_gemm_desc_t& g, hipStream_t st) {
     }
   }
   if (use256) {
-    const int cus = cu_budget();
+    const int cus = cu_budget(st);
     int grid = big_tiles < cus ? (big_tiles + 7) / 8 * 8 : cus;  // multiple of 8: the XCD-contiguous slot map must be a bijection
     if (const int cap = get_option(OPT_GEMM_GRID)) grid = cap < grid ? (cap + 7) / 8 * 8 : grid;  // tuning aid: cap the persistent grid
     const int tune = get_option(OPT_GEMM_TUNE);
@@ -1106,6 +1213,9 @@ int launch_gemm_inst(const alpro_gemm_desc_t& g, hipStream_t st) {
 // with the identity map on this path (fc1 / BERT intermediate / MLM transform / mpm_head)
 template <typename T>
 int launch_gemm(const alpro_gemm_desc_t& g, hipStream_t st) {
+#ifdef ALPRO_ISA_QUICK   // tools/isa_quick.sh: two instantiations per dtype instead of nine (register-pressure iterations on the 8-phase kernel; never the product build)
+  return g.act == ALPRO_ACT_MUL_SAVED ? launch_gemm_inst<T, ALPRO_ACT_MUL_SAVED, ALPRO_MAP_IDENTITY>(g, st) : launch_gemm_inst<T, ALPRO_ACT_NONE, ALPRO_MAP_IDENTITY>(g, st);
+#else
   if (g.act != ALPRO_ACT_NONE) {
     if (g.map_mode != ALPRO_MAP_IDENTITY) {
       set_error("alpro_gemm: an activation cannot be combined with a row map");
@@ -1123,6 +1233,7 @@ int launch_gemm(const alpro_gemm_desc_t& g, hipStream_t st) {
     case ALPRO_MAP_FRAME_TOKENS: return launch_gemm_inst<T, ALPRO_ACT_NONE, ALPRO_MAP_FRAME_TOKENS>(g, st);
     default: return launch_gemm_inst<T, ALPRO_ACT_NONE, ALPRO_MAP_PATCH_EMBED>(g, st);
   }
+#endif
 }
 }  // namespace
 }  // namespace alpro
@@ -1185,6 +1296,10 @@ static int check_gemm_desc(const alpro_gemm_desc_t* d) {
 extern "C" int alpro_gemm(const alpro_gemm_desc_t* d, void* stream) {
   using namespace alpro;
   if (const int rc = check_gemm_desc(d)) return rc;
+#ifdef ALPRO_ISA_QUICK
+  return launch_gemm<f16_t>(*d, (hipStream_t)stream);
+#else
   ALPRO_DISPATCH_DTYPE(d->dtype, T, return launch_gemm<T>(*d, (hipStream_t)stream));
   return ALPRO_OK;
+#endif
 }

@@ -406,7 +406,7 @@ struct TnPlan {
 // of partial tiles cost on the way to C: through fp32 fabric atomics ~2 TB/s (1.14 us per MB) when every workgroup finishes at
 // once, through the workspace (plain stores + tn_reduce_kernel) about a third of that.  36 tiles -> 7 ranges = 252 workgroups
 // in ONE round; 9 tiles -> 28 ranges; a 30522-row vocabulary projection (360 tiles) at 2560 tokens -> no split.
-TnPlan tn_plan(int M, int N, int K, bool ws) {
+TnPlan tn_plan(int M, int N, int K, bool ws, int cus) {
   TnPlan p;
   p.tn = (N + TW - 1) / TW;
   p.tiles = p.tn * ((K + TW - 1) / TW);
@@ -418,7 +418,7 @@ TnPlan tn_plan(int M, int N, int K, bool ws) {
   } else {
     const double set_us = (ws ? 0.4e-6 : 1.14e-6) * 4.0 * (double)N * (double)K;
     double best_t = 1e30;
-    const int cus = cu_budget();   // 256, or fewer while a collective's kernels hold CUs: one workgroup per CU, so rounds are counted over these
+    // cus: 256, or fewer while a collective's kernels hold CUs (cu_budget of the launch stream): one workgroup per CU, so rounds are counted over these
     for (int r = 1; r <= 256; ++r) {
       const int per_try = (p.total_steps + r - 1) / r;
       if (per_try < 4 && r > 1) break;
@@ -438,10 +438,38 @@ TnPlan tn_plan(int M, int N, int K, bool ws) {
 }
 }  // namespace
 
+// The plan depends on the CU budget of the stream the launch will go to (round 5: per-stream option), which this query does not know:
+// it answers with the largest workspace any budget's plan needs (25 plans; memoised per shape).
 extern "C" size_t alpro_gemm_tn_workspace_bytes(int M, int N, int K) {
   if (M <= 0 || N <= 0 || K <= 0) return 0;
-  const TnPlan p = tn_plan(M, N, K, true);
-  return (p.part_floats + p.cs_floats) * sizeof(float);
+  struct Memo { int M, N, K, forced; size_t bytes; };
+  static Memo memo[64];
+  static int n_memo = 0, lock = 0;
+  const int forced = get_option(OPT_TN_SPLITS);
+  while (__atomic_exchange_n(&lock, 1, __ATOMIC_ACQUIRE)) {}
+  for (int i = 0; i < n_memo; ++i)
+    if (memo[i].M == M && memo[i].N == N && memo[i].K == K && memo[i].forced == forced) {
+      const size_t b = memo[i].bytes;
+      __atomic_store_n(&lock, 0, __ATOMIC_RELEASE);
+      return b;
+    }
+  __atomic_store_n(&lock, 0, __ATOMIC_RELEASE);
+  size_t best = 0;
+  for (int cus = 64; cus <= 256; cus += 8) {
+    const TnPlan p = tn_plan(M, N, K, true, cus);
+    const size_t b = (p.part_floats + p.cs_floats) * sizeof(float);
+    best = b > best ? b : best;
+  }
+  while (__atomic_exchange_n(&lock, 1, __ATOMIC_ACQUIRE)) {}
+  if (n_memo < 64) memo[n_memo++] = Memo{M, N, K, forced, best};
+  __atomic_store_n(&lock, 0, __ATOMIC_RELEASE);
+  return best;
+}
+
+extern "C" int alpro_gemm_tn_ranges(int M, int N, int K, int compute_units) {
+  if (M <= 0 || N <= 0 || K <= 0) return 0;
+  const int cus = (compute_units >= 64 && compute_units < 256) ? compute_units / 8 * 8 : 256;
+  return tn_plan(M, N, K, true, cus).ranges;
 }
 
 extern "C" int alpro_gemm_tn_acc_ws(const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc, int dtype, int M, int N,
@@ -452,7 +480,7 @@ extern "C" int alpro_gemm_tn_acc_ws(const void* A, int64_t lda, const void* B, i
               "alpro_gemm_tn_acc: lda/ldb must be multiples of 8 covering N/K rounded up to 8 (16-byte chunks are read whole)");
   ALPRO_CHECK(((uintptr_t)A % 16) == 0 && ((uintptr_t)B % 16) == 0, "alpro_gemm_tn_acc: operands must be 16-byte aligned");
   const bool ws = workspace != nullptr;
-  const TnPlan p = tn_plan(M, N, K, ws);
+  const TnPlan p = tn_plan(M, N, K, ws, cu_budget((hipStream_t)stream));
   float* part = nullptr;
   float* part_cs = nullptr;
   if (ws) {

@@ -20,10 +20,10 @@ EMIT_NONE, EMIT_ROWS, EMIT_FRAME, EMIT_SKIP_CLS = 0, 1, 2, 3
 _TORCH_DTYPE = {F32: torch.float32, BF16: torch.bfloat16, F16: torch.float16}
 _CODE = {v: k for k, v in _TORCH_DTYPE.items()}
 
-EXPORTS = ["alpro_hip_last_error", "alpro_hip_abi_version", "alpro_hip_set_option", "alpro_gemm", "alpro_layernorm_fwd",
+EXPORTS = ["alpro_hip_last_error", "alpro_hip_abi_version", "alpro_hip_set_option", "alpro_hip_set_stream_option", "alpro_gemm", "alpro_layernorm_fwd",
            "alpro_attn_temporal_fwd", "alpro_attn_fwd", "alpro_patchify", "alpro_cls_mean_residual",
            "alpro_vit_final_pool", "alpro_bert_embed_fwd", "alpro_cast_from_f32", "alpro_attn_bwd", "alpro_attn_temporal_bwd",
-           "alpro_layernorm_bwd", "alpro_transpose", "alpro_transpose_batch", "alpro_gelu_bwd", "alpro_cls_mean_bwd", "alpro_scatter_add_rows", "alpro_gather_cast", "alpro_sumsq", "alpro_adamw_step", "alpro_gemm_tn_acc", "alpro_gemm_tn_acc_ws", "alpro_gemm_tn_workspace_bytes", "alpro_colsum_acc", "alpro_softmax_xent", "alpro_vtc_loss_fwd", "alpro_vtc_loss_bwd", "alpro_prepare_clips", "alpro_loss_scale_update", "alpro_add_layernorm_fwd", "alpro_layernorm_bwd_emit", "alpro_gemm_batch", "alpro_tproj_small", "alpro_attn_cls_fwd", "alpro_gemm_rows_f32"]
+           "alpro_layernorm_bwd", "alpro_transpose", "alpro_transpose_batch", "alpro_gelu_bwd", "alpro_cls_mean_bwd", "alpro_scatter_add_rows", "alpro_gather_cast", "alpro_sumsq", "alpro_adamw_step", "alpro_gemm_tn_acc", "alpro_gemm_tn_acc_ws", "alpro_gemm_tn_workspace_bytes", "alpro_gemm_tn_ranges", "alpro_colsum_acc", "alpro_softmax_xent", "alpro_vtc_loss_fwd", "alpro_vtc_loss_bwd", "alpro_prepare_clips", "alpro_loss_scale_update", "alpro_add_layernorm_fwd", "alpro_layernorm_bwd_emit", "alpro_gemm_batch", "alpro_tproj_small", "alpro_attn_cls_fwd", "alpro_gemm_rows_f32"]
 
 
 class GemmDesc(ctypes.Structure):
@@ -50,7 +50,7 @@ class TransposeJob(ctypes.Structure):
                 ("R", ctypes.c_int32), ("C", ctypes.c_int32), ("Rpad", ctypes.c_int32), ("tile0", ctypes.c_int32)]   # 48 bytes
 
 
-ABI_VERSION = 16
+ABI_VERSION = 17
 _lib = None
 
 
@@ -87,6 +87,7 @@ def load():
     lib.alpro_gemm_tn_acc_ws.argtypes = [vp, i64, vp, i64, vp, i64, i32, i32, i32, i32, vp, vp, ctypes.c_size_t, vp]
     lib.alpro_gemm_tn_workspace_bytes.argtypes = [i32, i32, i32]
     lib.alpro_gemm_tn_workspace_bytes.restype = ctypes.c_size_t
+    lib.alpro_gemm_tn_ranges.argtypes = [i32, i32, i32, i32]
     lib.alpro_colsum_acc.argtypes = [vp, i64, vp, i32, i32, i32, vp]
     lib.alpro_transpose_batch.argtypes = [vp, i32, i32, i32, vp]
     lib.alpro_adamw_step.argtypes = [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, f32, vp, f32, f32, vp, i32, i32, i32, vp]
@@ -103,6 +104,7 @@ def load():
     lib.alpro_bert_embed_fwd.argtypes = [vp, vp, vp, vp, vp, vp, f32, vp, vp, i32, vp, vp, i32, i32, i32, f32, u32, vp]
     lib.alpro_cast_from_f32.argtypes = [vp, vp, i32, i64, vp]
     lib.alpro_hip_set_option.argtypes = [ctypes.c_char_p, i32]
+    lib.alpro_hip_set_stream_option.argtypes = [vp, ctypes.c_char_p, i32]
     lib.alpro_prepare_clips.argtypes = [vp, i32, vp, f32, ctypes.POINTER(f32), ctypes.POINTER(f32), vp, vp, vp, i32, i32, i32, i32, vp]
     lib.alpro_vtc_loss_fwd.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp]
     lib.alpro_vtc_loss_bwd.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
@@ -112,7 +114,7 @@ def load():
     return lib
 
 
-_OPTION_DEFAULTS = {"gemm_tile": 0, "gemm_grid": 0, "gemm_tune": 1, "tn_splits": 0, "tn_kind": 0, "gemm_tail": 1, "attn_bwd": 1, "attn_order": 0, "gemm_kind": 1, "cu_budget": 0, "ln_grid": 0}
+_OPTION_DEFAULTS = {"gemm_tile": 0, "gemm_grid": 0, "gemm_tune": 1, "tn_splits": 0, "tn_kind": 0, "gemm_tail": 1, "attn_bwd": 1, "attn_order": 0, "gemm_kind": 1, "cu_budget": 0, "ln_grid": 0, "gemm_sched": 1}
 _option_values = {}
 
 
@@ -121,9 +123,19 @@ def set_option(name, value):
     1 = default, best per shape, 2 key-owned; 3 / 4, the persistent key-owned variants, only in the --ablations build), 'gemm_tile', 'gemm_grid',
     'gemm_tune', 'gemm_kind' (identity-map 16-bit shapes: 0 = round-3 persistent kernel, 1 = 8-phase two-group kernel, the default), 'tn_splits'
     (token ranges of the weight-gradient GEMM), 'tn_kind' (0, 2 = two-group schedule; 1 = no wgrad epilogue, --ablations build only), 'cu_budget'
-    (CUs the persistent grids are sized for; 0 = all), 'ln_grid' (cap on the LayerNorm backward's workgroup count; 0 = the default plan)."""
+    (CUs the persistent grids are sized for; 0 = all), 'ln_grid' (cap on the LayerNorm backward's workgroup count; 0 = the default plan),
+    'gemm_sched' (8-phase GEMM: 1 = tiles from per-XCD ticket counters, the default; 0 = the static round-robin walk; results are bitwise equal)."""
     _check(load().alpro_hip_set_option(name.encode(), int(value)), "alpro_hip_set_option")
     _option_values[name] = int(value)
+
+
+def set_stream_option(name, value, stream=None):
+    """alpro_hip_set_stream_option: the knob `name` for launches on ONE stream (default: torch's current stream; pass a raw handle to address a
+    stream from another thread); value < 0 removes the override.  The library consults per-stream values for 'cu_budget' -- the situation a
+    launch runs in (a collective's kernels holding CUs next to THIS stream's work), not a property of the process.  Returns the stream handle."""
+    h = stream if stream is not None else (_stream() if torch.cuda.is_available() else ctypes.c_void_p(0))   # (CPU-only boxes: gloo tests of the exchange logic)
+    _check(load().alpro_hip_set_stream_option(h, name.encode(), int(value)), "alpro_hip_set_stream_option")
+    return h
 
 
 def get_option(name):

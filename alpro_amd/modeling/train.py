@@ -179,6 +179,9 @@ def dgrad(dy_t, wT, out_dtype=None, row_scale=None, row_scale_group=1, gelu_pre=
 _LIVE_ANCHORS = weakref.WeakSet()
 
 
+BACKWARD_EPOCH = [0]   # bumped by every anchored backward: "parameter gradients may have been written since" (FlatAdamW's fused zero_grad bookkeeping)
+
+
 class Anchor(torch.autograd.Function):
     """Ties a hand-written encoder backward into torch.autograd.
 
@@ -206,6 +209,7 @@ class Anchor(torch.autograd.Function):
     def backward(ctx, *grads):
         # what the run may assume about the rest of the backward pass: True = some other anchored backward has not run yet
         ctx.run.others_pending = any(c is not ctx for c in _LIVE_ANCHORS)
+        BACKWARD_EPOCH[0] += 1
         from alpro_amd import config as rt
         rt.check_backward_precision(getattr(ctx.run, "dt", None) or ctx.dt)
         try:

@@ -59,6 +59,11 @@ def real_grad(p):
     return None if (g is None or is_placeholder_grad(g)) else g
 
 
+def _backward_epoch():
+    from alpro_amd.modeling import train as tr
+    return tr.BACKWARD_EPOCH[0]
+
+
 class _FlatView:
     """What amp.master_params() yields for a FlatAdamW whose flat buffers exist: ONE object whose .grad is the whole flat gradient buffer, so
     the driver's `clip_grad_norm_(amp.master_params(optimizer), cfg.grad_norm)` (run_pretrain_sparse.py:633) is one norm and one scale over
@@ -91,6 +96,7 @@ class FlatAdamW:
         # zero_grad() that follows is free instead of a second 0.94 GB pass
         self.fused_zero_grad = fused_zero_grad
         self._g_clean = False
+        self._clean_epoch = -1
         self._cus_reserved = False
         self.step_count = 0
         self._pending_state = None  # load_state_dict() before the flat buffers exist: applied by _build()
@@ -136,12 +142,21 @@ class FlatAdamW:
         bump_param_epoch()
         register_flat_lp(fp, None, live)  # announces the flat range (weights.param_version); the 16-bit mirror follows in step()
         self._span = {id(p): (o, o + (p.numel() + 3) // 4 * 4) for p, o in zip(live, offs)}
+        # "step() left the gradient buffer zeroed" (fused_zero_grad) holds until something writes a gradient: the hand-written backward passes
+        # announce themselves (train.BACKWARD_EPOCH), torch's own accumulation (heads, temperature: a handful of tensors) through this hook --
+        # a driver that calls scaled_loss.backward() itself and then discards the step with zero_grad() must get a real clear (ADVICE r4)
+        if hasattr(torch.Tensor, "register_post_accumulate_grad_hook"):
+            for p in live:
+                p.register_post_accumulate_grad_hook(self._mark_dirty)
         if self.allreduce and self.overlap_backward and dist.collectives_active():
             dist.register_grads_final_hook(self._on_grads_final)
         if self._pending_state is not None:
             pend, self._pending_state = self._pending_state, None
             self._restore_moments(pend)
         return True
+
+    def _mark_dirty(self, _p=None):
+        self._g_clean = False
 
     def _layout(self):
         """[(index of the parameter in the constructor's list, flat offset, numel)]: what the m / v buffers mean."""
@@ -174,9 +189,10 @@ class FlatAdamW:
         if self.flat is None:
             for p in self.params:
                 p.grad = None
-        elif self._g_clean:
-            self._g_clean = False      # step() already cleared the buffer (fused_zero_grad)
+        elif self._g_clean and self._clean_epoch == _backward_epoch():
+            self._g_clean = False      # step() already cleared the buffer (fused_zero_grad) and no backward has written into it since
         else:
+            self._g_clean = False
             self.flat["g"].zero_()
 
     # ---- overlapped exchange -----------------------------------------------------------------------------
@@ -199,11 +215,17 @@ class FlatAdamW:
         return self._merge(spans)
 
     def _reserve_cus(self, on):
-        """While all-reduces launched from inside backward are in flight, the persistent GEMM grids / the weight-gradient range plan leave
-        dist.rccl_cu_reserve() CUs to RCCL's kernels (library option "cu_budget")."""
+        """While all-reduces launched from inside backward are in flight, the launches of THIS stream (the one backward runs on) plan for
+        dist.rccl_cu_reserve() fewer CUs: the weight-gradient GEMM's token-range plan is one unit per CU and cannot give a displaced unit to
+        anybody else, and the persistent NT grid leaves RCCL's channels room to start (round 5: the NT GEMM itself no longer needs this -- its
+        dynamic tile scheduler survives a taken CU --, and the knob is a per-stream override, not process-wide state)."""
         r = dist.rccl_cu_reserve()
         if r > 0 and on != self._cus_reserved:
-            hip.set_option("cu_budget", 256 - r if on else 0)
+            if on:
+                ncu = torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count if torch.cuda.is_available() else 256
+                self._cu_stream = hip.set_stream_option("cu_budget", max(64, ncu - r))
+            else:
+                hip.set_stream_option("cu_budget", -1, stream=getattr(self, "_cu_stream", None))
             self._cus_reserved = on
 
     def _launch(self, s, e):
@@ -220,6 +242,7 @@ class FlatAdamW:
         self._reduced.append((s, e))
 
     def _on_grads_final(self, params=None, all_but=None):
+        self._g_clean = False   # gradients are being written (a driver's own scaled_loss.backward() does not pass through backward(): ADVICE r4)
         if self.flat is None or not self.allreduce or not dist.collectives_active():
             return
         if all_but is not None and not any(id(p) in self._span for p in all_but):
@@ -253,6 +276,19 @@ class FlatAdamW:
         step()) divides in place instead and makes the next step() skip both its own exchange and the scaling."""
         if not self.allreduce or not dist.collectives_active():
             self._pre_synced = "avg" if average else None
+            return 0
+        if self._pre_synced is not None:
+            # the exchange of this step already happened -- amp.unscale_ finished an overlapped exchange that was still in flight ("sum"), or
+            # the caller synchronised twice (a facade that lost track: ADVICE r4).  A second all-reduce would multiply the gradients by
+            # world once more; only the averaging may still be owed.
+            if average and self._pre_synced == "sum":
+                if self.flat is not None:
+                    self.flat["g"].div_(dist.size())
+                else:
+                    for p in self.params:
+                        if real_grad(p) is not None:
+                            p.grad.div_(dist.size())
+                self._pre_synced = "avg"
             return 0
         if self.flat is None:  # first step: gradients are still separate tensors
             dist.allreduce_grads_(self.params, average=average)
@@ -318,6 +354,7 @@ class FlatAdamW:
                        float(self.max_grad_norm or 0.0), 1.0 / world, dyn_state=sc.state if sc is not None else None,
                        grads_scaled=self._grads_scaled, correct_bias=grp["correct_bias"], zero_grad=self.fused_zero_grad)
         self._g_clean = self.fused_zero_grad
+        self._clean_epoch = _backward_epoch()
         if sc is not None:  # overflow -> the kernel skipped the update; the schedule halves / grows the scale on the device
             dyn = sc.dynamic
             hip.loss_scale_update(sc.state, norm, sc.growth if dyn else 1.0, sc.backoff if dyn else 1.0, sc.window, sc.min_scale, sc.max_scale)

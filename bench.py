@@ -372,11 +372,26 @@ def main():
     ap.add_argument("--no-parity", action="store_true", help="skip the in-run parity measurement against tests/golden (a few seconds)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: become the launcher -- one rank per GPU under torch.distributed.run on this node (RCCL over xGMI),
+        # same flags; the launched ranks find WORLD_SIZE set and fall through.  (The driver's own torchrun command line lands below directly.)
+        import socket
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC for RCCL (see the environment notes in README.md)
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.stdout.flush()
+        os.execvpe(cmd[0], cmd, env)
+
     from alpro_amd import config as rt
     from alpro_amd import dist, hip
     dist.init()
     rank, world = dist.rank(), dist.size()
-    assert world == args.gpus or (args.gpus == 1 and world == 1), "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+    assert world == args.gpus, "--gpus %d but the process group has %d rank(s): launch as `python bench.py --gpus N` or under torch.distributed.run --nproc-per-node N" % (args.gpus, world)
     local = int(os.environ.get("LOCAL_RANK", "0")) % max(1, torch.cuda.device_count())  # (% only matters for gloo smoke runs)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define ALPRO_HIP_ABI_VERSION 16
+#define ALPRO_HIP_ABI_VERSION 17
 
 enum { ALPRO_OK = 0, ALPRO_ERR_INVALID = 1, ALPRO_ERR_LAUNCH = 2 };
 enum { ALPRO_F32 = 0, ALPRO_BF16 = 1, ALPRO_F16 = 2 };
@@ -56,6 +56,12 @@ int alpro_hip_abi_version(void);
  * epilogue -- timing only, results are garbage).  Defaults come from the
  * environment (ALPRO_GEMM_TILE, ...) once at load time; there is no reference counterpart (tools/ and bench.py use it). */
 int alpro_hip_set_option(const char* name, int value);
+/* Round 5: the same knobs scoped to ONE stream (value >= 0 sets the override for launches on `stream`, value < 0 removes it; launches on
+ * other streams keep the process-wide value).  The only option the library consults per stream today is "cu_budget" -- the number of
+ * compute units a launch may count on while a collective's kernels hold the rest (alpro_amd.optim sets it on the stream its backward runs
+ * on while the overlapped gradient exchange is in flight, run_pretrain_sparse.py:432,601); "gemm_sched" (1 = the persistent NT GEMM takes
+ * its tiles from per-XCD ticket counters, 0 = the static round-robin walk) is a process-wide A/B knob.  No reference counterpart. */
+int alpro_hip_set_stream_option(void* stream, const char* name, int value);
 
 /* ---------------------------------------------------------------------------------------------
  * C[map(m), n] = residual[map(m), n] + row_scale[m / row_scale_group] * act(alpha * sum_k A[m,k] W[n,k] + bias[n])
@@ -320,6 +326,10 @@ int alpro_gemm_tn_acc(const void* A, int64_t lda, const void* B, int64_t ldb, fl
  * the tokens: then workspace may be NULL and the call is alpro_gemm_tn_acc); it is scratch -- contents are dead when the call's
  * work has run, so one buffer can serve every call of a stream.  workspace == NULL: exactly alpro_gemm_tn_acc. */
 size_t alpro_gemm_tn_workspace_bytes(int M, int N, int K);
+/* Round 5: the token-range plan depends on the compute units the launch may count on (option "cu_budget" of the launch stream), which the
+ * size query above cannot know: it answers with the largest workspace any budget's plan needs.  alpro_gemm_tn_ranges gives the number of
+ * token ranges of the workspace plan for a given CU count (256 = the whole chip) -- for tests and the tuning tools. */
+int alpro_gemm_tn_ranges(int M, int N, int K, int compute_units);
 int alpro_gemm_tn_acc_ws(const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc, int dtype, int M,
                          int N, int K, float* colsum, void* workspace, size_t workspace_bytes, void* stream);
 

@@ -14,14 +14,22 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_bench_two_ranks_gloo_shared_gpu():
+@pytest.mark.parametrize("how", ["torchrun", "plain"])
+def test_bench_two_ranks_gloo_shared_gpu(how):
+    """how = torchrun: the driver's command line (python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...); how = plain:
+    `python bench.py --gpus N ...` with no rendezvous environment -- bench.py re-executes itself under torch.distributed.run."""
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
     env = dict(os.environ, ALPRO_DIST_BACKEND="gloo")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--batch", "2", "--frames", "2", "--steps", "1", "--warmup", "1"]
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    tail = [os.path.join(ROOT, "bench.py"), "--gpus", "2", "--batch", "2", "--frames", "2", "--steps", "1", "--warmup", "1"]
+    if how == "torchrun":
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port)] + tail
+    else:
+        cmd = [sys.executable] + tail
     out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]

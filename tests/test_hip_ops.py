@@ -5,11 +5,13 @@ the remaining difference is fp32 accumulation order (+ one output rounding when 
 16-bit), hence the tolerances below.  f32 is the exact mode: fp32 MFMA == fmaf chain.
 """
 import math
+import os
 
 import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 torch.backends.cuda.matmul.allow_tf32 = False
 
@@ -411,6 +413,15 @@ def test_gemm_8phase_kernel(dt, M, N, K, case):
             assert bool((guard[M:] == 7.0).all()), "kind %d wrote rows behind M" % kind
             if saved is not None:
                 outs[("saved", kind)] = saved.clone()
+    # round 5: the tile walk does not touch results -- the static round-robin walk (gemm_sched 0) and repeated launches of the dynamic one (tickets
+    # from per-XCD counters that the last workgroup of every launch hands back zeroed) are bitwise equal
+    with hip.option("gemm_sched", 0):
+        if saved is not None:
+            saved.zero_()
+        assert torch.equal(hip.gemm(A, W, **kw), outs[1]), "static walk differs"
+        assert saved is None or torch.equal(saved, outs[("saved", 1)])
+    for _ in range(2):
+        assert torch.equal(hip.gemm(A, W, **kw), outs[1]), "dynamic walk: a repeated launch differs"
     tol = (2e-5, 2e-4 * math.sqrt(K / 768)) if case.startswith("f32res") else OUT_TOL[dt]
     if case == "gelu_save":
         x = ref.clone().requires_grad_(True)
@@ -426,6 +437,50 @@ def test_gemm_8phase_kernel(dt, M, N, K, case):
     else:
         close(outs[1], ref, *tol, "8-phase kernel (%s)" % case)
     close(outs[1], outs[0].double().cpu(), tol[0] * 2, tol[1] * 2, "8-phase vs round-3 kernel")
+
+
+def _cu_thief():
+    """tools/cu_thief.hip (n resident workgroups with 64 KiB of LDS each: the footprint of a collective's channel kernels), built on the box."""
+    import ctypes
+    import subprocess
+    so = "/tmp/libcu_thief_test.so"
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O2", "-shared", "-fPIC", os.path.join(ROOT, "tools", "cu_thief.hip"), "-o", so])
+    lib = ctypes.CDLL(so)
+    lib.cu_thief_launch.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_void_p]
+    return lib
+
+
+@pytest.mark.parametrize("stolen", [8, 40])
+def test_gemm_tile_scheduler_with_compute_units_taken(stolen):
+    """The persistent 8-phase GEMM while another kernel holds CUs (a collective's channels during the overlapped gradient exchange,
+    run_pretrain_sparse.py:432,601): `stolen` workgroups of tools/cu_thief.hip stay resident on a second stream, so that many of the GEMM's 256
+    workgroups cannot start until somebody leaves.  With the dynamic walk the resident workgroups draw the displaced ones' tiles from the
+    per-XCD counters (and from other XCDs' when a list runs dry: the thief's CUs are not spread evenly); results are bitwise those of the
+    undisturbed launch, for both walks, launch after launch."""
+    import time
+    hip = _hip()
+    dt = torch.float16
+    M, N, K = 256 * 196 + 32, 768, 768          # the B = 32 projection: 591 tiles = 2.3 rounds of 256, ragged last tile row
+    a, w, b = rnd(M, K, seed=910), rnd(N, K, seed=911, scale=0.05), rnd(N, seed=912)
+    A, W, Bv = a.to(dt).cuda(), w.to(dt).cuda(), b.cuda()
+    ref = hip.gemm(A, W, bias=Bv)
+    torch.cuda.synchronize()
+    lib = _cu_thief()
+    side = torch.cuda.Stream()
+    buf = torch.zeros(64 * 65536, device="cuda")
+    started = torch.zeros(1, dtype=torch.int32, device="cuda")
+    rc = lib.cu_thief_launch(buf.data_ptr(), stolen, int(100e6 * 0.5), started.data_ptr(), side.cuda_stream)   # ~0.5 s of the 100 MHz wall clock
+    assert rc == 0
+    t0 = time.time()
+    while int(started.item()) < stolen:
+        assert time.time() - t0 < 10.0, "thief workgroups did not become resident"
+        time.sleep(0.001)
+    for sched in (1, 0, 1):
+        with hip.option("gemm_sched", sched):
+            for _ in range(3):
+                assert torch.equal(hip.gemm(A, W, bias=Bv), ref), "gemm_sched %d under contention" % sched
+    torch.cuda.synchronize()
+    assert torch.equal(hip.gemm(A, W, bias=Bv), ref)      # and undisturbed again afterwards (every launch left its scheduler block clean)
 
 
 @pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])

@@ -4,6 +4,7 @@ import ctypes
 import json
 import os
 import re
+import sys
 
 import pytest
 import torch
@@ -70,7 +71,10 @@ def test_transpose_job_layout_and_wgrad_workspace_plan():
     lib = hip.load()
     tile, M = 256 * 256 * 4, 100416
 
-    def ranges(m, n, k):
+    def ranges(m, n, k, cus=256):
+        return lib.alpro_gemm_tn_ranges(m, n, k, cus)
+
+    def ws_ranges(m, n, k):      # what the size query (stream-agnostic: the maximum over every CU budget's plan) provides room for
         tn, tk = (n + 255) // 256, (k + 255) // 256
         nbytes = lib.alpro_gemm_tn_workspace_bytes(m, n, k)
         per_range = tn * tk * tile + tk * tn * 256 * 4      # partial tiles + one bias-gradient partial per (range, k-tile)
@@ -78,6 +82,9 @@ def test_transpose_job_layout_and_wgrad_workspace_plan():
         return nbytes // per_range
     assert ranges(M, 3072, 768) == 7 and ranges(M, 768, 3072) == 7      # 36 tiles -> 252 workgroups
     assert ranges(M, 2304, 768) == 9 and ranges(M, 768, 768) == 28      # 27 -> 243, 9 -> 252
+    assert ranges(M, 3072, 768, 240) == 6 and ranges(M, 768, 768, 240) == 26   # 16 CUs left to a collective: 216 / 234 workgroups, still one round
+    for shp in ((M, 3072, 768), (M, 2304, 768), (M, 768, 768)):
+        assert ws_ranges(*shp) >= max(ranges(*shp, cus) for cus in range(64, 257, 8))
     assert lib.alpro_gemm_tn_workspace_bytes(64, 8, 8) == 256 * 4        # one range: no partial tiles, one bias-gradient partial row (summed in a fixed order by the reduce kernel)
     assert lib.alpro_gemm_tn_workspace_bytes(2560, 30522, 768) == 3 * 120 * 256 * 4   # vocabulary projection, not split: 3 k-tiles x (120 x 256) column partials
     assert lib.alpro_gemm_tn_workspace_bytes(0, 8, 8) == 0
@@ -899,17 +906,18 @@ def test_reference_driver_optimizer_lines_run_unchanged_on_the_fused_optimizer(m
 
 
 def test_overlapped_exchange_reserves_cus_for_the_collective_library(monkeypatch):
-    """while FlatAdamW's async all-reduces are in flight the persistent GEMM grids are sized for 256 - reserve CUs (library
-    option cu_budget), and back to all of them when the exchange has been waited for; dist.init caps RCCL at the same number of channels."""
+    """while FlatAdamW's async all-reduces are in flight the launches of the stream backward runs on plan for
+    (CUs - reserve) compute units -- a PER-STREAM override (alpro_hip_set_stream_option), removed on the same stream when the exchange has
+    been waited for; dist.init caps RCCL at the same number of channels."""
     from alpro_amd import dist, hip, optim
     calls = []
-    monkeypatch.setattr(hip, "set_option", lambda name, value: calls.append((name, value)))
+    monkeypatch.setattr(hip, "set_stream_option", lambda name, value, stream=None: calls.append((name, value, stream)) or "the-stream")
     opt = optim.FlatAdamW([torch.nn.Parameter(torch.zeros(8))], overlap_backward=True)
     assert dist.rccl_cu_reserve() == 16
     opt._reserve_cus(True)
     opt._reserve_cus(True)            # idempotent while the exchange is running
     opt._reserve_cus(False)
-    assert calls == [("cu_budget", 240), ("cu_budget", 0)]
+    assert calls == [("cu_budget", 240, None), ("cu_budget", -1, "the-stream")]
     monkeypatch.setenv("ALPRO_RCCL_CU_RESERVE", "0")
     opt._reserve_cus(True)
     assert len(calls) == 2            # reservation switched off: nothing is touched
@@ -985,8 +993,25 @@ def test_8phase_gemm_isa_keeps_the_orders_the_source_relies_on(tmp_path):
         assert count(r"\bglobal_load_lds_dwordx4\b") == 14, (head, count(r"global_load_lds"))
         assert count(r"s_waitcnt vmcnt\(2\)") == 2 and count(r"s_waitcnt.*vmcnt") == 2, head
         assert count(r"\bs_barrier\b") == 14, (head, count(r"\bs_barrier\b"))
-        for bad in (r"\bscratch_", r"\bbuffer_", r"\bflat_", r"\bglobal_(load|store)_(?!lds)", r"\bv_readlane", r"\bv_writelane"):
+        for bad in (r"\bscratch_", r"\bbuffer_", r"\bflat_", r"\bglobal_(load|store)_(?!lds)", r"\bglobal_atomic", r"\bv_readlane", r"\bv_writelane"):
             assert count(bad) == 0, (head, bad, [l for l in span if re.search(bad, l)][:3])
+        # round 5, the tile scheduler's ticket: a returning atomic whose result is awaited by the K loop's counted waits, not by the compiler.
+        # The register it lands in must be ONE register from the atomic to its reader: written only by returning ticket atomics (and its
+        # initialisation before the first of them), read only by v_readfirstlane BEHIND the K loop -- a copy in between would copy stale contents.
+        code = [l.split("//")[0] for l in lines]
+        tick = [i for i, l in enumerate(code) if re.search(r"\bglobal_atomic_add\b.*\bsc0\b", l)]
+        inflight = [i for i in tick if i < mf[0] or i > mf[-1]]
+        regs = {}
+        for i in inflight:
+            regs.setdefault(code[i].split()[1].rstrip(","), []).append(i)
+        carried = [r for r, at in regs.items() if any(i > mf[-1] for i in at) and any(i < mf[0] for i in at)]   # drawn before the first K loop AND behind an epilogue
+        assert len(carried) == 1, (head, regs)
+        reg = carried[0]
+        named = [(i, l.strip()) for i, l in enumerate(code) if re.search(r"\b%s\b" % reg, l) and i not in regs[reg]]
+        readers = [(i, l) for i, l in named if re.search(r"v_readfirstlane_b32 s\d+, %s$" % reg, l)]
+        writers = [(i, l) for i, l in named if (i, l) not in readers]
+        assert len(readers) == 1 and readers[0][0] > mf[-1], (head, named)
+        assert all(re.match(r"v_mov_b32_e32 %s, 0$" % reg, l) and i < min(regs[reg]) for i, l in writers), (head, writers)
         # epilogue: a fragment row is staged by 8 ds_write2_b32 per lane and read back by OTHER lanes with ds_read_b128 -- no read may be issued
         # inside a group of 8 writes (the round-4 bug: the compiler, reasoning per lane, had hoisted one above the last write; wave_lds_order())
         writes = 0
@@ -1018,3 +1043,26 @@ def test_8phase_gemm_isa_keeps_the_orders_the_source_relies_on(tmp_path):
                 assert not [l for l in span if re.search(bad, l)], (head, bad)
             assert sum(1 for l in span if re.search(r"s_waitcnt.*vmcnt", l)) == 1, head
         assert seen == 4, seen   # {bf16, f16} x {round-3 schedule, two-group schedule}
+
+
+def test_bench_launches_itself_for_more_than_one_gpu(monkeypatch):
+    """`python bench.py --gpus 4` without a rendezvous environment execs `python -m torch.distributed.run --nproc-per-node 4 bench.py --gpus 4 ...`
+    on 127.0.0.1 with its own flags passed through; under torchrun (WORLD_SIZE set) it does not."""
+    import bench
+    seen = {}
+
+    class Launched(Exception):
+        pass
+
+    def fake_exec(file, argv, env):
+        seen.update(file=file, argv=list(argv), env=env)
+        raise Launched()
+    monkeypatch.setattr(os, "execvpe", fake_exec)
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "3", "--warmup", "1", "--no-parity"])
+    with pytest.raises(Launched):
+        bench.main()
+    a = seen["argv"]
+    assert a[:3] == [sys.executable, "-m", "torch.distributed.run"] and "--nproc-per-node" in a and a[a.index("--nproc-per-node") + 1] == "4"
+    assert a[a.index("--master-addr") + 1] == "127.0.0.1" and a[-7:] == ["--gpus", "4", "--steps", "3", "--warmup", "1", "--no-parity"]
+    assert os.path.basename(a[-8]) == "bench.py" and seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"

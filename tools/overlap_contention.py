@@ -58,10 +58,11 @@ def main():
     buf = torch.zeros(64 * 65536, device=dev)
     started = torch.zeros(1, dtype=torch.int32, device=dev)
     rows = []
-    for stolen in (0, 8, 16, 32):
-        for budget in (256, 248, 240, 224):
-            if budget != 256 and budget < 256 - stolen - 8:
+    for sched, stolen, budget in [(s_, st, bu) for s_ in (1, 0) for st in (0, 8, 16, 32) for bu in (256, 248, 240, 224)]:
+        if True:
+            if budget != 256 and (budget != 256 - stolen or sched == 0):   # the policy diagonal, for the ticket walk; the static walk's table is profiles/r4_overlap_cu_contention.txt
                 continue
+            hip.set_option("gemm_sched", sched)
             hip.set_option("cu_budget", 0 if budget == 256 else budget)
             step()                                       # (plans / grids of this budget warm)
             torch.cuda.synchronize()
@@ -78,13 +79,16 @@ def main():
             torch.cuda.current_stream().synchronize()
             ms = (time.perf_counter() - t0) / args.steps * 1e3
             torch.cuda.synchronize()                              # (the thief runs out by itself)
-            rows.append((stolen, budget, ms))
-            print("stolen CUs %2d  cu_budget %3d  %.2f ms / step" % (stolen, budget, ms), flush=True)
+            rows.append((sched, stolen, budget, ms))
+            print("gemm_sched %d  stolen CUs %2d  cu_budget %3d  %.2f ms / step" % (sched, stolen, budget, ms), flush=True)
     hip.set_option("cu_budget", 0)
-    base = [ms for s, b, ms in rows if s == 0 and b == 256][0]
-    print("\nrelative to the undisturbed step (%.2f ms):" % base)
-    for s, b, ms in rows:
-        print("  stolen %2d budget %3d: %+.1f %%" % (s, b, 100.0 * (ms / base - 1.0)))
+    hip.set_option("gemm_sched", 1)
+    for sc in (1, 0):
+        base = [ms for s_, s, b, ms in rows if s_ == sc and s == 0 and b == 256][0]
+        print("\ngemm_sched %d (%s), relative to its undisturbed step (%.2f ms):" % (sc, "per-XCD ticket walk" if sc else "static round-robin walk", base))
+        for s_, s, b, ms in rows:
+            if s_ == sc:
+                print("  stolen %2d budget %3d: %+.1f %%" % (s, b, 100.0 * (ms / base - 1.0)))
 
 
 if __name__ == "__main__":
