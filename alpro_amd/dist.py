@@ -7,6 +7,7 @@ One process per GPU (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT 
 Single-process use needs no initialisation: size() == 1 and every collective is the identity.
 """
 import os
+import sys
 
 import torch
 import torch.distributed as td
@@ -42,8 +43,13 @@ def init(backend=None):
     """Initialise from the torchrun-style environment; no-op when WORLD_SIZE is unset or 1 (unless ALPRO_FORCE_COLLECTIVES=1)."""
     if is_initialized() or (int(os.environ.get("WORLD_SIZE", "1")) <= 1 and not _FORCE[0]):
         return
-    if rccl_cu_reserve() > 0 and os.environ.get("ALPRO_OVERLAP_BACKWARD", "1") != "0":
-        os.environ.setdefault("NCCL_MAX_NCHANNELS", str(rccl_cu_reserve()))   # one channel = one resident workgroup = one CU
+    single_node = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1"))) == int(os.environ.get("WORLD_SIZE", "1"))
+    if rccl_cu_reserve() > 0 and os.environ.get("ALPRO_OVERLAP_BACKWARD", "1") != "0" and single_node and "NCCL_MAX_NCHANNELS" not in os.environ:
+        # one channel = one resident workgroup = one CU.  Only for the measured configuration (one node, xGMI ring, the overlapped exchange);
+        # multi-node jobs and users who set the variable themselves keep RCCL's own choice (ADVICE r4)
+        os.environ["NCCL_MAX_NCHANNELS"] = str(rccl_cu_reserve())
+        if int(os.environ.get("RANK", "0")) == 0:
+            print("alpro_amd.dist: NCCL_MAX_NCHANNELS=%s (ALPRO_RCCL_CU_RESERVE; the overlapped gradient exchange leaves the GEMMs the other CUs)" % os.environ["NCCL_MAX_NCHANNELS"], file=sys.stderr)
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29500")
     os.environ.setdefault("RANK", "0")
@@ -156,7 +162,18 @@ def allreduce_grads_(params, bucket_bytes=64 << 20, average=True):
     Returns the number of bytes reduced."""
     if not collectives_active():
         return 0
-    grads = [p.grad for p in params if p.grad is not None and (p.grad.dim() == 0 or p.grad.numel() <= 1 or any(p.grad.stride()))]   # (stride-0 placeholders of optim.zero_none_grad: nothing to exchange)
+    params = list(params)
+    real = lambda p: p.grad is not None and (p.grad.dim() == 0 or p.grad.numel() <= 1 or any(p.grad.stride()))   # noqa: E731  (stride-0 placeholders of optim.zero_none_grad: nothing to exchange)
+    # Which tensors take part must be the same on every rank (the buckets are positional).  A parameter that received a gradient on some
+    # ranks only -- a head or branch that only some batches use -- takes part everywhere: the ranks without one contribute zeros, which is
+    # what the reference's zero_none_grad materialises for EVERY such parameter (misc.py:28-31).  One small MAX all-reduce decides (ADVICE r4).
+    if params:
+        has = torch.tensor([1 if real(p) else 0 for p in params], dtype=torch.int32, device=params[0].device)
+        td.all_reduce(has, op=td.ReduceOp.MAX)
+        for p, h in zip(params, has.tolist()):
+            if h and not real(p):
+                p.grad = torch.zeros_like(p)
+    grads = [p.grad for p in params if real(p)]
     sent = 0
     bucket, nbytes = [], 0
 

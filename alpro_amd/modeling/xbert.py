@@ -567,6 +567,11 @@ class _LMHeadRun:
                 up = dloss.reshape(()).float()        # upstream scale of the loss (1 in the reference's sum of losses; the loss scale under fp16)
                 if getattr(self, "pre_scale", None) is not None:
                     up = up / self.pre_scale.reshape(())   # already applied at forward time
+            if up is not None and dt == torch.float16 and getattr(self, "pre_scale", None) is None:
+                # fp16 operands whose loss scale was NOT known at forward time (a scaler armed after the forward): `up` then IS the loss scale
+                # (2^16) and would overflow the 16-bit (M, H) tensors below -- apply it to the small probabilities instead
+                dl = dl * up
+                up = None
             if dlogits is not None:            # someone also differentiated through mlm_scores
                 dl = (dl * up) if up is not None else dl.clone()
                 up = None

@@ -290,7 +290,7 @@ def mode_name(dtype):
     return "%s operands%s" % (dtype, " + precise CLS rows (fp32)" if rt.cls_precise(dt) else "")
 
 
-def measure_parity(dev, dtype):
+def measure_parity(dev, dtype, full_size_backward=False):
     """Parity of the benchmarked mode, measured in THIS process against what the REFERENCE produced for the same closed-form weights and inputs
     (tests/golden/*.npz, written by tests/golden/make_golden.py from /root/reference; weights / inputs regenerated by tests/golden/det_init.py):
       * VTC logits on ALL FOUR reference fixtures that hold them (tests/golden/parity_cases.py: retrieval 2 / 16 frames -- 1 video x n captions
@@ -350,8 +350,21 @@ def measure_parity(dev, dtype):
     out = dict(mode=mode_name(dtype), vtc_logits_max_abs_err=per[worst], vtc_logits_worst_fixture=worst, vtc_logits_max_abs_err_per_fixture=per,
                north_star_bar="VTC logits within 1e-3 of the reference", meets_bar=bool(per[worst] <= pc.NORTH_STAR_BAR))
     out.update(res)
+    # the tolerances this mode is HELD to (north_star: "within a stated fp tolerance"): the asserts of tests/test_model_parity.py for the benchmark mode
+    out["stated_tolerances"] = {
+        "vtc_logits_max_abs_err": pc.NORTH_STAR_BAR, "video_embeds_max_abs_err": 3e-3, "itm_scores_max_abs_err": 5e-3, "mlm_scores_max_abs_err (B=64 proxy)": 2e-2,
+        "itc_loss_abs_err": 1e-3, "grad_norm_rel_err_worst (fixture, 451 tensors)": 1e-2,
+        "full_size_backward (vs the exact fp32 HIP mode)": pc.FULL_SIZE_BACKWARD_LIMITS,
+        "note": "fp32 exact mode: 5e-6 on every output; bf16 operands cannot meet the 1e-3 VTC bar (2.9e-3 with precise CLS rows, 9.4e-3 without: profiles/r4_parity_pareto.txt)"}
+    out["within_stated_tolerances"] = bool(per[worst] <= pc.NORTH_STAR_BAR and res.get("video_embeds_max_abs_err", 0) <= 3e-3 and res.get("itm_scores_max_abs_err", 0) <= 5e-3
+                                           and res.get("itc_loss_abs_err", 0) <= 1e-3 and res.get("grad_norm_rel_err_worst", 0) <= 1e-2)
     out["fixtures"] = "tests/golden/{retrieval_T2_B3, pretrain_T8_B2, retrieval_T16_B2, pretrain_release_T4_L30_B2, retrieval_grads_T2_B3}.npz (outputs of the reference itself, make_golden.py); measured in this process"
     out["full_size_proxy"] = "tests/test_model_parity.py::test_full_size_pretrain_forward_in_the_bench_dtype_vs_the_exact_mode (B=64 x 8f against the exact fp32 HIP mode); measured numbers: profiles/r4_parity_pareto.txt"
+    if full_size_backward and dtype != "fp32":
+        # the backward at the benchmarked size: every parameter gradient of one B = 64 x 8f step against the exact fp32 HIP mode (~5 s)
+        bw = pc.full_size_backward_parity(BERT_CFG, VENC, make_cfg, dev, dtype=dtype, cls_precise=rt._cls_precise[0])   # (the mode the timed steps ran in)
+        out["full_size_backward"] = {k: (float("%.3e" % v) if isinstance(v, float) else v) for k, v in bw.items() if k != "losses_exact"}
+        out["full_size_backward"]["loss_abs_err"] = {k: float("%.2e" % v) for k, v in bw["loss_abs_err"].items()}
     return out
 
 
@@ -556,7 +569,7 @@ def main():
             if train:
                 opt = None
             torch.cuda.empty_cache()
-            result["parity"] = measure_parity(dev, args.dtype)
+            result["parity"] = measure_parity(dev, args.dtype, full_size_backward=train and B == 64 and T == 8)
         else:   # (--no-parity, or N > 1 where rank 0 alone cannot run it): say where the measured numbers of this mode live
             result["parity"] = {"mode": mode_name(args.dtype), "measured_in_this_run": False,
                                 "see": "profiles/r4_parity_pareto.txt (worst-of-four-fixture VTC-logit error and the B=64 proxy per mode); rerun with N=1 and without --no-parity to measure in-process"}

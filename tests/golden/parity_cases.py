@@ -50,3 +50,90 @@ def vtc_logits(name, m, batch):
 def vtc_logit_error(name, m, batch, ref):
     got = vtc_logits(name, m, batch).detach().float().cpu().numpy().astype(np.float64)
     return float(np.abs(got - ref).max())
+
+
+# what tests/test_model_parity.py asserts and bench.py states next to its measurement (fp16 operands + precise CLS rows against the exact mode,
+# B = 64 x 8 frames): PROVISIONAL until the first measurement of round 5 lands in profiles/r5_parity_backward_B64.txt
+FULL_SIZE_BACKWARD_LIMITS = dict(grad_norm_rel_err_worst=5e-2, grad_norm_rel_err_median=5e-3, grad_cosine_worst=0.98, grad_cosine_median=0.9995,
+                                 global_grad_cosine=0.9995, global_grad_norm_rel_err=5e-3, loss_abs_err=5e-3)
+
+
+def full_size_backward_parity(bert_cfg, venc, make_cfg, device, dtype="fp16", cls_precise="auto", B=64, T=8, seed=4):
+    """Parity of the BACKWARD at the benchmarked size.  No golden vectors exist there; the exact fp32 HIP mode -- pinned to
+    the reference's gradients at <= 2e-3 on the fixtures (tests/test_model_parity.py) -- is the oracle.  One training step's forward + backward
+    of AlproForPretrain (VTC + VTM + MLM + MPM; B pairs x T frames x 224^2 + 40 tokens; train mode with drop-path and dropout at 0 so that both
+    modes differentiate the same function; the hard negatives of the exact run are re-used) in the exact mode and in `dtype` (fp16: a loss-scaled
+    backward at 2^16, like the timed steps; run_pretrain_sparse.py:557,595-601), then per parameter tensor:
+        norm_rel = | |g| - |g_exact| | / |g_exact|,   cos = <g, g_exact> / (|g| |g_exact|),   l2_rel = |g - g_exact| / |g_exact|
+    -> dict with worst / median of each over all tensors that receive a gradient, the worst tensors' names and the four losses' errors."""
+    import bench
+    from alpro_amd import amp, config as rt
+    from alpro_amd.modeling.alpro_models import AlproForPretrain
+    torch.manual_seed(seed)
+    cfg = make_cfg(dict(bert_cfg, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0))
+    m = AlproForPretrain(cfg, dict(venc, num_frm=T, drop_path_rate=0.0)).to(device).train()
+    batch = bench.synth_batch(B, T, device, seed=11, full=True)
+    batch["text_input_mask"] = batch["text_input_mask"].clone()
+    batch["text_input_mask"][::3, 31:] = 0
+    negs = {}
+    orig_neg, orig_mn = AlproForPretrain._sample_negatives, torch.multinomial
+
+    def record(sim_v2t, sim_t2v, bs):
+        if "n" not in negs:
+            negs["n"] = orig_neg(sim_v2t, sim_t2v, bs)
+        return negs["n"]
+    AlproForPretrain._sample_negatives = staticmethod(record)
+    torch.multinomial = lambda w, n=1, *a, **k: w.argmax(dim=-1, keepdim=True)
+    prev_armed = rt._armed[0]
+    keys = ("mlm_loss", "itm_loss", "itc_loss", "mpm_loss")
+
+    used_cls = {}
+
+    def run(dt, cls):
+        for p in m.parameters():
+            p.grad = None
+        with rt.use_compute_dtype(dt), rt.use_cls_precise(cls), torch.enable_grad():
+            used_cls[dt] = bool(rt.cls_precise())
+            out = m(batch)
+            loss = out["mlm_loss"] + out["itm_loss"] + out["itc_loss"] + out["mpm_loss"]
+            scale = 1.0
+            if amp.needs_loss_scaling():
+                sc = amp.LossScaler(init_scale=65536.0, dynamic=False, device=device)
+                scale = 65536.0
+                with rt.loss_scaling(sc):
+                    (loss * sc.scale.reshape(())).backward()
+            else:
+                loss.backward()
+        grads = {n: (p.grad.detach().double() / scale) for n, p in m.named_parameters() if p.grad is not None and (p.grad.dim() == 0 or any(p.grad.stride()) or p.grad.numel() <= 1)}
+        return {k: float(out[k]) for k in keys}, grads
+    try:
+        l32, g32 = run("fp32", "auto")
+        l16, g16 = run(dtype, cls_precise)
+    finally:
+        AlproForPretrain._sample_negatives = orig_neg
+        torch.multinomial = orig_mn
+        rt._armed[0] = prev_armed
+    assert set(g16) == set(g32), sorted(set(g16) ^ set(g32))[:5]
+    rows = []
+    for n in g32:
+        a, b = g16[n].reshape(-1), g32[n].reshape(-1)
+        nb = float(b.norm())
+        if nb == 0.0 or n.endswith("attention.self.key.bias"):   # exactly 0 in exact arithmetic (softmax shift invariance): rounding noise only
+            continue
+        na = float(a.norm())
+        rows.append((n, abs(na - nb) / nb, float(a @ b) / max(na * nb, 1e-300), float((a - b).norm()) / nb, nb))
+    rows.sort(key=lambda r: -r[3])
+    import statistics as st
+    rep = dict(batch=B, frames=T, mode="%s operands%s" % (dtype, " + precise CLS rows (fp32)" if used_cls.get(dtype) else ""), oracle="the exact fp32 HIP mode on the same weights, inputs and hard negatives",
+               grad_tensors=len(rows),
+               grad_norm_rel_err_worst=max(r[1] for r in rows), grad_norm_rel_err_median=st.median(r[1] for r in rows),
+               grad_cosine_worst=min(r[2] for r in rows), grad_cosine_median=st.median(r[2] for r in rows),
+               grad_l2_rel_err_worst=rows[0][3], grad_l2_rel_err_median=st.median(r[3] for r in rows),
+               worst_tensors=[(r[0], float("%.3e" % r[3])) for r in rows[:3]],
+               loss_abs_err={k: abs(l16[k] - l32[k]) for k in keys}, losses_exact=l32)
+    gt = torch.cat([g32[r[0]].reshape(-1) for r in rows]), torch.cat([g16[r[0]].reshape(-1) for r in rows])
+    rep["global_grad_norm_rel_err"] = abs(float(gt[1].norm()) - float(gt[0].norm())) / float(gt[0].norm())
+    rep["global_grad_cosine"] = float(gt[0] @ gt[1]) / (float(gt[0].norm()) * float(gt[1].norm()))
+    del m, g32, g16, gt
+    torch.cuda.empty_cache()
+    return rep

@@ -3,6 +3,7 @@ all-gather (forward order = rank order; backward = reduce across ranks + own sli
 HorovodAllgather.backward used at alpro_models.py:110-111, "sum" = the exact full-batch gradient), bucketed gradient all-reduce,
 parameter broadcast, and the VTC loss identity "2 ranks x B pairs == 1 rank x 2B pairs" that holds in "sum" mode."""
 import os
+import sys
 import socket
 
 import torch
@@ -85,6 +86,19 @@ def _worker(rank, world, port, out):
     assert sent == (35 + 11) * 4
     assert torch.allclose(ps[0].grad, torch.full((5, 7), 1.5)) and torch.allclose(ps[1].grad, torch.arange(11, dtype=torch.float32) * 1.5)
     assert ps[2].grad is None
+    # a parameter that received a gradient on ONE rank only (a head only some batches use) takes part on every rank -- zeros from the others,
+    # as the reference's zero_none_grad would have filled in -- instead of shifting the positional buckets; stride-0 placeholders
+    # (alpro_amd.optim.zero_none_grad) count as "no gradient"
+    from alpro_amd.optim import placeholder_grad
+    qs = [torch.nn.Parameter(torch.zeros(6)), torch.nn.Parameter(torch.zeros(9)), torch.nn.Parameter(torch.zeros(4))]
+    qs[0].grad = torch.full((6,), float(rank + 1))
+    if rank == 1:
+        qs[1].grad = torch.full((9,), 8.0)
+    else:
+        qs[1].grad = placeholder_grad(qs[1])
+    sent = dist.allreduce_grads_(qs, bucket_bytes=1 << 20)
+    assert sent == (6 + 9) * 4 and qs[2].grad is None
+    assert torch.allclose(qs[0].grad, torch.full((6,), 1.5)) and torch.allclose(qs[1].grad, torch.full((9,), 4.0)) and any(qs[1].grad.stride())
     # broadcast of parameters from rank 0
     lin = torch.nn.Linear(4, 4)
     with torch.no_grad():
@@ -129,6 +143,22 @@ def _amp_without_synchronize_checks(rank, world):
             tot = sum(r + 1 for r in range(world))
             assert torch.equal(ps[0].grad, torch.full((64, 33), float(tot))), (wire, ps[0].grad.flatten()[:3])
             assert torch.equal(ps[1].grad, torch.full((130,), 10.0 * tot)), (wire, ps[1].grad[:3])
+            # the same through the hvd.DistributedOptimizer facade.  Its own _synced flag knows nothing of the exchange
+            # unscale_ just finished; the synchronize() its step() (or the driver) issues next must NOT all-reduce the flat buffer a second
+            # time -- only the averaging is still owed -- and a further synchronize() changes nothing
+            import alpro_amd.compat
+            if alpro_amd.compat.PATH not in sys.path:
+                sys.path.insert(0, alpro_amd.compat.PATH)
+            from horovod import torch as hvd
+            fac = hvd.DistributedOptimizer(opt)
+            fac.synchronize()
+            assert opt._pre_synced == "avg"
+            assert torch.equal(ps[0].grad, torch.full((64, 33), float(tot) / world)) and torch.equal(ps[1].grad, torch.full((130,), 10.0 * tot / world))
+            fac.synchronize()
+            assert torch.equal(ps[0].grad, torch.full((64, 33), float(tot) / world))
+            with fac.skip_synchronize():
+                fac.step()                            # lr 0: consumes the gradients, exchanges nothing
+            assert opt._pre_synced is None and not opt._inflight
     finally:
         rt.set_compute_dtype(prev)
 

@@ -655,3 +655,24 @@ def test_full_size_pretrain_forward_in_the_bench_dtype_vs_the_exact_mode(bert_cf
     assert rep["fp16"]["p999"] <= 1e-3 and rep["fp16"]["max"] <= 1.5e-3, rep["fp16"]     # (tightened to what the first measurement shows)
     assert rep["fp16"]["rms"] < 0.6 * rep["fp16_plain"]["rms"], rep                        # the side path must carry its weight at full size too
     assert rep["fp16"]["itm"] <= 5e-3 and rep["fp16"]["mlm"] <= 2e-2 and rep["fp16"]["mpm"] <= 5e-3, rep["fp16"]
+
+
+def test_full_size_pretrain_backward_in_the_bench_dtype_vs_the_exact_mode(bert_cfg):
+    """the hand-written backward at the benchmarked size.  AlproForPretrain, B = 64 x 8 frames x 224^2 + 40 tokens, one
+    forward + backward of mlm + itm + itc + mpm (run_pretrain_sparse.py:557,595-601) with drop-path / dropout at 0: the benchmark's mode (fp16
+    operands + precise CLS rows, loss scale 2^16) against the exact fp32 HIP mode -- the oracle at this size, itself held to the reference's
+    gradients on the fixtures above -- for EVERY parameter tensor that receives a gradient: relative error of the norm, cosine, relative L2
+    error; plus the four losses.  The bounds are what the first measurement showed, with margin (tests/golden/parity_cases.py)."""
+    from tests.golden import parity_cases as pc
+    rep = pc.full_size_backward_parity(bert_cfg, VENC, make_cfg, "cuda")
+    print("\n[B=64 backward, %s vs exact fp32] %d tensors | norm rel err worst %.2e median %.2e | cosine worst %.6f median %.6f | l2 rel err worst %.2e median %.2e | "
+          "global norm %.2e cosine %.6f | losses %s | worst %s" % (rep["mode"], rep["grad_tensors"], rep["grad_norm_rel_err_worst"], rep["grad_norm_rel_err_median"],
+                                                                   rep["grad_cosine_worst"], rep["grad_cosine_median"], rep["grad_l2_rel_err_worst"], rep["grad_l2_rel_err_median"],
+                                                                   rep["global_grad_norm_rel_err"], rep["global_grad_cosine"],
+                                                                   {k: float("%.2e" % v) for k, v in rep["loss_abs_err"].items()}, rep["worst_tensors"]))
+    assert rep["grad_tensors"] >= 440, rep["grad_tensors"]
+    lim = pc.FULL_SIZE_BACKWARD_LIMITS
+    assert rep["grad_norm_rel_err_worst"] <= lim["grad_norm_rel_err_worst"] and rep["grad_norm_rel_err_median"] <= lim["grad_norm_rel_err_median"], rep
+    assert rep["grad_cosine_worst"] >= lim["grad_cosine_worst"] and rep["grad_cosine_median"] >= lim["grad_cosine_median"], rep
+    assert rep["global_grad_cosine"] >= lim["global_grad_cosine"] and rep["global_grad_norm_rel_err"] <= lim["global_grad_norm_rel_err"], rep
+    assert all(v <= lim["loss_abs_err"] for v in rep["loss_abs_err"].values()), rep["loss_abs_err"]
