@@ -53,6 +53,21 @@ def cls_precise(dt=None):
     return _cls_precise[0] in ("1", "true", "on")
 
 
+# The chain's launches are skinny (32 ... 512 rows against whole weight matrices: latency, not throughput).  ALPRO_CLS_STREAM=1 issues them
+# on a second HIP stream, ordered against the main path by events (modeling/timesformer/vit.py::_ClsSide), so that they run beside the
+# block's big launches instead of between them (round 5; needs the dynamic tile scheduler: a persistent GEMM that finds a CU taken must not
+# wait a round for it).
+_cls_stream = [os.environ.get("ALPRO_CLS_STREAM", "0").lower() in ("1", "true", "on")]
+
+
+def cls_stream():
+    return _cls_stream[0]
+
+
+def set_cls_stream(v):
+    _cls_stream[0] = bool(v)
+
+
 def set_cls_precise(v):
     _cls_precise[0] = v.lower() if isinstance(v, str) else ("1" if v else "0")
 

@@ -446,7 +446,7 @@ def scatter_add_rows(src, idx, dst, idx_mod=0, skip_idx=-1):
     return dst
 
 
-def attn(qkv, batch, L, H, scale, key_bias=None, want_lse=False, drop_p=0.0, drop_seed=0, cls_q=None, cls_group=1):
+def attn(qkv, batch, L, H, scale, key_bias=None, want_lse=False, drop_p=0.0, drop_seed=0, cls_q=None, cls_group=1, cls_out=None):
     """-> out [, lse] [, cls_out].  cls_q (batch / cls_group, 3*H*64) fp32: also evaluate the CLS query (row 0 of every sequence) in fp32 from
     these unrounded q rows against the K / V staged in LDS -> cls_out (batch, H*64) fp32 (precise CLS rows, 16-bit dtypes only)."""
     lib = load()
@@ -455,12 +455,16 @@ def attn(qkv, batch, L, H, scale, key_bias=None, want_lse=False, drop_p=0.0, dro
     out = torch.empty((batch * L, H * 64), dtype=qkv.dtype, device=qkv.device)
     lse = torch.empty((batch, H, L), dtype=torch.float32, device=qkv.device) if want_lse else None
     kb = _dev(key_bias, torch.float32) if key_bias is not None else None
-    cls_out = None
-    if cls_q is not None:
+    if cls_q is None:
+        cls_out = None
+    else:
         _dev(cls_q, torch.float32)
         if cls_q.shape != (batch // cls_group, 3 * H * 64) or batch % cls_group or not cls_q.is_contiguous():
             raise RuntimeError("attn: cls_q %s does not match batch=%d H=%d cls_group=%d" % (tuple(cls_q.shape), batch, H, cls_group))
-        cls_out = torch.empty((batch, H * 64), dtype=torch.float32, device=qkv.device)
+        if cls_out is None:
+            cls_out = torch.empty((batch, H * 64), dtype=torch.float32, device=qkv.device)
+        assert cls_out.shape == (batch, H * 64) and cls_out.is_contiguous()
+        _dev(cls_out, torch.float32)
     _check(lib.alpro_attn_fwd(_ptr(qkv), _ptr(out), _CODE[qkv.dtype], batch, L, H, scale, _ptr(kb), _ptr(lse), drop_p, drop_seed,
                               _ptr(cls_q), cls_group, _ptr(cls_out), _stream()), "alpro_attn_fwd")
     res = (out,) + ((lse,) if want_lse else ()) + ((cls_out,) if cls_q is not None else ())

@@ -83,6 +83,53 @@ class Attention(nn.Module):
         self.proj = nn.Linear(dim, dim)
 
 
+class _ClsSide:
+    """The precise-CLS chain of the ViT blocks on a second stream (alpro_amd.config.cls_stream, round 5).
+
+    Per block the chain is: LayerNorm + q | k | v of the B CLS rows (needs only the block INPUT's CLS rows: the temporal half never touches
+    them) -> [the CLS query's attention, inside the main path's attention launch] -> projection of B*T rows -> frame mean + residual ->
+    norm2 + fc1 + GELU -> fc2 + residual, written over the 16-bit path's CLS rows of the block output.  Five skinny launches of 10-35 us
+    that each leave most of the chip idle when they sit BETWEEN the block's big launches.  Here they go to a side stream:
+        side:  [wait: block input ready]  snapshot x[:, 0], q|k|v rows                                   -> ev_q
+        main:  temporal half, add+norm1, qkv GEMM, [wait ev_q] attention (+ CLS query)                   -> ev_attn, ... fc2 -> ev_out
+        side:  [wait ev_attn / the main path's x2] proj rows, frame mean, fc1 rows, [wait ev_out] fc2 rows over out[:, 0]  -> done
+        main (next block):  [wait done] before its first read of the CLS rows (the add + norm1 kernel)
+    so the first part runs beside the temporal half and the second beside the MLP GEMMs.  All side-stream outputs live in buffers owned by
+    this object (no allocation crosses streams); the event order above is also what makes their re-use from block to block safe."""
+    _by_device = {}
+
+    def __init__(self, device):
+        self.stream = torch.cuda.Stream(device)
+        self.bufs = {}
+        self.done = None
+
+    @classmethod
+    def get(cls, device):
+        key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+        obj = cls._by_device.get(key)
+        if obj is None:
+            obj = cls._by_device[key] = cls(device)
+        return obj
+
+    def buf(self, name, shape, device):
+        t = self.bufs.get((name, shape))
+        if t is None:
+            t = self.bufs[(name, shape)] = torch.empty(shape, dtype=torch.float32, device=device)
+        return t
+
+    def wait_done(self):
+        """Main stream: the previous block's chain has written its CLS rows."""
+        if self.done is not None:
+            torch.cuda.current_stream().wait_event(self.done)
+            self.done = None
+
+    @classmethod
+    def join(cls, device):
+        obj = cls._by_device.get((device.type, device.index if device.index is not None else torch.cuda.current_device())) if device.type == "cuda" else None
+        if obj is not None:
+            obj.wait_done()
+
+
 class Block(nn.Module):
     def __init__(self, dim, num_heads, layer_num, mlp_ratio=4., qkv_bias=False, qk_scale=None, drop=0., attn_drop=0.,
                  drop_path=0.1, act_layer=nn.GELU, norm_layer=nn.LayerNorm, attention_type='divided_space_time',
@@ -146,10 +193,40 @@ class Block(nn.Module):
     # row that :165-167 replicates per frame: ONE row per clip) -> the CLS query's attention over the frame's tokens (K / V of the patch
     # tokens as the 16-bit GEMM produced them) -> proj -> frame mean + residual (:184-187) -> norm2 -> Mlp -> residual (:198-212).
     # B*T + 3*B fp32 rows per block against B*(1 + N*T) 16-bit rows; drop-path scales are the main path's.
-    def _cls_qkv(self, x_cls_in):
+    def _cls_qkv(self, x_cls_in, out=None):
         """(B, D) fp32 CLS rows of the block input -> their unrounded q | k | v (norm1 fused into the operand load)."""
         sa = self.attn
-        return hip.gemm_rows(x_cls_in, self._w("s_qkv", sa.qkv, torch.float32), bias=sa.qkv.bias, ln=(self.norm1.weight, self.norm1.bias, VIT_EPS))
+        return hip.gemm_rows(x_cls_in, self._w("s_qkv", sa.qkv, torch.float32), bias=sa.qkv.bias, ln=(self.norm1.weight, self.norm1.bias, VIT_EPS), out=out)
+
+    def _cls_side_begin(self, side, x, B, T, snapshot):
+        """Side stream, at block entry: (snapshot of) the block input's CLS rows and their q | k | v.  -> (x_cls_in, cls_q, o_c buffer)."""
+        main = torch.cuda.current_stream()
+        D = x.shape[-1]
+        ev_in = main.record_event()
+        with torch.cuda.stream(side.stream):
+            side.stream.wait_event(ev_in)
+            if snapshot:    # the inference path updates x in place
+                x_cls_in = side.buf("x_cls_in", (B, D), x.device)
+                x_cls_in.copy_(x[:, 0])
+            else:
+                x_cls_in = x[:, 0]
+            cls_q = self._cls_qkv(x_cls_in, out=side.buf("cls_q", (B, 3 * D), x.device))
+            side.ev_q = side.stream.record_event()
+        return x_cls_in, cls_q, side.buf("o_c", (B * T, D), x.device)
+
+    def _cls_side_finish(self, side, ev_mid, ev_out, x_cls_in, o_c, B, T, drop_s, drop_m, x2_out, out_out):
+        """Side stream: the chain behind the attention (ev_mid: o_c -- and, training, the main path's x2 -- are written; ev_out: so is the block output)."""
+        D = o_c.shape[-1]
+        sa, f32, dev = self.attn, torch.float32, o_c.device
+        with torch.cuda.stream(side.stream):
+            side.stream.wait_event(ev_mid)
+            p_c = hip.gemm_rows(o_c, self._w("s_proj", sa.proj, f32), bias=sa.proj.bias, row_scale=drop_s, out=side.buf("p_c", (B * T, D), dev))
+            hip.cls_mean_residual(x_cls_in, p_c, x2_out, B, T)
+            f1c = hip.gemm_rows(x2_out, self._w("fc1", self.mlp.fc1, f32), bias=self.mlp.fc1.bias, act=hip.ACT_GELU, ln=(self.norm2.weight, self.norm2.bias, VIT_EPS),
+                                out=side.buf("f1c", (B, self.mlp.fc1.out_features), dev))
+            side.stream.wait_event(ev_out)
+            hip.gemm_rows(f1c, self._w("fc2", self.mlp.fc2, f32), bias=self.mlp.fc2.bias, residual=x2_out, row_scale=drop_m, out=out_out)
+            side.done = side.stream.record_event()
 
     def _cls_chain(self, x_cls_in, o_c, B, T, drop_s, drop_m, x2_out, out_out):
         """x_cls_in: (B, D) fp32 CLS rows of the block input (a row-strided view is fine); o_c: (B*T, D) fp32 attention output of the CLS query of
@@ -203,7 +280,11 @@ class Block(nn.Module):
         ta, sa = self.temporal_attn, self.attn
         drop_t, drop_s, drop_m = self._drop(B * N, x.device), self._drop(B * T, x.device), self._drop(B, x.device)
         cp = rt.cls_precise(dt) and self.fuse_residual_ln and self.merge_temporal_proj
-        x_cls_in = x[:, 0].clone() if cp else None   # a COPY (x is updated in place below; .contiguous() of a one-clip batch is a view); the temporal half never touches the CLS row
+        side = _ClsSide.get(x.device) if (cp and rt.cls_stream() and x.is_cuda) else None
+        if side is not None:
+            x_cls_in, cls_q, o_c_buf = self._cls_side_begin(side, x, B, T, snapshot=True)
+        else:
+            x_cls_in = x[:, 0].clone() if cp else None   # a COPY (x is updated in place below; .contiguous() of a one-clip batch is a view); the temporal half never touches the CLS row
         # ---- temporal (vit.py:146-162)
         h = hip.layernorm(x, self.temporal_norm1.weight, self.temporal_norm1.bias, VIT_EPS, dt, rows=B * N * T,
                           map_mode=hip.MAP_SKIP_CLS, map_p0=N * T)
@@ -214,10 +295,16 @@ class Block(nn.Module):
             # streaming kernel each (alpro_add_layernorm_fwd) -- see the kernel's header comment in csrc/core.hip
             mg = self._merged_tproj(dt)
             d_t = hip.gemm(a, mg["w"], bias=mg["b1"], row_scale=drop_t, row_scale_group=T)
+            if side is not None:
+                side.wait_done()   # the previous block's chain has written this block's input CLS rows (first read: the kernel below)
             hs, _ = hip.add_layernorm(x, d_t, self.norm1.weight, self.norm1.bias, VIT_EPS, mode=hip.ADD_PRE_SPATIAL, x_out=x,
                                       delta_bias=self.temporal_fc.bias, T=T, N=N)
             qkv = hip.gemm(hs, self._w("s_qkv", sa.qkv, dt), bias=sa.qkv.bias)
-            if cp:   # the CLS query of every frame once more in fp32, inside the same attention launch
+            if side is not None:
+                torch.cuda.current_stream().wait_event(side.ev_q)
+                a, o_c = hip.attn(qkv, B * T, N + 1, H, sa.scale, cls_q=cls_q, cls_group=T, cls_out=o_c_buf)
+                ev_attn = torch.cuda.current_stream().record_event()
+            elif cp:   # the CLS query of every frame once more in fp32, inside the same attention launch
                 a, o_c = hip.attn(qkv, B * T, N + 1, H, sa.scale, cls_q=self._cls_qkv(x_cls_in), cls_group=T)
             else:
                 a = hip.attn(qkv, B * T, N + 1, H, sa.scale)
@@ -229,7 +316,10 @@ class Block(nn.Module):
         f1 = hip.gemm(h2, self._w("fc1", self.mlp.fc1, dt), bias=self.mlp.fc1.bias, act=hip.ACT_GELU)
         hip.gemm(f1, self._w("fc2", self.mlp.fc2, dt), out=xf, bias=self.mlp.fc2.bias, out_dtype=torch.float32, residual=xf,
                  row_scale=drop_m, row_scale_group=S)
-        if cp:
+        if side is not None:
+            self._cls_side_finish(side, ev_attn, torch.cuda.current_stream().record_event(), x_cls_in, o_c, B, T, drop_s, drop_m,
+                                  side.buf("x2_c", (B, D), x.device), x[:, 0])
+        elif cp:
             self._cls_chain(x_cls_in, o_c, B, T, drop_s, drop_m, torch.empty_like(x_cls_in), x[:, 0])
         return x
 
@@ -244,6 +334,10 @@ class Block(nn.Module):
         dev = x.device
         sv = {"x": x, "dims": (B, T, N, S, D, H), "dt": dt}
         sv["drop_t"], sv["drop_s"], sv["drop_m"] = self._drop(B * N, dev), self._drop(B * T, dev), self._drop(B, dev)
+        side = None
+        if rt.cls_precise(dt) and rt.cls_stream() and x.is_cuda and self.fuse_residual_ln and self.merge_temporal_proj:
+            side = _ClsSide.get(dev)
+            x_cls_in, cls_q, o_c_buf = self._cls_side_begin(side, x, B, T, snapshot=False)
         h = hip.layernorm(x, self.temporal_norm1.weight, self.temporal_norm1.bias, VIT_EPS, dt, rows=B * N * T,
                           map_mode=hip.MAP_SKIP_CLS, map_p0=N * T)
         qkv_t = hip.gemm(h, self._w("t_qkv", ta.qkv, dt), bias=ta.qkv.bias)
@@ -253,18 +347,25 @@ class Block(nn.Module):
             pr = None
             mg = self._merged_tproj(dt)
             d_t = hip.gemm(a_t, mg["w"], bias=mg["b1"], row_scale=sv["drop_t"], row_scale_group=T)
+            if side is not None:
+                side.wait_done()   # the previous block's chain has written this block's input CLS rows (first read: the kernel below)
             hs, xt = hip.add_layernorm(x, d_t, self.norm1.weight, self.norm1.bias, VIT_EPS, mode=hip.ADD_PRE_SPATIAL,
                                        delta_bias=self.temporal_fc.bias, T=T, N=N)
             del d_t
             qkv_s = hip.gemm(hs, self._w("s_qkv", sa.qkv, dt), bias=sa.qkv.bias)
             o_c = None
-            if rt.cls_precise(dt):
+            if side is not None:
+                torch.cuda.current_stream().wait_event(side.ev_q)
+                a_s, lse_s, o_c = hip.attn(qkv_s, B * T, N + 1, H, sa.scale, want_lse=True, cls_q=cls_q, cls_group=T, cls_out=o_c_buf)
+            elif rt.cls_precise(dt):
                 a_s, lse_s, o_c = hip.attn(qkv_s, B * T, N + 1, H, sa.scale, want_lse=True, cls_q=self._cls_qkv(x[:, 0]), cls_group=T)
             else:
                 a_s, lse_s = hip.attn(qkv_s, B * T, N + 1, H, sa.scale, want_lse=True)
             d_s = hip.gemm(a_s, self._w("s_proj", sa.proj, dt), bias=sa.proj.bias, row_scale=sv["drop_s"], row_scale_group=N + 1)
             h2, x2 = hip.add_layernorm(xt, d_s, self.norm2.weight, self.norm2.bias, VIT_EPS, mode=hip.ADD_PRE_MLP, T=T, N=N)
             del d_s
+            if side is not None:
+                ev_x2 = torch.cuda.current_stream().record_event()   # o_c and the main path's x2 (whose CLS rows the chain overwrites) are written
         else:
             xt = torch.empty_like(x)
             xt[:, 0] = x[:, 0]
@@ -294,7 +395,9 @@ class Block(nn.Module):
         out = torch.empty_like(x)
         hip.gemm(f1, self._w("fc2", self.mlp.fc2, dt), out=out.view(B * S, D), bias=self.mlp.fc2.bias, out_dtype=torch.float32,
                  residual=x2.view(B * S, D), row_scale=sv["drop_m"], row_scale_group=S)
-        if rt.cls_precise(dt) and self.fuse_residual_ln and self.merge_temporal_proj:
+        if side is not None:
+            self._cls_side_finish(side, ev_x2, torch.cuda.current_stream().record_event(), x_cls_in, o_c, B, T, sv["drop_s"], sv["drop_m"], x2[:, 0], out[:, 0])
+        elif rt.cls_precise(dt) and self.fuse_residual_ln and self.merge_temporal_proj:
             # precise CLS rows: the block output's CLS row and the saved pre-MLP stream's CLS row (norm2's backward input) take the fp32 values;
             # the backward differentiates the 16-bit graph as before (its CLS-row operands differ from these by one rounding)
             self._cls_chain(x[:, 0], o_c, B, T, sv["drop_s"], sv["drop_m"], x2[:, 0], out[:, 0])
@@ -729,6 +832,7 @@ class VisionTransformer(nn.Module):
         tok, T, W, N = self._embed(x)
         for blk in self.blocks:
             tok = blk(tok, B, T, W)
+        _ClsSide.join(tok.device)
         y = hip.layernorm(tok, self.norm.weight, self.norm.bias, VIT_EPS, torch.float32).view(B, -1, self.embed_dim)
         return y if return_all_tokens else y[:, 0]
 
@@ -780,6 +884,7 @@ class TimeSformer(nn.Module):
         tok, T, W, N = m._embed(x)
         for blk in m.blocks:
             tok = blk(tok, B, T, W)
+        _ClsSide.join(tok.device)
         out32, _ = hip.vit_final_pool(tok, m.norm.weight, m.norm.bias, VIT_EPS, B, T, N, torch.float32)
         return out32
 
@@ -793,6 +898,7 @@ class TimeSformer(nn.Module):
         tok, T, W, N = m._embed(x)
         for blk in m.blocks[:-1]:
             tok = blk(tok, B, T, W)
+        _ClsSide.join(tok.device)
         cls = m.blocks[-1].forward_cls(tok, B, T, W)
         return hip.layernorm(cls, m.norm.weight, m.norm.bias, VIT_EPS, torch.float32)
 
@@ -826,6 +932,7 @@ class _VisualRun:
             tok, sv = blk.forward_train(tok, B, T, W)
             blk._presampled = None
             self.saved.append(sv)
+        _ClsSide.join(tok.device)
         self.tok = tok
         out32, _ = hip.vit_final_pool(tok, m.norm.weight, m.norm.bias, VIT_EPS, B, T, N, torch.float32)
         return out32

@@ -676,3 +676,45 @@ def test_full_size_pretrain_backward_in_the_bench_dtype_vs_the_exact_mode(bert_c
     assert rep["grad_cosine_worst"] >= lim["grad_cosine_worst"] and rep["grad_cosine_median"] >= lim["grad_cosine_median"], rep
     assert rep["global_grad_cosine"] >= lim["global_grad_cosine"] and rep["global_grad_norm_rel_err"] <= lim["global_grad_norm_rel_err"], rep
     assert all(v <= lim["loss_abs_err"] for v in rep["loss_abs_err"].values()), rep["loss_abs_err"]
+
+
+def test_cls_chain_on_a_side_stream_is_result_neutral():
+    """Round 5 (alpro_amd.config.cls_stream): the precise-CLS chain of the ViT blocks issued on a second HIP stream -- the same launches, ordered
+    against the main path by events instead of by stream order -- gives bit-identical results on every path that carries it: the in-place
+    inference forward (also through forward_cls, the prompter's entry), and the out-of-place training forward + hand-written backward
+    (outputs, saved pre-MLP CLS rows via the parameter gradients).  Several passes back to back: the side buffers are re-used from block to
+    block and from pass to pass."""
+    from alpro_amd import config as rt
+    from alpro_amd.modeling.timesformer.vit import TimeSformer
+    torch.manual_seed(21)
+    T, B = 4, 6
+    enc = TimeSformer(dict(VENC, num_frm=T, drop_path_rate=0.0), input_format="RGB").cuda()
+    x = torch.randn(B, 3, T, 224, 224, device="cuda")
+    dout = torch.randn(B, 197, 768, device="cuda") * 1e-2
+    res = {}
+    prev = rt.cls_stream()
+    try:
+        for on in (False, True, True, False):
+            rt.set_cls_stream(on)
+            with rt.use_compute_dtype("bf16"), rt.use_cls_precise("1"):
+                enc.eval()
+                with torch.no_grad():
+                    y = enc.forward_features(x)
+                    c = enc.forward_cls(x)
+                enc.train()
+                for p in enc.parameters():
+                    p.grad = None
+                with torch.enable_grad():
+                    yt = enc.forward_features(x)
+                    (yt * dout).sum().backward()
+                g = torch.cat([p.grad.reshape(-1) for p in enc.parameters() if p.grad is not None])
+            torch.cuda.synchronize()
+            cur = (y.clone(), c.clone(), yt.detach().clone(), g.clone())
+            if not res:
+                res["ref"] = cur
+            else:
+                for a, b, what in zip(cur, res["ref"], ("forward_features", "forward_cls", "training forward", "parameter gradients")):
+                    assert torch.equal(a, b), "%s differs with cls_stream=%s" % (what, on)
+    finally:
+        rt.set_cls_stream(prev)
+    assert bool(torch.isfinite(res["ref"][3]).all()) and float(res["ref"][3].abs().sum()) > 0
