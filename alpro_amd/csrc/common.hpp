@@ -226,14 +226,25 @@ int get_option(int which);
 int get_stream_option(int which, hipStream_t st);
 
 // ---- dynamic tile scheduler of the persistent GEMM grids (round 5) ------------------------------------------------------------------
-// One 64-byte block of device memory per launch: [0..7] per-XCD ticket counters, [8] workgroups finished.  Blocks come from a per-device
-// ring (lazily allocated, zero-filled once); the last workgroup of a launch hands its block back zeroed, so a block is clean again long
-// before the ring wraps (RING launches later, same device; launches on one stream are ordered anyway).
+// One block of device memory per launch: [0..7] per-XCD ticket counters, [SCHED_CLAIM0 + w] the claim word of workgroup w (its two static
+// tiles).  Every (device, stream) owns a PAIR of blocks used alternately: launch n works on block n & 1 and its first workgroup zeroes the
+// other one -- the block of launch n - 1, which is complete because launches of one stream are ordered.  No workgroup ever waits for a
+// "last one out" count, and no block is shared between streams.
+constexpr int SCHED_CLAIM0 = 8, SCHED_MAX_WG = 256, SCHED_BLOCK_U32 = SCHED_CLAIM0 + SCHED_MAX_WG;
 struct TileSched {
-  uint32_t* blk;       // nullptr = static walk (option gemm_sched 0)
+  uint32_t* blk;       // nullptr = static walk (option gemm_sched 0, a stream that is being captured, or no block pair left)
+  uint32_t* prev;      // the block of this stream's previous launch, zeroed by workgroup 0 (never nullptr when blk is set)
   uint32_t magic_ntn;  // ceil(2^32 / ntn): tile / ntn == umulhi(tile, magic_ntn) (ntn > 1)
 };
-uint32_t* sched_block_next();   // nullptr on allocation failure (the caller falls back to the static walk)
+// Picks the stream's next block and keeps the stream's slot locked until the destructor runs, i.e. until the caller has enqueued the launch:
+// two host threads launching on one stream cannot interleave "pick" and "enqueue" in opposite orders.
+struct SchedLaunch {
+  uint32_t* cur = nullptr;
+  uint32_t* prev = nullptr;
+  void* slot = nullptr;
+  SchedLaunch(hipStream_t st, bool enabled);
+  ~SchedLaunch();
+};
 inline uint32_t magic_u32(uint32_t d) { return (uint32_t)(((1ull << 32) + d - 1) / d); }
 // Compute units the persistent GEMM grids and the weight-gradient range plan may count on (round 4): 256, or less while a collective's kernels
 // hold CUs (alpro_amd.dist sets "cu_budget" while the overlapped gradient exchange is in flight: a persistent one-workgroup-per-CU launch that

@@ -78,35 +78,60 @@ int get_stream_option(int which, hipStream_t st) {
 
 // ---- tile-scheduler blocks (common.hpp) ---------------------------------------------------------------------------------------------
 namespace {
-constexpr int kSchedRing = 1024, kSchedBlockU32 = 16;   // 64 KiB per device
-uint32_t* g_sched_ring[64];
-unsigned g_sched_pos[64];
-int g_sched_lock = 0;
+constexpr int kSchedSlots = 64;   // (device, stream) pairs with a block pair of their own; further streams run the static walk
+struct SchedSlot {
+  int dev;
+  hipStream_t st;
+  uint32_t* pair;   // 2 x SCHED_BLOCK_U32 dwords
+  unsigned n;
+  int lock;
+};
+SchedSlot g_sched[kSchedSlots];
+int g_nsched = 0, g_sched_table_lock = 0;
+uint32_t* g_sched_pool[64];   // per device: kSchedSlots pairs, allocated at the first persistent launch on the device (the one allocation this library makes)
+int g_sched_pool_used[64];
 }  // namespace
 
-uint32_t* sched_block_next() {
+SchedLaunch::SchedLaunch(hipStream_t st, bool enabled) {
+  if (!enabled) return;
   int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
-  dev &= 63;
-  uint32_t* ring = __atomic_load_n(&g_sched_ring[dev], __ATOMIC_ACQUIRE);
-  if (!ring) {
-    while (__atomic_exchange_n(&g_sched_lock, 1, __ATOMIC_ACQUIRE)) {}
-    ring = g_sched_ring[dev];
-    if (!ring) {   // first persistent launch on this device: the one allocation this library makes (64 KiB, never freed)
-      void* p = nullptr;
-      if (hipMalloc(&p, (size_t)kSchedRing * kSchedBlockU32 * sizeof(uint32_t)) == hipSuccess &&
-          hipMemset(p, 0, (size_t)kSchedRing * kSchedBlockU32 * sizeof(uint32_t)) == hipSuccess && hipDeviceSynchronize() == hipSuccess) {
-        ring = (uint32_t*)p;
-        __atomic_store_n(&g_sched_ring[dev], ring, __ATOMIC_RELEASE);
-      } else {
-        (void)hipGetLastError();
-      }
-    }
-    __atomic_store_n(&g_sched_lock, 0, __ATOMIC_RELEASE);
-    if (!ring) return nullptr;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return;
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(st, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) {   // a captured launch is replayed with the SAME block: static walk
+    (void)hipGetLastError();
+    return;
   }
-  const unsigned pos = __atomic_fetch_add(&g_sched_pos[dev], 1u, __ATOMIC_RELAXED) % kSchedRing;
-  return ring + (size_t)pos * kSchedBlockU32;
+  SchedSlot* s = nullptr;
+  while (__atomic_exchange_n(&g_sched_table_lock, 1, __ATOMIC_ACQUIRE)) {}
+  for (int i = 0; i < g_nsched; ++i)
+    if (g_sched[i].dev == dev && g_sched[i].st == st) s = &g_sched[i];
+  if (!s && g_nsched < kSchedSlots) {
+    if (!g_sched_pool[dev]) {
+      void* pmem = nullptr;
+      const size_t bytes = (size_t)kSchedSlots * 2 * SCHED_BLOCK_U32 * sizeof(uint32_t);
+      if (hipMalloc(&pmem, bytes) == hipSuccess && hipMemset(pmem, 0, bytes) == hipSuccess && hipDeviceSynchronize() == hipSuccess) g_sched_pool[dev] = (uint32_t*)pmem;
+      else (void)hipGetLastError();
+    }
+    if (g_sched_pool[dev] && g_sched_pool_used[dev] < kSchedSlots) {
+      s = &g_sched[g_nsched++];
+      s->dev = dev;
+      s->st = st;
+      s->pair = g_sched_pool[dev] + (size_t)g_sched_pool_used[dev]++ * 2 * SCHED_BLOCK_U32;
+      s->n = 0;
+      s->lock = 0;
+    }
+  }
+  __atomic_store_n(&g_sched_table_lock, 0, __ATOMIC_RELEASE);
+  if (!s) return;
+  while (__atomic_exchange_n(&s->lock, 1, __ATOMIC_ACQUIRE)) {}
+  slot = s;
+  cur = s->pair + (size_t)(s->n & 1u) * SCHED_BLOCK_U32;
+  prev = s->pair + (size_t)((s->n + 1u) & 1u) * SCHED_BLOCK_U32;
+  ++s->n;
+}
+
+SchedLaunch::~SchedLaunch() {
+  if (slot) __atomic_store_n(&((SchedSlot*)slot)->lock, 0, __ATOMIC_RELEASE);
 }
 
 int check_launch(const char* what) {

@@ -267,8 +267,10 @@ __device__ __forceinline__ void epi_rows16_c16(const alpro_gemm_desc_t& g, const
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] = apply_act<T, ACT>(v[e]) * rs;
     if (g.drop_seed) {
-      const uint32_t th = drop_thresh24(g.drop_p);
-      const float ks = 1.0f / (1.0f - g.drop_p);
+      float dp = g.drop_p;
+      asm volatile("" : "+s"(dp));   // keeps 1 / (1 - p) (and its packed-multiply splat) from being hoisted over the K loop as a kernel invariant, where it is spilled and reloaded per pass
+      const uint32_t th = drop_thresh24(dp);
+      const float ks = 1.0f / (1.0f - dp);
       const uint64_t i0 = (uint64_t)(g.m_off + m) * (uint64_t)g.N + (uint64_t)n;
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] = drop_keep(g.drop_seed, i0 + e, th) ? v[e] * ks : 0.f;
@@ -795,66 +797,120 @@ __global__ __launch_bounds__(NT2, 2) void gemm_nt256q_kernel(const alpro_gemm_de
   //     j -> tile (j / 32) * 256 + y * 32 + (j % 32),        j = 0, 1, 2, ...  while that is < nblk,
   // i.e. the tiles the round-4 static walk (workgroup slot s of 256 takes s, s + 256, ...) gave to the XCD's 32 workgroups, in the order
   // it visited them: at any moment an XCD works on a contiguous run of tiles, so the tn tiles of an A row panel meet in ONE L2.
-  //   gemm_sched 0 (sc.blk == nullptr): workgroup idx of the XCD takes j = idx, idx + p, ... (p = gridDim.x / 8) -- with 256 workgroups
-  //     exactly that static walk.
-  //   gemm_sched 1: j comes from the XCD's ticket counter: one agent-scope atomic per tile, issued by wave 0 behind an epilogue TWO tiles
-  //     ahead of the tile it pays for and read back behind the next K loop -- nothing is added to the K loop, nobody waits for it.
-  //     A workgroup that cannot be resident -- another kernel holds its CU: RCCL's channels during the overlapped gradient exchange, a
-  //     side stream -- simply draws no tickets; the others finish its share one tile at a time instead of the launch waiting a whole
-  //     extra round for it (profiles/r4_overlap_cu_contention.txt: +42 % with 8 of 256 CUs taken).  When a list runs dry the workgroup
-  //     moves on to the next XCD's counter (steals), so the last partial round spreads over all XCDs.
+  //   gemm_sched 0 (sc.blk == nullptr): workgroup idx of the XCD takes j = idx, idx + p, idx + 2p, ... (p = gridDim.x / 8) -- with 256
+  //     workgroups exactly that static walk.
+  //   gemm_sched 1: the first TWO tiles of a workgroup are the static ones (j = idx, idx + p: no atomic stands between the launch and the first
+  //     MFMA); every further j comes from the XCD's ticket counter, j = 2p + ticket: one agent-scope atomic per tile, issued by wave 0 behind
+  //     an epilogue two tiles ahead of the tile it pays for and read back behind the next K loop -- nothing is added to the K loop.
+  //     A workgroup that cannot be resident -- another kernel holds its CU: RCCL's channels during the overlapped gradient exchange, a side
+  //     stream -- draws no tickets: the resident ones finish its share of the lists one tile at a time instead of the launch waiting a whole
+  //     extra round for it (profiles/r4_overlap_cu_contention.txt: +42 % with 8 of 256 CUs taken).  Its two STATIC tiles are covered by a
+  //     claim word per workgroup: a workgroup claims its own pair with one atomic at its start (the answer is awaited by the pipeline fill's
+  //     own wait), and a workgroup that has run out of work -- own list dry: it then looks at all eight counters and all claim words with
+  //     ONE pair of loads -- takes tickets of other XCDs' lists and, after those, the pair of a workgroup that has not started yet.
+  //     Nobody waits for anybody; the block of counters / claim words is zeroed by the NEXT launch of the same stream (TileSched::prev).
   // Results do not depend on who computes a tile: bitwise identical under either walk.
+  const uint32_t p = gridDim.x >> 3;
   auto list_tile = [&](int y, uint32_t j) -> int {
     const uint32_t t = ((j >> 5) << 8) + ((uint32_t)y << 5) + (j & 31u);
     return (j < 0x100000u && t < (uint32_t)nblk) ? (int)t : -1;
   };
+  auto list_len = [&](int y) -> int {   // number of valid positions of XCD y's list
+    const int rem = (nblk & 255) - 32 * y;
+    return (nblk >> 8) * 32 + (rem < 0 ? 0 : (rem > 32 ? 32 : rem));
+  };
   // Mailbox wave 0 -> everybody: two dwords at the start of the A-half-1 slot of parity 1.  That slot's last reader is phase 3 of a tile's
   // last K-tile and its next writer the copy of phase 2 of the following tile's first K-tile (two barriers into that tile): dead in between.
-  volatile int* mbox = (volatile int*)(smem + STAGE2_BYTES + HALF2_BYTES);
+  // (an LDS-address-space pointer: through a generic pointer the accesses become FLAT instructions, which count on vmcnt AND lgkmcnt and made
+  // every read wait for the epilogue's stores)
+  typedef __attribute__((address_space(3))) volatile int lds_int_t;
+  lds_int_t* mbox = (lds_int_t*)(__attribute__((address_space(3))) char*)(smem + STAGE2_BYTES + HALF2_BYTES);
   // walk state (wave 0's copy is the one that counts).  Dynamic: how many XCD lists have run dry for this workgroup (tickets are drawn from
   // XCD (own + wstate) % 8).  Static: the workgroup's next list position.
-  uint32_t wstate = sc.blk ? 0u : (uint32_t)(blockIdx.x >> 3);
-  // One ticket of the current list's counter, lane 0 of wave 0 only (`on`; otherwise the instruction runs with an empty EXEC mask).  The
-  // value lands in `r` when the memory system answers: whoever reads it waits first (s_waitcnt vmcnt), like for the copies.  "+v": `r` is ONE
-  // register from here to its reader -- a compiler-inserted copy in between would copy the old contents (a CPU test checks the built ISA).
+  uint32_t wstate = sc.blk ? 0u : (uint32_t)(blockIdx.x >> 3) + 2 * p;
+  // One returning atomic, lane 0 of wave 0 only (`on`; otherwise the instruction runs with an empty EXEC mask): `add` = a ticket of the
+  // current list's counter, else the claim (atomic or) of workgroup `w`'s word.  The value lands in `r` when the memory system answers:
+  // whoever reads it waits first (s_waitcnt vmcnt), like for the copies.  "+v": `r` is ONE register from here to its reader -- a
+  // compiler-inserted copy in between would copy the old contents (a CPU test checks the built ISA).
   auto ticket_issue = [&](uint32_t& r, bool on) {
     uint64_t sv;
     const uint32_t m = (uint32_t)__builtin_amdgcn_readfirstlane(on ? 1 : 0);
     asm volatile("s_mov_b64 %1, exec\n\ts_mov_b32 exec_lo, %5\n\ts_mov_b32 exec_hi, 0\n\tglobal_atomic_add %0, %2, %3, %4 sc0\n\ts_mov_b64 exec, %1"
                  : "+v"(r), "=&s"(sv) : "v"(((blockIdx.x + wstate) & 7u) * 4u), "v"(1u), "s"(sc.blk), "s"(m) : "memory");
   };
+  auto claim_issue = [&](uint32_t& r, uint32_t w, uint32_t bits, bool on) {   // bit 0 / bit 1: the first / second static tile of workgroup w
+    uint64_t sv;
+    const uint32_t m = (uint32_t)__builtin_amdgcn_readfirstlane(on ? 1 : 0);
+    asm volatile("s_mov_b64 %1, exec\n\ts_mov_b32 exec_lo, %5\n\ts_mov_b32 exec_hi, 0\n\tglobal_atomic_or %0, %2, %3, %4 sc0\n\ts_mov_b64 exec, %1"
+                 : "+v"(r), "=&s"(sv) : "v"((SCHED_CLAIM0 + w) * 4u), "v"(bits), "s"(sc.blk), "s"(m) : "memory");
+  };
   // ticket -> tile of the list tickets are currently drawn from; a dry list moves the workgroup on to the next XCD's
   auto ticket_tile = [&](uint32_t k) -> int {
     int t;
     if (sc.blk) {
-      t = list_tile((int)((blockIdx.x + wstate) & 7u), k);
+      t = list_tile((int)((blockIdx.x + wstate) & 7u), 2 * p + k);
       if (t < 0) ++wstate;
     } else {
       t = list_tile((int)(blockIdx.x & 7u), wstate);
-      wstate += gridDim.x >> 3;
+      wstate += p;
     }
     return t;
   };
-  // Blocking form, start of the workgroup and after a list ran dry: wave 0 draws TWO tiles (own list first, then the other XCDs' in turn)
-  // and posts them (-1: nothing left anywhere); one barrier.  Every wave calls it; no copy may be in flight (the caller drained vmcnt).
-  auto acquire2 = [&](int& t0, int& t1) {
+  // A workgroup out of work (dynamic walk; every wave calls it, one barrier; no copy in flight: the caller drained vmcnt).  Wave 0 reads the
+  // eight counters and the claim words (two loads), then
+  //   * takes two tickets of the first list (own XCD's first) that still has positions left, or, when every list is dry and this workgroup has
+  //     finished at least one tile (`rescue`: by then every workgroup that CAN be resident has claimed its pair),
+  //   * claims the static pair of a workgroup whose claim word is still zero,
+  // and posts the pair (-1, -1: nothing left anywhere).  A ticket that comes back beyond its list, or a claim somebody else won, means the
+  // picture was stale: look again.
+  auto steal = [&](int& t0, int& t1, bool rescue) {
     if (wave == 0) {
       int a = -1, b = -1;
-      if (!sc.blk) {
-        a = ticket_tile(0);
-        b = a >= 0 ? ticket_tile(0) : -1;
-      } else {
-        while (b < 0 && wstate < 8) {
-          uint32_t k0 = 0, k1 = 0;
-          ticket_issue(k0, true);
-          if (a < 0) ticket_issue(k1, true);
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-          const bool two = a < 0;
-          const int u0 = list_tile((int)((blockIdx.x + wstate) & 7u), __builtin_amdgcn_readfirstlane(k0));
-          const int u1 = two ? list_tile((int)((blockIdx.x + wstate) & 7u), __builtin_amdgcn_readfirstlane(k1)) : -1;
-          if (two) { a = u0; b = u1; } else { b = u0; }
-          if (b < 0) ++wstate;   // (tickets of one list come back in increasing order: u1 valid implies u0 valid)
+      for (int tries = 0; tries < 64 && a < 0; ++tries) {
+        const uint32_t cnt = lane < 8 ? __hip_atomic_load(sc.blk + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+        u32x4 clm;   // claim words of workgroups 4 lane .. 4 lane + 3 (agent-scope loads: the words are set by other XCDs' atomics)
+        clm.x = __hip_atomic_load(sc.blk + SCHED_CLAIM0 + 4 * lane + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        clm.y = __hip_atomic_load(sc.blk + SCHED_CLAIM0 + 4 * lane + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        clm.z = __hip_atomic_load(sc.blk + SCHED_CLAIM0 + 4 * lane + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        clm.w = __hip_atomic_load(sc.blk + SCHED_CLAIM0 + 4 * lane + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int y = -1;
+        for (int i = 0; i < 8 && y < 0; ++i) {
+          const int c = (int)((blockIdx.x + i) & 7u);
+          if ((int)__builtin_amdgcn_readlane(cnt, c) < list_len(c) - (int)(2 * p)) y = c;
         }
+        if (y >= 0) {
+          uint32_t k0 = 0, k1 = 0;
+          wstate = (uint32_t)((y - (int)(blockIdx.x & 7u)) & 7);   // tickets are drawn from (own + wstate) % 8 from here on
+          ticket_issue(k0, true);
+          ticket_issue(k1, true);
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          a = list_tile(y, 2 * p + __builtin_amdgcn_readfirstlane(k0));
+          b = list_tile(y, 2 * p + __builtin_amdgcn_readfirstlane(k1));
+          continue;
+        }
+        if (!rescue) break;
+        // static tiles nobody has claimed: lane l holds the claim words of workgroups 4 l .. 4 l + 3 (bit 0 / 1 = first / second tile taken);
+        // those below gridDim.x count.  ONE tile per rescue: the tiles of a workgroup that could not start spread over as many helpers.
+        const uint32_t w0 = 4u * lane;
+        const bool open = (w0 < gridDim.x && (clm.x & 3u) != 3u) || (w0 + 1 < gridDim.x && (clm.y & 3u) != 3u) || (w0 + 2 < gridDim.x && (clm.z & 3u) != 3u) ||
+                          (w0 + 3 < gridDim.x && (clm.w & 3u) != 3u);
+        const uint64_t any = __builtin_amdgcn_ballot_w64(open);
+        if (!any) break;
+        const uint32_t r0 = blockIdx.x & 63u;   // start the search at a lane that depends on the workgroup: helpers spread
+        const uint64_t rot = (any >> r0) | (r0 ? (any << (64u - r0)) : 0ull);
+        const int l = (int)((__builtin_ctzll(rot) + r0) & 63u);
+        const uint32_t c4[4] = {(uint32_t)__builtin_amdgcn_readlane(clm.x, l), (uint32_t)__builtin_amdgcn_readlane(clm.y, l), (uint32_t)__builtin_amdgcn_readlane(clm.z, l),
+                                (uint32_t)__builtin_amdgcn_readlane(clm.w, l)};
+        int e = -1;
+#pragma unroll
+        for (int i = 3; i >= 0; --i)
+          if (4u * l + i < gridDim.x && (c4[i] & 3u) != 3u) e = i;
+        const uint32_t w = 4u * l + (uint32_t)e;
+        const uint32_t bit = (c4[e] & 1u) ? 2u : 1u;
+        uint32_t old = 3;
+        claim_issue(old, w, bit, true);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if ((__builtin_amdgcn_readfirstlane(old) & bit) == 0) a = list_tile((int)(w & 7u), (w >> 3) + (bit == 2u ? p : 0u));   // (-1: that workgroup had no such tile -- look again)
       }
       mbox[0] = a;
       mbox[1] = b;
@@ -920,10 +976,26 @@ __global__ __launch_bounds__(NT2, 2) void gemm_nt256q_kernel(const alpro_gemm_de
   };
 
   uint32_t tk = 0;   // the ticket in flight (lane 0 of wave 0): drawn behind tile i - 1's epilogue for tile i + 2, read back behind tile i's K loop
+  // the static pair, and (dynamic walk) its claim: in flight under the pipeline fill.  Workgroup 0 also hands the block of this stream's
+  // PREVIOUS launch back zeroed (that launch is complete: same stream).
+  int cur_t = list_tile((int)(blockIdx.x & 7u), blockIdx.x >> 3), nxt_t = list_tile((int)(blockIdx.x & 7u), (blockIdx.x >> 3) + p);
+  if (sc.prev && blockIdx.x == 0 && wave == 0) {
+#pragma unroll
+    for (int i = 0; i < (SCHED_BLOCK_U32 + 63) / 64; ++i)
+      if (i * 64 + lane < SCHED_BLOCK_U32) sc.prev[i * 64 + lane] = 0u;
+  }
+  claim_issue(tk, blockIdx.x, 3u, wave == 0 && sc.blk);   // (the answer travels in the ticket register: the first ticket is drawn after it has been read)
+  bool fresh = sc.blk != nullptr;   // the static pair's claim is in flight
+  bool have = cur_t >= 0, worked = false;
   while (true) {
-  int cur_t, nxt_t;
-  acquire2(cur_t, nxt_t);
-  if (cur_t < 0) break;
+  if (!have) {
+    if (!sc.blk) break;
+    fresh = false;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (steal()'s own waits count on an empty queue)
+    steal(cur_t, nxt_t, worked);
+    if (cur_t < 0) break;
+  }
+  have = false;
   Tile cur = tile_base(cur_t);
   Tile nxt = tile_base(nxt_t >= 0 ? nxt_t : cur_t);   // (no next tile: the run-ahead copies re-read this tile's first K-tiles into dead slots)
   // pipeline fill: K-tile 0 complete in parity 0, W-half 0 of K-tile 1 on its way into parity 1
@@ -931,7 +1003,24 @@ __global__ __launch_bounds__(NT2, 2) void gemm_nt256q_kernel(const alpro_gemm_de
   for (int hs = 0; hs < 4; ++hs) copy_half(hs < 2 ? cur.a[hs] : cur.w, hs, 0);
   copy_half(cur.w + ROWB, 2, 1);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (fresh && wave == 0) {   // are the static tiles still this workgroup's?  (wave 0's wait above covered the claim)
+    mbox[0] = (int)(__builtin_amdgcn_readfirstlane(tk) & 3u);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
   barrier();
+  if (fresh) {
+    fresh = false;
+    const int gone = __builtin_amdgcn_readfirstlane(mbox[0]);   // bit 0 / 1: somebody rescued the first / second one while this workgroup waited for a CU
+    if (gone) {
+      barrier();   // (everybody has read the mailbox before it is written again)
+      int t0 = (gone & 1) ? -1 : cur_t, t1 = (gone & 2) ? -1 : nxt_t;
+      if (t0 < 0) { t0 = t1; t1 = -1; }
+      cur_t = t0;
+      nxt_t = t1;
+      have = cur_t >= 0;
+      continue;   // fill the pipeline again for what is left, or look for other work
+    }
+  }
   ticket_issue(tk, wave == 0 && sc.blk && nxt_t >= 0);   // for the tile after next
 
   while (true) {
@@ -1053,7 +1142,7 @@ __global__ __launch_bounds__(NT2, 2) void gemm_nt256q_kernel(const alpro_gemm_de
         }
       }
       // fp32 output (launcher: ACT none, identity map, no C2 / dropout): C = residual + row_scale * (alpha * acc + bias) -- the MLP's fc2 with its
-      // fp32 residual (vit.py:212).  A staged fragment row is 16 rows x 16 float4; le l finishes pieces l, l+64, l+128, l+192 = rows
+      // fp32 residual (vit.py:212).  A staged fragment row is 16 rows x 16 float4; lane l finishes pieces l, l+64, l+128, l+192 = rows
       // (l >> 4) + 4j, columns 4 (l & 15) .. +3: whole 256-byte row segments per 16 lanes, the residual pieces of the NEXT fragment row in flight.
       if constexpr (MAP == ALPRO_MAP_IDENTITY && ACT == ALPRO_ACT_NONE) {
         if (g.c_dtype == ALPRO_F32) {
@@ -1088,6 +1177,7 @@ __global__ __launch_bounds__(NT2, 2) void gemm_nt256q_kernel(const alpro_gemm_de
         }
       }
     }
+    worked = true;
     if (nxt_t < 0) break;
     cur = nxt;
     cur_t = nxt_t;
@@ -1095,17 +1185,12 @@ __global__ __launch_bounds__(NT2, 2) void gemm_nt256q_kernel(const alpro_gemm_de
     nxt = tile_base(nxt_t >= 0 ? nxt_t : cur_t);
     ticket_issue(tk, wave == 0 && sc.blk && nxt_t >= 0);
   }
-  // this list is dry: the run-ahead copies went into dead slots and must have landed before the stage buffers are filled again (or, at
-  // the end, before the LDS belongs to someone else); acquire2() tries the other XCDs' lists next
+  // out of work: the run-ahead copies went into dead slots and must have landed before the stage buffers are filled again (or, at the end,
+  // before the LDS belongs to someone else); steal() looks for other lists' tickets / unclaimed pairs next
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  cur_t = -1;
   }
-  if (sc.blk && threadIdx.x == 0) {   // last workgroup out hands the scheduler block back zeroed (every workgroup's last ticket has returned by now)
-    const uint32_t d = __hip_atomic_fetch_add(sc.blk + 8, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (d == gridDim.x - 1) {
-#pragma unroll
-      for (int i = 0; i < 9; ++i) __hip_atomic_store(sc.blk + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
 template <typename T, int ACT, int MAP>
@@ -1165,9 +1250,14 @@ int launch_gemm_inst(const alpro_gemm_desc_t& g, hipStream_t st) {
       int grid = cu_budget(st);
       if (const int cap = get_option(OPT_GEMM_GRID)) grid = cap < grid ? (cap + 7) / 8 * 8 : grid;
       TileSched sc;
-      sc.blk = get_option(OPT_GEMM_SCHED) == 1 ? sched_block_next() : nullptr;
+      sc.blk = sc.prev = nullptr;
       sc.magic_ntn = magic_u32((uint32_t)(g.N / BN2));
-      hipLaunchKernelGGL((gemm_nt256q_kernel<T, ACT, MAP>), dim3(grid), dim3(NT2), 2 * STAGE2_BYTES + EPI_BYTES, st, gq, sc);
+      {
+        SchedLaunch blocks(get_option(OPT_GEMM_SCHED) == 1 ? st : nullptr, get_option(OPT_GEMM_SCHED) == 1);   // (holds the stream's block pair until the launch is enqueued)
+        sc.blk = blocks.cur;
+        sc.prev = blocks.prev;
+        hipLaunchKernelGGL((gemm_nt256q_kernel<T, ACT, MAP>), dim3(grid), dim3(NT2), 2 * STAGE2_BYTES + EPI_BYTES, st, gq, sc);
+      }
       if (m_rem && !ragged_in_kernel) {
         alpro_gemm_desc_t gr = g;
         gr.M = m_rem;

@@ -999,23 +999,42 @@ def test_8phase_gemm_isa_keeps_the_orders_the_source_relies_on(tmp_path):
         assert count(r"\bs_barrier\b") == 14, (head, count(r"\bs_barrier\b"))
         for bad in (r"\bscratch_", r"\bbuffer_", r"\bflat_", r"\bglobal_(load|store)_(?!lds)", r"\bglobal_atomic", r"\bv_readlane", r"\bv_writelane"):
             assert count(bad) == 0, (head, bad, [l for l in span if re.search(bad, l)][:3])
-        # round 5, the tile scheduler's ticket: a returning atomic whose result is awaited by the K loop's counted waits, not by the compiler.
-        # The register it lands in must be ONE register from the atomic to its reader: written only by returning ticket atomics (and its
-        # initialisation before the first of them), read only by v_readfirstlane BEHIND the K loop -- a copy in between would copy stale contents.
-        code = [l.split("//")[0] for l in lines]
-        tick = [i for i, l in enumerate(code) if re.search(r"\bglobal_atomic_add\b.*\bsc0\b", l)]
-        inflight = [i for i in tick if i < mf[0] or i > mf[-1]]
-        regs = {}
-        for i in inflight:
-            regs.setdefault(code[i].split()[1].rstrip(","), []).append(i)
-        carried = [r for r, at in regs.items() if any(i > mf[-1] for i in at) and any(i < mf[0] for i in at)]   # drawn before the first K loop AND behind an epilogue
-        assert len(carried) == 1, (head, regs)
-        reg = carried[0]
-        named = [(i, l.strip()) for i, l in enumerate(code) if re.search(r"\b%s\b" % reg, l) and i not in regs[reg]]
-        readers = [(i, l) for i, l in named if re.search(r"v_readfirstlane_b32 s\d+, %s$" % reg, l)]
+        # round 5, the tile scheduler's returning atomics (a ticket per tile; the claim of the static pair at the start): their results are
+        # awaited by waits the SOURCE places (the K loop's counted waits, the pipeline fill's vmcnt(0)), not by the compiler -- which believes
+        # the register is written when the instruction issues.  So the register must be ONE register from the atomic to its reader: after a
+        # returning atomic, the next instruction that names its destination must be the v_readfirstlane that consumes it (another atomic
+        # into the same register -- the steady-state ticket shares it with the first one -- or, for the atomic at the end of the tile loop,
+        # the end of the function), and nothing else may write it but its initialisation ahead of the first atomic.  A copy or a re-use in
+        # between would read stale contents.
+        code = [l.split("//")[0].strip() for l in lines]
+        atoms = [i for i, l in enumerate(code) if re.search(r"\bglobal_atomic_(add|or)\b.*\bsc0\b", l)]
+        assert len(atoms) >= 6 and not [i for i in atoms if mf[0] <= i <= mf[-1]], (head, atoms)
+        carried = set()
+        for i in atoms:
+            reg = code[i].split()[1].rstrip(",")
+            nxt = next((j for j in range(i + 1, len(code)) if re.search(r"\b%s\b" % reg, code[j])), None)
+            if nxt is None:
+                carried.add(reg)   # the ticket drawn behind an epilogue: read behind the NEXT K loop (checked below)
+                continue
+            if re.search(r"\bglobal_atomic_(add|or)\b", code[nxt]) and code[nxt].split()[1].rstrip(",") == reg:
+                continue
+            assert re.match(r"v_readfirstlane_b32 s\d+, %s$" % reg, code[nxt]), (head, i, code[i], nxt, code[nxt])
+            if nxt > mf[-1] > i:
+                carried.add(reg)
+        assert len(carried) == 1, (head, carried)   # exactly one register is in flight across the K loop
+        reg = carried.pop()
+        at = [i for i in atoms if code[i].split()[1].rstrip(",") == reg]
+        named = [(i, l) for i, l in enumerate(code) if re.search(r"\b%s\b" % reg, l) and i not in at]
+        readers = [(i, l) for i, l in named if re.match(r"v_readfirstlane_b32 s\d+, %s$" % reg, l)]
         writers = [(i, l) for i, l in named if (i, l) not in readers]
-        assert len(readers) == 1 and readers[0][0] > mf[-1], (head, named)
-        assert all(re.match(r"v_mov_b32_e32 %s, 0$" % reg, l) and i < min(regs[reg]) for i, l in writers), (head, writers)
+        # one register for the three in-flight atomics: [claim of the static pair] -> read behind the pipeline fill -> [first ticket] -> K loop
+        # -> read behind it -> ... -> [ticket behind the epilogue] -> (tile loop) -> K loop -> the same read
+        at.sort()
+        assert len(at) == 3 and "global_atomic_or" in code[at[0]] and len(readers) == 2, (head, named, at)
+        # (block placement is the compiler's: only the claim's read ahead of the K loop and the ticket's read behind it are positional)
+        assert at[0] < readers[0][0] < mf[0] < mf[-1] < readers[1][0] and at[0] < at[1], (head, named, at)
+        assert all(re.match(r"v_mov_b32_e32 %s, 0$" % reg, l) and i < min(at) for i, l in writers), (head, writers)
+        assert not any("flat_" in l for l in code), head   # the mailbox is an LDS pointer (a generic one turns into FLAT loads that wait for every store)
         # epilogue: a fragment row is staged by 8 ds_write2_b32 per lane and read back by OTHER lanes with ds_read_b128 -- no read may be issued
         # inside a group of 8 writes (the round-4 bug: the compiler, reasoning per lane, had hoisted one above the last write; wave_lds_order())
         writes = 0

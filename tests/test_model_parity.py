@@ -670,6 +670,7 @@ def test_full_size_pretrain_backward_in_the_bench_dtype_vs_the_exact_mode(bert_c
                                                                    rep["grad_cosine_worst"], rep["grad_cosine_median"], rep["grad_l2_rel_err_worst"], rep["grad_l2_rel_err_median"],
                                                                    rep["global_grad_norm_rel_err"], rep["global_grad_cosine"],
                                                                    {k: float("%.2e" % v) for k, v in rep["loss_abs_err"].items()}, rep["worst_tensors"]))
+    assert not rep["nonfinite_tensors"], rep["nonfinite_tensors"]
     assert rep["grad_tensors"] >= 440, rep["grad_tensors"]
     lim = pc.FULL_SIZE_BACKWARD_LIMITS
     assert rep["grad_norm_rel_err_worst"] <= lim["grad_norm_rel_err_worst"] and rep["grad_norm_rel_err_median"] <= lim["grad_norm_rel_err_median"], rep

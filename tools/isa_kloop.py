@@ -36,7 +36,7 @@ def main():
             cnt(r"v_(read|write)lane", span), cnt(r"global_atomic", span), cnt(r"\bs_load_", span)))
         print("   whole kernel: scratch %d  lane-spill ops %d" % (cnt(r"\bscratch_", lines), cnt(r"v_(read|write)lane", lines)))
         for i, l in enumerate(lines):
-            if "global_atomic_add" in l and "sc0" in l:
+            if re.search(r"global_atomic_(add|or)\b", l) and "sc0" in l:
                 reg = l.split()[1].rstrip(",")
                 uses = [(j, lines[j]) for j in range(len(lines)) if re.search(r"\b%s\b" % reg, lines[j]) and j != i]
                 print("   ticket atomic at %d -> %s; other instructions naming it: %s" % (i, reg, [(j, u[:60]) for j, u in uses][:8]))
