@@ -53,19 +53,23 @@ def cls_precise(dt=None):
     return _cls_precise[0] in ("1", "true", "on")
 
 
-# The chain's launches are skinny (32 ... 512 rows against whole weight matrices: latency, not throughput).  ALPRO_CLS_STREAM=1 issues them
-# on a second HIP stream, ordered against the main path by events (modeling/timesformer/vit.py::_ClsSide), so that they run beside the
-# block's big launches instead of between them (round 5; needs the dynamic tile scheduler: a persistent GEMM that finds a CU taken must not
-# wait a round for it).
-_cls_stream = [os.environ.get("ALPRO_CLS_STREAM", "0").lower() in ("1", "true", "on")]
+# The chain's launches are skinny (32 ... 512 rows against whole weight matrices: latency, not throughput).  On a second HIP stream, ordered
+# against the main path by events (modeling/timesformer/vit.py::_ClsSide), they run beside the block's big launches instead of between them
+# (round 5; it rests on the dynamic tile scheduler: a persistent GEMM that finds a CU taken must not wait a round for it).  Measured
+# (profiles/r5_cls_stream_ab.txt): B = 32 encoder forward 18.48 -> 18.01 ms, training step unchanged (161.6 ms either way).
+# ALPRO_CLS_STREAM = infer (default: the inference forward only) | 1 (training forward too) | 0.
+_cls_stream = [os.environ.get("ALPRO_CLS_STREAM", "infer").lower()]
 
 
-def cls_stream():
-    return _cls_stream[0]
+def cls_stream(training=False):
+    v = _cls_stream[0]
+    if v in ("1", "true", "on"):
+        return True
+    return v == "infer" and not training
 
 
 def set_cls_stream(v):
-    _cls_stream[0] = bool(v)
+    _cls_stream[0] = v.lower() if isinstance(v, str) else ("1" if v else "0")
 
 
 def set_cls_precise(v):

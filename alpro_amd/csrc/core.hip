@@ -293,6 +293,73 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
 }
 
 
+// ---- the fusion encoder's input as a row gather (round 5) -----------------------------------------------------------------------
+// alpro_models.py:278-281,325-330,360-363 build the three fusion batches with torch.cat over text / video embeddings and gathers of the
+// hard negatives ("text_embeds[neg_text]"); batched into one 4B-sequence pass that was five cat kernels over up to 186 MB, an index kernel,
+// and under autograd three sorted index_put_ plus the accumulation adds of every tensor that is used more than once (1.2 ms per step).
+// Here sequence s of the fusion batch IS (text pool row ti[s], video pool row vi[s]): one pass writes the fp32 stream and the 16-bit
+// operand copy of the first fusion layer, and the backward sums, for every pool row, the gradients of the sequences that used it in
+// ascending sequence order (no atomics: bit-reproducible).
+template <typename T>
+__global__ __launch_bounds__(256) void gather_seq_fwd_kernel(const float* __restrict__ text, const float* __restrict__ video, const int64_t* __restrict__ ti,
+                                                            const int64_t* __restrict__ vi, float* __restrict__ out32, T* __restrict__ out_t, int S, int Lt, int Lv) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int L = Lt + Lv;
+  const int64_t rows = (int64_t)S * L;
+  for (int64_t m = (int64_t)blockIdx.x * 4 + wave; m < rows; m += (int64_t)gridDim.x * 4) {
+    const int s = (int)(m / L), l = (int)(m - (int64_t)s * L);
+    const float* src = l < Lt ? text + ((int64_t)ti[s] * Lt + l) * LN_D : video + ((int64_t)vi[s] * Lv + (l - Lt)) * LN_D;
+    float v[12];
+    ln_load(src, lane, v);
+    ln_store<float>(out32 + m * LN_D, lane, v);
+    if (out_t) ln_store<T>(out_t + m * LN_D, lane, v);
+  }
+}
+
+// one wave per pool row (text rows first, then video rows): d[pool row] = sum over the sequences s (ascending) whose index points at it of
+// d32[s, l] (+ d_t[s, l], the 16-bit part of the gradient the first fusion layer hands back: xbert._BertRun.backward)
+template <typename T>
+__global__ __launch_bounds__(256) void gather_seq_bwd_kernel(const float* __restrict__ d32, const T* __restrict__ d_t, const int64_t* __restrict__ ti,
+                                                            const int64_t* __restrict__ vi, float* __restrict__ dtext, float* __restrict__ dvideo, int S, int Pt,
+                                                            int Pv, int Lt, int Lv) {
+  extern __shared__ int idx_s[];   // ti | vi
+  for (int i = threadIdx.x; i < 2 * S; i += blockDim.x) idx_s[i] = (int)(i < S ? ti[i] : vi[i - S]);
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int L = Lt + Lv;
+  const int64_t rows = (int64_t)Pt * Lt + (int64_t)Pv * Lv;
+  for (int64_t r = (int64_t)blockIdx.x * 4 + wave; r < rows; r += (int64_t)gridDim.x * 4) {
+    const bool is_text = r < (int64_t)Pt * Lt;
+    const int64_t q = is_text ? r : r - (int64_t)Pt * Lt;
+    const int Lp = is_text ? Lt : Lv;
+    const int pidx = (int)(q / Lp), l = (int)(q - (int64_t)pidx * Lp);
+    const int* ix = idx_s + (is_text ? 0 : S);
+    float acc[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) acc[i] = 0.f;
+    for (int s = 0; s < S; ++s) {
+      if (ix[s] != pidx) continue;
+      const int64_t m = (int64_t)s * L + (is_text ? l : Lt + l);
+      float v[12];
+      ln_load_nt(d32 + m * LN_D, lane, v);
+#pragma unroll
+      for (int i = 0; i < 12; ++i) acc[i] += v[i];
+      if (d_t) {
+#pragma unroll
+        for (int i = 0; i < LN_V; ++i) {
+          const u32x2 u = *(const u32x2*)(d_t + m * LN_D + i * 256 + lane * 4);
+          const uint32_t ux = u.x, uy = u.y;
+          acc[4 * i] += to_f32(T{(uint16_t)(ux & 0xFFFFu)});
+          acc[4 * i + 1] += to_f32(T{(uint16_t)(ux >> 16)});
+          acc[4 * i + 2] += to_f32(T{(uint16_t)(uy & 0xFFFFu)});
+          acc[4 * i + 3] += to_f32(T{(uint16_t)(uy >> 16)});
+        }
+      }
+    }
+    ln_store<float>((is_text ? dtext : dvideo) + q * LN_D, lane, acc);
+  }
+}
+
 // ---- residual add fused into the LayerNorm that follows it ---------------------------------------------------------------------
 // Every residual branch of the path ends in "x' = x + scale * Linear(...)" and is followed by a LayerNorm of x' (vit.py:162 -> :180,
 // :196 -> :200; xbert.py:358-359, 436-437).  Done in the Linear's GEMM epilogue, the fp32 read-modify-write of x (8 B / element through a
@@ -628,6 +695,29 @@ extern "C" int alpro_patchify(const float* img, void* out, int dtype, int BT, in
   const int64_t total = (int64_t)BT * (Himg / 16) * (Wimg / 16) * C * 256 / (dtype == ALPRO_F32 ? 4 : 8);
   ALPRO_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL(patchify_kernel<T>, dim3(grid_for(total, 256, 256 * 32)), dim3(256), 0, (hipStream_t)stream, img, (T*)out, BT, C, Himg, Wimg));
   return check_launch("alpro_patchify");
+}
+
+extern "C" int alpro_gather_seq_fwd(const float* text, const float* video, const int64_t* ti, const int64_t* vi, float* out32, void* out_t, int dtype, int S,
+                                    int Lt, int Lv, int D, void* stream) {
+  ALPRO_CHECK(text && video && ti && vi && out32 && S > 0 && Lt > 0 && Lv > 0, "alpro_gather_seq_fwd: bad args");
+  ALPRO_CHECK(D == LN_D, "alpro_gather_seq_fwd: D=%d unsupported (hidden size is 768 on this path)", D);
+  ALPRO_CHECK(dtype == ALPRO_BF16 || dtype == ALPRO_F16 || !out_t, "alpro_gather_seq_fwd: the operand copy is 16-bit (fp32 mode: pass NULL)");
+  const int grid = grid_for((int64_t)S * (Lt + Lv), 4, 256 * 32);
+  if (dtype == ALPRO_BF16) hipLaunchKernelGGL(gather_seq_fwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, text, video, ti, vi, out32, (bf16_t*)out_t, S, Lt, Lv);
+  else hipLaunchKernelGGL(gather_seq_fwd_kernel<f16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, text, video, ti, vi, out32, (f16_t*)out_t, S, Lt, Lv);
+  return check_launch("alpro_gather_seq_fwd");
+}
+
+extern "C" int alpro_gather_seq_bwd(const float* d32, const void* d_t, int dtype, const int64_t* ti, const int64_t* vi, float* dtext, float* dvideo, int S, int Pt,
+                                    int Pv, int Lt, int Lv, int D, void* stream) {
+  ALPRO_CHECK(d32 && ti && vi && dtext && dvideo && S > 0 && S <= 8192 && Pt > 0 && Pv > 0 && Lt > 0 && Lv > 0, "alpro_gather_seq_bwd: bad args");
+  ALPRO_CHECK(D == LN_D, "alpro_gather_seq_bwd: D=%d unsupported (hidden size is 768 on this path)", D);
+  ALPRO_CHECK(dtype == ALPRO_BF16 || dtype == ALPRO_F16 || !d_t, "alpro_gather_seq_bwd: the 16-bit gradient part needs a 16-bit dtype");
+  const int grid = grid_for((int64_t)Pt * Lt + (int64_t)Pv * Lv, 4, 256 * 32);
+  const size_t lds = (size_t)2 * S * sizeof(int);
+  if (dtype == ALPRO_BF16) hipLaunchKernelGGL(gather_seq_bwd_kernel<bf16_t>, dim3(grid), dim3(256), lds, (hipStream_t)stream, d32, (const bf16_t*)d_t, ti, vi, dtext, dvideo, S, Pt, Pv, Lt, Lv);
+  else hipLaunchKernelGGL(gather_seq_bwd_kernel<f16_t>, dim3(grid), dim3(256), lds, (hipStream_t)stream, d32, (const f16_t*)d_t, ti, vi, dtext, dvideo, S, Pt, Pv, Lt, Lv);
+  return check_launch("alpro_gather_seq_bwd");
 }
 
 extern "C" int alpro_cls_mean_residual(const float* x_in, int64_t ld_batch_in, const float* side, float* x_out,

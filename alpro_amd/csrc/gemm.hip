@@ -811,6 +811,8 @@ __global__ __launch_bounds__(NT2, 2) void gemm_nt256q_kernel(const alpro_gemm_de
   //     Nobody waits for anybody; the block of counters / claim words is zeroed by the NEXT launch of the same stream (TileSched::prev).
   // Results do not depend on who computes a tile: bitwise identical under either walk.
   const uint32_t p = gridDim.x >> 3;
+  const uint64_t t_start = wall_clock64();
+  constexpr uint32_t RESCUE_TICKS = 1000;   // 10 us of the 100 MHz wall clock
   auto list_tile = [&](int y, uint32_t j) -> int {
     const uint32_t t = ((j >> 5) << 8) + ((uint32_t)y << 5) + (j & 31u);
     return (j < 0x100000u && t < (uint32_t)nblk) ? (int)t : -1;
@@ -857,16 +859,20 @@ __global__ __launch_bounds__(NT2, 2) void gemm_nt256q_kernel(const alpro_gemm_de
     return t;
   };
   // A workgroup out of work (dynamic walk; every wave calls it, one barrier; no copy in flight: the caller drained vmcnt).  Wave 0 reads the
-  // eight counters and the claim words (two loads), then
-  //   * takes two tickets of the first list (own XCD's first) that still has positions left, or, when every list is dry and this workgroup has
-  //     finished at least one tile (`rescue`: by then every workgroup that CAN be resident has claimed its pair),
-  //   * claims the static pair of a workgroup whose claim word is still zero,
-  // and posts the pair (-1, -1: nothing left anywhere).  A ticket that comes back beyond its list, or a claim somebody else won, means the
-  // picture was stale: look again.
-  auto steal = [&](int& t0, int& t1, bool rescue) {
+  // eight counters and the claim words (five loads in flight together), then
+  //   * takes ONE ticket of the first list (own XCD's first) that still has positions left -- one, not a pair: the last partial round then
+  //     spreads over everybody who is out of work instead of the first arrivals taking two tiles each --, or, when every list is dry,
+  //   * claims ONE static tile nobody has claimed yet (a workgroup that could not start: some other kernel holds its CU).  Which one is drawn
+  //     from a hash of the workgroup id over all open tiles, so that a few hundred helpers arriving together do not all go for the same word.
+  //     Rescue waits until RESCUE_TICKS after this workgroup's own start (`t_start`, 100 MHz wall clock): by then every workgroup that CAN be
+  //     resident has started and claimed its pair (a later rescue of a workgroup that starts at that very moment is still correct: the claim
+  //     atomic arbitrates; it only costs that workgroup its pipeline fill),
+  // and posts the tile (-1: nothing left anywhere).  A ticket that comes back beyond its list, or a claim somebody else won, means the picture
+  // was stale: look again.
+  auto steal = [&](int& t0, int& t1) {
     if (wave == 0) {
-      int a = -1, b = -1;
-      for (int tries = 0; tries < 64 && a < 0; ++tries) {
+      int a = -1;
+      for (int tries = 0; tries < 96 && a < 0; ++tries) {
         const uint32_t cnt = lane < 8 ? __hip_atomic_load(sc.blk + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
         u32x4 clm;   // claim words of workgroups 4 lane .. 4 lane + 3 (agent-scope loads: the words are set by other XCDs' atomics)
         clm.x = __hip_atomic_load(sc.blk + SCHED_CLAIM0 + 4 * lane + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -879,39 +885,44 @@ __global__ __launch_bounds__(NT2, 2) void gemm_nt256q_kernel(const alpro_gemm_de
           if ((int)__builtin_amdgcn_readlane(cnt, c) < list_len(c) - (int)(2 * p)) y = c;
         }
         if (y >= 0) {
-          uint32_t k0 = 0, k1 = 0;
+          uint32_t k0 = 0;
           wstate = (uint32_t)((y - (int)(blockIdx.x & 7u)) & 7);   // tickets are drawn from (own + wstate) % 8 from here on
           ticket_issue(k0, true);
-          ticket_issue(k1, true);
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
           a = list_tile(y, 2 * p + __builtin_amdgcn_readfirstlane(k0));
-          b = list_tile(y, 2 * p + __builtin_amdgcn_readfirstlane(k1));
           continue;
         }
-        if (!rescue) break;
-        // static tiles nobody has claimed: lane l holds the claim words of workgroups 4 l .. 4 l + 3 (bit 0 / 1 = first / second tile taken);
-        // those below gridDim.x count.  ONE tile per rescue: the tiles of a workgroup that could not start spread over as many helpers.
+        // open static tiles: slot s = 2 i + b of a lane is tile b (0 = first, 1 = second) of workgroup 4 lane + i; workgroups below gridDim.x count
         const uint32_t w0 = 4u * lane;
-        const bool open = (w0 < gridDim.x && (clm.x & 3u) != 3u) || (w0 + 1 < gridDim.x && (clm.y & 3u) != 3u) || (w0 + 2 < gridDim.x && (clm.z & 3u) != 3u) ||
-                          (w0 + 3 < gridDim.x && (clm.w & 3u) != 3u);
-        const uint64_t any = __builtin_amdgcn_ballot_w64(open);
-        if (!any) break;
-        const uint32_t r0 = blockIdx.x & 63u;   // start the search at a lane that depends on the workgroup: helpers spread
-        const uint64_t rot = (any >> r0) | (r0 ? (any << (64u - r0)) : 0ull);
-        const int l = (int)((__builtin_ctzll(rot) + r0) & 63u);
-        const uint32_t c4[4] = {(uint32_t)__builtin_amdgcn_readlane(clm.x, l), (uint32_t)__builtin_amdgcn_readlane(clm.y, l), (uint32_t)__builtin_amdgcn_readlane(clm.z, l),
-                                (uint32_t)__builtin_amdgcn_readlane(clm.w, l)};
-        int e = -1;
+        const uint32_t words[4] = {clm.x, clm.y, clm.z, clm.w};
+        uint64_t open[8];
+        int total = 0;
 #pragma unroll
-        for (int i = 3; i >= 0; --i)
-          if (4u * l + i < gridDim.x && (c4[i] & 3u) != 3u) e = i;
-        const uint32_t w = 4u * l + (uint32_t)e;
-        const uint32_t bit = (c4[e] & 1u) ? 2u : 1u;
+        for (int sl = 0; sl < 8; ++sl) {
+          open[sl] = __builtin_amdgcn_ballot_w64(w0 + (sl >> 1) < gridDim.x && ((words[sl >> 1] >> (sl & 1)) & 1u) == 0u);
+          total += __builtin_popcountll(open[sl]);
+        }
+        if (total == 0) break;
+        while ((uint32_t)(wall_clock64() - t_start) < RESCUE_TICKS) __builtin_amdgcn_s_sleep(8);
+        int q = (int)(((blockIdx.x + 1u) * 0x9E3779B1u >> 12) % (uint32_t)total);   // the q-th open tile, q spread over the helpers
+        uint32_t w = 0, bit = 0;
+#pragma unroll
+        for (int sl = 0; sl < 8; ++sl) {
+          const int n = __builtin_popcountll(open[sl]);
+          if (bit == 0 && q < n) {
+            uint64_t msk = open[sl];
+            for (int i = 0; i < q; ++i) msk &= msk - 1;
+            w = 4u * (uint32_t)__builtin_ctzll(msk) + (uint32_t)(sl >> 1);
+            bit = 1u << (sl & 1);
+          }
+          q -= n;
+        }
         uint32_t old = 3;
         claim_issue(old, w, bit, true);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if ((__builtin_amdgcn_readfirstlane(old) & bit) == 0) a = list_tile((int)(w & 7u), (w >> 3) + (bit == 2u ? p : 0u));   // (-1: that workgroup had no such tile -- look again)
       }
+      const int b = -1;
       mbox[0] = a;
       mbox[1] = b;
     }
@@ -986,13 +997,13 @@ __global__ __launch_bounds__(NT2, 2) void gemm_nt256q_kernel(const alpro_gemm_de
   }
   claim_issue(tk, blockIdx.x, 3u, wave == 0 && sc.blk);   // (the answer travels in the ticket register: the first ticket is drawn after it has been read)
   bool fresh = sc.blk != nullptr;   // the static pair's claim is in flight
-  bool have = cur_t >= 0, worked = false;
+  bool have = cur_t >= 0;
   while (true) {
   if (!have) {
     if (!sc.blk) break;
     fresh = false;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (steal()'s own waits count on an empty queue)
-    steal(cur_t, nxt_t, worked);
+    steal(cur_t, nxt_t);
     if (cur_t < 0) break;
   }
   have = false;
@@ -1177,7 +1188,6 @@ __global__ __launch_bounds__(NT2, 2) void gemm_nt256q_kernel(const alpro_gemm_de
         }
       }
     }
-    worked = true;
     if (nxt_t < 0) break;
     cur = nxt;
     cur_t = nxt_t;

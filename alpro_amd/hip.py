@@ -23,7 +23,7 @@ _CODE = {v: k for k, v in _TORCH_DTYPE.items()}
 EXPORTS = ["alpro_hip_last_error", "alpro_hip_abi_version", "alpro_hip_set_option", "alpro_hip_set_stream_option", "alpro_gemm", "alpro_layernorm_fwd",
            "alpro_attn_temporal_fwd", "alpro_attn_fwd", "alpro_patchify", "alpro_cls_mean_residual",
            "alpro_vit_final_pool", "alpro_bert_embed_fwd", "alpro_cast_from_f32", "alpro_attn_bwd", "alpro_attn_temporal_bwd",
-           "alpro_layernorm_bwd", "alpro_transpose", "alpro_transpose_batch", "alpro_gelu_bwd", "alpro_cls_mean_bwd", "alpro_scatter_add_rows", "alpro_gather_cast", "alpro_sumsq", "alpro_adamw_step", "alpro_gemm_tn_acc", "alpro_gemm_tn_acc_ws", "alpro_gemm_tn_workspace_bytes", "alpro_gemm_tn_ranges", "alpro_colsum_acc", "alpro_softmax_xent", "alpro_vtc_loss_fwd", "alpro_vtc_loss_bwd", "alpro_prepare_clips", "alpro_loss_scale_update", "alpro_add_layernorm_fwd", "alpro_layernorm_bwd_emit", "alpro_gemm_batch", "alpro_tproj_small", "alpro_attn_cls_fwd", "alpro_gemm_rows_f32"]
+           "alpro_layernorm_bwd", "alpro_transpose", "alpro_transpose_batch", "alpro_gelu_bwd", "alpro_cls_mean_bwd", "alpro_scatter_add_rows", "alpro_gather_cast", "alpro_sumsq", "alpro_adamw_step", "alpro_gemm_tn_acc", "alpro_gemm_tn_acc_ws", "alpro_gemm_tn_workspace_bytes", "alpro_gemm_tn_ranges", "alpro_colsum_acc", "alpro_softmax_xent", "alpro_vtc_loss_fwd", "alpro_vtc_loss_bwd", "alpro_prepare_clips", "alpro_loss_scale_update", "alpro_add_layernorm_fwd", "alpro_layernorm_bwd_emit", "alpro_gemm_batch", "alpro_tproj_small", "alpro_attn_cls_fwd", "alpro_gemm_rows_f32", "alpro_gather_seq_fwd", "alpro_gather_seq_bwd"]
 
 
 class GemmDesc(ctypes.Structure):
@@ -105,6 +105,8 @@ def load():
     lib.alpro_cast_from_f32.argtypes = [vp, vp, i32, i64, vp]
     lib.alpro_hip_set_option.argtypes = [ctypes.c_char_p, i32]
     lib.alpro_hip_set_stream_option.argtypes = [vp, ctypes.c_char_p, i32]
+    lib.alpro_gather_seq_fwd.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]
+    lib.alpro_gather_seq_bwd.argtypes = [vp, vp, i32, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]
     lib.alpro_prepare_clips.argtypes = [vp, i32, vp, f32, ctypes.POINTER(f32), ctypes.POINTER(f32), vp, vp, vp, i32, i32, i32, i32, vp]
     lib.alpro_vtc_loss_fwd.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp]
     lib.alpro_vtc_loss_bwd.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
@@ -520,6 +522,33 @@ def patchify(img, dtype):
     out = torch.empty((BT * (Hh // 16) * (Ww // 16), C * 256), dtype=dtype, device=img.device)
     _check(lib.alpro_patchify(_ptr(img), _ptr(out), _CODE[dtype], BT, C, Hh, Ww, _stream()), "alpro_patchify")
     return out
+
+
+def gather_seq(text, video, ti, vi, dtype=None):
+    """The fusion encoder's input (alpro_gather_seq_fwd): text (Pt, Lt, D) and video (Pv, Lv, D) fp32 pools, ti / vi (S,) int64 ->
+    (out32 (S*(Lt+Lv), D) fp32, out_t in `dtype` or None)."""
+    lib = load()
+    _dev(text, torch.float32); _dev(video, torch.float32); _dev(ti, torch.int64); _dev(vi, torch.int64)
+    assert text.is_contiguous() and video.is_contiguous() and ti.is_contiguous() and vi.is_contiguous() and ti.numel() == vi.numel()
+    S, Lt, Lv, D = ti.numel(), text.shape[1], video.shape[1], text.shape[2]
+    out32 = torch.empty((S * (Lt + Lv), D), dtype=torch.float32, device=text.device)
+    out_t = torch.empty((S * (Lt + Lv), D), dtype=dtype, device=text.device) if dtype not in (None, torch.float32) else None
+    _check(lib.alpro_gather_seq_fwd(_ptr(text), _ptr(video), _ptr(ti), _ptr(vi), _ptr(out32), _ptr(out_t), _CODE[dtype] if out_t is not None else F32, S, Lt, Lv, D, _stream()),
+           "alpro_gather_seq_fwd")
+    return out32, out_t
+
+
+def gather_seq_bwd(d32, d_t, ti, vi, Pt, Pv, Lt, Lv):
+    """-> (dtext (Pt, Lt, D), dvideo (Pv, Lv, D)) fp32: per pool row the sum over the sequences that used it (alpro_gather_seq_bwd)."""
+    lib = load()
+    _dev(d32, torch.float32)
+    D = d32.shape[-1]
+    assert d32.is_contiguous() and (d_t is None or (d_t.is_contiguous() and d_t.shape == d32.shape))
+    dtext = torch.empty((Pt, Lt, D), dtype=torch.float32, device=d32.device)
+    dvideo = torch.empty((Pv, Lv, D), dtype=torch.float32, device=d32.device)
+    _check(lib.alpro_gather_seq_bwd(_ptr(d32), _ptr(d_t), _CODE[d_t.dtype] if d_t is not None else F32, _ptr(ti), _ptr(vi), _ptr(dtext), _ptr(dvideo), ti.numel(), Pt, Pv, Lt, Lv, D,
+                                    _stream()), "alpro_gather_seq_bwd")
+    return dtext, dvideo
 
 
 def cls_mean_residual(x_in, side, x_out, B, T):

@@ -13,6 +13,8 @@ Encoders run in libalpro_hip.so (alpro_amd.modeling.timesformer.vit / xbert).  T
 value-preserving: hard negatives are drawn with ONE batched torch.multinomial per direction instead
 of 2B `.item()` host syncs (alpro_models.py:301-313); Horovod is replaced by alpro_amd.dist (RCCL).
 """
+import os
+
 import numpy as np
 import torch
 import torch.nn.functional as F
@@ -175,6 +177,7 @@ class AlproForPretrain(AlproBaseModel):
         self.prompter = Prompter(config, video_enc_cfg)  # frozen teacher for pseudo labels
         self.use_mask_prob = 0
         self.batch_encoder_passes = True  # one 4B fusion pass / one 2B text pass instead of the reference's 3 / 2 calls
+        self.gather_fusion_input = os.environ.get("ALPRO_GATHER_FUSION", "1") != "0"   # the 4B fusion batch as a row gather (alpro_gather_seq_*), 0 = torch.cat + autograd (A/B)
         self.mpm_head = nn.Sequential(nn.Linear(config.hidden_size, config.hidden_size * 2), nn.ReLU(True),
                                       nn.Linear(config.hidden_size * 2, self.prompter.entity_num))
 
@@ -209,11 +212,20 @@ class AlproForPretrain(AlproBaseModel):
             text_feat = self._text_feat(text_embeds)
             vtc_loss, sim_v2t, sim_t2v, _ = self._vtc(video_feat, text_feat)
             neg_video, neg_text = self._sample_negatives(sim_v2t, sim_t2v, b)
-            t_all = torch.cat([text_embeds, text_embeds, text_embeds[neg_text], mlm_text_embeds], dim=0)
             ta_all = torch.cat([text_atts, text_atts, text_atts[neg_text], text_atts], dim=0)
-            v_all = torch.cat([video_embeds, video_embeds[neg_video], video_embeds, video_embeds], dim=0)
             va_all = torch.cat([video_atts] * 4, dim=0)
-            fused = self._fusion(torch.cat([t_all, v_all], dim=1), torch.cat([ta_all, va_all], dim=1))
+            if self.gather_fusion_input:
+                # sequence s of the 4B fusion batch = [text pool row ti[s] ; video pool row vi[s]] over the pools (both = [captions ; masked captions],
+                # video_embeds): positives, negative videos, negative texts, MLM pairs -- the rows the reference's cats hold, never materialised by torch
+                ar = torch.arange(b, device=device)
+                ti = torch.cat([ar, ar, neg_text, ar + b])
+                vi = torch.cat([ar, neg_video, ar, ar])
+                fused = self.text_encoder.bert(encoder_embeds_parts=(both, video_embeds, ti, vi), attention_mask=torch.cat([ta_all, va_all], dim=1), return_dict=True,
+                                               mode='fusion').last_hidden_state
+            else:
+                t_all = torch.cat([text_embeds, text_embeds, text_embeds[neg_text], mlm_text_embeds], dim=0)
+                v_all = torch.cat([video_embeds, video_embeds[neg_video], video_embeds, video_embeds], dim=0)
+                fused = self._fusion(torch.cat([t_all, v_all], dim=1), torch.cat([ta_all, va_all], dim=1))
             encoder_outputs_pos, neg, mlm_out = fused[:b], fused[b:3 * b], fused[3 * b:]
             vtm_logits = _linear32(torch.cat([encoder_outputs_pos[:, 0, :], neg[:, 0, :]], dim=0), self.itm_head)
             vtm_labels = torch.cat([torch.ones(b, dtype=torch.long), torch.zeros(2 * b, dtype=torch.long)], dim=0).to(device)

@@ -280,7 +280,7 @@ class Block(nn.Module):
         ta, sa = self.temporal_attn, self.attn
         drop_t, drop_s, drop_m = self._drop(B * N, x.device), self._drop(B * T, x.device), self._drop(B, x.device)
         cp = rt.cls_precise(dt) and self.fuse_residual_ln and self.merge_temporal_proj
-        side = _ClsSide.get(x.device) if (cp and rt.cls_stream() and x.is_cuda) else None
+        side = _ClsSide.get(x.device) if (cp and rt.cls_stream(False) and x.is_cuda) else None
         if side is not None:
             x_cls_in, cls_q, o_c_buf = self._cls_side_begin(side, x, B, T, snapshot=True)
         else:
@@ -335,7 +335,7 @@ class Block(nn.Module):
         sv = {"x": x, "dims": (B, T, N, S, D, H), "dt": dt}
         sv["drop_t"], sv["drop_s"], sv["drop_m"] = self._drop(B * N, dev), self._drop(B * T, dev), self._drop(B, dev)
         side = None
-        if rt.cls_precise(dt) and rt.cls_stream() and x.is_cuda and self.fuse_residual_ln and self.merge_temporal_proj:
+        if rt.cls_precise(dt) and rt.cls_stream(True) and x.is_cuda and self.fuse_residual_ln and self.merge_temporal_proj:
             side = _ClsSide.get(dev)
             x_cls_in, cls_q, o_c_buf = self._cls_side_begin(side, x, B, T, snapshot=False)
         h = hip.layernorm(x, self.temporal_norm1.weight, self.temporal_norm1.bias, VIT_EPS, dt, rows=B * N * T,

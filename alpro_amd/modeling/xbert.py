@@ -378,21 +378,35 @@ class BertModel(BertPreTrainedModel):
         """(B, L) {0,1} -> additive fp32 bias (1 - m) * -10000 (xbert.py:936-937)."""
         return ((1.0 - attention_mask.to(torch.float32)) * -10000.0).contiguous()
 
-    def forward(self, input_ids=None, attention_mask=None, encoder_embeds=None, return_dict=True, mode='multi_modal', **unused):
+    def forward(self, input_ids=None, attention_mask=None, encoder_embeds=None, return_dict=True, mode='multi_modal', encoder_embeds_parts=None, **unused):
+        """encoder_embeds_parts (this repo's extension; the reference passes encoder_embeds): (text_pool (Pt, Lt, D), video_pool (Pv, Lv, D), ti (S,),
+        vi (S,)) -- the fusion batch as a gather, sequence s = [text_pool[ti[s]] ; video_pool[vi[s]]], i.e. what the reference's
+        torch.cat([text_embeds, video_embeds], dim=1) over concatenated / index-selected batches holds (alpro_models.py:278-281,325-330,360-363),
+        built by one kernel and differentiated by one (alpro_gather_seq_fwd / _bwd) instead of materialised by torch.cat and autograd."""
+        parts = encoder_embeds_parts
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
             lo, hi = self.encoder.layer_range(mode)
             params = [p for i in range(lo, hi) for p in self.encoder.layer[i].parameters()]
-            if encoder_embeds is None:
+            if encoder_embeds is None and parts is None:
                 params += list(self.embeddings.parameters())
             run = _BertRun(self, input_ids, attention_mask, mode)
-            out = tr.run_anchored(run, [encoder_embeds] if encoder_embeds is not None else [], params)
+            if parts is not None:
+                run.parts = (parts[2].contiguous(), parts[3].contiguous())
+                out = tr.run_anchored(run, [parts[0], parts[1]], params)
+            else:
+                out = tr.run_anchored(run, [encoder_embeds] if encoder_embeds is not None else [], params)
             if not return_dict:
                 return (out,)
             return SimpleNamespace(last_hidden_state=out, pooler_output=None, hidden_states=None, attentions=None,
                                    past_key_values=None, cross_attentions=None)
         dt = rt.compute_dtype()
         cfg = self.config
-        if encoder_embeds is None:
+        if parts is not None:
+            B, L = parts[2].numel(), parts[0].shape[1] + parts[1].shape[1]
+            h32, h_t = hip.gather_seq(parts[0].contiguous().float(), parts[1].contiguous().float(), parts[2].contiguous(), parts[3].contiguous(), dt)
+            if h_t is None:
+                h_t = h32
+        elif encoder_embeds is None:
             B, L = input_ids.shape
             emb = self.embeddings
             ep = float(cfg.hidden_dropout_prob) if emb.training else 0.0
@@ -421,12 +435,21 @@ class _BertRun:
 
     def __init__(self, model, input_ids, attention_mask, mode):
         self.m, self.ids, self.mask, self.mode = model, input_ids, attention_mask, mode
+        self.parts = None   # (ti, vi): the input is a gather of (text pool, video pool) sequences, the two activations of forward()
 
-    def forward(self, encoder_embeds=None):
+    def forward(self, encoder_embeds=None, video_pool=None):
         m, cfg = self.m, self.m.config
         dt = rt.compute_dtype()
         emb = m.embeddings
-        if encoder_embeds is None:
+        if self.parts is not None:
+            text_pool = encoder_embeds
+            ti, vi = self.parts
+            B, L = ti.numel(), text_pool.shape[1] + video_pool.shape[1]
+            self.pool_dims = (text_pool.shape[0], video_pool.shape[0], text_pool.shape[1], video_pool.shape[1])
+            h32, h_t = hip.gather_seq(text_pool.contiguous().float(), video_pool.contiguous().float(), ti, vi, dt)
+            if h_t is None:
+                h_t = h32
+        elif encoder_embeds is None:
             B, L = self.ids.shape
             self.ids = self.ids.contiguous()
             word = emb.word_embeddings.weight
@@ -443,7 +466,7 @@ class _BertRun:
         mask = self.mask if self.mask is not None else torch.ones((B, L), device=h32.device)
         kb = m.key_bias(mask)
         self.dims = (B, L)
-        self.from_ids = encoder_embeds is None
+        self.from_ids = encoder_embeds is None and self.parts is None
         self.saved = []
         lo, hi = m.encoder.layer_range(self.mode)
         self.range = (lo, hi)
@@ -459,6 +482,10 @@ class _BertRun:
         d32, d_t = dout.reshape(B * L, -1).contiguous(), None
         for i in range(hi - 1, lo - 1, -1):
             d32, d_t = m.encoder.layer[i].backward(self.saved.pop(), d32, d_t)
+        if self.parts is not None:   # per pool row, the sum over the sequences that used it (and of the 16-bit + fp32 parts of the gradient)
+            if d_t is not None and d_t.dtype == torch.float32:
+                d32, d_t = d32 + d_t, None
+            return hip.gather_seq_bwd(d32.contiguous(), None if d_t is None else d_t.contiguous(), self.parts[0], self.parts[1], *self.pool_dims)
         if not self.from_ids:
             return (d32 + d_t.float()).view(B, L, -1)
         # embeddings: LN backward on word + type0 + pos, then scatter the row gradients into the tables

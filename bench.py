@@ -254,6 +254,11 @@ def measure_divst(dev, T, model=None, B=32, iters=5):
         marks[-1][1] = e1
         tails.append((ea, e1))
         return out
+    # The region is timed with HIP events on the MAIN stream, so it is measured with the precise-CLS chain on that stream too (ALPRO_CLS_STREAM=0 for
+    # this pass): every launch the sub-blocks need is then inside the region.  On its side stream (the inference default) part of the chain runs
+    # beside the MLP half and the region would both lose that work and gain the main stream's waits (profiles/r5_cls_stream_ab.txt).
+    prev_cs = rt._cls_stream[0]
+    rt.set_cls_stream("0")
     with torch.no_grad():
         for _ in range(2):
             model.forward_features(x)
@@ -269,6 +274,7 @@ def measure_divst(dev, T, model=None, B=32, iters=5):
             torch.cuda.synchronize()
         finally:
             vit.Block.forward, hip.cls_mean_residual, hip.add_layernorm = orig_fwd, orig_cls, orig_add
+            rt.set_cls_stream(prev_cs)
     # The PRE_MLP kernel is the spatial half's residual add (reads x and the 16-bit delta, writes x': 7.5 of its 9 KB per row) AND the MLP
     # half's norm2 (the 16-bit normalised row: 1.5 KB).  Its time is attributed 5/6 to the attention sub-blocks, 1/6 to the MLP.
     tail_ms = sum(a.elapsed_time(b) for a, b in tails) / iters

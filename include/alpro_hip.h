@@ -202,6 +202,17 @@ int alpro_patchify(const float* img, void* out, int dtype, int BT, int C, int Hi
 int alpro_prepare_clips(const void* raw, int raw_is_u8, const int* boxes, float scale, const float* mean3, const float* std3, float* visual,
                         float* crop, float* context, int B, int T, int H, int W, void* stream);
 
+/* Round 5: the input of the fusion encoder as a gather of sequences (alpro_models.py:278-281, 325-330, 360-363: torch.cat of text and video
+ * embeddings, with `text_embeds[neg_text]` / `video_embeds[neg_video]` for the hard negatives).  Sequence s of the (S, Lt + Lv, D) fusion batch
+ * is text-pool sequence ti[s] followed by video-pool sequence vi[s]:
+ *   fwd: out32[s] = [text[ti[s]] ; video[vi[s]]] (fp32) and, if out_t != NULL, the same rows in `dtype` (the first fusion layer's GEMM operand).
+ *   bwd: dtext[p] = sum_{s: ti[s] == p} (d32[s, :Lt] + d_t[s, :Lt]),  dvideo[p] = sum_{s: vi[s] == p} (d32[s, Lt:] + d_t[s, Lt:]), s ascending
+ *        (d_t: optional 16-bit part of the gradient; every pool row is written, rows nobody used with zeros).  D == 768. */
+int alpro_gather_seq_fwd(const float* text, const float* video, const int64_t* ti, const int64_t* vi, float* out32, void* out_t, int dtype, int S,
+                         int Lt, int Lv, int D, void* stream);
+int alpro_gather_seq_bwd(const float* d32, const void* d_t, int dtype, const int64_t* ti, const int64_t* vi, float* dtext, float* dvideo, int S, int Pt,
+                         int Pv, int Lt, int Lv, int D, void* stream);
+
 /* x_out[b, 0, :] = x_in[b, 0, :] + mean_t side[b*T + t, :]   (vit.py:184-187,195-196) */
 int alpro_cls_mean_residual(const float* x_in, int64_t ld_batch_in, const float* side, float* x_out,
                             int64_t ld_batch_out, int B, int T, int D, void* stream);

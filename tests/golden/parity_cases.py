@@ -53,9 +53,10 @@ def vtc_logit_error(name, m, batch, ref):
 
 
 # what tests/test_model_parity.py asserts and bench.py states next to its measurement (fp16 operands + precise CLS rows against the exact mode,
-# B = 64 x 8 frames): PROVISIONAL until the first measurement of round 5 lands in profiles/r5_parity_backward_B64.txt
-FULL_SIZE_BACKWARD_LIMITS = dict(grad_norm_rel_err_worst=5e-2, grad_norm_rel_err_median=5e-3, grad_cosine_worst=0.98, grad_cosine_median=0.9995,
-                                 global_grad_cosine=0.9995, global_grad_norm_rel_err=5e-3, loss_abs_err=5e-3)
+# B = 64 x 8 frames): about twice the first measurement (profiles/r5_parity_backward_B64.txt: l2 rel err worst 4.7e-3 / median 3.0e-3, cosine worst
+# 0.999989, norm rel err worst 9.0e-4, global cosine 0.999997, losses <= 2.8e-4)
+FULL_SIZE_BACKWARD_LIMITS = dict(grad_l2_rel_err_worst=1e-2, grad_l2_rel_err_median=6e-3, grad_norm_rel_err_worst=3e-3, grad_norm_rel_err_median=5e-4,
+                                 grad_cosine_worst=0.9999, grad_cosine_median=0.99998, global_grad_cosine=0.99999, global_grad_norm_rel_err=5e-4, loss_abs_err=1e-3)
 
 
 def full_size_backward_parity(bert_cfg, venc, make_cfg, device, dtype="fp16", cls_precise="auto", B=64, T=8, seed=4, loss_scale=65536.0):

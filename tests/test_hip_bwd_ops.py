@@ -1041,3 +1041,33 @@ def test_reductions_run_to_run_reproducibility():
     runs = [vtc() for _ in range(3)]
     for r in runs[1:]:
         assert all(torch.equal(a, b) for a, b in zip(r, runs[0]))
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16, torch.float16])
+def test_gather_seq_forward_and_backward(dt):
+    """alpro_gather_seq_fwd / _bwd (round 5): the fusion batch [text_pool[ti[s]] ; video_pool[vi[s]]] against torch.cat of index-selected pools
+    (what alpro_models.py:278-281,325-330,360-363 build), its fp32 and operand-dtype copies bitwise; the backward against autograd of the same
+    expression in fp64 (repeated and unused pool rows included), run twice -- bitwise equal (fixed summation order)."""
+    hip = _hip()
+    Pt, Pv, Lt, Lv, D, S = 6, 3, 5, 9, 768, 11
+    g = torch.Generator().manual_seed(77)
+    text, video = torch.randn(Pt, Lt, D, generator=g), torch.randn(Pv, Lv, D, generator=g)
+    ti = torch.tensor([0, 0, 3, 5, 2, 2, 2, 1, 5, 0, 3])          # row 4 unused
+    vi = torch.tensor([2, 2, 2, 0, 0, 2, 0, 2, 2, 0, 2])          # row 1 unused
+    ref = torch.cat([text[ti], video[vi]], dim=1)
+    out32, out_t = hip.gather_seq(text.cuda(), video.cuda(), ti.cuda(), vi.cuda(), dt)
+    assert torch.equal(out32.cpu().view(S, Lt + Lv, D), ref)
+    if dt == torch.float32:
+        assert out_t is None
+    else:
+        assert torch.equal(out_t.cpu().view(S, Lt + Lv, D), ref.to(dt))
+    d32 = torch.randn(S * (Lt + Lv), D, generator=g)
+    d_t = None if dt == torch.float32 else (torch.randn(S * (Lt + Lv), D, generator=g) * 0.1).to(dt)
+    t64, v64 = text.double().requires_grad_(True), video.double().requires_grad_(True)
+    up = d32.double() + (0 if d_t is None else d_t.double())
+    (torch.cat([t64[ti], v64[vi]], dim=1).reshape(-1, D) * up).sum().backward()
+    a = hip.gather_seq_bwd(d32.cuda(), None if d_t is None else d_t.cuda(), ti.cuda(), vi.cuda(), Pt, Pv, Lt, Lv)
+    b = hip.gather_seq_bwd(d32.cuda(), None if d_t is None else d_t.cuda(), ti.cuda(), vi.cuda(), Pt, Pv, Lt, Lv)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    assert torch.allclose(a[0].cpu().double(), t64.grad, rtol=1e-6, atol=1e-6) and torch.allclose(a[1].cpu().double(), v64.grad, rtol=1e-6, atol=1e-6)
+    assert float(a[0][4].abs().sum()) == 0.0 and float(a[1][1].abs().sum()) == 0.0      # unused pool rows get zeros, not garbage
