@@ -534,6 +534,62 @@ __global__ __launch_bounds__(256) void scatter_add_mod_kernel(const float* __res
   }
 }
 
+// ---- indexed scatter in a fixed order (round 5): the word-embedding table's gradient (xbert.py:203-210 backward) ---------------------------
+// dst[idx[i]] += src[i] with duplicates ([CLS], [SEP], [MASK] appear hundreds of times) added in ascending i, one writer per destination row.
+// Rounds 1-4 went through torch's sort-based index_put_ for that (0.36 ms per step of generic sort / gather / scatter kernels).  Two launches
+// here: (1) ONE workgroup sorts the composite keys (idx << 13 | i) of up to 8192 rows in LDS (bitonic network, 32 KiB); (2) one wave per
+// sorted position: the head of a run of equal destinations sums the run's rows in key order (= ascending i) and adds the total to the table.
+constexpr int SCATTER_SORT_MAX = 8192;
+__global__ __launch_bounds__(1024) void scatter_sort_keys_kernel(const int64_t* __restrict__ idx, int rows, uint32_t* __restrict__ keys_out) {
+  __shared__ uint32_t k[SCATTER_SORT_MAX];
+  for (int i = threadIdx.x; i < SCATTER_SORT_MAX; i += 1024) k[i] = i < rows ? (((uint32_t)idx[i] << 13) | (uint32_t)i) : 0xFFFFFFFFu;
+  __syncthreads();
+  for (int size = 2; size <= SCATTER_SORT_MAX; size <<= 1) {
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      for (int t = threadIdx.x; t < SCATTER_SORT_MAX / 2; t += 1024) {
+        const int lo = 2 * t - (t & (stride - 1));   // the lower element of the t-th compare-exchange pair at this stride
+        const int hi = lo + stride;
+        const bool up = (lo & size) == 0;
+        const uint32_t a = k[lo], b = k[hi];
+        if ((a > b) == up) {
+          k[lo] = b;
+          k[hi] = a;
+        }
+      }
+      __syncthreads();
+    }
+  }
+  for (int i = threadIdx.x; i < SCATTER_SORT_MAX; i += 1024) keys_out[i] = k[i];
+}
+
+__global__ __launch_bounds__(256) void scatter_add_runs_kernel(const float* __restrict__ src, const uint32_t* __restrict__ keys, float* __restrict__ dst, int rows,
+                                                               int64_t skip_idx) {
+  const int lane = threadIdx.x & 63;
+  const int pos = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (pos >= rows) return;
+  const uint32_t key = keys[pos];
+  const uint32_t dest = key >> 13;
+  if ((pos > 0 && (keys[pos - 1] >> 13) == dest) || (int64_t)dest == skip_idx) return;   // not the head of its run / the padding row (nn.Embedding(padding_idx))
+  float acc[12];
+#pragma unroll
+  for (int i = 0; i < 12; ++i) acc[i] = 0.f;
+  for (int q = pos; q < rows; ++q) {
+    const uint32_t kq = keys[q];
+    if ((kq >> 13) != dest) break;
+    float v[12];
+    ld12_nt(src + (int64_t)(kq & 8191u) * LN_D, lane, v);
+#pragma unroll
+    for (int i = 0; i < 12; ++i) acc[i] += v[i];
+  }
+  float* d = dst + (int64_t)dest * LN_D;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    float4* p = (float4*)(d + i * 256 + lane * 4);
+    const float4 c = *p;
+    *p = make_float4(c.x + acc[4 * i], c.y + acc[4 * i + 1], c.z + acc[4 * i + 2], c.w + acc[4 * i + 3]);
+  }
+}
+
 // ---- small per-block terms of the merged temporal projection W_e = W_fc W_p (vit.py:157-162), all ViT blocks in one launch -------------
 //   mode 0 (after an optimizer step):  b1[n] = sum_m W_fc[n, m] b_p[m]                      (the merged bias under the drop-path scale)
 //   mode 1 (backward, product rule):   g_fc[n, m] += db1[n] b_p[m];   g_bp[m] += sum_n W_fc[n, m] db1[n]
@@ -712,6 +768,17 @@ extern "C" int alpro_cls_mean_bwd(const float* dx_out, int64_t ld_batch, float* 
   ALPRO_CHECK(dx_out && dside && B > 0 && T > 0 && D > 0, "alpro_cls_mean_bwd: bad args");
   hipLaunchKernelGGL(cls_mean_bwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, dx_out, ld_batch, dside, B, T, D);
   return check_launch("alpro_cls_mean_bwd");
+}
+
+extern "C" int alpro_scatter_add_rows_ordered(const float* src, const int64_t* idx, float* dst, int rows, int D, int64_t dst_rows, int64_t skip_idx, uint32_t* keys_ws,
+                                              void* stream) {
+  ALPRO_CHECK(src && idx && dst && keys_ws && rows > 0, "alpro_scatter_add_rows_ordered: bad args");
+  ALPRO_CHECK(D == LN_D, "alpro_scatter_add_rows_ordered: D=%d unsupported", D);
+  ALPRO_CHECK(rows <= SCATTER_SORT_MAX && dst_rows > 0 && dst_rows <= (1 << 19), "alpro_scatter_add_rows_ordered: at most %d source rows and 2^19 table rows (got %d, %lld)",
+              SCATTER_SORT_MAX, rows, (long long)dst_rows);
+  hipLaunchKernelGGL(scatter_sort_keys_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, idx, rows, keys_ws);
+  hipLaunchKernelGGL(scatter_add_runs_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, src, keys_ws, dst, rows, skip_idx);
+  return check_launch("alpro_scatter_add_rows_ordered");
 }
 
 extern "C" int alpro_scatter_add_rows(const float* src, const int64_t* idx, float* dst, int rows, int idx_mod, int D, int64_t skip_idx, void* stream) {

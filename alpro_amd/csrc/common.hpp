@@ -154,6 +154,45 @@ template <typename T> __device__ __forceinline__ float gelu_grad(float x) {
   }
 }
 
+// gelu(x) and gelu'(x) for TWO elements with ONE exponential each (round 5).  Phi(-|x|) = 0.5 erfc(|x| / sqrt 2) = exp(-x^2 / 2) * g(|x|) with
+// g(t) = 0.5 erfcx(t / sqrt 2), and exp(-x^2 / 2) is what phi(x) needs anyway: g is smooth and slowly varying, a degree-9 polynomial in |x|
+// (weighted minimax fit, the weight being the exponential in front of it: |Phi error| <= 3.2e-7 in fp32 arithmetic on [0, 13], checked against
+// scipy's erfc in the fit script's output recorded in DESIGN.md) replaces the second v_exp_f32 of the round-3 form (erfc ~= 2^q(z) plus a
+// separate exp for phi).  Written on 2-vectors so that the nine Horner steps are v_pk_fma_f32 (two elements per issue slot): per pair of
+// elements 9 + ~10 VALU slots and 2 transcendentals, against 25 + 4.  The GELU-saving fc1 epilogue spent about 40 % of a tile's time here.
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void gelu_and_grad2(f32x2v x, f32x2v& y, f32x2v& dy) {
+  const f32x2v t = {fabsf(x.x), fabsf(x.y)};
+  f32x2v p = t * (f32x2v){-8.062383613e-06f, -8.062383613e-06f} + (f32x2v){1.519315725e-04f, 1.519315725e-04f};
+  p = p * t + (f32x2v){-1.271098853e-03f, -1.271098853e-03f};
+  p = p * t + (f32x2v){6.382599637e-03f, 6.382599637e-03f};
+  p = p * t + (f32x2v){-2.223049180e-02f, -2.223049180e-02f};
+  p = p * t + (f32x2v){5.949637600e-02f, 5.949637600e-02f};
+  p = p * t + (f32x2v){-1.317726293e-01f, -1.317726293e-01f};
+  p = p * t + (f32x2v){2.497522130e-01f, 2.497522130e-01f};
+  p = p * t + (f32x2v){-3.989226083e-01f, -3.989226083e-01f};
+  p = p * t + (f32x2v){4.999997430e-01f, 4.999997430e-01f};
+  const f32x2v a = x * x * (f32x2v){-0.72134752044448170368f, -0.72134752044448170368f};   // -x^2 / 2 in the log2 domain
+  const f32x2v e = {__builtin_amdgcn_exp2f(a.x), __builtin_amdgcn_exp2f(a.y)};           // exp(-x^2 / 2)
+  const f32x2v h = e * p;                                                                // Phi(-|x|)
+  const f32x2v cdf = {0.5f + copysignf(0.5f - h.x, x.x), 0.5f + copysignf(0.5f - h.y, x.y)};
+  y = x * cdf;
+  dy = cdf + x * (e * (f32x2v){0.39894228040143267794f, 0.39894228040143267794f});
+}
+
+// gelu(x) alone on two elements: gelu_fast's arithmetic (erfc ~= 2^q(z), one exponential per element) with the polynomial on 2-vectors
+__device__ __forceinline__ f32x2v gelu_fast2(f32x2v x) {
+  const f32x2v z = (f32x2v){fabsf(x.x), fabsf(x.y)} * (f32x2v){0.70710678118654752440f, 0.70710678118654752440f};
+  f32x2v q = z * (f32x2v){-0.00296695f, -0.00296695f} + (f32x2v){0.02966973f, 0.02966973f};
+  q = z * q + (f32x2v){-0.14875628f, -0.14875628f};
+  q = z * q + (f32x2v){-0.91847146f, -0.91847146f};
+  q = z * q + (f32x2v){-1.62789348f, -1.62789348f};
+  q = z * q + (f32x2v){-1.0f, -1.0f};
+  const f32x2v h = {__builtin_amdgcn_exp2f(q.x), __builtin_amdgcn_exp2f(q.y)};
+  const f32x2v cdf = {0.5f + copysignf(0.5f - h.x, x.x), 0.5f + copysignf(0.5f - h.y, x.y)};
+  return x * cdf;
+}
+
 // gelu(x) and gelu'(x) together (the forward of a GELU Linear that keeps gelu' for its backward): Phi(x) is shared
 template <typename T> __device__ __forceinline__ void gelu_and_grad(float x, float& y, float& dy) {
   if constexpr (sizeof(T) == 4) {
@@ -194,6 +233,11 @@ __device__ __forceinline__ void dma16(const void* src, uint32_t lds_addr) {
 // consumers (profiles/r2_gemm_epilogue_experiments.txt, experiment 10d); on the GEMM's own 16-bit outputs it LOSES 1.8 ms.
 __device__ __forceinline__ void store16_sc1(void* p, const u32x4& v) {
   asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+}
+// A SCALAR load of read-only data at a wave-uniform index (s_load_dword: counted on lgkmcnt, not on vmcnt -- it cannot put a vmcnt(0) join
+// between an epilogue's output stores).  The constant address space is what makes the compiler pick the scalar path.
+__device__ __forceinline__ float sload_f32(const float* p, uint32_t idx) {
+  return *((const __attribute__((address_space(4))) float*)p + __builtin_amdgcn_readfirstlane(idx));
 }
 __device__ __forceinline__ uint32_t lds_addr_of(const void* p) { return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)p; }
 

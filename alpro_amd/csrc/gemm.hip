@@ -237,25 +237,55 @@ __device__ __forceinline__ void epi_prefetch_res(const alpro_gemm_desc_t& g, int
 // 16-bit outputs under the identity map (qkv / proj / fc1 / every dgrad): 8 columns per lane -> one 16-byte store per
 // lane, 8 rows per wave instruction.  The store path is ISSUE-bound per CU (~one wave-store per ~100 cycles measured),
 // so halving the number of store instructions halves the epilogue tail.  Whole block in range (FAST) only.
-template <typename T, int ACT, int PASSES = 2, int ABL = 0>
+// Round 5: no vector-memory load sits behind a run-time test inside a pass.  Rounds 3-4 tested g.row_scale / g.residual per pass; the row scale was
+// a conditional per-lane load, and the join behind a conditional load is closed with s_waitcnt vmcnt(0): every one of a tile's 16 passes
+// waited for the previous pass's output store to be acknowledged -- and, in the MUL_SAVED form, for the saved-factor rows fetched AHEAD, which
+// defeated the run-ahead.  Now (i) the fp32 residual is a template parameter (RES: the caller tests the pointer once per tile), and (ii) the
+// row scale of a pass comes from SCALAR loads: a pass covers 8 consecutive rows, which lie in at most two groups when row_scale_group >= 8
+// (launcher: drop-path scales per 8-frame token group, per 197-token frame, per clip) -- one wave-uniform division, two s_load_dword, a
+// compare per lane.  The plain GEMMs (qkv, fc1, dgrads) have no load at all in their passes: the stores stream.
+template <typename T, int ACT, int PASSES = 2, int ABL = 0, bool RES = true>
 __device__ __forceinline__ void epi_rows16_c16(const alpro_gemm_desc_t& g, const float* stage, int m_base, int n_base, int lane, const float (&bias)[8],
                                                const u32x4* pre_c2 = nullptr) {
   const int c8 = (lane & 7) * 8;
   const int n = n_base + c8;
+  float rsv[PASSES];
+#pragma unroll
+  for (int p = 0; p < PASSES; ++p) rsv[p] = 1.0f;
+  if (g.row_scale) {
+#pragma unroll
+    for (int p = 0; p < PASSES; ++p) {
+      const uint32_t m0 = (uint32_t)g.m_off + (uint32_t)__builtin_amdgcn_readfirstlane(m_base) + p * 8;   // first row of the pass (wave-uniform; rows < 2^31)
+      const uint32_t gi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(m0 / (uint32_t)g.row_scale_group));
+      const uint32_t edge = (gi + 1) * (uint32_t)g.row_scale_group;
+      const float lo = sload_f32(g.row_scale, gi), hi = sload_f32(g.row_scale, edge < (uint32_t)g.m_off + (uint32_t)g.M ? gi + 1 : gi);
+      rsv[p] = (m0 + (uint32_t)(lane >> 3)) >= edge ? hi : lo;
+    }
+  }
 #pragma unroll
   for (int p = 0; p < PASSES; ++p) {
     const int row = p * 8 + (lane >> 3);
     const int64_t m = m_base + row;
     const float4 a0 = *(const float4*)(stage + row * 64 + c8), a1 = *(const float4*)(stage + row * 64 + c8 + 4);
     float v[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
-    const float rs = g.row_scale ? g.row_scale[(g.m_off + m) / g.row_scale_group] : 1.0f;
+    const float rs = rsv[p];
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] = g.alpha * v[e] + bias[e];
     if ((ACT == ALPRO_ACT_GELU || ACT == ALPRO_ACT_RELU) && g.C2) __builtin_nontemporal_store(pack_chunk<T>(v), (u32x4*)((T*)g.C2 + m * g.ldc2 + n));
     if (ACT == ALPRO_ACT_GELU_SAVE_GRAD) {
       float dv[8];
+      if constexpr (sizeof(T) == 2) {   // 16-bit storage: the one-exponential form on pairs (common.hpp gelu_and_grad2)
 #pragma unroll
-      for (int e = 0; e < 8; ++e) gelu_and_grad<T>(v[e], v[e], dv[e]);
+        for (int e = 0; e < 8; e += 2) {
+          f32x2v yy, dd;
+          gelu_and_grad2((f32x2v){v[e], v[e + 1]}, yy, dd);
+          v[e] = yy.x; v[e + 1] = yy.y;
+          dv[e] = dd.x; dv[e + 1] = dd.y;
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) gelu_and_grad<T>(v[e], v[e], dv[e]);
+      }
       __builtin_nontemporal_store(pack_chunk<T>(dv), (u32x4*)((T*)g.C2 + m * g.ldc2 + n));
     }
     if (ACT == ALPRO_ACT_GELU_BWD || ACT == ALPRO_ACT_MUL_SAVED) {
@@ -264,8 +294,17 @@ __device__ __forceinline__ void epi_rows16_c16(const alpro_gemm_desc_t& g, const
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] *= (ACT == ALPRO_ACT_MUL_SAVED) ? pre[e] : gelu_grad<T>(pre[e]);
     }
+    if constexpr (ACT == ALPRO_ACT_GELU && sizeof(T) == 2) {   // the same arithmetic as gelu_fast, polynomial on pairs (v_pk_fma_f32)
 #pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = apply_act<T, ACT>(v[e]) * rs;
+      for (int e = 0; e < 8; e += 2) {
+        const f32x2v yy = gelu_fast2((f32x2v){v[e], v[e + 1]});
+        v[e] = yy.x * rs;
+        v[e + 1] = yy.y * rs;
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = apply_act<T, ACT>(v[e]) * rs;
+    }
     if (g.drop_seed) {
       float dp = g.drop_p;
       asm volatile("" : "+s"(dp));   // keeps 1 / (1 - p) (and its packed-multiply splat) from being hoisted over the K loop as a kernel invariant, where it is spilled and reloaded per pass
@@ -275,9 +314,11 @@ __device__ __forceinline__ void epi_rows16_c16(const alpro_gemm_desc_t& g, const
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] = drop_keep(g.drop_seed, i0 + e, th) ? v[e] * ks : 0.f;
     }
-    if (g.residual) {
-      const f32x4 r0 = __builtin_nontemporal_load((const f32x4*)(g.residual + m * g.ldr + n)), r1 = __builtin_nontemporal_load((const f32x4*)(g.residual + m * g.ldr + n + 4));
-      v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w; v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w;
+    if constexpr (RES) {
+      if (g.residual) {
+        const f32x4 r0 = __builtin_nontemporal_load((const f32x4*)(g.residual + m * g.ldr + n)), r1 = __builtin_nontemporal_load((const f32x4*)(g.residual + m * g.ldr + n + 4));
+        v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w; v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w;
+      }
     }
     if (ABL == 1) {  // ablation (gemm_tune 3): everything but the global store
       u32x4 keep = pack_chunk<T>(v);
@@ -692,7 +733,7 @@ __global__ __launch_bounds__(NT2, 2) void gemm_nt256p_kernel(const alpro_gemm_de
       const bool fast = epi_fast_ok(g, mb, 128, nb);
       bool c16 = false;
       if constexpr (sizeof(T) == 2 && MAP == ALPRO_MAP_IDENTITY)
-        c16 = fast && g.c_dtype != ALPRO_F32 && ((g.ldc & 7) == 0) && (!g.C2 || (g.ldc2 & 7) == 0);
+        c16 = fast && g.c_dtype != ALPRO_F32 && ((g.ldc & 7) == 0) && (!g.C2 || (g.ldc2 & 7) == 0) && (!g.row_scale || g.row_scale_group >= 8);
       if (c16) {
         if constexpr (sizeof(T) == 2 && MAP == ALPRO_MAP_IDENTITY) {
           float bias8[8];
@@ -830,6 +871,17 @@ __global__ __launch_bounds__(NT2, 2) void gemm_nt256q_kernel(const alpro_gemm_de
   // walk state (wave 0's copy is the one that counts).  Dynamic: how many XCD lists have run dry for this workgroup (tickets are drawn from
   // XCD (own + wstate) % 8).  Static: the workgroup's next list position.
   uint32_t wstate = sc.blk ? 0u : (uint32_t)(blockIdx.x >> 3) + 2 * p;
+  // Tickets a workgroup may still draw AHEAD (pipelined, two tiles before it can start them): its fair share of its own list,
+  // ceil((len - 2p) / p).  Without the cap a workgroup that runs a few hundred ns ahead of a neighbour draws the list's last ticket while the
+  // neighbour still has two tiles to go, and the launch ends one tile later than the static walk (measured on the qkv shape at B = 64, whose
+  // lists divide exactly: +8 %).  Whatever is left when a workgroup is OUT of work -- tickets of workgroups that never started, the other
+  // XCDs' lists -- goes through steal(), one tile at a time, to whoever is idle then.
+  int quota = 0;
+  bool pending = false;   // a pipelined ticket is in flight
+  if (sc.blk) {
+    const int mine = list_len((int)(blockIdx.x & 7u)) - (int)(2 * p);
+    quota = mine > 0 ? (mine + (int)p - 1) / (int)p : 0;
+  }
   // One returning atomic, lane 0 of wave 0 only (`on`; otherwise the instruction runs with an empty EXEC mask): `add` = a ticket of the
   // current list's counter, else the claim (atomic or) of workgroup `w`'s word.  The value lands in `r` when the memory system answers:
   // whoever reads it waits first (s_waitcnt vmcnt), like for the copies.  "+v": `r` is ONE register from here to its reader -- a
@@ -1005,6 +1057,7 @@ __global__ __launch_bounds__(NT2, 2) void gemm_nt256q_kernel(const alpro_gemm_de
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (steal()'s own waits count on an empty queue)
     steal(cur_t, nxt_t);
     if (cur_t < 0) break;
+    quota = 0;   // from here on one tile at a time, when idle
   }
   have = false;
   Tile cur = tile_base(cur_t);
@@ -1032,7 +1085,9 @@ __global__ __launch_bounds__(NT2, 2) void gemm_nt256q_kernel(const alpro_gemm_de
       continue;   // fill the pipeline again for what is left, or look for other work
     }
   }
-  ticket_issue(tk, wave == 0 && sc.blk && nxt_t >= 0);   // for the tile after next
+  pending = sc.blk && nxt_t >= 0 && quota > 0;
+  quota -= pending ? 1 : 0;
+  ticket_issue(tk, wave == 0 && pending);   // for the tile after next
 
   while (true) {
     const int tile = cur_t;
@@ -1107,7 +1162,7 @@ __global__ __launch_bounds__(NT2, 2) void gemm_nt256q_kernel(const alpro_gemm_de
       ktile(std::integral_constant<int, 1>{}, t + 1);
     }
     if (wave == 0) {   // the tile after next: the ticket drawn a tile ago has landed (every counted wait of this K loop was issued behind it)
-      mbox[0] = nxt_t >= 0 ? ticket_tile(__builtin_amdgcn_readfirstlane(tk)) : -1;   // (a dry list: -1, and the blocking form behind the next tile starts at the next XCD's)
+      mbox[0] = (pending || (!sc.blk && nxt_t >= 0)) ? ticket_tile(__builtin_amdgcn_readfirstlane(tk)) : -1;   // (no ticket drawn / a dry list: -1 -- steal() behind the next tile looks further)
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
     if (wr == 0) barrier();   // re-align: both wave rows run their epilogues at the same time
@@ -1136,20 +1191,34 @@ __global__ __launch_bounds__(NT2, 2) void gemm_nt256q_kernel(const alpro_gemm_de
 #pragma unroll
           for (int e = 0; e < 8; ++e) bias8[e] = g.bias ? g.bias[nb + (le & 7) * 8 + e] : 0.f;
           constexpr bool READS_C2 = ACT == ALPRO_ACT_GELU_BWD || ACT == ALPRO_ACT_MUL_SAVED;
-          u32x4 pring[2][2];   // the saved factor rows of the NEXT fragment row are in flight while this one is finished
+          // The saved-factor rows (MUL_SAVED: gelu' of the forward, 16 bits) are fetched PD fragment rows ahead of their use.  A fragment row of
+          // the epilogue takes ~0.5 us and an HBM round trip 1-2 us: with one row of run-ahead (round 4) every row waited for its loads -- the
+          // whole gap between this dgrad (0.34 of peak in the step) and the plain 16-bit-output GEMM (0.40).  The ring lives in the registers the
+          // K loop's fragments occupied (64 of them are free here): PD = 2 -> 3 x 8 registers (PD = 3 spills).
+          constexpr int PD = 2, RING = PD + 1;
+          u32x4 pring[RING][2];
           auto load_pre = [&](int mf, u32x4(&pp)[2]) {
 #pragma unroll
             for (int p = 0; p < 2; ++p)
               pp[p] = __builtin_nontemporal_load((const u32x4*)((const T*)g.C2 + (int64_t)(mb + mf * 16 + p * 8 + (le >> 3)) * g.ldc2 + nb + (le & 7) * 8));
           };
-          if (READS_C2 && rows_ok(0)) load_pre(0, pring[0]);
+          if (READS_C2) {
 #pragma unroll
-          for (int mf = 0; mf < 8; ++mf) {
-            if (!rows_ok(mf)) break;   // ragged last tile row: fragment rows at or beyond M are not stored (M % 16 == 0: launcher)
-            if (READS_C2 && mf + 1 < 8 && rows_ok(mf + 1)) load_pre(mf + 1, pring[(mf + 1) & 1]);
-            stage_rows(mf);
-            epi_rows16_c16<T, ACT, 2>(g, stage, mb + mf * 16, nb, le, bias8, READS_C2 ? pring[mf & 1] : nullptr);
+            for (int mf = 0; mf < PD; ++mf)
+              if (rows_ok(mf)) load_pre(mf, pring[mf]);
           }
+          auto rows_loop = [&](auto res_tag) {
+            constexpr bool RES = decltype(res_tag)::value;
+#pragma unroll
+            for (int mf = 0; mf < 8; ++mf) {
+              if (!rows_ok(mf)) break;   // ragged last tile row: fragment rows at or beyond M are not stored (M % 16 == 0: launcher)
+              if (READS_C2 && mf + PD < 8 && rows_ok(mf + PD)) load_pre(mf + PD, pring[(mf + PD) % RING]);
+              stage_rows(mf);
+              epi_rows16_c16<T, ACT, 2, 0, RES>(g, stage, mb + mf * 16, nb, le, bias8, READS_C2 ? pring[mf % RING] : nullptr);
+            }
+          };
+          if (g.residual) rows_loop(std::true_type{});   // (see epi_rows16_c16: no conditional vector load inside the passes)
+          else rows_loop(std::false_type{});
         }
       }
       // fp32 output (launcher: ACT none, identity map, no C2 / dropout): C = residual + row_scale * (alpha * acc + bias) -- the MLP's fc2 with its
@@ -1161,30 +1230,55 @@ __global__ __launch_bounds__(NT2, 2) void gemm_nt256q_kernel(const alpro_gemm_de
           float bias4[4];
           load_bias4(g, nb + c4, bias4);
           float* Cf = (float*)g.C;
-          f32x4 rn[4], rc[4];
+          // Round 5: the residual rows run PD fragment rows ahead in a register ring and the row scales come WITHOUT a branch inside the
+          // row loop.  (Round 4 held one row of run-ahead and a conditional row-scale load per row: the join behind it is closed with
+          // s_waitcnt vmcnt(0), so every fragment row waited for the residual rows just requested AND for its predecessor's stores.)
+          // The row scale of a fragment row: its 16 rows span at most two groups when row_scale_group >= 16 (the drop-path scale of fc2:
+          // one value per clip of 1569 rows) -- one scalar division per fragment row, one or two scalar loads, a compare per row.
+          constexpr int PD = 1, RING = PD + 1;   // (two rows ahead do not fit: 48 registers next to the 128 accumulators spill into the row loop)
+          f32x4 ring[RING][4];
           auto load_res = [&](int mf, f32x4(&rr)[4]) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) rr[j] = __builtin_nontemporal_load((const f32x4*)(g.residual + (int64_t)(mb + mf * 16 + r0e + 4 * j) * g.ldr + nb + c4));
           };
-          if (g.residual && rows_ok(0)) load_res(0, rc);
+          auto f32_rows = [&](auto res_tag) {
+            constexpr bool HAS_RES = decltype(res_tag)::value;
+            if constexpr (HAS_RES) {
 #pragma unroll
-          for (int mf = 0; mf < 8; ++mf) {
-            if (!rows_ok(mf)) break;
-            if (g.residual && mf + 1 < 8 && rows_ok(mf + 1)) load_res(mf + 1, rn);
-            stage_rows(mf);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              const int row = r0e + 4 * j;
-              const int64_t m = mb + mf * 16 + row;
-              const float4 a = *(const float4*)(stage + row * 64 + c4);
-              const float rs = g.row_scale ? g.row_scale[(g.m_off + m) / g.row_scale_group] : 1.0f;
-              f32x4 v = {(g.alpha * a.x + bias4[0]) * rs, (g.alpha * a.y + bias4[1]) * rs, (g.alpha * a.z + bias4[2]) * rs, (g.alpha * a.w + bias4[3]) * rs};
-              if (g.residual) v += rc[j];
-              __builtin_nontemporal_store(v, (f32x4*)(Cf + m * g.ldc + nb + c4));
+              for (int mf = 0; mf < PD; ++mf)
+                if (rows_ok(mf)) load_res(mf, ring[mf]);
             }
 #pragma unroll
-            for (int j = 0; j < 4; ++j) rc[j] = rn[j];
-          }
+            for (int mf = 0; mf < 8; ++mf) {
+              if (!rows_ok(mf)) break;
+              if constexpr (HAS_RES) {
+                if (mf + PD < 8 && rows_ok(mf + PD)) load_res(mf + PD, ring[(mf + PD) % RING]);
+              }
+              float rs_lo = 1.0f, rs_hi = 1.0f;
+              uint32_t edge = 0;   // first row (absolute, with m_off; rows < 2^31) of the second group
+              if (g.row_scale) {   // scalar loads (wave-uniform addresses): no vector-memory join
+                const uint32_t m0 = (uint32_t)g.m_off + (uint32_t)(mb + mf * 16);
+                const uint32_t gi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(m0 / (uint32_t)g.row_scale_group));
+                edge = (gi + 1) * (uint32_t)g.row_scale_group;
+                rs_lo = sload_f32(g.row_scale, gi);
+                rs_hi = sload_f32(g.row_scale, edge < (uint32_t)g.m_off + (uint32_t)g.M ? gi + 1 : gi);
+              }
+              stage_rows(mf);
+#pragma unroll
+              for (int j = 0; j < 4; ++j) {
+                const int row = r0e + 4 * j;
+                const int64_t m = mb + mf * 16 + row;
+                const float4 a = *(const float4*)(stage + row * 64 + c4);
+                const float rs = ((uint32_t)g.m_off + (uint32_t)m) >= edge ? rs_hi : rs_lo;   // (no row scale: both are 1)
+                f32x4 v = {(g.alpha * a.x + bias4[0]) * rs, (g.alpha * a.y + bias4[1]) * rs, (g.alpha * a.z + bias4[2]) * rs, (g.alpha * a.w + bias4[3]) * rs};
+                if constexpr (HAS_RES) v += ring[mf % RING][j];
+                __builtin_nontemporal_store(v, (f32x4*)(Cf + m * g.ldc + nb + c4));
+              }
+            }
+          };
+          // (row_scale_group < 16 would need a scale per row: not a shape of this model -- the launcher keeps such descriptors off this kernel)
+          if (g.residual) f32_rows(std::true_type{});
+          else f32_rows(std::false_type{});
         }
       }
     }
@@ -1193,7 +1287,9 @@ __global__ __launch_bounds__(NT2, 2) void gemm_nt256q_kernel(const alpro_gemm_de
     cur_t = nxt_t;
     nxt_t = __builtin_amdgcn_readfirstlane(mbox[0]);
     nxt = tile_base(nxt_t >= 0 ? nxt_t : cur_t);
-    ticket_issue(tk, wave == 0 && sc.blk && nxt_t >= 0);
+    pending = sc.blk && nxt_t >= 0 && quota > 0;
+    quota -= pending ? 1 : 0;
+    ticket_issue(tk, wave == 0 && pending);
   }
   // out of work: the run-ahead copies went into dead slots and must have landed before the stage buffers are filled again (or, at the end,
   // before the LDS belongs to someone else); steal() looks for other lists' tickets / unclaimed pairs next
@@ -1239,9 +1335,10 @@ int launch_gemm_inst(const alpro_gemm_desc_t& g, hipStream_t st) {
     // K-tiles; a ragged M (the ViT's B * 1569 token rows: M % 256 = 64) is split -- whole tiles here, the remaining rows on the 128 x 128 kernel
     // in a second launch -- when the epilogue does not index by absolute row (row scale, dropout)
     const int m_full = g.M / BM2 * BM2, m_rem = g.M - m_full;
-    const bool c16 = g.c_dtype != ALPRO_F32 && (g.ldc & 7) == 0 && (!g.C2 || (g.ldc2 & 7) == 0) && (!g.residual || (g.ldr & 3) == 0) && ((uintptr_t)g.C % 16) == 0;
+    const bool c16 = g.c_dtype != ALPRO_F32 && (g.ldc & 7) == 0 && (!g.C2 || (g.ldc2 & 7) == 0) && (!g.residual || (g.ldr & 3) == 0) && ((uintptr_t)g.C % 16) == 0 &&
+                     (!g.row_scale || g.row_scale_group >= 8);   // (a pass of 8 rows takes its scales from at most two groups: epi_rows16_c16)
     const bool c32 = g.c_dtype == ALPRO_F32 && ACT == ALPRO_ACT_NONE && !g.C2 && !g.drop_seed && (g.ldc & 3) == 0 && (!g.residual || ((g.ldr & 3) == 0 && ((uintptr_t)g.residual % 16) == 0)) &&
-                     ((uintptr_t)g.C % 16) == 0;
+                     ((uintptr_t)g.C % 16) == 0 && (!g.row_scale || g.row_scale_group >= 16);   // (the fp32 epilogue takes a fragment row's scales from at most two groups)
     const bool shape = (g.N % BN2) == 0 && ((g.lda * 2) % 128) == 0 && ((g.ldw * 2) % 128) == 0 && (g.K % 128) == 0 && g.K >= 256 &&
                        (int64_t)g.M * g.lda * 2 < (int64_t)0xFFFF0000 && (int64_t)g.N * g.ldw * 2 < (int64_t)0xFFFF0000;
     // ragged M: when the remainder is a multiple of 16 rows the kernel takes the partial tile row itself (invalid copy pieces re-read valid rows,

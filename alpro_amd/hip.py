@@ -23,7 +23,7 @@ _CODE = {v: k for k, v in _TORCH_DTYPE.items()}
 EXPORTS = ["alpro_hip_last_error", "alpro_hip_abi_version", "alpro_hip_set_option", "alpro_hip_set_stream_option", "alpro_gemm", "alpro_layernorm_fwd",
            "alpro_attn_temporal_fwd", "alpro_attn_fwd", "alpro_patchify", "alpro_cls_mean_residual",
            "alpro_vit_final_pool", "alpro_bert_embed_fwd", "alpro_cast_from_f32", "alpro_attn_bwd", "alpro_attn_temporal_bwd",
-           "alpro_layernorm_bwd", "alpro_transpose", "alpro_transpose_batch", "alpro_gelu_bwd", "alpro_cls_mean_bwd", "alpro_scatter_add_rows", "alpro_gather_cast", "alpro_sumsq", "alpro_adamw_step", "alpro_gemm_tn_acc", "alpro_gemm_tn_acc_ws", "alpro_gemm_tn_workspace_bytes", "alpro_gemm_tn_ranges", "alpro_colsum_acc", "alpro_softmax_xent", "alpro_vtc_loss_fwd", "alpro_vtc_loss_bwd", "alpro_prepare_clips", "alpro_loss_scale_update", "alpro_add_layernorm_fwd", "alpro_layernorm_bwd_emit", "alpro_gemm_batch", "alpro_tproj_small", "alpro_attn_cls_fwd", "alpro_gemm_rows_f32", "alpro_gather_seq_fwd", "alpro_gather_seq_bwd"]
+           "alpro_layernorm_bwd", "alpro_transpose", "alpro_transpose_batch", "alpro_gelu_bwd", "alpro_cls_mean_bwd", "alpro_scatter_add_rows", "alpro_gather_cast", "alpro_sumsq", "alpro_adamw_step", "alpro_gemm_tn_acc", "alpro_gemm_tn_acc_ws", "alpro_gemm_tn_workspace_bytes", "alpro_gemm_tn_ranges", "alpro_colsum_acc", "alpro_softmax_xent", "alpro_vtc_loss_fwd", "alpro_vtc_loss_bwd", "alpro_prepare_clips", "alpro_loss_scale_update", "alpro_add_layernorm_fwd", "alpro_layernorm_bwd_emit", "alpro_gemm_batch", "alpro_tproj_small", "alpro_attn_cls_fwd", "alpro_gemm_rows_f32", "alpro_gather_seq_fwd", "alpro_gather_seq_bwd", "alpro_scatter_add_rows_ordered"]
 
 
 class GemmDesc(ctypes.Structure):
@@ -105,6 +105,7 @@ def load():
     lib.alpro_cast_from_f32.argtypes = [vp, vp, i32, i64, vp]
     lib.alpro_hip_set_option.argtypes = [ctypes.c_char_p, i32]
     lib.alpro_hip_set_stream_option.argtypes = [vp, ctypes.c_char_p, i32]
+    lib.alpro_scatter_add_rows_ordered.argtypes = [vp, vp, vp, i32, i32, i64, i64, vp, vp]
     lib.alpro_gather_seq_fwd.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]
     lib.alpro_gather_seq_bwd.argtypes = [vp, vp, i32, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]
     lib.alpro_prepare_clips.argtypes = [vp, i32, vp, f32, ctypes.POINTER(f32), ctypes.POINTER(f32), vp, vp, vp, i32, i32, i32, i32, vp]
@@ -431,6 +432,9 @@ def cls_mean_bwd(dx_out, B, T):
     return dside
 
 
+_SCATTER_KEYS = {}   # device -> 8192-entry key workspace of alpro_scatter_add_rows_ordered (used in stream order)
+
+
 def scatter_add_rows(src, idx, dst, idx_mod=0, skip_idx=-1):
     """dst[idx[i]] += src[i] (idx None: row i % idx_mod); rows whose index is skip_idx contribute nothing (nn.Embedding's padding_idx).
     Reproducible mode (the default, see set_deterministic): the position form runs the one-writer-per-row kernel; the indexed form goes
@@ -440,6 +444,14 @@ def scatter_add_rows(src, idx, dst, idx_mod=0, skip_idx=-1):
     _dev(src, torch.float32); _dev(dst, torch.float32)
     if idx is not None and _DETERMINISTIC[0]:
         idx = _dev(idx, torch.int64).view(-1)
+        if src.shape[0] <= 8192 and dst.shape[0] <= (1 << 19) and src.is_contiguous() and dst.is_contiguous():
+            # round 5: the library's own ordered scatter (keys sorted in LDS by one workgroup, one writer per destination row, ascending source order)
+            ws = _SCATTER_KEYS.get(src.device)
+            if ws is None:
+                ws = _SCATTER_KEYS[src.device] = torch.empty(8192, dtype=torch.int32, device=src.device)
+            _check(lib.alpro_scatter_add_rows_ordered(_ptr(src), _ptr(idx), _ptr(dst), src.shape[0], src.shape[1], dst.shape[0], int(skip_idx), _ptr(ws), _stream()),
+                   "alpro_scatter_add_rows_ordered")
+            return dst
         rows = src if skip_idx < 0 else src * (idx != skip_idx).unsqueeze(1).to(src.dtype)
         dst.index_put_((idx,), rows, accumulate=True)
         return dst

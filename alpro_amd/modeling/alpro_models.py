@@ -55,6 +55,30 @@ class _Linear32(torch.autograd.Function):
         return dx, dw, db
 
 
+class _FusionOutputs(torch.autograd.Function):
+    """What the heads read out of the 4B-sequence fusion output (B positives, 2B hard negatives, B MLM pairs; alpro_models.py:283,331-338,
+    366-371,215-218): the 3B [CLS] rows (ITM head), the MLM pairs' text rows (LM head) and the positives' patch rows (MPM head), as three
+    contiguous tensors.  As plain slices each of them costs autograd a full-size zero tensor (186 MB at B = 64) plus an accumulation add when
+    the pieces meet again (1.3 GB of traffic, ~0.5 ms per step); here the backward zero-fills the gradient ONCE and copies the three pieces in."""
+
+    @staticmethod
+    def forward(ctx, fused, b, txt_len):
+        ctx.shape, ctx.b, ctx.txt_len = fused.shape, b, txt_len
+        return fused[:3 * b, 0, :].contiguous(), fused[3 * b:, :txt_len].contiguous(), fused[:b, txt_len + 1:].contiguous()
+
+    @staticmethod
+    def backward(ctx, d_cls, d_mlm, d_vis):
+        b, Lt = ctx.b, ctx.txt_len
+        d = torch.zeros(ctx.shape, dtype=torch.float32, device=(d_cls if d_cls is not None else d_mlm if d_mlm is not None else d_vis).device)
+        if d_cls is not None:
+            d[:3 * b, 0, :] = d_cls
+        if d_mlm is not None:
+            d[3 * b:, :Lt] = d_mlm
+        if d_vis is not None:
+            d[:b, Lt + 1:] = d_vis
+        return d, None, None
+
+
 def _pad_k(t):
     """Zero-pad the contraction dim to a multiple of 32 (alpro_gemm's K granule in fp32)."""
     k = t.shape[1]
@@ -202,6 +226,7 @@ class AlproForPretrain(AlproBaseModel):
         video_feat = self._video_feat(video_embeds)
         video_atts = torch.ones(video_embeds.size()[:-1], dtype=torch.long, device=device)
         text_atts = batch['text_input_mask']
+        pos_patch_rows = None
         if 'mlm_labels' in batch and self.batch_encoder_passes:
             # Same sequences through the same weights as the reference's three fusion calls (positive pairs :278, 2B negatives
             # :325, MLM pairs :360) and two text-encoder calls (:99, :354), but as ONE 4B-sequence fusion batch and ONE
@@ -226,12 +251,18 @@ class AlproForPretrain(AlproBaseModel):
                 t_all = torch.cat([text_embeds, text_embeds, text_embeds[neg_text], mlm_text_embeds], dim=0)
                 v_all = torch.cat([video_embeds, video_embeds[neg_video], video_embeds, video_embeds], dim=0)
                 fused = self._fusion(torch.cat([t_all, v_all], dim=1), torch.cat([ta_all, va_all], dim=1))
-            encoder_outputs_pos, neg, mlm_out = fused[:b], fused[b:3 * b], fused[3 * b:]
-            vtm_logits = _linear32(torch.cat([encoder_outputs_pos[:, 0, :], neg[:, 0, :]], dim=0), self.itm_head)
+            txt_len = text_atts.shape[1]
+            if self.gather_fusion_input and use_mpm:
+                cls_rows, mlm_rows, pos_patch_rows = _FusionOutputs.apply(fused, b, txt_len)
+                encoder_outputs_pos = None
+            else:
+                encoder_outputs_pos, neg, mlm_out = fused[:b], fused[b:3 * b], fused[3 * b:]
+                cls_rows, mlm_rows, pos_patch_rows = torch.cat([encoder_outputs_pos[:, 0, :], neg[:, 0, :]], dim=0), mlm_out[:, :txt_len], None
+            vtm_logits = _linear32(cls_rows, self.itm_head)
             vtm_labels = torch.cat([torch.ones(b, dtype=torch.long), torch.zeros(2 * b, dtype=torch.long)], dim=0).to(device)
             vtm_loss = F.cross_entropy(vtm_logits, vtm_labels)
             mlm_labels = batch['mlm_labels']
-            mlm_logits, mlm_loss = self.text_encoder.cls.predictions.forward_with_loss(mlm_out[:, :text_atts.shape[1]], mlm_labels)
+            mlm_logits, mlm_loss = self.text_encoder.cls.predictions.forward_with_loss(mlm_rows, mlm_labels)
         else:
             text_embeds = self._text_embeds(batch['text_input_ids'], text_atts)
             text_feat = self._text_feat(text_embeds)
@@ -243,7 +274,7 @@ class AlproForPretrain(AlproBaseModel):
                 mlm_logits = mlm_loss = mlm_labels = None
         if use_mpm:
             mpm_labels, ignore_masks = self.get_pseudo_labels(batch)
-            mpm_loss, mpm_logits = self.compute_mpm_with_encoder_out(encoder_outputs_pos, text_atts, mpm_labels, ignore_masks, batch['mpm_mask'])
+            mpm_loss, mpm_logits = self.compute_mpm_with_encoder_out(encoder_outputs_pos, text_atts, mpm_labels, ignore_masks, batch['mpm_mask'], visual_output=pos_patch_rows)
         else:
             mpm_loss = mpm_logits = mpm_labels = None
         return dict(itc_loss=vtc_loss, mlm_scores=mlm_logits, mlm_loss=mlm_loss, mlm_labels=mlm_labels, itm_scores=vtm_logits,
@@ -265,11 +296,13 @@ class AlproForPretrain(AlproBaseModel):
         mlm_logits, mlm_loss = self.text_encoder.cls.predictions.forward_with_loss(out[:, :txt_len], mlm_labels)
         return mlm_loss, mlm_logits, mlm_labels
 
-    def compute_mpm_with_encoder_out(self, encoder_outputs, text_atts, soft_labels, ignore_masks, patch_masks):
-        """alpro_models.py:209-232 (encoder_outputs: last_hidden_state tensor of the positive fusion pass)."""
-        hidden = encoder_outputs.last_hidden_state if hasattr(encoder_outputs, "last_hidden_state") else encoder_outputs
-        txt_len = text_atts.shape[1]
-        visual_output = hidden[:, txt_len + 1:]
+    def compute_mpm_with_encoder_out(self, encoder_outputs, text_atts, soft_labels, ignore_masks, patch_masks, visual_output=None):
+        """alpro_models.py:209-232 (encoder_outputs: last_hidden_state tensor of the positive fusion pass; visual_output: its patch rows
+        [:, txt_len + 1:] when the caller has cut them out already)."""
+        if visual_output is None:
+            hidden = encoder_outputs.last_hidden_state if hasattr(encoder_outputs, "last_hidden_state") else encoder_outputs
+            txt_len = text_atts.shape[1]
+            visual_output = hidden[:, txt_len + 1:]
         bsz = patch_masks.shape[0]
         inv = (1 - patch_masks.view(bsz, -1)).unsqueeze(-1)
         num_masked = torch.sum(inv.squeeze(-1), dim=-1, keepdim=True)

@@ -320,6 +320,11 @@ int alpro_cls_mean_bwd(const float* dx_out, int64_t ld_batch, float* dside, int 
  * idx == NULL and skip_idx < 0 (the position table): one wave per destination row adds its rows in ascending order -- bit-reproducible.
  * With idx: fp32 atomics, the duplicates' order varies run to run (the reproducible caller sorts: alpro_amd/hip.py scatter_add_rows). */
 int alpro_scatter_add_rows(const float* src, const int64_t* idx, float* dst, int rows, int idx_mod, int D, int64_t skip_idx, void* stream);
+/* Round 5: the indexed form in a FIXED order without torch's sort-based index_put_: dst[idx[i], :] += src[i, :], duplicates added in ascending
+ * i, one writer per destination row (idx values in [0, dst_rows), dst_rows <= 2^19; rows <= 8192: the keys are sorted by one workgroup in
+ * LDS).  keys_ws: 8192 uint32 of scratch.  Rows with idx == skip_idx are dropped (-1 = none). */
+int alpro_scatter_add_rows_ordered(const float* src, const int64_t* idx, float* dst, int rows, int D, int64_t dst_rows, int64_t skip_idx, uint32_t* keys_ws,
+                                   void* stream);
 
 /* Weight gradient without transposed copies: C[N, K] (fp32, ATOMICALLY accumulated) += A[M, N]^T B[M, K], A = dY and
  * B = X row-major in a 16-bit dtype, contraction over tokens split across the grid (gemm_tn.hip).  C must be
