@@ -1161,10 +1161,27 @@ __global__ __launch_bounds__(NT2, 2) void gemm_nt256q_kernel(const alpro_gemm_de
       ktile(std::integral_constant<int, 0>{}, t);
       ktile(std::integral_constant<int, 1>{}, t + 1);
     }
+    // Where the NEXT ticket is drawn.  Behind the epilogue it has ~2 us until the next K loop's first counted wait, which is in-order: it also
+    // waits for this atomic.  32 workgroups of an XCD that run in lockstep hit their counter together, the last of them is served ~3 us later,
+    // and on a long launch (the B = 64 qkv GEMM: 14 tiles per workgroup) those stalls added up to +5 % over the static walk.  An epilogue
+    // without loads has no wait of its own behind its first fragment row (the bias values are the only thing it fetches), so there the ticket
+    // goes out right behind that row (another ~3 us of slack); the epilogues that fetch rows all along (saved factor, fp32 residual: their
+    // counted waits would stall on the atomic) keep drawing behind themselves.
+    constexpr bool EPI_LOADS = ACT == ALPRO_ACT_GELU_BWD || ACT == ALPRO_ACT_MUL_SAVED;
+    const bool early = !EPI_LOADS && !g.residual;
+    int nn_w0 = -1;
     if (wave == 0) {   // the tile after next: the ticket drawn a tile ago has landed (every counted wait of this K loop was issued behind it)
-      mbox[0] = (pending || (!sc.blk && nxt_t >= 0)) ? ticket_tile(__builtin_amdgcn_readfirstlane(tk)) : -1;   // (no ticket drawn / a dry list: -1 -- steal() behind the next tile looks further)
+      nn_w0 = (pending || (!sc.blk && nxt_t >= 0)) ? ticket_tile(__builtin_amdgcn_readfirstlane(tk)) : -1;   // (no ticket drawn / a dry list: -1 -- steal() behind the next tile looks further)
+      mbox[0] = nn_w0;
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
+    auto early_ticket = [&] {   // wave 0, behind the first fragment row of a load-free epilogue
+      if (wave == 0 && early) {
+        pending = sc.blk && nn_w0 >= 0 && nxt_t >= 0 && quota > 0;
+        quota -= pending ? 1 : 0;
+        ticket_issue(tk, pending);
+      }
+    };
     if (wr == 0) barrier();   // re-align: both wave rows run their epilogues at the same time
 
     // ---- epilogue: one 16-row fragment row (16 x 64 fp32 = 4 KiB of wave-private LDS) at a time
@@ -1215,6 +1232,9 @@ __global__ __launch_bounds__(NT2, 2) void gemm_nt256q_kernel(const alpro_gemm_de
               if (READS_C2 && mf + PD < 8 && rows_ok(mf + PD)) load_pre(mf + PD, pring[(mf + PD) % RING]);
               stage_rows(mf);
               epi_rows16_c16<T, ACT, 2, 0, RES>(g, stage, mb + mf * 16, nb, le, bias8, READS_C2 ? pring[mf % RING] : nullptr);
+              if constexpr (!RES && !READS_C2) {
+                if (mf == 0) early_ticket();
+              }
             }
           };
           if (g.residual) rows_loop(std::true_type{});   // (see epi_rows16_c16: no conditional vector load inside the passes)
@@ -1274,6 +1294,9 @@ __global__ __launch_bounds__(NT2, 2) void gemm_nt256q_kernel(const alpro_gemm_de
                 if constexpr (HAS_RES) v += ring[mf % RING][j];
                 __builtin_nontemporal_store(v, (f32x4*)(Cf + m * g.ldc + nb + c4));
               }
+              if constexpr (!HAS_RES) {
+                if (mf == 0) early_ticket();
+              }
             }
           };
           // (row_scale_group < 16 would need a scale per row: not a shape of this model -- the launcher keeps such descriptors off this kernel)
@@ -1287,9 +1310,11 @@ __global__ __launch_bounds__(NT2, 2) void gemm_nt256q_kernel(const alpro_gemm_de
     cur_t = nxt_t;
     nxt_t = __builtin_amdgcn_readfirstlane(mbox[0]);
     nxt = tile_base(nxt_t >= 0 ? nxt_t : cur_t);
-    pending = sc.blk && nxt_t >= 0 && quota > 0;
-    quota -= pending ? 1 : 0;
-    ticket_issue(tk, wave == 0 && pending);
+    if (!early) {
+      pending = sc.blk && nxt_t >= 0 && quota > 0;
+      quota -= pending ? 1 : 0;
+      ticket_issue(tk, wave == 0 && pending);
+    }
   }
   // out of work: the run-ahead copies went into dead slots and must have landed before the stage buffers are filled again (or, at the end,
   // before the LDS belongs to someone else); steal() looks for other lists' tickets / unclaimed pairs next

@@ -334,10 +334,10 @@ class Block(nn.Module):
         dev = x.device
         sv = {"x": x, "dims": (B, T, N, S, D, H), "dt": dt}
         sv["drop_t"], sv["drop_s"], sv["drop_m"] = self._drop(B * N, dev), self._drop(B * T, dev), self._drop(B, dev)
-        side = None
+        cside = None
         if rt.cls_precise(dt) and rt.cls_stream(True) and x.is_cuda and self.fuse_residual_ln and self.merge_temporal_proj:
-            side = _ClsSide.get(dev)
-            x_cls_in, cls_q, o_c_buf = self._cls_side_begin(side, x, B, T, snapshot=False)
+            cside = _ClsSide.get(dev)
+            x_cls_in, cls_q, o_c_buf = self._cls_side_begin(cside, x, B, T, snapshot=False)
         h = hip.layernorm(x, self.temporal_norm1.weight, self.temporal_norm1.bias, VIT_EPS, dt, rows=B * N * T,
                           map_mode=hip.MAP_SKIP_CLS, map_p0=N * T)
         qkv_t = hip.gemm(h, self._w("t_qkv", ta.qkv, dt), bias=ta.qkv.bias)
@@ -347,15 +347,15 @@ class Block(nn.Module):
             pr = None
             mg = self._merged_tproj(dt)
             d_t = hip.gemm(a_t, mg["w"], bias=mg["b1"], row_scale=sv["drop_t"], row_scale_group=T)
-            if side is not None:
-                side.wait_done()   # the previous block's chain has written this block's input CLS rows (first read: the kernel below)
+            if cside is not None:
+                cside.wait_done()   # the previous block's chain has written this block's input CLS rows (first read: the kernel below)
             hs, xt = hip.add_layernorm(x, d_t, self.norm1.weight, self.norm1.bias, VIT_EPS, mode=hip.ADD_PRE_SPATIAL,
                                        delta_bias=self.temporal_fc.bias, T=T, N=N)
             del d_t
             qkv_s = hip.gemm(hs, self._w("s_qkv", sa.qkv, dt), bias=sa.qkv.bias)
             o_c = None
-            if side is not None:
-                torch.cuda.current_stream().wait_event(side.ev_q)
+            if cside is not None:
+                torch.cuda.current_stream().wait_event(cside.ev_q)
                 a_s, lse_s, o_c = hip.attn(qkv_s, B * T, N + 1, H, sa.scale, want_lse=True, cls_q=cls_q, cls_group=T, cls_out=o_c_buf)
             elif rt.cls_precise(dt):
                 a_s, lse_s, o_c = hip.attn(qkv_s, B * T, N + 1, H, sa.scale, want_lse=True, cls_q=self._cls_qkv(x[:, 0]), cls_group=T)
@@ -364,7 +364,7 @@ class Block(nn.Module):
             d_s = hip.gemm(a_s, self._w("s_proj", sa.proj, dt), bias=sa.proj.bias, row_scale=sv["drop_s"], row_scale_group=N + 1)
             h2, x2 = hip.add_layernorm(xt, d_s, self.norm2.weight, self.norm2.bias, VIT_EPS, mode=hip.ADD_PRE_MLP, T=T, N=N)
             del d_s
-            if side is not None:
+            if cside is not None:
                 ev_x2 = torch.cuda.current_stream().record_event()   # o_c and the main path's x2 (whose CLS rows the chain overwrites) are written
         else:
             xt = torch.empty_like(x)
@@ -395,8 +395,8 @@ class Block(nn.Module):
         out = torch.empty_like(x)
         hip.gemm(f1, self._w("fc2", self.mlp.fc2, dt), out=out.view(B * S, D), bias=self.mlp.fc2.bias, out_dtype=torch.float32,
                  residual=x2.view(B * S, D), row_scale=sv["drop_m"], row_scale_group=S)
-        if side is not None:
-            self._cls_side_finish(side, ev_x2, torch.cuda.current_stream().record_event(), x_cls_in, o_c, B, T, sv["drop_s"], sv["drop_m"], x2[:, 0], out[:, 0])
+        if cside is not None:
+            self._cls_side_finish(cside, ev_x2, torch.cuda.current_stream().record_event(), x_cls_in, o_c, B, T, sv["drop_s"], sv["drop_m"], x2[:, 0], out[:, 0])
         elif rt.cls_precise(dt) and self.fuse_residual_ln and self.merge_temporal_proj:
             # precise CLS rows: the block output's CLS row and the saved pre-MLP stream's CLS row (norm2's backward input) take the fp32 values;
             # the backward differentiates the 16-bit graph as before (its CLS-row operands differ from these by one rounding)

@@ -1027,10 +1027,12 @@ def test_8phase_gemm_isa_keeps_the_orders_the_source_relies_on(tmp_path):
         named = [(i, l) for i, l in enumerate(code) if re.search(r"\b%s\b" % reg, l) and i not in at]
         readers = [(i, l) for i, l in named if re.match(r"v_readfirstlane_b32 s\d+, %s$" % reg, l)]
         writers = [(i, l) for i, l in named if (i, l) not in readers]
-        # one register for the three in-flight atomics: [claim of the static pair] -> read behind the pipeline fill -> [first ticket] -> K loop
+        # one register for the in-flight atomics: [claim of the static pair] -> read behind the pipeline fill -> [first ticket] -> K loop
         # -> read behind it -> ... -> [ticket behind the epilogue] -> (tile loop) -> K loop -> the same read
         at.sort()
-        assert len(at) == 3 and "global_atomic_or" in code[at[0]] and len(readers) == 2, (head, named, at)
+        # (3 .. 6 draw sites: the claim, the first ticket, the one behind an epilogue, and the ones behind the first fragment row of the load-free
+        # epilogue forms)
+        assert 3 <= len(at) <= 6 and "global_atomic_or" in code[at[0]] and len(readers) == 2, (head, named, at)
         # (block placement is the compiler's: only the claim's read ahead of the K loop and the ticket's read behind it are positional)
         assert at[0] < readers[0][0] and at[0] < at[1], (head, named, at)
         assert all(re.match(r"v_mov_b32_e32 %s, 0$" % reg, l) and i < min(at) for i, l in writers), (head, writers)
