@@ -270,11 +270,11 @@ int get_option(int which);
 int get_stream_option(int which, hipStream_t st);
 
 // ---- dynamic tile scheduler of the persistent GEMM grids (round 5) ------------------------------------------------------------------
-// One block of device memory per launch: [0..63] the ticket counters of the 64 tile lists (8 per XCD), [SCHED_CLAIM0 + w] the claim word of workgroup w (its two static
+// One block of device memory per launch: [0..7] per-XCD ticket counters, [SCHED_CLAIM0 + w] the claim word of workgroup w (its two static
 // tiles).  Every (device, stream) owns a PAIR of blocks used alternately: launch n works on block n & 1 and its first workgroup zeroes the
 // other one -- the block of launch n - 1, which is complete because launches of one stream are ordered.  No workgroup ever waits for a
 // "last one out" count, and no block is shared between streams.
-constexpr int SCHED_CLAIM0 = 64, SCHED_MAX_WG = 256, SCHED_BLOCK_U32 = SCHED_CLAIM0 + SCHED_MAX_WG;
+constexpr int SCHED_CLAIM0 = 8, SCHED_MAX_WG = 256, SCHED_BLOCK_U32 = SCHED_CLAIM0 + SCHED_MAX_WG;
 struct TileSched {
   uint32_t* blk;       // nullptr = static walk (option gemm_sched 0, a stream that is being captured, or no block pair left)
   uint32_t* prev;      // the block of this stream's previous launch, zeroed by workgroup 0 (never nullptr when blk is set)

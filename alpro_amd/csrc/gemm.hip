@@ -834,42 +834,33 @@ __global__ __launch_bounds__(NT2, 2) void gemm_nt256q_kernel(const alpro_gemm_de
   const uint32_t lds_base = lds_addr_of(smem);
 
   // ---- which tiles (round 5) ----------------------------------------------------------------------------------------------------
-  // Tiles are numbered row-panel-major (tile = tm * ntn + tn).  Every round of 256 consecutive tiles is dealt to the 8 XCDs in chunks of 32
-  // (XCD y: tiles 32 y .. 32 y + 31 of the round -- what the round-4 static walk gave its 32 workgroups: at any moment an XCD works on a
-  // contiguous run of tiles, so the tn tiles of an A row panel meet in ONE L2), and an XCD's chunk to its 8 LISTS in runs of 4.  List
-  // l = 8 y + q:        position j  ->  tile (j / 4) * 256 + 32 y + 4 q + (j % 4),        j = 0, 1, 2, ...  while that is < nblk.
-  // Workgroup (XCD y = blockIdx % 8, idx = blockIdx / 8) belongs to list q = idx % 8 as member r = idx / 8; a list has nmem = 4 members
-  // with 256 workgroups (3 or 4 when the launch is sized for fewer CUs).
-  //   gemm_sched 0 (sc.blk == nullptr): member r takes j = r, r + nmem, r + 2 nmem, ... -- a static walk (a permutation of round 4's
-  //     within each chunk).
-  //   gemm_sched 1: the first TWO tiles of a workgroup are the static ones (j = r, r + nmem: no atomic stands between the launch and the
-  //     first MFMA); every further j comes from the list's ticket counter, j = 2 nmem + ticket: one agent-scope atomic per tile, issued by
-  //     wave 0 a tile ahead and read back behind the next K loop -- nothing is added to the K loop.  Four workgroups share a counter: with
-  //     one counter per XCD (first form of this round) the 32 workgroups of an XCD, which run in lockstep, hit it together, the last one
-  //     was served microseconds later, and the K loop's first counted wait -- in order: it waits for the atomic too -- stalled on it
-  //     (+6 % on the B = 64 qkv GEMM, 12 draws per workgroup).
+  // Tiles are numbered row-panel-major (tile = tm * ntn + tn) and dealt to the 8 XCDs in chunks of 32: XCD y's LIST is
+  //     j -> tile (j / 32) * 256 + y * 32 + (j % 32),        j = 0, 1, 2, ...  while that is < nblk,
+  // i.e. the tiles the round-4 static walk (workgroup slot s of 256 takes s, s + 256, ...) gave to the XCD's 32 workgroups, in the order
+  // it visited them: at any moment an XCD works on a contiguous run of tiles, so the tn tiles of an A row panel meet in ONE L2.
+  //   gemm_sched 0 (sc.blk == nullptr): workgroup idx of the XCD takes j = idx, idx + p, idx + 2p, ... (p = gridDim.x / 8) -- with 256
+  //     workgroups exactly that static walk.
+  //   gemm_sched 1: the first TWO tiles of a workgroup are the static ones (j = idx, idx + p: no atomic stands between the launch and the first
+  //     MFMA); every further j comes from the XCD's ticket counter, j = 2p + ticket: one agent-scope atomic per tile, issued by wave 0 behind
+  //     an epilogue two tiles ahead of the tile it pays for and read back behind the next K loop -- nothing is added to the K loop.
   //     A workgroup that cannot be resident -- another kernel holds its CU: RCCL's channels during the overlapped gradient exchange, a side
   //     stream -- draws no tickets: the resident ones finish its share of the lists one tile at a time instead of the launch waiting a whole
   //     extra round for it (profiles/r4_overlap_cu_contention.txt: +42 % with 8 of 256 CUs taken).  Its two STATIC tiles are covered by a
   //     claim word per workgroup: a workgroup claims its own pair with one atomic at its start (the answer is awaited by the pipeline fill's
-  //     own wait), and a workgroup that has run out of work -- own list dry: it then looks at all 64 counters and all claim words with
-  //     five loads in flight together -- takes a ticket of the nearest list that has some left and, after those, a static tile of a
-  //     workgroup that has not started.  Nobody waits for anybody; the block of counters / claim words is zeroed by the NEXT launch of
-  //     the same stream (TileSched::prev).
+  //     own wait), and a workgroup that has run out of work -- own list dry: it then looks at all eight counters and all claim words with
+  //     ONE pair of loads -- takes tickets of other XCDs' lists and, after those, the pair of a workgroup that has not started yet.
+  //     Nobody waits for anybody; the block of counters / claim words is zeroed by the NEXT launch of the same stream (TileSched::prev).
   // Results do not depend on who computes a tile: bitwise identical under either walk.
-  const uint32_t p = gridDim.x >> 3;                                   // workgroups per XCD
-  const uint32_t own = (blockIdx.x & 7u) * 8u + ((blockIdx.x >> 3) & 7u);   // own list
-  const uint32_t rank = blockIdx.x >> 6;                               // member index in it
+  const uint32_t p = gridDim.x >> 3;
   const uint64_t t_start = wall_clock64();
   constexpr uint32_t RESCUE_TICKS = 1000;   // 10 us of the 100 MHz wall clock
-  auto list_nmem = [&](uint32_t l) -> uint32_t { return (p + 7u - (l & 7u)) >> 3; };
-  auto list_tile = [&](uint32_t l, uint32_t j) -> int {
-    const uint32_t t = ((j >> 2) << 8) + ((l >> 3) << 5) + ((l & 7u) << 2) + (j & 3u);
+  auto list_tile = [&](int y, uint32_t j) -> int {
+    const uint32_t t = ((j >> 5) << 8) + ((uint32_t)y << 5) + (j & 31u);
     return (j < 0x100000u && t < (uint32_t)nblk) ? (int)t : -1;
   };
-  auto list_len = [&](uint32_t l) -> int {   // number of valid positions of list l
-    const int rem = (nblk & 255) - (int)(((l >> 3) << 5) + ((l & 7u) << 2));
-    return (nblk >> 8) * 4 + (rem < 0 ? 0 : (rem > 4 ? 4 : rem));
+  auto list_len = [&](int y) -> int {   // number of valid positions of XCD y's list
+    const int rem = (nblk & 255) - 32 * y;
+    return (nblk >> 8) * 32 + (rem < 0 ? 0 : (rem > 32 ? 32 : rem));
   };
   // Mailbox wave 0 -> everybody: two dwords at the start of the A-half-1 slot of parity 1.  That slot's last reader is phase 3 of a tile's
   // last K-tile and its next writer the copy of phase 2 of the following tile's first K-tile (two barriers into that tile): dead in between.
@@ -877,18 +868,19 @@ __global__ __launch_bounds__(NT2, 2) void gemm_nt256q_kernel(const alpro_gemm_de
   // every read wait for the epilogue's stores)
   typedef __attribute__((address_space(3))) volatile int lds_int_t;
   lds_int_t* mbox = (lds_int_t*)(__attribute__((address_space(3))) char*)(smem + STAGE2_BYTES + HALF2_BYTES);
-  // walk state (wave 0's copy is the one that counts).  Dynamic: the list tickets are drawn from (own at first; steal() moves it).  Static: the
-  // workgroup's next position in its own list.
-  uint32_t wstate = sc.blk ? own : rank + 2 * list_nmem(own);
-  // Tickets a workgroup may still draw AHEAD (pipelined, a tile before it can start them): its fair share of its own list,
-  // ceil((len - 2 nmem) / nmem).  Without the cap a workgroup that runs a few hundred ns ahead of a neighbour draws the list's last ticket
-  // while the neighbour still has two tiles to go, and the launch ends one tile later than the static walk.  Whatever is left when a workgroup
-  // is OUT of work -- tickets of workgroups that never started, other lists -- goes through steal(), one tile at a time, to whoever is idle then.
+  // walk state (wave 0's copy is the one that counts).  Dynamic: how many XCD lists have run dry for this workgroup (tickets are drawn from
+  // XCD (own + wstate) % 8).  Static: the workgroup's next list position.
+  uint32_t wstate = sc.blk ? 0u : (uint32_t)(blockIdx.x >> 3) + 2 * p;
+  // Tickets a workgroup may still draw AHEAD (pipelined, two tiles before it can start them): its fair share of its own list,
+  // ceil((len - 2p) / p).  Without the cap a workgroup that runs a few hundred ns ahead of a neighbour draws the list's last ticket while the
+  // neighbour still has two tiles to go, and the launch ends one tile later than the static walk (measured on the qkv shape at B = 64, whose
+  // lists divide exactly: +8 %).  Whatever is left when a workgroup is OUT of work -- tickets of workgroups that never started, the other
+  // XCDs' lists -- goes through steal(), one tile at a time, to whoever is idle then.
   int quota = 0;
   bool pending = false;   // a pipelined ticket is in flight
   if (sc.blk) {
-    const int nm = (int)list_nmem(own), mine = list_len(own) - 2 * nm;
-    quota = mine > 0 ? (mine + nm - 1) / nm : 0;
+    const int mine = list_len((int)(blockIdx.x & 7u)) - (int)(2 * p);
+    quota = mine > 0 ? (mine + (int)p - 1) / (int)p : 0;
   }
   // One returning atomic, lane 0 of wave 0 only (`on`; otherwise the instruction runs with an empty EXEC mask): `add` = a ticket of the
   // current list's counter, else the claim (atomic or) of workgroup `w`'s word.  The value lands in `r` when the memory system answers:
@@ -898,7 +890,7 @@ __global__ __launch_bounds__(NT2, 2) void gemm_nt256q_kernel(const alpro_gemm_de
     uint64_t sv;
     const uint32_t m = (uint32_t)__builtin_amdgcn_readfirstlane(on ? 1 : 0);
     asm volatile("s_mov_b64 %1, exec\n\ts_mov_b32 exec_lo, %5\n\ts_mov_b32 exec_hi, 0\n\tglobal_atomic_add %0, %2, %3, %4 sc0\n\ts_mov_b64 exec, %1"
-                 : "+v"(r), "=&s"(sv) : "v"((sc.blk ? wstate : 0u) * 4u), "v"(1u), "s"(sc.blk), "s"(m) : "memory");
+                 : "+v"(r), "=&s"(sv) : "v"(((blockIdx.x + wstate) & 7u) * 4u), "v"(1u), "s"(sc.blk), "s"(m) : "memory");
   };
   auto claim_issue = [&](uint32_t& r, uint32_t w, uint32_t bits, bool on) {   // bit 0 / bit 1: the first / second static tile of workgroup w
     uint64_t sv;
@@ -906,22 +898,22 @@ __global__ __launch_bounds__(NT2, 2) void gemm_nt256q_kernel(const alpro_gemm_de
     asm volatile("s_mov_b64 %1, exec\n\ts_mov_b32 exec_lo, %5\n\ts_mov_b32 exec_hi, 0\n\tglobal_atomic_or %0, %2, %3, %4 sc0\n\ts_mov_b64 exec, %1"
                  : "+v"(r), "=&s"(sv) : "v"((SCHED_CLAIM0 + w) * 4u), "v"(bits), "s"(sc.blk), "s"(m) : "memory");
   };
-  // ticket -> tile of the list tickets are currently drawn from (-1: that list is dry -- steal() looks further when the workgroup runs out)
+  // ticket -> tile of the list tickets are currently drawn from; a dry list moves the workgroup on to the next XCD's
   auto ticket_tile = [&](uint32_t k) -> int {
-    if (sc.blk) return list_tile(wstate, 2 * list_nmem(wstate) + k);
-    const int t = list_tile(own, wstate);
-    wstate += list_nmem(own);
+    int t;
+    if (sc.blk) {
+      t = list_tile((int)((blockIdx.x + wstate) & 7u), 2 * p + k);
+      if (t < 0) ++wstate;
+    } else {
+      t = list_tile((int)(blockIdx.x & 7u), wstate);
+      wstate += p;
+    }
     return t;
   };
-  // the static pair of workgroup w: tile b (0 / 1)
-  auto static_tile = [&](uint32_t w, uint32_t b) -> int {
-    const uint32_t l = (w & 7u) * 8u + ((w >> 3) & 7u);
-    return list_tile(l, (w >> 6) + b * list_nmem(l));
-  };
   // A workgroup out of work (dynamic walk; every wave calls it, one barrier; no copy in flight: the caller drained vmcnt).  Wave 0 reads the
-  // 64 counters (lane l: list l) and the claim words (lane l: workgroups 4 l .. 4 l + 3) -- five loads in flight together -- then
-  //   * takes ONE ticket of the nearest list (own first, then the own XCD's, then the other XCDs': index distance) that still has positions
-  //     left -- one, not a pair: the last partial round then spreads over everybody who is out of work --, or, when every list is dry,
+  // eight counters and the claim words (five loads in flight together), then
+  //   * takes ONE ticket of the first list (own XCD's first) that still has positions left -- one, not a pair: the last partial round then
+  //     spreads over everybody who is out of work instead of the first arrivals taking two tiles each --, or, when every list is dry,
   //   * claims ONE static tile nobody has claimed yet (a workgroup that could not start: some other kernel holds its CU).  Which one is drawn
   //     from a hash of the workgroup id over all open tiles, so that a few hundred helpers arriving together do not all go for the same word.
   //     Rescue waits until RESCUE_TICKS after this workgroup's own start (`t_start`, 100 MHz wall clock): by then every workgroup that CAN be
@@ -933,20 +925,23 @@ __global__ __launch_bounds__(NT2, 2) void gemm_nt256q_kernel(const alpro_gemm_de
     if (wave == 0) {
       int a = -1;
       for (int tries = 0; tries < 96 && a < 0; ++tries) {
-        const uint32_t cnt = __hip_atomic_load(sc.blk + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t cnt = lane < 8 ? __hip_atomic_load(sc.blk + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
         u32x4 clm;   // claim words of workgroups 4 lane .. 4 lane + 3 (agent-scope loads: the words are set by other XCDs' atomics)
         clm.x = __hip_atomic_load(sc.blk + SCHED_CLAIM0 + 4 * lane + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         clm.y = __hip_atomic_load(sc.blk + SCHED_CLAIM0 + 4 * lane + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         clm.z = __hip_atomic_load(sc.blk + SCHED_CLAIM0 + 4 * lane + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         clm.w = __hip_atomic_load(sc.blk + SCHED_CLAIM0 + 4 * lane + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const uint64_t left = __builtin_amdgcn_ballot_w64((int)cnt < list_len((uint32_t)lane) - 2 * (int)list_nmem((uint32_t)lane));
-        if (left) {
-          const uint64_t rot = (left >> own) | (own ? (left << (64u - own)) : 0ull);
-          wstate = (uint32_t)((__builtin_ctzll(rot) + own) & 63u);   // tickets are drawn from this list from here on
+        int y = -1;
+        for (int i = 0; i < 8 && y < 0; ++i) {
+          const int c = (int)((blockIdx.x + i) & 7u);
+          if ((int)__builtin_amdgcn_readlane(cnt, c) < list_len(c) - (int)(2 * p)) y = c;
+        }
+        if (y >= 0) {
           uint32_t k0 = 0;
+          wstate = (uint32_t)((y - (int)(blockIdx.x & 7u)) & 7);   // tickets are drawn from (own + wstate) % 8 from here on
           ticket_issue(k0, true);
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-          a = ticket_tile(__builtin_amdgcn_readfirstlane(k0));
+          a = list_tile(y, 2 * p + __builtin_amdgcn_readfirstlane(k0));
           continue;
         }
         // open static tiles: slot s = 2 i + b of a lane is tile b (0 = first, 1 = second) of workgroup 4 lane + i; workgroups below gridDim.x count
@@ -966,7 +961,7 @@ __global__ __launch_bounds__(NT2, 2) void gemm_nt256q_kernel(const alpro_gemm_de
 #pragma unroll
         for (int sl = 0; sl < 8; ++sl) {
           const int n = __builtin_popcountll(open[sl]);
-          if (bit == 0 && q >= 0 && q < n) {
+          if (bit == 0 && q < n) {
             uint64_t msk = open[sl];
             for (int i = 0; i < q; ++i) msk &= msk - 1;
             w = 4u * (uint32_t)__builtin_ctzll(msk) + (uint32_t)(sl >> 1);
@@ -977,7 +972,7 @@ __global__ __launch_bounds__(NT2, 2) void gemm_nt256q_kernel(const alpro_gemm_de
         uint32_t old = 3;
         claim_issue(old, w, bit, true);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if ((__builtin_amdgcn_readfirstlane(old) & bit) == 0) a = static_tile(w, bit >> 1);   // (-1: that workgroup had no such tile -- look again)
+        if ((__builtin_amdgcn_readfirstlane(old) & bit) == 0) a = list_tile((int)(w & 7u), (w >> 3) + (bit == 2u ? p : 0u));   // (-1: that workgroup had no such tile -- look again)
       }
       const int b = -1;
       mbox[0] = a;
@@ -1046,7 +1041,7 @@ __global__ __launch_bounds__(NT2, 2) void gemm_nt256q_kernel(const alpro_gemm_de
   uint32_t tk = 0;   // the ticket in flight (lane 0 of wave 0): drawn behind tile i - 1's epilogue for tile i + 2, read back behind tile i's K loop
   // the static pair, and (dynamic walk) its claim: in flight under the pipeline fill.  Workgroup 0 also hands the block of this stream's
   // PREVIOUS launch back zeroed (that launch is complete: same stream).
-  int cur_t = static_tile(blockIdx.x, 0), nxt_t = static_tile(blockIdx.x, 1);
+  int cur_t = list_tile((int)(blockIdx.x & 7u), blockIdx.x >> 3), nxt_t = list_tile((int)(blockIdx.x & 7u), (blockIdx.x >> 3) + p);
   if (sc.prev && blockIdx.x == 0 && wave == 0) {
 #pragma unroll
     for (int i = 0; i < (SCHED_BLOCK_U32 + 63) / 64; ++i)
