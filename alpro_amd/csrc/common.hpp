@@ -262,7 +262,7 @@ __device__ __forceinline__ void attn_unit(int blk, int nblk, int H, int order, i
     h = blk - b * H;
   }
 }
-enum { OPT_GEMM_TILE = 0, OPT_GEMM_GRID = 1, OPT_GEMM_TUNE = 2, OPT_TN_SPLITS = 3, OPT_TN_KIND = 4, OPT_GEMM_TAIL = 5, OPT_ATTN_BWD = 6, OPT_ATTN_ORDER = 7, OPT_GEMM_KIND = 8, OPT_CU_BUDGET = 9, OPT_LN_GRID = 10, OPT_GEMM_SCHED = 11, OPT_COUNT = 12 };
+enum { OPT_GEMM_TILE = 0, OPT_GEMM_GRID = 1, OPT_GEMM_TUNE = 2, OPT_TN_SPLITS = 3, OPT_TN_KIND = 4, OPT_GEMM_TAIL = 5, OPT_ATTN_BWD = 6, OPT_ATTN_ORDER = 7, OPT_GEMM_KIND = 8, OPT_CU_BUDGET = 9, OPT_LN_GRID = 10, OPT_GEMM_SCHED = 11, OPT_GEMM_EPI = 12, OPT_COUNT = 13 };
 int get_option(int which);
 // Per-stream override of an option (round 5: alpro_hip_set_stream_option).  cu_budget is the one knob that describes the SITUATION a launch
 // runs in (a collective's kernels holding CUs next to this stream's work) rather than the library: the optimizer sets it on the stream its
@@ -279,6 +279,7 @@ struct TileSched {
   uint32_t* blk;       // nullptr = static walk (option gemm_sched 0, a stream that is being captured, or no block pair left)
   uint32_t* prev;      // the block of this stream's previous launch, zeroed by workgroup 0 (never nullptr when blk is set)
   uint32_t magic_ntn;  // ceil(2^32 / ntn): tile / ntn == umulhi(tile, magic_ntn) (ntn > 1)
+  uint32_t epi;        // option gemm_epi: 1 = packed 16-bit epilogue where it applies (default), 0 = the staged fp32 epilogue everywhere
 };
 // Picks the stream's next block and keeps the stream's slot locked until the destructor runs, i.e. until the caller has enqueued the launch:
 // two host threads launching on one stream cannot interleave "pick" and "enqueue" in opposite orders.

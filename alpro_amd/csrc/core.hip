@@ -19,8 +19,8 @@ void set_error(const char* fmt, ...) {
 }
 
 namespace {
-const char* const kOptNames[OPT_COUNT] = {"gemm_tile", "gemm_grid", "gemm_tune", "tn_splits", "tn_kind", "gemm_tail", "attn_bwd", "attn_order", "gemm_kind", "cu_budget", "ln_grid", "gemm_sched"};
-const char* const kOptEnv[OPT_COUNT] = {"ALPRO_GEMM_TILE", "ALPRO_GEMM_GRID", "ALPRO_GEMM_TUNE", "ALPRO_TN_SPLITS", "ALPRO_TN_KIND", "ALPRO_GEMM_TAIL", "ALPRO_ATTN_BWD", "ALPRO_ATTN_ORDER", "ALPRO_GEMM_KIND", "ALPRO_CU_BUDGET", "ALPRO_LN_GRID", "ALPRO_GEMM_SCHED"};
+const char* const kOptNames[OPT_COUNT] = {"gemm_tile", "gemm_grid", "gemm_tune", "tn_splits", "tn_kind", "gemm_tail", "attn_bwd", "attn_order", "gemm_kind", "cu_budget", "ln_grid", "gemm_sched", "gemm_epi"};
+const char* const kOptEnv[OPT_COUNT] = {"ALPRO_GEMM_TILE", "ALPRO_GEMM_GRID", "ALPRO_GEMM_TUNE", "ALPRO_TN_SPLITS", "ALPRO_TN_KIND", "ALPRO_GEMM_TAIL", "ALPRO_ATTN_BWD", "ALPRO_ATTN_ORDER", "ALPRO_GEMM_KIND", "ALPRO_CU_BUDGET", "ALPRO_LN_GRID", "ALPRO_GEMM_SCHED", "ALPRO_GEMM_EPI"};
 int g_opts[OPT_COUNT];
 // Values that change RESULTS (gemm_tune 3 / 4 / 10 / 11 / 12: epilogue / synchronisation ablations; tn_kind 1: weight gradient without
 // its epilogue) exist only in the measurement build (-DALPRO_ABLATIONS, `python -m alpro_amd.build --ablations`, used by tools/); the
@@ -40,7 +40,7 @@ struct OptInit {
   OptInit() {
     for (int i = 0; i < OPT_COUNT; ++i) {
       const char* e = getenv(kOptEnv[i]);
-      const int dflt = (i == OPT_GEMM_TUNE || i == OPT_GEMM_TAIL || i == OPT_ATTN_BWD || i == OPT_GEMM_KIND || i == OPT_GEMM_SCHED) ? 1 : 0;
+      const int dflt = (i == OPT_GEMM_TUNE || i == OPT_GEMM_TAIL || i == OPT_ATTN_BWD || i == OPT_GEMM_KIND || i == OPT_GEMM_SCHED || i == OPT_GEMM_EPI) ? 1 : 0;
       g_opts[i] = e ? atoi(e) : dflt;
       if (!option_allowed(i, g_opts[i])) {
         fprintf(stderr, "libalpro_hip: %s=%d is a result-corrupting ablation and is not part of this build (ignored)\n", kOptEnv[i], g_opts[i]);

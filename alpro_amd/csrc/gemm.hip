@@ -822,7 +822,7 @@ template <> struct Mma16<f16_t> {
 };
 
 template <typename T, int ACT, int MAP>
-__global__ __launch_bounds__(NT2, 2) void gemm_nt256q_kernel(const alpro_gemm_desc_t g, const TileSched sc) {
+__global__ __launch_bounds__(NT2, 2) __attribute__((amdgpu_num_vgpr(127))) void gemm_nt256q_kernel(const alpro_gemm_desc_t g, const TileSched sc) {
   static_assert(sizeof(T) == 2, "16-bit operands only");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -884,8 +884,8 @@ __global__ __launch_bounds__(NT2, 2) void gemm_nt256q_kernel(const alpro_gemm_de
   }
   // One returning atomic, lane 0 of wave 0 only (`on`; otherwise the instruction runs with an empty EXEC mask): `add` = a ticket of the
   // current list's counter, else the claim (atomic or) of workgroup `w`'s word.  The value lands in `r` when the memory system answers:
-  // whoever reads it waits first (s_waitcnt vmcnt), like for the copies.  "+v": `r` is ONE register from here to its reader -- a
-  // compiler-inserted copy in between would copy the old contents (a CPU test checks the built ISA).
+  // whoever reads it waits first (s_waitcnt vmcnt), like for the copies.  These two forms are for the BLOCKING draws of steal(): `r` is read
+  // behind a vmcnt(0) a few instructions on ("+v": one register from the atomic to its reader; a CPU test checks the built ISA).
   auto ticket_issue = [&](uint32_t& r, bool on) {
     uint64_t sv;
     const uint32_t m = (uint32_t)__builtin_amdgcn_readfirstlane(on ? 1 : 0);
@@ -897,6 +897,28 @@ __global__ __launch_bounds__(NT2, 2) void gemm_nt256q_kernel(const alpro_gemm_de
     const uint32_t m = (uint32_t)__builtin_amdgcn_readfirstlane(on ? 1 : 0);
     asm volatile("s_mov_b64 %1, exec\n\ts_mov_b32 exec_lo, %5\n\ts_mov_b32 exec_hi, 0\n\tglobal_atomic_or %0, %2, %3, %4 sc0\n\ts_mov_b64 exec, %1"
                  : "+v"(r), "=&s"(sv) : "v"((SCHED_CLAIM0 + w) * 4u), "v"(bits), "s"(sc.blk), "s"(m) : "memory");
+  };
+  // The PIPELINED draws (the static pair's claim, the ticket for the tile after next) answer into v255, a register the compiler does not own
+  // (the kernel is built with amdgpu_num_vgpr(127): on gfx90a+ the number counts per register-file half, i.e. v0-v253 are the compiler's): their answers are in flight across a pipeline fill / a whole K loop, and a compiler-owned register
+  // may be copied or re-assigned at any block boundary in between -- a copy of a register with an atomic in flight copies the OLD contents
+  // (it happened whenever an epilogue variant was added: the allocator split the live range).  tk_read() is placed behind a counted wait
+  // that was issued after the atomic.
+  auto ticket_issue_tk = [&](bool on) {
+    uint64_t sv;
+    const uint32_t m = (uint32_t)__builtin_amdgcn_readfirstlane(on ? 1 : 0);
+    asm volatile("s_mov_b64 %0, exec\n\ts_mov_b32 exec_lo, %4\n\ts_mov_b32 exec_hi, 0\n\tglobal_atomic_add v255, %1, %2, %3 sc0\n\ts_mov_b64 exec, %0"
+                 : "=&s"(sv) : "v"(((blockIdx.x + wstate) & 7u) * 4u), "v"(1u), "s"(sc.blk), "s"(m) : "memory", "v255");
+  };
+  auto claim_issue_tk = [&](uint32_t w, uint32_t bits, bool on) {
+    uint64_t sv;
+    const uint32_t m = (uint32_t)__builtin_amdgcn_readfirstlane(on ? 1 : 0);
+    asm volatile("s_mov_b64 %0, exec\n\ts_mov_b32 exec_lo, %4\n\ts_mov_b32 exec_hi, 0\n\tglobal_atomic_or v255, %1, %2, %3 sc0\n\ts_mov_b64 exec, %0"
+                 : "=&s"(sv) : "v"((SCHED_CLAIM0 + w) * 4u), "v"(bits), "s"(sc.blk), "s"(m) : "memory", "v255");
+  };
+  auto tk_read = [&]() -> uint32_t {   // lane 0's answer (wave 0)
+    uint32_t r;
+    asm volatile("v_readfirstlane_b32 %0, v255" : "=s"(r) : : "memory");
+    return r;
   };
   // ticket -> tile of the list tickets are currently drawn from; a dry list moves the workgroup on to the next XCD's
   auto ticket_tile = [&](uint32_t k) -> int {
@@ -1038,7 +1060,7 @@ __global__ __launch_bounds__(NT2, 2) void gemm_nt256q_kernel(const alpro_gemm_de
     __builtin_amdgcn_sched_barrier(0);
   };
 
-  uint32_t tk = 0;   // the ticket in flight (lane 0 of wave 0): drawn behind tile i - 1's epilogue for tile i + 2, read back behind tile i's K loop
+  // (the ticket in flight -- lane 0 of wave 0, v255: drawn behind tile i - 1's epilogue for tile i + 2, read back behind tile i's K loop)
   // the static pair, and (dynamic walk) its claim: in flight under the pipeline fill.  Workgroup 0 also hands the block of this stream's
   // PREVIOUS launch back zeroed (that launch is complete: same stream).
   int cur_t = list_tile((int)(blockIdx.x & 7u), blockIdx.x >> 3), nxt_t = list_tile((int)(blockIdx.x & 7u), (blockIdx.x >> 3) + p);
@@ -1047,7 +1069,7 @@ __global__ __launch_bounds__(NT2, 2) void gemm_nt256q_kernel(const alpro_gemm_de
     for (int i = 0; i < (SCHED_BLOCK_U32 + 63) / 64; ++i)
       if (i * 64 + lane < SCHED_BLOCK_U32) sc.prev[i * 64 + lane] = 0u;
   }
-  claim_issue(tk, blockIdx.x, 3u, wave == 0 && sc.blk);   // (the answer travels in the ticket register: the first ticket is drawn after it has been read)
+  claim_issue_tk(blockIdx.x, 3u, wave == 0 && sc.blk);   // (the answer travels in the ticket register: the first ticket is drawn after it has been read)
   bool fresh = sc.blk != nullptr;   // the static pair's claim is in flight
   bool have = cur_t >= 0;
   while (true) {
@@ -1068,7 +1090,7 @@ __global__ __launch_bounds__(NT2, 2) void gemm_nt256q_kernel(const alpro_gemm_de
   copy_half(cur.w + ROWB, 2, 1);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   if (fresh && wave == 0) {   // are the static tiles still this workgroup's?  (wave 0's wait above covered the claim)
-    mbox[0] = (int)(__builtin_amdgcn_readfirstlane(tk) & 3u);
+    mbox[0] = (int)(tk_read() & 3u);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   }
   barrier();
@@ -1087,7 +1109,7 @@ __global__ __launch_bounds__(NT2, 2) void gemm_nt256q_kernel(const alpro_gemm_de
   }
   pending = sc.blk && nxt_t >= 0 && quota > 0;
   quota -= pending ? 1 : 0;
-  ticket_issue(tk, wave == 0 && pending);   // for the tile after next
+  ticket_issue_tk(wave == 0 && pending);   // for the tile after next
 
   while (true) {
     const int tile = cur_t;
@@ -1162,16 +1184,20 @@ __global__ __launch_bounds__(NT2, 2) void gemm_nt256q_kernel(const alpro_gemm_de
       ktile(std::integral_constant<int, 1>{}, t + 1);
     }
     // Where the NEXT ticket is drawn.  Behind the epilogue it has ~2 us until the next K loop's first counted wait, which is in-order: it also
-    // waits for this atomic.  32 workgroups of an XCD that run in lockstep hit their counter together, the last of them is served ~3 us later,
-    // and on a long launch (the B = 64 qkv GEMM: 14 tiles per workgroup) those stalls added up to +5 % over the static walk.  An epilogue
-    // without loads has no wait of its own behind its first fragment row (the bias values are the only thing it fetches), so there the ticket
-    // goes out right behind that row (another ~3 us of slack); the epilogues that fetch rows all along (saved factor, fp32 residual: their
-    // counted waits would stall on the atomic) keep drawing behind themselves.
+    // waits for this atomic, and 32 workgroups of an XCD that run in lockstep hit their counter together.  An epilogue without loads has no
+    // wait of its own behind its first fragment row (the bias values are the only thing it fetches), so there the ticket goes out right
+    // behind that row (another ~3 us of slack); the epilogues that fetch rows all along (saved factor, fp32 residual: their counted waits
+    // would stall on the atomic) keep drawing behind themselves.  (Measured effect of the early draw: within noise.  The +5 % of the B = 64
+    // qkv shape it was introduced against turned out to be the first-shape-of-the-process artefact of the probe -- clocks still settling:
+    // profiles/r5_gemm_stagger_probe.txt, first against last column.)
     constexpr bool EPI_LOADS = ACT == ALPRO_ACT_GELU_BWD || ACT == ALPRO_ACT_MUL_SAVED;
+    constexpr bool PK_ACT = MAP == ALPRO_MAP_IDENTITY && (ACT == ALPRO_ACT_NONE || ACT == ALPRO_ACT_GELU || ACT == ALPRO_ACT_RELU || ACT == ALPRO_ACT_GELU_SAVE_GRAD);
+    const bool pk = PK_ACT && sc.epi != 0 && g.c_dtype != ALPRO_F32 && !g.residual && !g.row_scale && !g.drop_seed && tm0 + wr * 128 + 128 <= g.M &&
+                    !(ACT != ALPRO_ACT_GELU_SAVE_GRAD && g.C2);
     const bool early = !EPI_LOADS && !g.residual;
     int nn_w0 = -1;
     if (wave == 0) {   // the tile after next: the ticket drawn a tile ago has landed (every counted wait of this K loop was issued behind it)
-      nn_w0 = (pending || (!sc.blk && nxt_t >= 0)) ? ticket_tile(__builtin_amdgcn_readfirstlane(tk)) : -1;   // (no ticket drawn / a dry list: -1 -- steal() behind the next tile looks further)
+      nn_w0 = (pending || (!sc.blk && nxt_t >= 0)) ? ticket_tile(tk_read()) : -1;   // (no ticket drawn / a dry list: -1 -- steal() behind the next tile looks further)
       mbox[0] = nn_w0;
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
@@ -1179,7 +1205,7 @@ __global__ __launch_bounds__(NT2, 2) void gemm_nt256q_kernel(const alpro_gemm_de
       if (wave == 0 && early) {
         pending = sc.blk && nn_w0 >= 0 && nxt_t >= 0 && quota > 0;
         quota -= pending ? 1 : 0;
-        ticket_issue(tk, pending);
+        ticket_issue_tk(pending);
       }
     };
     if (wr == 0) barrier();   // re-align: both wave rows run their epilogues at the same time
@@ -1204,10 +1230,87 @@ __global__ __launch_bounds__(NT2, 2) void gemm_nt256q_kernel(const alpro_gemm_de
       };
       if (g.c_dtype != ALPRO_F32) {
         if constexpr (MAP == ALPRO_MAP_IDENTITY) {
+          constexpr bool READS_C2 = ACT == ALPRO_ACT_GELU_BWD || ACT == ALPRO_ACT_MUL_SAVED;
+          // The PACKED path (round 5): bias / activation / conversion to 16 bits happen in the accumulator layout, and what crosses the LDS is
+          // the 16-bit result -- two fragment rows (32 x 64) per pass as 8-byte units of four rows x one column, one ds_write_b64 per
+          // fragment instead of four ds_write_b32 (the staging writes are what an epilogue costs first: 128 ds_write_b32 per wave at 4 LDS
+          // cycles each = 2 us per tile, all eight waves on the one LDS pipe), four ds_read_b128 per lane (8 columns x 4 rows) and 16 v_perm
+          // to turn them into four 16-byte row pieces.  For the epilogues that need nothing in the OUTPUT layout: no residual, row scale,
+          // dropout or saved factor, full fragment rows.  The 16-byte pieces of a 64-byte block are XORed with the row group so that the 16
+          // lanes of a ds_read_b128 group hit 16 different slots.  Same values as the staged fp32 path (every step is elementwise).
+          if (pk) {
+            if constexpr (PK_ACT) {
+              typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+              typedef __attribute__((address_space(3))) char lds_char_t;
+              lds_char_t* st8 = (lds_char_t*)(smem + 2 * STAGE2_BYTES) + wave * (16 * 64 * 4);
+              float bcol[4];
+#pragma unroll
+              for (int nf = 0; nf < 4; ++nf) bcol[nf] = g.bias ? g.bias[nb + nf * 16 + l15] : 0.f;
+              const int kgx = le >> 3, cg = le & 7;
+              const int woff = kg * 512 + (l15 >> 3) * 64 + ((((l15 >> 1) & 3) ^ kg) << 4) + (l15 & 1) * 8;   // + f * 2048 + nf * 128
+              const int roff = kgx * 512 + cg * 64;                                                            // + ((j ^ (kgx & 3)) << 4)
+              const int64_t ldc = g.ldc, ldc2 = g.ldc2;
+              T* Cb = (T*)g.C + (int64_t)(mb + 4 * kgx) * ldc + nb + 8 * cg;
+              T* C2b = ACT == ALPRO_ACT_GELU_SAVE_GRAD ? (T*)g.C2 + (int64_t)(mb + 4 * kgx) * ldc2 + nb + 8 * cg : nullptr;
+              auto drain = [&](T* base, int64_t ld, int u) {   // the staged 32 x 64 block -> four row pieces per lane
+                u32x4 q[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) q[j] = *(const __attribute__((address_space(3))) u32x4*)(st8 + roff + ((j ^ (kgx & 3)) << 4));
+                wave_lds_order();
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                  u32x4 o;
+#pragma unroll
+                  for (int j = 0; j < 4; ++j) {
+                    const uint32_t a = (r & 2) ? q[j].y : q[j].x, b = (r & 2) ? q[j].w : q[j].z;   // column 2j / 2j + 1, rows (r & 2), (r & 2) + 1
+                    o[j] = __builtin_amdgcn_perm(b, a, (r & 1) ? 0x07060302u : 0x05040100u);
+                  }
+                  __builtin_nontemporal_store(o, (u32x4*)(base + (int64_t)(32 * u + r) * ld));
+                }
+              };
+#pragma unroll
+              for (int u = 0; u < 4; ++u) {
+                u32x2_t dpk[2][4];
+                wave_lds_order();
+#pragma unroll
+                for (int f = 0; f < 2; ++f)
+#pragma unroll
+                  for (int nf = 0; nf < 4; ++nf) {
+                    float v[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = g.alpha * acc[2 * u + f][nf][r] + bcol[nf];
+                    if constexpr (ACT == ALPRO_ACT_GELU_SAVE_GRAD) {
+                      f32x2v y0, d0, y1, d1;
+                      gelu_and_grad2((f32x2v){v[0], v[1]}, y0, d0);
+                      gelu_and_grad2((f32x2v){v[2], v[3]}, y1, d1);
+                      v[0] = y0.x; v[1] = y0.y; v[2] = y1.x; v[3] = y1.y;
+                      dpk[f][nf] = (u32x2_t){pack2(d0.x, d0.y, (T*)0), pack2(d1.x, d1.y, (T*)0)};
+                    } else if constexpr (ACT == ALPRO_ACT_GELU) {
+                      const f32x2v y0 = gelu_fast2((f32x2v){v[0], v[1]}), y1 = gelu_fast2((f32x2v){v[2], v[3]});
+                      v[0] = y0.x; v[1] = y0.y; v[2] = y1.x; v[3] = y1.y;
+                    } else {
+#pragma unroll
+                      for (int r = 0; r < 4; ++r) v[r] = apply_act<T, ACT>(v[r]);
+                    }
+                    *(__attribute__((address_space(3))) u32x2_t*)(st8 + woff + f * 2048 + nf * 128) = (u32x2_t){pack2(v[0], v[1], (T*)0), pack2(v[2], v[3], (T*)0)};
+                  }
+                wave_lds_order();
+                drain(Cb, ldc, u);
+                if constexpr (ACT == ALPRO_ACT_GELU_SAVE_GRAD) {
+#pragma unroll
+                  for (int f = 0; f < 2; ++f)
+#pragma unroll
+                    for (int nf = 0; nf < 4; ++nf) *(__attribute__((address_space(3))) u32x2_t*)(st8 + woff + f * 2048 + nf * 128) = dpk[f][nf];
+                  wave_lds_order();
+                  drain(C2b, ldc2, u);
+                }
+                if (u == 0) early_ticket();
+              }
+            }
+          } else {
           float bias8[8];
 #pragma unroll
           for (int e = 0; e < 8; ++e) bias8[e] = g.bias ? g.bias[nb + (le & 7) * 8 + e] : 0.f;
-          constexpr bool READS_C2 = ACT == ALPRO_ACT_GELU_BWD || ACT == ALPRO_ACT_MUL_SAVED;
           // The saved-factor rows (MUL_SAVED: gelu' of the forward, 16 bits) are fetched PD fragment rows ahead of their use.  A fragment row of
           // the epilogue takes ~0.5 us and an HBM round trip 1-2 us: with one row of run-ahead (round 4) every row waited for its loads -- the
           // whole gap between this dgrad (0.34 of peak in the step) and the plain 16-bit-output GEMM (0.40).  The ring lives in the registers the
@@ -1239,6 +1342,7 @@ __global__ __launch_bounds__(NT2, 2) void gemm_nt256q_kernel(const alpro_gemm_de
           };
           if (g.residual) rows_loop(std::true_type{});   // (see epi_rows16_c16: no conditional vector load inside the passes)
           else rows_loop(std::false_type{});
+          }
         }
       }
       // fp32 output (launcher: ACT none, identity map, no C2 / dropout): C = residual + row_scale * (alpha * acc + bias) -- the MLP's fc2 with its
@@ -1313,7 +1417,7 @@ __global__ __launch_bounds__(NT2, 2) void gemm_nt256q_kernel(const alpro_gemm_de
     if (!early) {
       pending = sc.blk && nxt_t >= 0 && quota > 0;
       quota -= pending ? 1 : 0;
-      ticket_issue(tk, wave == 0 && pending);
+      ticket_issue_tk(wave == 0 && pending);
     }
   }
   // out of work: the run-ahead copies went into dead slots and must have landed before the stage buffers are filled again (or, at the end,
@@ -1384,6 +1488,7 @@ int launch_gemm_inst(const alpro_gemm_desc_t& g, hipStream_t st) {
       TileSched sc;
       sc.blk = sc.prev = nullptr;
       sc.magic_ntn = magic_u32((uint32_t)(g.N / BN2));
+      sc.epi = (uint32_t)get_option(OPT_GEMM_EPI);
       {
         SchedLaunch blocks(get_option(OPT_GEMM_SCHED) == 1 ? st : nullptr, get_option(OPT_GEMM_SCHED) == 1);   // (holds the stream's block pair until the launch is enqueued)
         sc.blk = blocks.cur;

@@ -1001,52 +1001,45 @@ def test_8phase_gemm_isa_keeps_the_orders_the_source_relies_on(tmp_path):
             assert count(bad) == 0, (head, bad, [l for l in span if re.search(bad, l)][:3])
         # round 5, the tile scheduler's returning atomics (a ticket per tile; the claim of the static pair at the start): their results are
         # awaited by waits the SOURCE places (the K loop's counted waits, the pipeline fill's vmcnt(0)), not by the compiler -- which believes
-        # the register is written when the instruction issues.  So the register must be ONE register from the atomic to its reader: after a
-        # returning atomic, the next instruction that names its destination must be the v_readfirstlane that consumes it (another atomic
-        # into the same register -- the steady-state ticket shares it with the first one -- or, for the atomic at the end of the tile loop,
-        # the end of the function), and nothing else may write it but its initialisation ahead of the first atomic.  A copy or a re-use in
-        # between would read stale contents.
+        # the register is written when the instruction issues, and which may copy or re-assign any register it owns at any block boundary
+        # (it did, every time an epilogue variant was added).  The PIPELINED draws therefore answer into v255, which the compiler does not own
+        # (amdgpu_num_vgpr(127) = v0..v253): nothing but those atomics and the v_readfirstlane that consumes them may name v254 / v255.  The
+        # BLOCKING draws of the out-of-work scan use compiler registers and are read behind their own vmcnt(0) a few instructions on.
         code = [l.split("//")[0].strip() for l in lines]
         atoms = [i for i, l in enumerate(code) if re.search(r"\bglobal_atomic_(add|or)\b.*\bsc0\b", l)]
-        assert len(atoms) >= 5 and not [i for i in atoms if mf[0] <= i <= mf[-1]], (head, atoms)   # claim, first ticket, steady ticket + the blocking ticket / claim of the out-of-work scan
-        carried = set()
-        for i in atoms:
+        assert len(atoms) >= 5 and not [i for i in atoms if mf[0] <= i <= mf[-1]], (head, atoms)   # claim, first ticket, steady ticket(s) + the blocking ticket / claim of the scan
+        top = [(i, l) for i, l in enumerate(code) if re.search(r"\bv25[45]\b|\bv\[\d+:25[45]\]", l)]
+        pinned = [i for i, l in top if re.match(r"global_atomic_(add|or) v255, v\d+, v\d+, s\[\d+:\d+\] sc0$", l)]
+        readers = [i for i, l in top if re.match(r"v_readfirstlane_b32 s\d+, v255$", l)]
+        assert len(pinned) + len(readers) == len(top), (head, [l for i, l in top if i not in pinned and i not in readers][:4])
+        assert 3 <= len(pinned) <= 7 and "global_atomic_or" in code[pinned[0]] and len(readers) == 2, (head, top)
+        assert pinned[0] < readers[0], (head, top)   # (block placement is the compiler's: only the claim's read behind the claim is positional)
+        for i in atoms:   # the blocking ones: next use of the destination is the read, within a few instructions, behind a full wait
+            if i in pinned:
+                continue
             reg = code[i].split()[1].rstrip(",")
-            nxt = next((j for j in range(i + 1, len(code)) if re.search(r"\b%s\b" % reg, code[j])), None)
-            if nxt is None:
-                carried.add(reg)   # the ticket drawn behind an epilogue: read behind the NEXT K loop (checked below)
-                continue
-            if re.search(r"\bglobal_atomic_(add|or)\b", code[nxt]) and code[nxt].split()[1].rstrip(",") == reg:
-                continue
-            assert re.match(r"v_readfirstlane_b32 s\d+, %s$" % reg, code[nxt]), (head, i, code[i], nxt, code[nxt])
-            if "global_atomic_add" in code[i] and nxt - i > 150:
-                carried.add(reg)   # (its reader sits a K loop away; the blocking ones are read within a few instructions)
-        assert len(carried) == 1, (head, carried)   # exactly one register is in flight across the K loop
-        reg = carried.pop()
-        at = [i for i in atoms if code[i].split()[1].rstrip(",") == reg]
-        named = [(i, l) for i, l in enumerate(code) if re.search(r"\b%s\b" % reg, l) and i not in at]
-        readers = [(i, l) for i, l in named if re.match(r"v_readfirstlane_b32 s\d+, %s$" % reg, l)]
-        writers = [(i, l) for i, l in named if (i, l) not in readers]
-        # one register for the in-flight atomics: [claim of the static pair] -> read behind the pipeline fill -> [first ticket] -> K loop
-        # -> read behind it -> ... -> [ticket behind the epilogue] -> (tile loop) -> K loop -> the same read
-        at.sort()
-        # (3 .. 6 draw sites: the claim, the first ticket, the one behind an epilogue, and the ones behind the first fragment row of the load-free
-        # epilogue forms)
-        assert 3 <= len(at) <= 6 and "global_atomic_or" in code[at[0]] and len(readers) == 2, (head, named, at)
-        # (block placement is the compiler's: only the claim's read ahead of the K loop and the ticket's read behind it are positional)
-        assert at[0] < readers[0][0] and at[0] < at[1], (head, named, at)
-        assert all(re.match(r"v_mov_b32_e32 %s, 0$" % reg, l) and i < min(at) for i, l in writers), (head, writers)
+            nxt = next(j for j in range(i + 1, len(code)) if re.search(r"\b%s\b" % reg, code[j]))
+            assert nxt - i < 12 and re.match(r"v_readfirstlane_b32 s\d+, %s$" % reg, code[nxt]), (head, i, code[i], nxt, code[nxt])
+            assert any(re.search(r"s_waitcnt vmcnt\(0\)", l) for l in code[i + 1:nxt]), (head, code[i:nxt + 1])
         assert not any("flat_" in l for l in code), head   # the mailbox is an LDS pointer (a generic one turns into FLAT loads that wait for every store)
         # epilogue: a fragment row is staged by 8 ds_write2_b32 per lane and read back by OTHER lanes with ds_read_b128 -- no read may be issued
         # inside a group of 8 writes (the round-4 bug: the compiler, reasoning per lane, had hoisted one above the last write; wave_lds_order())
         # (round 5: the whole function is scanned -- the compiler places the epilogue variants before or behind the K loop as it likes; the K
-        # loop itself holds no ds_write2_b32, its fragment reads see a multiple of 8)
-        writes = 0
+        # loop itself holds no ds_write2_b32, its fragment reads see a multiple of 8).  The packed 16-bit epilogue stages two fragment rows
+        # with 4 ds_write2_b64: the same rule with groups of 4.
+        writes = writes64 = 0
         for l in lines:
             if re.search(r"\bds_write2_b32\b", l):
                 writes += 1
+            elif re.search(r"\bds_write2_b64\b", l):
+                writes64 += 1
             elif re.search(r"\bds_read_b128\b", l):
                 assert writes % 8 == 0, (head, "ds_read_b128 issued after %d of 8 staging writes" % (writes % 8))
+                assert writes64 % 4 == 0, (head, "ds_read_b128 issued after %d of 4 packed staging writes" % (writes64 % 4))
+        assert not [l for l in lines if re.search(r"\bds_write_b64\b", l)], head   # (an unpaired one would break the count above)
+        # packed path: 4 passes x 4 writes (x 2 for gelu + gelu') in the activations that have it
+        act = int(re.search(r"ELi(\d+)ELi\d+EEE", head).group(1))
+        assert writes64 == {0: 16, 1: 16, 2: 16, 4: 32}.get(act, 0), (head, writes64)
         # 8 fragment rows x 8 writes per epilogue form compiled into this instantiation: 16-bit output with / without an fp32 residual, and
         # (activation NONE only) fp32 output with / without one
         assert writes in (128, 256), (head, writes)
