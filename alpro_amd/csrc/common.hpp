@@ -68,6 +68,15 @@ template <> __device__ __forceinline__ void unpack_chunk<f16_t>(const u32x4& c, 
   }
 }
 
+template <typename T> __device__ __forceinline__ void unpack_pair(uint32_t w, float& lo, float& hi);
+template <> __device__ __forceinline__ void unpack_pair<bf16_t>(uint32_t w, float& lo, float& hi) {
+  lo = u2f(w << 16);
+  hi = u2f(w & 0xffff0000u);
+}
+template <> __device__ __forceinline__ void unpack_pair<f16_t>(uint32_t w, float& lo, float& hi) {
+  lo = (float)__builtin_bit_cast(_Float16, (uint16_t)(w & 0xffffu));
+  hi = (float)__builtin_bit_cast(_Float16, (uint16_t)(w >> 16));
+}
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));

@@ -806,6 +806,36 @@ __global__ __launch_bounds__(NT2, 2) void gemm_nt256p_kernel(const alpro_gemm_de
 //    WAR  a slot last read in LOAD(kr) is idle once barrier 2kr+2 has passed (the upper group's reads retire inside its MFMA(kr));
 //         its refill is issued in LOAD(kw), kw >= kr + 2, i.e. after barrier 2kw-1 >= 2kr+3.  (A-half h: kr = phase 3 of K-tile t-1, kw =
 //         phase 1 / 2 of K-tile t; W-half 1: kr = phase 2 of t-1, kw = phase 3 of t; W-half 0: kr = phase 2 of t, kw = phase 4 of t.)
+// Would launch_gemm send this descriptor to the 8-phase kernel (gemm_nt256q_kernel)?  Eligible: 16-bit operands, identity map, 16-bit output
+// through the 16-byte-store epilogue or fp32 output through the fp32 one, whole 256-column tiles, 128-byte-aligned operand rows, an even number
+// >= 4 of 64-deep K-tiles, 32-bit operand offsets, >= 160 whole tiles (below that the 128 x 128 kernel fills the chip better).
+// Ragged M: when the remainder is a multiple of 16 rows the kernel takes the partial tile row itself (invalid copy pieces re-read valid rows,
+// the epilogue skips rows beyond M) -- ONE launch; the round-4 first form ran the remainder as a second launch on the 128 x 128 kernel: 46
+// launches of ~46 us per training step at B = 64 (M = 100416 = 392 * 256 + 64), serialised behind the main kernel.  Other remainders still
+// take that split (the remainder launch carries m_off: row scale / dropout index by absolute row).
+static bool q_kernel_takes(const alpro_gemm_desc_t& g, bool* ragged_in_kernel) {
+  constexpr int BM2q = 256, BN2q = 256;
+  if (g.dtype == ALPRO_F32 || g.map_mode != ALPRO_MAP_IDENTITY) return false;
+  const int m_full = g.M / BM2q * BM2q, m_rem = g.M - m_full;
+  const bool c16 = g.c_dtype != ALPRO_F32 && (g.ldc & 7) == 0 && (!g.C2 || g.c2_tiled || (g.ldc2 & 7) == 0) && (!g.residual || (g.ldr & 3) == 0) && ((uintptr_t)g.C % 16) == 0 &&
+                   (!g.row_scale || g.row_scale_group >= 8);   // (a pass of 8 rows takes its scales from at most two groups: epi_rows16_c16)
+  const bool c32 = g.c_dtype == ALPRO_F32 && g.act == ALPRO_ACT_NONE && !g.C2 && !g.drop_seed && (g.ldc & 3) == 0 && (!g.residual || ((g.ldr & 3) == 0 && ((uintptr_t)g.residual % 16) == 0)) &&
+                   ((uintptr_t)g.C % 16) == 0 && (!g.row_scale || g.row_scale_group >= 16);   // (the fp32 epilogue takes a fragment row's scales from at most two groups)
+  const bool shape = (g.N % BN2q) == 0 && ((g.lda * 2) % 128) == 0 && ((g.ldw * 2) % 128) == 0 && (g.K % 128) == 0 && g.K >= 256 &&
+                     (int64_t)g.M * g.lda * 2 < (int64_t)0xFFFF0000 && (int64_t)g.N * g.ldw * 2 < (int64_t)0xFFFF0000;
+  *ragged_in_kernel = m_rem > 0 && (m_rem % 16) == 0;
+  const int full_tiles = (g.N / BN2q) * (m_full / BM2q);
+  const int force = get_option(OPT_GEMM_TILE);
+  return get_option(OPT_GEMM_KIND) == 1 && (c16 || c32) && shape && (force ? force == 256 : full_tiles >= 160);
+}
+// ... and may its C2 buffer be in the tile layout (alpro_hip.h: c2_tiled)?  Every tile of the output must go through the kernel's packed
+// epilogue: the GELU_SAVE_GRAD / MUL_SAVED pair without anything that epilogue does not do, and no second launch for a remainder.
+static bool c2_tiled_ok(const alpro_gemm_desc_t& g) {
+  const int m_rem = g.M % 256;
+  return (g.act == ALPRO_ACT_GELU_SAVE_GRAD || g.act == ALPRO_ACT_MUL_SAVED) && g.C2 && ((uintptr_t)g.C2 % 16) == 0 && g.c_dtype != ALPRO_F32 && !g.residual && !g.row_scale &&
+         !g.drop_seed && (m_rem % 16) == 0;
+}
+
 constexpr int HALF2_BYTES = 128 * ROWB;           // 16 KiB: 128 rows x 128 bytes
 constexpr int STAGE2_BYTES = 4 * HALF2_BYTES;     // one K-tile parity: A0 | A1 | W0 | W1
 
@@ -1191,9 +1221,12 @@ __global__ __launch_bounds__(NT2, 2) __attribute__((amdgpu_num_vgpr(127))) void 
     // qkv shape it was introduced against turned out to be the first-shape-of-the-process artefact of the probe -- clocks still settling:
     // profiles/r5_gemm_stagger_probe.txt, first against last column.)
     constexpr bool EPI_LOADS = ACT == ALPRO_ACT_GELU_BWD || ACT == ALPRO_ACT_MUL_SAVED;
-    constexpr bool PK_ACT = MAP == ALPRO_MAP_IDENTITY && (ACT == ALPRO_ACT_NONE || ACT == ALPRO_ACT_GELU || ACT == ALPRO_ACT_RELU || ACT == ALPRO_ACT_GELU_SAVE_GRAD);
-    const bool pk = PK_ACT && sc.epi != 0 && g.c_dtype != ALPRO_F32 && !g.residual && !g.row_scale && !g.drop_seed && tm0 + wr * 128 + 128 <= g.M &&
-                    !(ACT != ALPRO_ACT_GELU_SAVE_GRAD && g.C2);
+    constexpr bool PK_ACT = MAP == ALPRO_MAP_IDENTITY && (ACT == ALPRO_ACT_NONE || ACT == ALPRO_ACT_GELU || ACT == ALPRO_ACT_RELU || ACT == ALPRO_ACT_GELU_SAVE_GRAD ||
+                                                        ACT == ALPRO_ACT_MUL_SAVED);
+    // (the saved-factor multiply takes it only when the factor lies in the tile layout -- c2_tiled, below; the launcher refuses a tiled
+    // descriptor this test would send down the staged path)
+    const bool pk = PK_ACT && (sc.epi != 0 || g.c2_tiled) && g.c_dtype != ALPRO_F32 && !g.residual && !g.row_scale && !g.drop_seed &&
+                    (ACT == ALPRO_ACT_GELU_SAVE_GRAD || (ACT == ALPRO_ACT_MUL_SAVED ? g.c2_tiled != 0 : !g.C2));
     const bool early = !EPI_LOADS && !g.residual;
     int nn_w0 = -1;
     if (wave == 0) {   // the tile after next: the ticket drawn a tile ago has landed (every counted wait of this K loop was issued behind it)
@@ -1238,7 +1271,9 @@ __global__ __launch_bounds__(NT2, 2) __attribute__((amdgpu_num_vgpr(127))) void 
           // to turn them into four 16-byte row pieces.  For the epilogues that need nothing in the OUTPUT layout: no residual, row scale,
           // dropout or saved factor, full fragment rows.  The 16-byte pieces of a 64-byte block are XORed with the row group so that the 16
           // lanes of a ds_read_b128 group hit 16 different slots.  Same values as the staged fp32 path (every step is elementwise).
-          if (pk) {
+          if (pk && mb >= g.M) {
+            // (a wave of the last tile row without a valid row)
+          } else if (pk) {
             if constexpr (PK_ACT) {
               typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
               typedef __attribute__((address_space(3))) char lds_char_t;
@@ -1252,6 +1287,13 @@ __global__ __launch_bounds__(NT2, 2) __attribute__((amdgpu_num_vgpr(127))) void 
               const int64_t ldc = g.ldc, ldc2 = g.ldc2;
               T* Cb = (T*)g.C + (int64_t)(mb + 4 * kgx) * ldc + nb + 8 * cg;
               T* C2b = ACT == ALPRO_ACT_GELU_SAVE_GRAD ? (T*)g.C2 + (int64_t)(mb + 4 * kgx) * ldc2 + nb + 8 * cg : nullptr;
+              // The saved factor in the TILE layout (c2_tiled; gelu' of fc1, written by the GELU_SAVE_GRAD form and read back by the MUL_SAVED
+              // dgrad of fc2 -- nobody else looks at it): element (fragment row mf, fragment nf, row r of the lane's four, lane) of wave w of
+              // tile t lives at ((t * 8 + w) * 8 + mf) * 1024 + (nf >> 1) * 512 + lane * 8 + (nf & 1) * 4 + r -- i.e. exactly the accumulator
+              // registers, 16 bits each, two 16-byte pieces per lane and fragment row, 1 KiB contiguous per store / load instruction.  Neither
+              // kernel sends it through the LDS, and the dgrad multiplies in fp32 BEFORE the conversion, like the staged path does.
+              T* C2t = (ACT == ALPRO_ACT_GELU_SAVE_GRAD || ACT == ALPRO_ACT_MUL_SAVED) ? (T*)g.C2 + ((int64_t)tile * 8 + wave) * 8192 + le * 8 : nullptr;
+              const int rows_here = g.M - mb;   // (> 0: waves without a valid row do not get here; >= 128 on all but the last tile row)
               auto drain = [&](T* base, int64_t ld, int u) {   // the staged 32 x 64 block -> four row pieces per lane
                 u32x4 q[4];
 #pragma unroll
@@ -1265,9 +1307,25 @@ __global__ __launch_bounds__(NT2, 2) __attribute__((amdgpu_num_vgpr(127))) void 
                     const uint32_t a = (r & 2) ? q[j].y : q[j].x, b = (r & 2) ? q[j].w : q[j].z;   // column 2j / 2j + 1, rows (r & 2), (r & 2) + 1
                     o[j] = __builtin_amdgcn_perm(b, a, (r & 1) ? 0x07060302u : 0x05040100u);
                   }
-                  __builtin_nontemporal_store(o, (u32x4*)(base + (int64_t)(32 * u + r) * ld));
+                  if (32 * u + 4 * kgx + r < rows_here) __builtin_nontemporal_store(o, (u32x4*)(base + (int64_t)(32 * u + r) * ld));
                 }
               };
+              constexpr bool MULS = ACT == ALPRO_ACT_MUL_SAVED;
+              // saved-factor passes in flight: two buffers of 16 registers; pass u + 2 is requested into pass u's buffer as soon as pass u's
+              // products are formed, i.e. 1.5 passes (~1.5 us) ahead of its use (a third buffer spills accumulators at the path's entry)
+              constexpr int PDU = 2, RINGU = MULS ? 2 : 1;
+              u32x4 sring[RINGU][2][2];
+              auto load_saved = [&](int u, u32x4(&ss)[2][2]) {
+#pragma unroll
+                for (int f = 0; f < 2; ++f)
+#pragma unroll
+                  for (int j = 0; j < 2; ++j) ss[f][j] = __builtin_nontemporal_load((const u32x4*)(C2t + (2 * u + f) * 1024 + j * 512));
+              };
+              if constexpr (MULS) {
+#pragma unroll
+                for (int u = 0; u < PDU; ++u) load_saved(u, sring[u]);
+              }
+              const bool tiled = g.c2_tiled != 0;
 #pragma unroll
               for (int u = 0; u < 4; ++u) {
                 u32x2_t dpk[2][4];
@@ -1288,6 +1346,13 @@ __global__ __launch_bounds__(NT2, 2) __attribute__((amdgpu_num_vgpr(127))) void 
                     } else if constexpr (ACT == ALPRO_ACT_GELU) {
                       const f32x2v y0 = gelu_fast2((f32x2v){v[0], v[1]}), y1 = gelu_fast2((f32x2v){v[2], v[3]});
                       v[0] = y0.x; v[1] = y0.y; v[2] = y1.x; v[3] = y1.y;
+                    } else if constexpr (MULS) {
+                      const u32x4& sv = sring[u % RINGU][f][nf >> 1];
+                      float pre[4];
+                      unpack_pair<T>((nf & 1) ? sv.z : sv.x, pre[0], pre[1]);
+                      unpack_pair<T>((nf & 1) ? sv.w : sv.y, pre[2], pre[3]);
+#pragma unroll
+                      for (int r = 0; r < 4; ++r) v[r] *= pre[r];
                     } else {
 #pragma unroll
                       for (int r = 0; r < 4; ++r) v[r] = apply_act<T, ACT>(v[r]);
@@ -1295,14 +1360,25 @@ __global__ __launch_bounds__(NT2, 2) __attribute__((amdgpu_num_vgpr(127))) void 
                     *(__attribute__((address_space(3))) u32x2_t*)(st8 + woff + f * 2048 + nf * 128) = (u32x2_t){pack2(v[0], v[1], (T*)0), pack2(v[2], v[3], (T*)0)};
                   }
                 wave_lds_order();
+                if constexpr (MULS) {
+                  if (u + PDU < 4) load_saved(u + PDU, sring[u % RINGU]);
+                }
                 drain(Cb, ldc, u);
                 if constexpr (ACT == ALPRO_ACT_GELU_SAVE_GRAD) {
+                  if (tiled) {
 #pragma unroll
-                  for (int f = 0; f < 2; ++f)
+                    for (int f = 0; f < 2; ++f)
 #pragma unroll
-                    for (int nf = 0; nf < 4; ++nf) *(__attribute__((address_space(3))) u32x2_t*)(st8 + woff + f * 2048 + nf * 128) = dpk[f][nf];
-                  wave_lds_order();
-                  drain(C2b, ldc2, u);
+                      for (int j = 0; j < 2; ++j)
+                        __builtin_nontemporal_store(mk4(dpk[f][2 * j].x, dpk[f][2 * j].y, dpk[f][2 * j + 1].x, dpk[f][2 * j + 1].y), (u32x4*)(C2t + (2 * u + f) * 1024 + j * 512));
+                  } else {
+#pragma unroll
+                    for (int f = 0; f < 2; ++f)
+#pragma unroll
+                      for (int nf = 0; nf < 4; ++nf) *(__attribute__((address_space(3))) u32x2_t*)(st8 + woff + f * 2048 + nf * 128) = dpk[f][nf];
+                    wave_lds_order();
+                    drain(C2b, ldc2, u);
+                  }
                 }
                 if (u == 0) early_ticket();
               }
@@ -1464,19 +1540,10 @@ int launch_gemm_inst(const alpro_gemm_desc_t& g, hipStream_t st) {
     // K-tiles; a ragged M (the ViT's B * 1569 token rows: M % 256 = 64) is split -- whole tiles here, the remaining rows on the 128 x 128 kernel
     // in a second launch -- when the epilogue does not index by absolute row (row scale, dropout)
     const int m_full = g.M / BM2 * BM2, m_rem = g.M - m_full;
-    const bool c16 = g.c_dtype != ALPRO_F32 && (g.ldc & 7) == 0 && (!g.C2 || (g.ldc2 & 7) == 0) && (!g.residual || (g.ldr & 3) == 0) && ((uintptr_t)g.C % 16) == 0 &&
-                     (!g.row_scale || g.row_scale_group >= 8);   // (a pass of 8 rows takes its scales from at most two groups: epi_rows16_c16)
-    const bool c32 = g.c_dtype == ALPRO_F32 && ACT == ALPRO_ACT_NONE && !g.C2 && !g.drop_seed && (g.ldc & 3) == 0 && (!g.residual || ((g.ldr & 3) == 0 && ((uintptr_t)g.residual % 16) == 0)) &&
-                     ((uintptr_t)g.C % 16) == 0 && (!g.row_scale || g.row_scale_group >= 16);   // (the fp32 epilogue takes a fragment row's scales from at most two groups)
-    const bool shape = (g.N % BN2) == 0 && ((g.lda * 2) % 128) == 0 && ((g.ldw * 2) % 128) == 0 && (g.K % 128) == 0 && g.K >= 256 &&
-                       (int64_t)g.M * g.lda * 2 < (int64_t)0xFFFF0000 && (int64_t)g.N * g.ldw * 2 < (int64_t)0xFFFF0000;
-    // ragged M: when the remainder is a multiple of 16 rows the kernel takes the partial tile row itself (invalid copy pieces re-read valid rows,
-    // the epilogue skips fragment rows beyond M) -- ONE launch; the round-4 first form ran the remainder as a second launch on the 128 x 128
-    // kernel: 46 launches of ~46 us per training step at B = 64 (M = 100416 = 392 * 256 + 64), serialised behind the main kernel.  Other
-    // remainders still take that split (the remainder launch carries m_off: row scale / dropout index by absolute row).
-    const bool ragged_in_kernel = m_rem > 0 && (m_rem % 16) == 0;
-    const int full_tiles = (g.N / BN2) * (m_full / BM2);
-    if (get_option(OPT_GEMM_KIND) == 1 && (c16 || c32) && shape && (force ? force == 256 : full_tiles >= 160)) {
+    bool ragged_in_kernel = false;
+    const bool take_q = q_kernel_takes(g, &ragged_in_kernel);
+    ALPRO_CHECK(!g.c2_tiled || (take_q && c2_tiled_ok(g)), "alpro_gemm: c2_tiled is not available for this descriptor (M=%d N=%d K=%d act=%d): ask alpro_gemm_c2_tiled_rows first", g.M, g.N, g.K, g.act);
+    if (take_q) {
       alpro_gemm_desc_t gq = g;
       if (!ragged_in_kernel) gq.M = m_full;
       const int tiles = (g.N / BN2) * ((gq.M + BM2 - 1) / BM2);
@@ -1611,13 +1678,29 @@ static int check_gemm_desc(const alpro_gemm_desc_t* d) {
   ALPRO_CHECK(d->map_mode >= 0 && d->map_mode <= 3, "alpro_gemm: bad map_mode %d", d->map_mode);
   ALPRO_CHECK(d->act >= 0 && d->act <= ALPRO_ACT_MUL_SAVED, "alpro_gemm: bad act %d", d->act);
   ALPRO_CHECK(!d->bias2 || d->map_mode == ALPRO_MAP_SKIP_CLS, "alpro_gemm: bias2 is only defined under the SKIP_CLS map");
-  ALPRO_CHECK((d->act != ALPRO_ACT_GELU_BWD && d->act != ALPRO_ACT_MUL_SAVED && d->act != ALPRO_ACT_GELU_SAVE_GRAD) || (d->C2 && d->N % 8 == 0 && d->ldc2 % 8 == 0),
+  ALPRO_CHECK((d->act != ALPRO_ACT_GELU_BWD && d->act != ALPRO_ACT_MUL_SAVED && d->act != ALPRO_ACT_GELU_SAVE_GRAD) || (d->C2 && d->N % 8 == 0 && (d->c2_tiled || d->ldc2 % 8 == 0)),
               "alpro_gemm: GELU_BWD / MUL_SAVED / GELU_SAVE_GRAD need the C2 buffer (N, ldc2 multiples of 8)");
   ALPRO_CHECK(!d->drop_seed || (d->map_mode == ALPRO_MAP_IDENTITY && d->drop_p > 0.f && d->drop_p < 1.f), "alpro_gemm: dropout needs the identity map and 0 < p < 1");
-  ALPRO_CHECK(!d->C2 || (d->N % 4 == 0 && d->ldc2 % 4 == 0 && d->ldc % 4 == 0), "alpro_gemm: C2 needs N, ldc, ldc2 multiples of 4");
+  ALPRO_CHECK(!d->C2 || (d->N % 4 == 0 && (d->c2_tiled || d->ldc2 % 4 == 0) && d->ldc % 4 == 0), "alpro_gemm: C2 needs N, ldc, ldc2 multiples of 4");
+  ALPRO_CHECK(!d->c2_tiled || d->act == ALPRO_ACT_GELU_SAVE_GRAD || d->act == ALPRO_ACT_MUL_SAVED, "alpro_gemm: c2_tiled is for GELU_SAVE_GRAD / MUL_SAVED only");
   ALPRO_CHECK(d->map_mode != ALPRO_MAP_FRAME_TOKENS || d->side, "alpro_gemm: FRAME_TOKENS needs a side buffer");
   ALPRO_CHECK(!d->row_scale || d->row_scale_group > 0, "alpro_gemm: row_scale_group must be > 0");
   return ALPRO_OK;
+}
+
+extern "C" int64_t alpro_gemm_c2_tiled_rows(int64_t M, int64_t N, int64_t K, int dtype) {
+  using namespace alpro;
+  if (M <= 0 || N <= 0 || K <= 0 || M > 0x7fffffff || N > 0x7fffffff || K > 0x7fffffff || (dtype != ALPRO_F16 && dtype != ALPRO_BF16)) return 0;
+  alpro_gemm_desc_t g = {};
+  g.A = g.W = (const void*)(uintptr_t)256;   // (never dereferenced: alignment only)
+  g.C = g.C2 = (void*)(uintptr_t)256;
+  g.M = (int)M; g.N = (int)N; g.K = (int)K;
+  g.lda = g.ldw = K; g.ldc = N;
+  g.dtype = g.c_dtype = dtype;
+  g.act = ALPRO_ACT_GELU_SAVE_GRAD;
+  g.c2_tiled = 1;
+  bool ragged = false;
+  return (q_kernel_takes(g, &ragged) && c2_tiled_ok(g)) ? (M + 255) / 256 * 256 : 0;
 }
 
 extern "C" int alpro_gemm(const alpro_gemm_desc_t* d, void* stream) {

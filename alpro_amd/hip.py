@@ -20,7 +20,7 @@ EMIT_NONE, EMIT_ROWS, EMIT_FRAME, EMIT_SKIP_CLS = 0, 1, 2, 3
 _TORCH_DTYPE = {F32: torch.float32, BF16: torch.bfloat16, F16: torch.float16}
 _CODE = {v: k for k, v in _TORCH_DTYPE.items()}
 
-EXPORTS = ["alpro_hip_last_error", "alpro_hip_abi_version", "alpro_hip_set_option", "alpro_hip_set_stream_option", "alpro_gemm", "alpro_layernorm_fwd",
+EXPORTS = ["alpro_hip_last_error", "alpro_hip_abi_version", "alpro_hip_set_option", "alpro_hip_set_stream_option", "alpro_gemm", "alpro_gemm_c2_tiled_rows", "alpro_layernorm_fwd",
            "alpro_attn_temporal_fwd", "alpro_attn_fwd", "alpro_patchify", "alpro_cls_mean_residual",
            "alpro_vit_final_pool", "alpro_bert_embed_fwd", "alpro_cast_from_f32", "alpro_attn_bwd", "alpro_attn_temporal_bwd",
            "alpro_layernorm_bwd", "alpro_transpose", "alpro_transpose_batch", "alpro_gelu_bwd", "alpro_cls_mean_bwd", "alpro_scatter_add_rows", "alpro_gather_cast", "alpro_sumsq", "alpro_adamw_step", "alpro_gemm_tn_acc", "alpro_gemm_tn_acc_ws", "alpro_gemm_tn_workspace_bytes", "alpro_gemm_tn_ranges", "alpro_colsum_acc", "alpro_softmax_xent", "alpro_vtc_loss_fwd", "alpro_vtc_loss_bwd", "alpro_prepare_clips", "alpro_loss_scale_update", "alpro_add_layernorm_fwd", "alpro_layernorm_bwd_emit", "alpro_gemm_batch", "alpro_tproj_small", "alpro_attn_cls_fwd", "alpro_gemm_rows_f32", "alpro_gather_seq_fwd", "alpro_gather_seq_bwd", "alpro_scatter_add_rows_ordered"]
@@ -37,7 +37,8 @@ class GemmDesc(ctypes.Structure):
                 ("map_mode", ctypes.c_int), ("map_p0", ctypes.c_int), ("map_p1", ctypes.c_int),
                 ("side", ctypes.c_void_p), ("ld_side", ctypes.c_int64),
                 ("C2", ctypes.c_void_p), ("ldc2", ctypes.c_int64),
-                ("drop_p", ctypes.c_float), ("drop_seed", ctypes.c_uint32), ("bias2", ctypes.c_void_p), ("m_off", ctypes.c_int64)]
+                ("drop_p", ctypes.c_float), ("drop_seed", ctypes.c_uint32), ("bias2", ctypes.c_void_p), ("m_off", ctypes.c_int64),
+                ("c2_tiled", ctypes.c_int32), ("reserved0", ctypes.c_int32)]
 
 
 class TprojJob(ctypes.Structure):
@@ -50,7 +51,7 @@ class TransposeJob(ctypes.Structure):
                 ("R", ctypes.c_int32), ("C", ctypes.c_int32), ("Rpad", ctypes.c_int32), ("tile0", ctypes.c_int32)]   # 48 bytes
 
 
-ABI_VERSION = 17
+ABI_VERSION = 18
 _lib = None
 
 
@@ -195,10 +196,12 @@ def torch_dtype(code):
 # ------------------------------------------------------------------------------------------------
 def gemm(a, w, out=None, bias=None, act=ACT_NONE, out_dtype=None, alpha=1.0, row_scale=None, row_scale_group=1,
          residual=None, map_mode=MAP_IDENTITY, map_p0=0, map_p1=0, side=None, out_rows=None, pre_act=None, drop_p=0.0, drop_seed=0, bias2=None,
-         _desc_only=False):
+         c2_tiled=False, _desc_only=False):
     """out[map(m)] = residual[map(m)] + row_scale * act(alpha * a @ w.T + bias) [+ bias2]   (see alpro_gemm).
     act=ACT_GELU_BWD: out = (alpha * a @ w.T + bias) * gelu'(pre_act) (pre_act read only).
-    act=ACT_GELU_SAVE_GRAD: out = gelu(..), pre_act (required) RECEIVES gelu'(..); act=ACT_MUL_SAVED: out = (..) * pre_act (read only)."""
+    act=ACT_GELU_SAVE_GRAD: out = gelu(..), pre_act (required) RECEIVES gelu'(..); act=ACT_MUL_SAVED: out = (..) * pre_act (read only).
+    c2_tiled: pre_act is a buffer of gemm_c2_tiled_rows(M, N, K, dtype) > 0 rows in the library's tile layout (written by GELU_SAVE_GRAD, read
+    by MUL_SAVED of the same (M, N); nothing else may interpret it)."""
     lib = load()
     _dev(a); _dev(w, a.dtype)
     M, K = a.shape
@@ -224,12 +227,24 @@ def gemm(a, w, out=None, bias=None, act=ACT_NONE, out_dtype=None, alpha=1.0, row
     d.ld_side = side.shape[-1] if side is not None else 0
     d.C2 = _dev(pre_act, a.dtype).data_ptr() if pre_act is not None else None
     d.ldc2 = pre_act.shape[-1] if pre_act is not None else 0
+    d.c2_tiled = 1 if c2_tiled else 0
+    if c2_tiled:
+        assert pre_act is not None and pre_act.is_contiguous() and pre_act.numel() >= gemm_c2_tiled_rows(M, N, K, a.dtype) * N > 0, "c2_tiled needs a gemm_c2_tiled_rows(M, N, K) x N buffer"
     d.drop_p, d.drop_seed = drop_p, drop_seed
     d.bias2 = _dev(bias2, torch.float32).data_ptr() if bias2 is not None else None
     if _desc_only:
         return d, out
     _check(lib.alpro_gemm(ctypes.byref(d), _stream()), "alpro_gemm")
     return out
+
+
+def gemm_c2_tiled_rows(M, N, K, dtype):
+    """Rows of the (rows, N) buffer a tile-layout pre_act needs for this GEMM shape, or 0 when the shape does not run on the kernel that has
+    the tile layout under the current options (alpro_gemm_c2_tiled_rows): then use the row layout."""
+    lib = load()
+    lib.alpro_gemm_c2_tiled_rows.restype = ctypes.c_int64
+    lib.alpro_gemm_c2_tiled_rows.argtypes = [ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_int]
+    return int(lib.alpro_gemm_c2_tiled_rows(M, N, K, _CODE[dtype])) if dtype in (torch.float16, torch.bfloat16) else 0
 
 
 class GemmBatch:

@@ -389,9 +389,10 @@ class Block(nn.Module):
                      map_mode=hip.MAP_FRAME_TOKENS, map_p0=T, map_p1=N, side=side)
             hip.cls_mean_residual(xt, side, x2, B, T)
             h2 = hip.layernorm(x2, self.norm2.weight, self.norm2.bias, VIT_EPS, dt)
-        u = torch.empty((B * S, self.mlp.fc1.out_features), dtype=dt, device=dev)
-        sv["u_grad"] = tr.SAVE_GELU_GRAD   # u holds gelu'(fc1 output) (round 3) rather than the fc1 output itself
-        f1 = hip.gemm(h2, self._w("fc1", self.mlp.fc1, dt), bias=self.mlp.fc1.bias, act=hip.ACT_GELU_SAVE_GRAD if sv["u_grad"] else hip.ACT_GELU, pre_act=u)
+        u, sv["u_tiled"] = tr.gelu_save_buffer(B * S, self.mlp.fc1.out_features, D, dt, dev)
+        sv["u_grad"] = tr.SAVE_GELU_GRAD   # u holds gelu'(fc1 output) (round 3) rather than the fc1 output itself (round 5: in the GEMM's tile order)
+        f1 = hip.gemm(h2, self._w("fc1", self.mlp.fc1, dt), bias=self.mlp.fc1.bias, act=hip.ACT_GELU_SAVE_GRAD if sv["u_grad"] else hip.ACT_GELU, pre_act=u,
+                      c2_tiled=sv["u_tiled"])
         out = torch.empty_like(x)
         hip.gemm(f1, self._w("fc2", self.mlp.fc2, dt), out=out.view(B * S, D), bias=self.mlp.fc2.bias, out_dtype=torch.float32,
                  residual=x2.view(B * S, D), row_scale=sv["drop_m"], row_scale_group=S)
@@ -497,7 +498,7 @@ class Block(nn.Module):
         if dz is None:
             dz = hip.gather_cast(dx, dt, row_scale=sv["drop_m"], row_scale_group=S)
         tr.wgrad(dz, sv["f1"], self.mlp.fc2.weight, self.mlp.fc2.bias)
-        du = tr.dgrad(dz, self._wt("fc2", self.mlp.fc2, dt), gelu_pre=sv["u"], gelu_saved_grad=sv.get("u_grad", False))
+        du = tr.dgrad(dz, self._wt("fc2", self.mlp.fc2, dt), gelu_pre=sv["u"], gelu_saved_grad=sv.get("u_grad", False), gelu_tiled=sv.get("u_tiled", False))
         del dz
         tr.wgrad(du, sv["h2"], self.mlp.fc1.weight, self.mlp.fc1.bias)
         dh2 = tr.dgrad(du, self._wt("fc1", self.mlp.fc1, dt))

@@ -156,7 +156,18 @@ def wgrad(dy_t, x_t, weight, bias, bias_done=False):
 SAVE_GELU_GRAD = os.environ.get("ALPRO_SAVE_GELU_GRAD", "1") != "0"   # GELU Linears keep gelu'(pre-activation) instead of the pre-activation (0 = round-2 form, A/B)
 
 
-def dgrad(dy_t, wT, out_dtype=None, row_scale=None, row_scale_group=1, gelu_pre=None, gelu_saved_grad=False):
+TILED_GELU_GRAD = os.environ.get("ALPRO_TILED_GELU_GRAD", "1") != "0"   # the saved gelu' lives in the GEMM's tile layout where the library offers it (0 = rows, A/B)
+
+
+def gelu_save_buffer(M, N, K, dt, device):
+    """(buffer, tiled) for what a GELU Linear (M, K) -> (M, N) keeps for its backward.  With SAVE_GELU_GRAD the buffer holds gelu'(..) and only
+    the two GEMM epilogues ever look at it (GELU_SAVE_GRAD writes, MUL_SAVED of the following Linear's dgrad reads): where the library runs both
+    on its 8-phase kernel it is kept in that kernel's private tile order (hip.gemm c2_tiled) and never crosses the LDS."""
+    rows = hip.gemm_c2_tiled_rows(M, N, K, dt) if (SAVE_GELU_GRAD and TILED_GELU_GRAD) else 0
+    return torch.empty((rows or M, N), dtype=dt, device=device), rows > 0
+
+
+def dgrad(dy_t, wT, out_dtype=None, row_scale=None, row_scale_group=1, gelu_pre=None, gelu_saved_grad=False, gelu_tiled=False):
     """dX = dy @ W using the cached transposed operand wT (K, N64); dy_t (M, N).
     gelu_pre: what the forward of the GELU Linear that produced this Linear's input kept in its C2 buffer -- the pre-activation
     (dX *= gelu'(pre) recomputed in the epilogue) or, with gelu_saved_grad, gelu'(pre) itself (dX *= saved, ALPRO_ACT_MUL_SAVED).
@@ -169,7 +180,8 @@ def dgrad(dy_t, wT, out_dtype=None, row_scale=None, row_scale_group=1, gelu_pre=
         dy_t = torch.nn.functional.pad(dy_t, (0, pad))
         w = wT
     return hip.gemm(dy_t, w, out_dtype=out_dtype or dy_t.dtype, row_scale=row_scale, row_scale_group=row_scale_group,
-                    act=(hip.ACT_MUL_SAVED if gelu_saved_grad else hip.ACT_GELU_BWD) if gelu_pre is not None else hip.ACT_NONE, pre_act=gelu_pre)
+                    act=(hip.ACT_MUL_SAVED if gelu_saved_grad else hip.ACT_GELU_BWD) if gelu_pre is not None else hip.ACT_NONE, pre_act=gelu_pre,
+                    c2_tiled=gelu_tiled and gelu_saved_grad)
 
 
 # Anchored runs whose backward has not executed yet (weak: an abandoned graph drops out when it is freed).  A run may only declare

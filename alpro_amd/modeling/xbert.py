@@ -166,13 +166,13 @@ class BertLayer(nn.Module):
             ctx, lse, ctx_c = hip.attn(qkv, B, L, H, scale, key_bias, want_lse=True, drop_p=ap, drop_seed=seed_a, cls_q=self._cls_qkv(hc), cls_group=1)
         else:
             ctx, lse = hip.attn(qkv, B, L, H, scale, key_bias, want_lse=True, drop_p=ap, drop_seed=seed_a)
-        u = torch.empty((h_t.shape[0], self.intermediate.dense.out_features), dtype=dt, device=h_t.device) if save else None
+        u, u_tiled = tr.gelu_save_buffer(h_t.shape[0], self.intermediate.dense.out_features, h_t.shape[1], dt, h_t.device) if save else (None, False)
         if self.fuse_residual_ln:
             # the two dense Linears write their (dropped-out) 16-bit output only; residual add + post-LayerNorm are one streaming kernel
             # (alpro_add_layernorm_fwd), which also leaves the pre-LayerNorm sums s1 / s2 the backward needs (training only)
             d1 = hip.gemm(ctx, self._ops.get("ao_w", so.dense.weight, dt), bias=so.dense.bias, drop_p=hp, drop_seed=seed1)
             a_t, a32, s1 = hip.add_layernorm(h32, d1, so.LayerNorm.weight, so.LayerNorm.bias, eps, out32=True, want_x=save)
-            it = hip.gemm(a_t, self._ops.get("i_w", self.intermediate.dense.weight, dt), bias=self.intermediate.dense.bias, act=(hip.ACT_GELU_SAVE_GRAD if (save and tr.SAVE_GELU_GRAD) else hip.ACT_GELU), pre_act=u)
+            it = hip.gemm(a_t, self._ops.get("i_w", self.intermediate.dense.weight, dt), bias=self.intermediate.dense.bias, act=(hip.ACT_GELU_SAVE_GRAD if (save and tr.SAVE_GELU_GRAD) else hip.ACT_GELU), pre_act=u, c2_tiled=u_tiled)
             d2 = hip.gemm(it, self._ops.get("o_w", self.output.dense.weight, dt), bias=self.output.dense.bias, drop_p=hp, drop_seed=seed2)
             o_t, o32, s2 = hip.add_layernorm(a32, d2, self.output.LayerNorm.weight, self.output.LayerNorm.bias, eps, out32=True, want_x=save)
             if cp:
@@ -188,11 +188,11 @@ class BertLayer(nn.Module):
             s1 = hip.gemm(ctx, self._ops.get("ao_w", so.dense.weight, dt), bias=so.dense.bias, out_dtype=torch.float32, residual=h32,
                           drop_p=hp, drop_seed=seed1)
             a_t, a32 = hip.layernorm(s1, so.LayerNorm.weight, so.LayerNorm.bias, eps, dt, out32=True)
-            it = hip.gemm(a_t, self._ops.get("i_w", self.intermediate.dense.weight, dt), bias=self.intermediate.dense.bias, act=(hip.ACT_GELU_SAVE_GRAD if (save and tr.SAVE_GELU_GRAD) else hip.ACT_GELU), pre_act=u)
+            it = hip.gemm(a_t, self._ops.get("i_w", self.intermediate.dense.weight, dt), bias=self.intermediate.dense.bias, act=(hip.ACT_GELU_SAVE_GRAD if (save and tr.SAVE_GELU_GRAD) else hip.ACT_GELU), pre_act=u, c2_tiled=u_tiled)
             s2 = hip.gemm(it, self._ops.get("o_w", self.output.dense.weight, dt), bias=self.output.dense.bias, out_dtype=torch.float32, residual=a32,
                           drop_p=hp, drop_seed=seed2)
             o_t, o32 = hip.layernorm(s2, self.output.LayerNorm.weight, self.output.LayerNorm.bias, eps, dt, out32=True)
-        sv = dict(h_t=h_t, qkv=qkv, ctx=ctx, lse=lse, s1=s1, a_t=a_t, u=u, u_grad=tr.SAVE_GELU_GRAD, it=it, s2=s2, kb=key_bias, dims=(B, L, H, scale), dt=dt,
+        sv = dict(h_t=h_t, qkv=qkv, ctx=ctx, lse=lse, s1=s1, a_t=a_t, u=u, u_grad=tr.SAVE_GELU_GRAD, u_tiled=u_tiled, it=it, s2=s2, kb=key_bias, dims=(B, L, H, scale), dt=dt,
                   drop=(hp, seed1, seed2, ap, seed_a)) if save else None
         return o32, o_t, sv
 
@@ -222,7 +222,7 @@ class BertLayer(nn.Module):
         hp, seed1, seed2, ap, seed_a = sv["drop"]
         ds2, ds2_t = ln_bwd(self.output.LayerNorm, sv["s2"], do_t, do32, seed2)   # ds2 is also d(a32): identity residual; ds2_t: through the FFN-output dropout
         tr.wgrad(ds2_t, sv["it"], self.output.dense.weight, self.output.dense.bias)
-        du = tr.dgrad(ds2_t, tr.transposed_operand(self._ops, "o_w^T", self.output.dense.weight, dt), gelu_pre=sv["u"], gelu_saved_grad=sv.get("u_grad", False))
+        du = tr.dgrad(ds2_t, tr.transposed_operand(self._ops, "o_w^T", self.output.dense.weight, dt), gelu_pre=sv["u"], gelu_saved_grad=sv.get("u_grad", False), gelu_tiled=sv.get("u_tiled", False))
         tr.wgrad(du, sv["a_t"], self.intermediate.dense.weight, self.intermediate.dense.bias)
         da_t = tr.dgrad(du, tr.transposed_operand(self._ops, "i_w^T", self.intermediate.dense.weight, dt))
         ds1, ds1_t = ln_bwd(so.LayerNorm, sv["s1"], da_t, ds2, seed1)       # ds1 is also d(h32): identity residual; ds1_t: through the attention-output dropout

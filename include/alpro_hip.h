@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define ALPRO_HIP_ABI_VERSION 17
+#define ALPRO_HIP_ABI_VERSION 18
 
 enum { ALPRO_OK = 0, ALPRO_ERR_INVALID = 1, ALPRO_ERR_LAUNCH = 2 };
 enum { ALPRO_F32 = 0, ALPRO_BF16 = 1, ALPRO_F16 = 2 };
@@ -103,7 +103,17 @@ typedef struct {
   int64_t m_off;          /* round 4: absolute index of row 0 for what the epilogue indexes by row -- row_scale[(m_off + m) / group] and the
                              dropout hash (m_off + m) * N + n.  0 for callers; the library sets it on the second launch when it splits a
                              ragged M into whole 256-row tiles + a remainder. */
+  int32_t c2_tiled;       /* round 5: C2 is in the TILE layout of the 8-phase kernel instead of (M, ldc2) rows -- only for the pair
+                             ALPRO_ACT_GELU_SAVE_GRAD (writes gelu') / ALPRO_ACT_MUL_SAVED (reads it back) of one (M, N) output shape, and
+                             only when alpro_gemm_c2_tiled_rows(M, N, K, dtype) > 0: C2 then holds that many rows of N 16-bit elements
+                             (M rounded up to whole 256-row tiles) whose order is private to the library.  ldc2 is ignored. */
+  int32_t reserved0;
 } alpro_gemm_desc_t;
+
+/* Rows of the (rows, N) 16-bit buffer a tile-layout C2 needs for an (M, N, K) GEMM of `dtype` operands with contiguous operands (lda = ldw = K,
+ * ldc = N), or 0 when this shape would not run on the 8-phase kernel's packed epilogue under the current options (then keep c2_tiled = 0 and the
+ * row layout).  The same answer must hold for the forward (GELU_SAVE_GRAD) and the backward (MUL_SAVED) launch: both have the same (M, N). */
+int64_t alpro_gemm_c2_tiled_rows(int64_t M, int64_t N, int64_t K, int dtype);
 
 int alpro_gemm(const alpro_gemm_desc_t* d, void* stream);
 

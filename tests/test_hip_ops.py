@@ -439,6 +439,47 @@ def test_gemm_8phase_kernel(dt, M, N, K, case):
     close(outs[1], outs[0].double().cpu(), tol[0] * 2, tol[1] * 2, "8-phase vs round-3 kernel")
 
 
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("M", [14 * 256, 14 * 256 + 64, 41 * 256 + 144])
+def test_gemm_saved_gelu_grad_in_the_tile_layout(dt, M):
+    """Round 5: the gelu' a GELU Linear keeps for its backward may live in the 8-phase kernel's tile layout (desc.c2_tiled; buffer of
+    alpro_gemm_c2_tiled_rows rows) -- written by GELU_SAVE_GRAD, read back by MUL_SAVED of the same (M, N), never through the LDS.  Both
+    outputs (gelu(..) of the forward, dX of the backward) must equal the row-layout pair bit for bit, ragged last tile row included; shapes
+    the kernel does not take answer 0 rows and a tiled descriptor for them is refused."""
+    hip = _hip()
+    N, K = 3072, 768
+    a, w1, b1 = rnd(M, K, seed=910), rnd(N, K, seed=911, scale=0.05), rnd(N, seed=912)
+    dy, w2t = rnd(M, K, seed=913), rnd(N, K, seed=914, scale=0.05)          # fc2's dgrad: dX1 (M, N) = dY (M, K) @ W2 (K, N) = dY @ (W2^T as (N, K))^T
+    A, W1, DY, W2T = a.to(dt).cuda(), w1.to(dt).cuda(), dy.to(dt).cuda(), w2t.to(dt).cuda()
+    B1 = b1.cuda()
+    rows = hip.gemm_c2_tiled_rows(M, N, K, dt)
+    assert rows == (M + 255) // 256 * 256
+    u_rows = torch.empty(M, N, dtype=dt, device="cuda")
+    y_rows = hip.gemm(A, W1, bias=B1, act=hip.ACT_GELU_SAVE_GRAD, pre_act=u_rows)
+    dx_rows = hip.gemm(DY, W2T, act=hip.ACT_MUL_SAVED, pre_act=u_rows)
+    u_tile = torch.full((rows, N), float("nan"), dtype=dt, device="cuda")
+    guard = torch.full((M + 256, N), 7.0, dtype=dt, device="cuda")       # rows behind M of the row-layout outputs stay untouched
+    y_tile = hip.gemm(A, W1, out=guard[:M], bias=B1, act=hip.ACT_GELU_SAVE_GRAD, pre_act=u_tile, c2_tiled=True)
+    assert torch.equal(y_tile, y_rows) and bool((guard[M:] == 7.0).all())
+    dx_tile = hip.gemm(DY, W2T, act=hip.ACT_MUL_SAVED, pre_act=u_tile, c2_tiled=True)
+    assert torch.equal(dx_tile, dx_rows)
+    # the tile layout is a permutation of the rows layout inside every (wave, fragment row) block of 16 x 64 elements
+    t0 = u_tile.view(-1)[:1024].float().sort().values
+    r0 = u_rows[:16, :64].reshape(-1).float().sort().values
+    assert torch.equal(t0, r0)
+    # against fp64 of the rounded operands (the pair's semantics): dX = (dY W2) * gelu'(A W1^T + b1)
+    pre = A[:256].double() @ W1.double().t() + B1.double()
+    gp = 0.5 * (1 + torch.erf(pre / 2 ** 0.5)) + pre * torch.exp(-0.5 * pre * pre) / (2 * 3.141592653589793) ** 0.5
+    ref = (DY[:256].double() @ W2T.double().t()) * gp
+    err = (dx_tile[:256].double() - ref).abs().max() / ref.abs().max()
+    assert err < (2e-3 if dt == torch.float16 else 1.5e-2), err
+    # not available: too few tiles for the 8-phase kernel / an fp32 GEMM -> 0 rows, and the launch refuses the flag
+    assert hip.gemm_c2_tiled_rows(512, N, K, dt) == 0 and hip.gemm_c2_tiled_rows(M, N, K, torch.float32) == 0
+    with pytest.raises(Exception):
+        with hip.option("gemm_kind", 0):   # (the round-3 kernel has no tile layout)
+            hip.gemm(A, W1, bias=B1, act=hip.ACT_GELU_SAVE_GRAD, pre_act=u_tile, c2_tiled=True)
+
+
 def _cu_thief():
     """tools/cu_thief.hip (n resident workgroups with 64 KiB of LDS each: the footprint of a collective's channel kernels), built on the box."""
     import ctypes

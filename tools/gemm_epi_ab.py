@@ -61,6 +61,47 @@ def main():
         same = torch.equal(res[0][0], res[1][0]) and (pre is None or o.get("mul") or torch.equal(res[0][1], res[1][1]))
         tf = 2.0 * M * N * K / min(cells[1], cells[3]) / 1e6
         print("%-30s | %9.1f %9.1f | %9.1f %9.1f | %+6.1f%% | %s   (%.0f TF/s packed)" % (name, *cells, 100.0 * ((cells[1] + cells[3]) / (cells[0] + cells[2]) - 1.0), same, tf), flush=True)
+    tiled_pair(dt)
+
+
+def tiled_pair(dt):
+    """fc1 forward (gelu + gelu') and fc2 dgrad (x gelu') at B = 64 with the saved factor in rows against the tile layout"""
+    M, N, K = 100416, 3072, 768
+    g = torch.Generator(device="cuda").manual_seed(1)
+    A = torch.randn(M, K, device="cuda", generator=g).to(dt)
+    W1 = (torch.randn(N, K, device="cuda", generator=g) * 0.05).to(dt)
+    DY = torch.randn(M, K, device="cuda", generator=g).to(dt)
+    W2T = (torch.randn(N, K, device="cuda", generator=g) * 0.05).to(dt)
+    b1 = torch.randn(N, device="cuda", generator=g)
+    out = torch.empty(M, N, dtype=dt, device="cuda")
+    rows = hip.gemm_c2_tiled_rows(M, N, K, dt)
+    bufs = {False: torch.empty(M, N, dtype=dt, device="cuda"), True: torch.empty(max(rows, 1), N, dtype=dt, device="cuda")}
+    res = {}
+    print("\nsaved gelu' in rows / in the tile layout (us per launch; %d buffer rows)" % rows)
+    for what in ("fc1 gelu+gelu' B=64", "fc2 dgrad x gelu' B=64"):
+        cells = []
+        for tiled in (False, True, False, True):
+            if tiled and not rows:
+                cells.append(float("nan"))
+                continue
+            def run():
+                if what.startswith("fc1"):
+                    hip.gemm(A, W1, out=out, bias=b1, act=hip.ACT_GELU_SAVE_GRAD, pre_act=bufs[tiled], c2_tiled=tiled)
+                else:
+                    hip.gemm(DY, W2T, out=out, act=hip.ACT_MUL_SAVED, pre_act=bufs[tiled], c2_tiled=tiled)
+            for _ in range(3):
+                run()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(20):
+                run()
+            e1.record()
+            e1.synchronize()
+            res[(what, tiled)] = out.clone()
+            cells.append(e0.elapsed_time(e1) / 20 * 1e3)
+        same = rows and torch.equal(res[(what, False)], res[(what, True)])
+        print("%-30s | rows %8.1f tiled %8.1f | rows %8.1f tiled %8.1f | %+6.1f%% | same bits %s   (%.0f TF/s tiled)" % (
+            what, *cells, 100.0 * ((cells[1] + cells[3]) / (cells[0] + cells[2]) - 1.0), same, 2.0 * M * N * K / min(cells[1], cells[3]) / 1e6), flush=True)
 
 
 if __name__ == "__main__":
