@@ -365,7 +365,7 @@ def measure_parity(dev, dtype, full_size_backward=False):
     out["within_stated_tolerances"] = bool(per[worst] <= pc.NORTH_STAR_BAR and res.get("video_embeds_max_abs_err", 0) <= 3e-3 and res.get("itm_scores_max_abs_err", 0) <= 5e-3
                                            and res.get("itc_loss_abs_err", 0) <= 1e-3 and res.get("grad_norm_rel_err_worst", 0) <= 1e-2)
     out["fixtures"] = "tests/golden/{retrieval_T2_B3, pretrain_T8_B2, retrieval_T16_B2, pretrain_release_T4_L30_B2, retrieval_grads_T2_B3}.npz (outputs of the reference itself, make_golden.py); measured in this process"
-    out["full_size_proxy"] = "tests/test_model_parity.py::test_full_size_pretrain_forward_in_the_bench_dtype_vs_the_exact_mode (B=64 x 8f against the exact fp32 HIP mode); measured numbers: profiles/r4_parity_pareto.txt"
+    out["full_size_proxy"] = "tests/test_model_parity.py::test_full_size_pretrain_forward_in_the_bench_dtype_vs_the_exact_mode (B=64 x 8f against the exact fp32 HIP mode); measured numbers: profiles/r4_parity_pareto.txt (forward), profiles/r5_parity_backward_B64.txt (backward)"
     if full_size_backward and dtype != "fp32":
         # the backward at the benchmarked size: every parameter gradient of one B = 64 x 8f step against the exact fp32 HIP mode (~5 s)
         bw = pc.full_size_backward_parity(BERT_CFG, VENC, make_cfg, dev, dtype=dtype, cls_precise=rt._cls_precise[0])   # (the mode the timed steps ran in)
@@ -578,7 +578,7 @@ def main():
             result["parity"] = measure_parity(dev, args.dtype, full_size_backward=train and B == 64 and T == 8)
         else:   # (--no-parity, or N > 1 where rank 0 alone cannot run it): say where the measured numbers of this mode live
             result["parity"] = {"mode": mode_name(args.dtype), "measured_in_this_run": False,
-                                "see": "profiles/r4_parity_pareto.txt (worst-of-four-fixture VTC-logit error and the B=64 proxy per mode); rerun with N=1 and without --no-parity to measure in-process"}
+                                "see": "profiles/r4_parity_pareto.txt (worst-of-four-fixture VTC-logit error and the B=64 proxy per mode), profiles/r5_parity_backward_B64.txt (B=64 backward against the exact fp32 HIP mode); rerun with N=1 and without --no-parity to measure in-process"}
         if not args.no_cpu_baseline and world == 1:  # reported at N=1 only (rank 0 would keep its peers waiting at N>1)
             result["cpu_baseline"] = cpu_baseline_train(T) if train else cpu_baseline(T)
         print(json.dumps(result), flush=True)
