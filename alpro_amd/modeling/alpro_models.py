@@ -28,6 +28,11 @@ from alpro_amd.modeling.xbert import BertForMaskedLM, BertModel
 _VISUAL_CLASSES = {"TimeSformer": TimeSformer}
 
 
+def _rows_ok(M, N, K):
+    """shapes alpro_gemm_rows_f32 takes (include/alpro_hip.h): few rows, N % 16 == 0, K % 64 == 0"""
+    return M <= 512 and N % 16 == 0 and K % 64 == 0
+
+
 def _linear32(x, lin):
     """nn.Linear on fp32 rows through alpro_gemm's exact fp32 MFMA path (heads only)."""
     x = x.contiguous().float()
@@ -42,6 +47,8 @@ class _Linear32(torch.autograd.Function):
         K = x.shape[1]
         if K % 32 != 0:
             raise RuntimeError("head Linear in_features must be a multiple of 32")
+        if _rows_ok(x.shape[0], w.shape[0], K):   # a handful of rows: the skinny fp32 kernel (11-35 us) instead of a 128 x 128-tile launch (60-140 us)
+            return hip.gemm_rows(x, w.detach().contiguous(), bias=None if b is None else b.detach())
         return hip.gemm(x, w.detach().contiguous(), bias=None if b is None else b.detach(), out_dtype=torch.float32)
 
     @staticmethod
@@ -49,7 +56,13 @@ class _Linear32(torch.autograd.Function):
         x, w = ctx.saved_tensors
         g = g.contiguous()
         # tiny (B x 256 x 768) products: dX = g W, dW = g^T X, db = sum g -- NT GEMMs on transposed copies
-        dx = hip.gemm(_pad_k(g), _pad_k(w.detach().t().contiguous()), out_dtype=torch.float32) if ctx.needs_input_grad[0] else None
+        dx = None
+        if ctx.needs_input_grad[0]:
+            wt = w.detach().t().contiguous()
+            if _rows_ok(g.shape[0], wt.shape[0], 64):   # (contraction dim zero-padded to the skinny kernel's 64-granule: mpm_head's 1000 classes)
+                dx = hip.gemm_rows(_pad_k(g, 64), _pad_k(wt, 64))
+            else:
+                dx = hip.gemm(_pad_k(g), _pad_k(wt), out_dtype=torch.float32)
         dw = hip.gemm(_pad_k(g.t().contiguous()), _pad_k(x.t().contiguous()), out_dtype=torch.float32) if ctx.needs_input_grad[1] else None
         db = g.sum(0) if ctx.has_bias and ctx.needs_input_grad[2] else None
         return dx, dw, db
@@ -79,10 +92,10 @@ class _FusionOutputs(torch.autograd.Function):
         return d, None, None
 
 
-def _pad_k(t):
-    """Zero-pad the contraction dim to a multiple of 32 (alpro_gemm's K granule in fp32)."""
+def _pad_k(t, granule=32):
+    """Zero-pad the contraction dim to a multiple of 32 (alpro_gemm's K granule in fp32; 64: alpro_gemm_rows_f32's)."""
     k = t.shape[1]
-    r = (-k) % 32
+    r = (-k) % granule
     return t if r == 0 else F.pad(t, (0, r))
 
 
