@@ -937,13 +937,13 @@ __global__ __launch_bounds__(NT2, 2) __attribute__((amdgpu_num_vgpr(127))) void 
     uint64_t sv;
     const uint32_t m = (uint32_t)__builtin_amdgcn_readfirstlane(on ? 1 : 0);
     asm volatile("s_mov_b64 %0, exec\n\ts_mov_b32 exec_lo, %4\n\ts_mov_b32 exec_hi, 0\n\tglobal_atomic_add v255, %1, %2, %3 sc0\n\ts_mov_b64 exec, %0"
-                 : "=&s"(sv) : "v"(((blockIdx.x + wstate) & 7u) * 4u), "v"(1u), "s"(sc.blk), "s"(m) : "memory", "v255");
+                 : "=&s"(sv) : "v"(((blockIdx.x + wstate) & 7u) * 4u), "v"(1u), "s"(sc.blk), "s"(m) : "memory", "v255");   // (the clobber is what makes the compiler COUNT v255 into the kernel's register allocation -- without it an instantiation that needs 240 registers gets 240 and the atomic writes outside the wave's file; the "reserved register" warning is expected)
   };
   auto claim_issue_tk = [&](uint32_t w, uint32_t bits, bool on) {
     uint64_t sv;
     const uint32_t m = (uint32_t)__builtin_amdgcn_readfirstlane(on ? 1 : 0);
     asm volatile("s_mov_b64 %0, exec\n\ts_mov_b32 exec_lo, %4\n\ts_mov_b32 exec_hi, 0\n\tglobal_atomic_or v255, %1, %2, %3 sc0\n\ts_mov_b64 exec, %0"
-                 : "=&s"(sv) : "v"((SCHED_CLAIM0 + w) * 4u), "v"(bits), "s"(sc.blk), "s"(m) : "memory", "v255");
+                 : "=&s"(sv) : "v"((SCHED_CLAIM0 + w) * 4u), "v"(bits), "s"(sc.blk), "s"(m) : "memory", "v255");   // (the clobber is what makes the compiler COUNT v255 into the kernel's register allocation -- without it an instantiation that needs 240 registers gets 240 and the atomic writes outside the wave's file; the "reserved register" warning is expected)
   };
   auto tk_read = [&]() -> uint32_t {   // lane 0's answer (wave 0)
     uint32_t r;

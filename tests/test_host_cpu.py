@@ -1044,6 +1044,12 @@ def test_8phase_gemm_isa_keeps_the_orders_the_source_relies_on(tmp_path):
         # (activation NONE only) fp32 output with / without one
         assert writes in (128, 256), (head, writes)
     assert seen == 12, seen   # {bf16, f16} x 6 activations, identity map
+    # ... and v255 must EXIST in every instantiation: the kernel's register allocation is what the compiler counted, and it counts v255 only
+    # because the atomics' asm lists it as clobbered (without that an instantiation that needs 240 registers is allocated 240 and the atomic
+    # would write outside the wave's register file)
+    notes = subprocess.run([os.path.join(llvm, "llvm-readelf"), "--notes", str(tmp_path / dev[0])], check=True, capture_output=True, text=True).stdout
+    counts = re.findall(r"\.name:\s*(\S*gemm_nt256q_kernel\S*)[\s\S]*?\.vgpr_count:\s*(\d+)", notes)
+    assert len(counts) == 12 and all(int(c) == 256 for _, c in counts), counts
     # the weight-gradient kernel counts its ring of copies the same way (one counted wait per 32-token stage): no foreign vector-memory traffic
     obj = os.path.join(ROOT, "alpro_amd", "lib", "obj", "gemm_tn.o")
     if os.path.exists(obj):
