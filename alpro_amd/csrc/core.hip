@@ -40,7 +40,9 @@ struct OptInit {
   OptInit() {
     for (int i = 0; i < OPT_COUNT; ++i) {
       const char* e = getenv(kOptEnv[i]);
-      const int dflt = (i == OPT_GEMM_TUNE || i == OPT_GEMM_TAIL || i == OPT_ATTN_BWD || i == OPT_GEMM_KIND || i == OPT_GEMM_SCHED || i == OPT_GEMM_EPI) ? 1 : 0;
+      const int dflt = (i == OPT_GEMM_TUNE || i == OPT_GEMM_TAIL || i == OPT_ATTN_BWD || i == OPT_GEMM_KIND || i == OPT_GEMM_SCHED || i == OPT_GEMM_EPI) ? 1
+                       : i == OPT_TN_KIND ? 2   // (round 5: the two-group schedule of the weight-gradient kernel, -1.2 % on its 29.7 ms in the step: profiles/r5_tn_kind_ab.txt)
+                                          : 0;
       g_opts[i] = e ? atoi(e) : dflt;
       if (!option_allowed(i, g_opts[i])) {
         fprintf(stderr, "libalpro_hip: %s=%d is a result-corrupting ablation and is not part of this build (ignored)\n", kOptEnv[i], g_opts[i]);

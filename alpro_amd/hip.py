@@ -118,7 +118,7 @@ def load():
     return lib
 
 
-_OPTION_DEFAULTS = {"gemm_tile": 0, "gemm_grid": 0, "gemm_tune": 1, "tn_splits": 0, "tn_kind": 0, "gemm_tail": 1, "attn_bwd": 1, "attn_order": 0, "gemm_kind": 1, "cu_budget": 0, "ln_grid": 0, "gemm_sched": 1, "gemm_epi": 1}
+_OPTION_DEFAULTS = {"gemm_tile": 0, "gemm_grid": 0, "gemm_tune": 1, "tn_splits": 0, "tn_kind": 2, "gemm_tail": 1, "attn_bwd": 1, "attn_order": 0, "gemm_kind": 1, "cu_budget": 0, "ln_grid": 0, "gemm_sched": 1, "gemm_epi": 1}
 _option_values = {}
 
 

@@ -202,7 +202,7 @@ def test_gemm_tn_acc(dt, M, N, K, atomic, tn_kind):
     c = c0.clone().cuda()
     bg = torch.full((ldn,), 2.0).cuda()
     hip.gemm_tn_acc(a.to(dt).cuda()[:, :N], b.to(dt).cuda(), c, colsum=bg, atomic=atomic)
-    hip.set_option("tn_kind", 0)
+    hip.set_option("tn_kind", hip._OPTION_DEFAULTS["tn_kind"])
     ref = c0.double() + a[:, :N].to(dt).double().T @ b.to(dt).double()
     close(c, ref, 2e-5, 2e-3 * math.sqrt(M / 1000.0), "gemm_tn_acc")
     close(bg[:N], 2 + a[:, :N].to(dt).double().sum(0), 1e-5, 1e-3, "gemm_tn_acc fused bias gradient")
