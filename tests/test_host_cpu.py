@@ -58,6 +58,26 @@ def test_gemm_desc_matches_header_layout():
     assert ctypes.sizeof(hip.GemmDesc) == 200
 
 
+def test_tile_layout_of_the_saved_gelu_grad_is_offered_where_the_8phase_kernel_runs():
+    """alpro_gemm_c2_tiled_rows is pure host logic (the launcher's own eligibility test on a contiguous descriptor): the ViT / fusion MLP shapes
+    get M rounded up to whole 256-row tiles, anything the 8-phase kernel does not take -- too few tiles, fp32 operands, N not a multiple of
+    256, a K the kernel's pipeline cannot run, a ragged remainder that would go to the 128 x 128 kernel -- gets 0 (= keep the row layout), and
+    turning the kernel off (gemm_kind 0) turns the offer off."""
+    from alpro_amd import hip
+    import torch
+    f16, bf16 = torch.float16, torch.bfloat16
+    assert hip.gemm_c2_tiled_rows(64 * 1569, 3072, 768, f16) == 100608           # the ViT's fc1 at B = 64 (M % 256 = 64)
+    assert hip.gemm_c2_tiled_rows(32 * 1569, 3072, 768, bf16) == 50432
+    assert hip.gemm_c2_tiled_rows(5120, 3072, 768, f16) == 5120                  # the text / fusion MLPs: 240 tiles
+    assert hip.gemm_c2_tiled_rows(2560, 3072, 768, f16) == 0                     # 120 tiles: the 128 x 128 kernel's
+    assert hip.gemm_c2_tiled_rows(100416, 3072, 768, torch.float32) == 0
+    assert hip.gemm_c2_tiled_rows(100416, 3000, 768, f16) == 0 and hip.gemm_c2_tiled_rows(100416, 3072, 128, f16) == 0
+    assert hip.gemm_c2_tiled_rows(100416 + 8, 3072, 768, f16) == 0               # remainder not a multiple of 16 rows: split launch
+    with hip.option("gemm_kind", 0):
+        assert hip.gemm_c2_tiled_rows(100416, 3072, 768, f16) == 0
+    assert hip.gemm_c2_tiled_rows(100416, 3072, 768, f16) == 100608
+
+
 def test_transpose_job_layout_and_wgrad_workspace_plan():
     """Host-side pieces of two entry points: the job record of alpro_transpose_batch mirrors the header, and
     alpro_gemm_tn_workspace_bytes (pure host arithmetic: the token-range plan of the weight-gradient GEMM) gives the documented
