@@ -1217,9 +1217,9 @@ __global__ __launch_bounds__(NT2, 2) __attribute__((amdgpu_num_vgpr(127))) void 
     // waits for this atomic, and 32 workgroups of an XCD that run in lockstep hit their counter together.  An epilogue without loads has no
     // wait of its own behind its first fragment row (the bias values are the only thing it fetches), so there the ticket goes out right
     // behind that row (another ~3 us of slack); the epilogues that fetch rows all along (saved factor, fp32 residual: their counted waits
-    // would stall on the atomic) keep drawing behind themselves.  (Measured effect of the early draw: within noise.  The +5 % of the B = 64
-    // qkv shape it was introduced against turned out to be the first-shape-of-the-process artefact of the probe -- clocks still settling:
-    // profiles/r5_gemm_stagger_probe.txt, first against last column.)
+    // would stall on the atomic) keep drawing behind themselves.  (Measured effect of the early draw: within noise.  Of the +6 % of the B = 64
+    // qkv shape it was introduced against, half was the first-measurement-of-the-process artefact of the probe -- clocks still settling,
+    // profiles/r5_gemm_stagger_probe.txt -- and +3 % is still there on that shape with a warm-up: profiles/r5_gemm_sched_contention.txt.)
     constexpr bool EPI_LOADS = ACT == ALPRO_ACT_GELU_BWD || ACT == ALPRO_ACT_MUL_SAVED;
     constexpr bool PK_ACT = MAP == ALPRO_MAP_IDENTITY && (ACT == ALPRO_ACT_NONE || ACT == ALPRO_ACT_GELU || ACT == ALPRO_ACT_RELU || ACT == ALPRO_ACT_GELU_SAVE_GRAD ||
                                                         ACT == ALPRO_ACT_MUL_SAVED);

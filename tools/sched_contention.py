@@ -46,17 +46,23 @@ def main():
             ref = hip.gemm(A, W, **kw).clone()
         cases.append((name, M, N, K, A, W, kw, out, ref))
     torch.cuda.synchronize()
+    # clocks settle over the first few hundred ms of load: the process' first measurements read 10-20 % slow otherwise (the "+6 % of the ticket
+    # walk on qkv B=64" of this table's first version, profiles/r5_gemm_stagger_probe.txt)
+    name, M, N, K, A, W, kw, out, ref = cases[0]
+    for _ in range(600):
+        hip.gemm(A, W, out=out, **kw)
+    torch.cuda.synchronize()
     table = {}
     for stolen in (0, 8, 16, 32):
         started.zero_()
         t_launch = time.time()
-        secs = 1.5
+        secs = 3.0
         if stolen:
             assert lib.cu_thief_launch(buf.data_ptr(), stolen, int(100e6 * secs), started.data_ptr(), side.cuda_stream) == 0
             while int(started.item()) < stolen:
                 time.sleep(0.001)
         for name, M, N, K, A, W, kw, out, ref in cases:
-            for sched in (0, 1):
+            for sched in (0, 1, 0, 1):   # A / B / A / B, the faster of the two
                 with hip.option("gemm_sched", sched):
                     for _ in range(3):
                         hip.gemm(A, W, out=out, **kw)
@@ -68,7 +74,9 @@ def main():
                     e1.synchronize()
                     ok = torch.equal(out, ref)
                 us = e0.elapsed_time(e1) / args.iters * 1e3
-                table[(name, stolen, sched)] = (us, 2.0 * M * N * K / us / 1e6, ok)
+                prev = table.get((name, stolen, sched))
+                if prev is None or us < prev[0] or not ok:
+                    table[(name, stolen, sched)] = (us, 2.0 * M * N * K / us / 1e6, ok and (prev is None or prev[2]))
         still = (time.time() - t_launch) < secs
         torch.cuda.synchronize()
         if stolen and not still:
