@@ -99,6 +99,8 @@ def load():
     lib.alpro_attn_fwd.argtypes = [vp, vp, i32, i32, i32, i32, f32, vp, vp, f32, u32, vp, i32, vp, vp]
     lib.alpro_attn_cls_fwd.argtypes = [vp, i32, vp, vp, vp, i32, i32, i32, i32, f32, f32, u32, vp]
     lib.alpro_gemm_rows_f32.argtypes = [vp, i64, vp, i64, vp, i64, i32, i32, i32, vp, i32, vp, vp, i64, vp, vp, f32, vp]
+    lib.alpro_gemm_c2_tiled_rows.argtypes = [i64, i64, i64, i32]
+    lib.alpro_gemm_c2_tiled_rows.restype = i64
     lib.alpro_patchify.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp]
     lib.alpro_cls_mean_residual.argtypes = [vp, i64, vp, vp, i64, i32, i32, i32, vp]
     lib.alpro_vit_final_pool.argtypes = [vp, vp, vp, f32, vp, vp, i32, i32, i32, i32, i32, vp]
@@ -228,8 +230,8 @@ def gemm(a, w, out=None, bias=None, act=ACT_NONE, out_dtype=None, alpha=1.0, row
     d.C2 = _dev(pre_act, a.dtype).data_ptr() if pre_act is not None else None
     d.ldc2 = pre_act.shape[-1] if pre_act is not None else 0
     d.c2_tiled = 1 if c2_tiled else 0
-    if c2_tiled:
-        assert pre_act is not None and pre_act.is_contiguous() and pre_act.numel() >= gemm_c2_tiled_rows(M, N, K, a.dtype) * N > 0, "c2_tiled needs a gemm_c2_tiled_rows(M, N, K) x N buffer"
+    if c2_tiled and not (pre_act is not None and pre_act.is_contiguous() and pre_act.numel() >= gemm_c2_tiled_rows(M, N, K, a.dtype) * N > 0):
+        raise RuntimeError("gemm: c2_tiled needs a contiguous pre_act buffer of gemm_c2_tiled_rows(M, N, K, dtype) x N elements (0 rows = not offered for this shape)")
     d.drop_p, d.drop_seed = drop_p, drop_seed
     d.bias2 = _dev(bias2, torch.float32).data_ptr() if bias2 is not None else None
     if _desc_only:
@@ -241,10 +243,7 @@ def gemm(a, w, out=None, bias=None, act=ACT_NONE, out_dtype=None, alpha=1.0, row
 def gemm_c2_tiled_rows(M, N, K, dtype):
     """Rows of the (rows, N) buffer a tile-layout pre_act needs for this GEMM shape, or 0 when the shape does not run on the kernel that has
     the tile layout under the current options (alpro_gemm_c2_tiled_rows): then use the row layout."""
-    lib = load()
-    lib.alpro_gemm_c2_tiled_rows.restype = ctypes.c_int64
-    lib.alpro_gemm_c2_tiled_rows.argtypes = [ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_int]
-    return int(lib.alpro_gemm_c2_tiled_rows(M, N, K, _CODE[dtype])) if dtype in (torch.float16, torch.bfloat16) else 0
+    return int(load().alpro_gemm_c2_tiled_rows(M, N, K, _CODE[dtype])) if dtype in (torch.float16, torch.bfloat16) else 0
 
 
 class GemmBatch:
