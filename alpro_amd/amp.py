@@ -111,7 +111,7 @@ def unscale_(optimizer, scaler):
             # step() that the summed gradients are already here -- a driver that calls optimizer.synchronize() inside the with block (the
             # reference's do) never gets here with handles pending
             inner._finish_exchange()
-            inner._pre_synced = "sum"
+            inner._note_synced("sum")
         flat["g"].mul_(inv)
     else:
         grads = _grads_of(inner)
@@ -133,7 +133,7 @@ def scale_loss(loss, optimizers, delay_unscale=False, **unused):
     for o in opts:
         getattr(o, "_opt", o)._grads_scaled = True
         if hasattr(getattr(o, "_opt", o), "_g_clean"):
-            getattr(o, "_opt", o)._g_clean = False   # gradients are about to be written by the caller's own scaled_loss.backward()
+            getattr(o, "_opt", o)._mark_dirty()      # gradients are about to be written by the caller's own scaled_loss.backward()
     with rt.loss_scaling(scaler):
         yield loss * scaler.scale.reshape(())
     if not delay_unscale:

@@ -23,7 +23,7 @@ if ABLATIONS:
     OBJDIR = os.path.join(LIBDIR, "obj_ablate")
 LIB = os.path.join(LIBDIR, "libalpro_hip_ablate.so" if ABLATIONS else "libalpro_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"] + (["-DALPRO_ABLATIONS"] if ABLATIONS else [])
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Werror=inline-asm"] + (["-DALPRO_ABLATIONS"] if ABLATIONS else [])
 
 
 def _sources():

@@ -913,7 +913,11 @@ __global__ __launch_bounds__(512) void attn_bwd16p_kernel(const T* __restrict__ 
     const uint32_t off = (uint32_t)row * (uint32_t)(ld * 2) + (uint32_t)(db ^ ((piece & 1) << 5));
     const uint64_t bp = (uint64_t)base;
     const uint64_t sb = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(bp >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)bp);
+    // reserved-register site (the product is built with -Werror=inline-asm; this one is deliberate): global_load_lds takes its LDS address from m0; listing it as clobbered is what keeps the compiler from assuming a value of its own survives the statement (it writes m0 itself before each of its own uses: LDS-DMA builtins, s_movrel); the K-loop ISA tests of tests/test_host_cpu.py read the built object
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(off), "s"(sb), "s"(dst) : "memory", "m0");
+#pragma clang diagnostic pop
   };
   // record of query tile tx of unit U -> ring slot: 12 pieces, this wave's are o = wave, wave + 8 -> array o >> 2 (Q, dO, O), piece o & 3
   auto issue_record_op = [&](const Unit& U, int tx, int slot, int i) {   // i = 0, 1: this wave's first / second piece

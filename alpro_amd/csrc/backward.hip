@@ -540,9 +540,14 @@ __global__ __launch_bounds__(256) void scatter_add_mod_kernel(const float* __res
 // here: (1) ONE workgroup sorts the composite keys (idx << 13 | i) of up to 8192 rows in LDS (bitonic network, 32 KiB); (2) one wave per
 // sorted position: the head of a run of equal destinations sums the run's rows in key order (= ascending i) and adds the total to the table.
 constexpr int SCATTER_SORT_MAX = 8192;
-__global__ __launch_bounds__(1024) void scatter_sort_keys_kernel(const int64_t* __restrict__ idx, int rows, uint32_t* __restrict__ keys_out) {
+__global__ __launch_bounds__(1024) void scatter_sort_keys_kernel(const int64_t* __restrict__ idx, int rows, int64_t dst_rows, uint32_t* __restrict__ keys_out) {
   __shared__ uint32_t k[SCATTER_SORT_MAX];
-  for (int i = threadIdx.x; i < SCATTER_SORT_MAX; i += 1024) k[i] = i < rows ? (((uint32_t)idx[i] << 13) | (uint32_t)i) : 0xFFFFFFFFu;
+  // An index outside [0, dst_rows) gets the padding key: its row is DROPPED (sorted behind every valid key, skipped by the run kernel).  Truncated
+  // into the 19-bit field it would have landed in somebody else's row -- or beyond the table (torch's index_put_ device-asserts there).
+  for (int i = threadIdx.x; i < SCATTER_SORT_MAX; i += 1024) {
+    const int64_t d = i < rows ? idx[i] : -1;
+    k[i] = (d >= 0 && d < dst_rows) ? (((uint32_t)d << 13) | (uint32_t)i) : 0xFFFFFFFFu;
+  }
   __syncthreads();
   for (int size = 2; size <= SCATTER_SORT_MAX; size <<= 1) {
     for (int stride = size >> 1; stride > 0; stride >>= 1) {
@@ -568,6 +573,7 @@ __global__ __launch_bounds__(256) void scatter_add_runs_kernel(const float* __re
   const int pos = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (pos >= rows) return;
   const uint32_t key = keys[pos];
+  if (key == 0xFFFFFFFFu) return;   // padding / an out-of-range index (dst_rows < 2^19: no valid key has this value)
   const uint32_t dest = key >> 13;
   if ((pos > 0 && (keys[pos - 1] >> 13) == dest) || (int64_t)dest == skip_idx) return;   // not the head of its run / the padding row (nn.Embedding(padding_idx))
   float acc[12];
@@ -774,9 +780,9 @@ extern "C" int alpro_scatter_add_rows_ordered(const float* src, const int64_t* i
                                               void* stream) {
   ALPRO_CHECK(src && idx && dst && keys_ws && rows > 0, "alpro_scatter_add_rows_ordered: bad args");
   ALPRO_CHECK(D == LN_D, "alpro_scatter_add_rows_ordered: D=%d unsupported", D);
-  ALPRO_CHECK(rows <= SCATTER_SORT_MAX && dst_rows > 0 && dst_rows <= (1 << 19), "alpro_scatter_add_rows_ordered: at most %d source rows and 2^19 table rows (got %d, %lld)",
+  ALPRO_CHECK(rows <= SCATTER_SORT_MAX && dst_rows > 0 && dst_rows < (1 << 19), "alpro_scatter_add_rows_ordered: at most %d source rows and fewer than 2^19 table rows (got %d, %lld)",
               SCATTER_SORT_MAX, rows, (long long)dst_rows);
-  hipLaunchKernelGGL(scatter_sort_keys_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, idx, rows, keys_ws);
+  hipLaunchKernelGGL(scatter_sort_keys_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, idx, rows, dst_rows, keys_ws);
   hipLaunchKernelGGL(scatter_add_runs_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, src, keys_ws, dst, rows, skip_idx);
   return check_launch("alpro_scatter_add_rows_ordered");
 }

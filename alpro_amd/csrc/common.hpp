@@ -235,7 +235,11 @@ __host__ __device__ inline uint32_t drop_thresh24(float p) { return (uint32_t)(p
 // the copies are tracked by hand with s_waitcnt vmcnt(N).  lds_addr: wave-uniform LDS byte address of the 1 KiB
 // piece; lane l's 16 bytes land at lds_addr + 16 l.
 __device__ __forceinline__ void dma16(const void* src, uint32_t lds_addr) {
+  // reserved-register site (the product is built with -Werror=inline-asm; this one is deliberate): global_load_lds takes its LDS address from m0; listing it as clobbered is what keeps the compiler from assuming a value of its own survives the statement (it writes m0 itself before each of its own uses: LDS-DMA builtins, s_movrel); the K-loop ISA tests of tests/test_host_cpu.py read the built object
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
   asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(lds_addr) : "memory", "m0");
+#pragma clang diagnostic pop
 }
 // 16-byte write-through store (sc1): the line leaves the XCD's L2 and lands memory-side.  Used for the attention outputs (read next by
 // the projection GEMM / the weight gradient): same speed as a non-temporal store for the attention kernel, ~0.3 % of the step for its
@@ -297,8 +301,10 @@ struct SchedLaunch {
   uint32_t* prev = nullptr;
   void* slot = nullptr;
   SchedLaunch(hipStream_t st, bool enabled);
+  void commit(bool launched);   // call once, right after the launch: advances the pair's parity only if the launch was accepted
   ~SchedLaunch();
 };
+int sched_set_workspace(hipStream_t st, void* ptr, size_t bytes);
 inline uint32_t magic_u32(uint32_t d) { return (uint32_t)(((1ull << 32) + d - 1) / d); }
 // Compute units the persistent GEMM grids and the weight-gradient range plan may count on (round 4): 256, or less while a collective's kernels
 // hold CUs (alpro_amd.dist sets "cu_budget" while the overlapped gradient exchange is in flight: a persistent one-workgroup-per-CU launch that

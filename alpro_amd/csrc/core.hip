@@ -79,19 +79,67 @@ int get_stream_option(int which, hipStream_t st) {
 }
 
 // ---- tile-scheduler blocks (common.hpp) ---------------------------------------------------------------------------------------------
+// Who owns the memory.  Each (device, stream) that launches the persistent 8-phase GEMM needs one PAIR of counter blocks (2 x 1056 bytes).
+//   * A caller that wants the library to allocate nothing registers its own: alpro_hip_set_sched_workspace(stream, ptr, bytes).
+//   * Otherwise the first such launch on a device makes ONE hipMalloc of kSchedSlots pairs (135 KB) for that device -- the only allocation
+//     this library ever makes -- and the stream's pair is cleared by a hipMemsetAsync ON THAT STREAM (ordered before the launch; no device-wide
+//     synchronisation, round 6).
+// A slot belongs to its (device, stream) until alpro_hip_release_stream(stream): a destroyed stream's handle value may be handed out again
+// by the runtime, so owners of short-lived streams release them (the re-created stream then starts from a cleared pair instead of
+// inheriting one).  With all kSchedSlots slots taken a further stream runs the static walk (same results, no CU-theft tolerance).
 namespace {
-constexpr int kSchedSlots = 64;   // (device, stream) pairs with a block pair of their own; further streams run the static walk
+constexpr int kSchedSlots = 64;
 struct SchedSlot {
   int dev;
   hipStream_t st;
   uint32_t* pair;   // 2 x SCHED_BLOCK_U32 dwords
-  unsigned n;
+  unsigned n;       // launches committed on this pair: launch n works on block n & 1 and zeroes the other
   int lock;
+  bool used, caller_owned;
 };
 SchedSlot g_sched[kSchedSlots];
-int g_nsched = 0, g_sched_table_lock = 0;
-uint32_t* g_sched_pool[64];   // per device: kSchedSlots pairs, allocated at the first persistent launch on the device (the one allocation this library makes)
-int g_sched_pool_used[64];
+int g_sched_table_lock = 0;
+uint32_t* g_sched_pool[64];   // per device: kSchedSlots pairs (slot i's pair is pool + i * pair size)
+constexpr size_t kPairBytes = (size_t)2 * SCHED_BLOCK_U32 * sizeof(uint32_t);
+struct TableGuard {
+  TableGuard() { while (__atomic_exchange_n(&g_sched_table_lock, 1, __ATOMIC_ACQUIRE)) {} }
+  ~TableGuard() { __atomic_store_n(&g_sched_table_lock, 0, __ATOMIC_RELEASE); }
+};
+SchedSlot* find_slot(int dev, hipStream_t st) {
+  for (int i = 0; i < kSchedSlots; ++i)
+    if (g_sched[i].used && g_sched[i].dev == dev && g_sched[i].st == st) return &g_sched[i];
+  return nullptr;
+}
+// a free slot for (dev, st) on `pair` (nullptr: the device pool's), cleared on the stream; nullptr when the table is full / the pool cannot be made
+SchedSlot* make_slot(int dev, hipStream_t st, uint32_t* pair) {
+  int at = -1;
+  for (int i = 0; i < kSchedSlots && at < 0; ++i)
+    if (!g_sched[i].used) at = i;
+  if (at < 0) return nullptr;
+  const bool own = pair != nullptr;
+  if (!own) {
+    if (!g_sched_pool[dev]) {
+      void* pmem = nullptr;
+      if (hipMalloc(&pmem, kSchedSlots * kPairBytes) == hipSuccess) g_sched_pool[dev] = (uint32_t*)pmem;
+      else (void)hipGetLastError();
+    }
+    if (!g_sched_pool[dev]) return nullptr;
+    pair = g_sched_pool[dev] + (size_t)at * 2 * SCHED_BLOCK_U32;
+  }
+  if (hipMemsetAsync(pair, 0, kPairBytes, st) != hipSuccess) {
+    (void)hipGetLastError();
+    return nullptr;
+  }
+  SchedSlot* s = &g_sched[at];
+  s->dev = dev;
+  s->st = st;
+  s->pair = pair;
+  s->n = 0;
+  s->lock = 0;
+  s->caller_owned = own;
+  s->used = true;
+  return s;
+}
 }  // namespace
 
 SchedLaunch::SchedLaunch(hipStream_t st, bool enabled) {
@@ -104,36 +152,42 @@ SchedLaunch::SchedLaunch(hipStream_t st, bool enabled) {
     return;
   }
   SchedSlot* s = nullptr;
-  while (__atomic_exchange_n(&g_sched_table_lock, 1, __ATOMIC_ACQUIRE)) {}
-  for (int i = 0; i < g_nsched; ++i)
-    if (g_sched[i].dev == dev && g_sched[i].st == st) s = &g_sched[i];
-  if (!s && g_nsched < kSchedSlots) {
-    if (!g_sched_pool[dev]) {
-      void* pmem = nullptr;
-      const size_t bytes = (size_t)kSchedSlots * 2 * SCHED_BLOCK_U32 * sizeof(uint32_t);
-      if (hipMalloc(&pmem, bytes) == hipSuccess && hipMemset(pmem, 0, bytes) == hipSuccess && hipDeviceSynchronize() == hipSuccess) g_sched_pool[dev] = (uint32_t*)pmem;
-      else (void)hipGetLastError();
-    }
-    if (g_sched_pool[dev] && g_sched_pool_used[dev] < kSchedSlots) {
-      s = &g_sched[g_nsched++];
-      s->dev = dev;
-      s->st = st;
-      s->pair = g_sched_pool[dev] + (size_t)g_sched_pool_used[dev]++ * 2 * SCHED_BLOCK_U32;
-      s->n = 0;
-      s->lock = 0;
-    }
+  {
+    TableGuard g;
+    s = find_slot(dev, st);
+    if (!s) s = make_slot(dev, st, nullptr);
   }
-  __atomic_store_n(&g_sched_table_lock, 0, __ATOMIC_RELEASE);
   if (!s) return;
   while (__atomic_exchange_n(&s->lock, 1, __ATOMIC_ACQUIRE)) {}
   slot = s;
   cur = s->pair + (size_t)(s->n & 1u) * SCHED_BLOCK_U32;
   prev = s->pair + (size_t)((s->n + 1u) & 1u) * SCHED_BLOCK_U32;
-  ++s->n;
+}
+
+// The pair's parity moves on only when the launch was accepted: a launch that failed at enqueue never ran, so `cur` is still
+// clear and `prev` still holds the previous launch's counts -- exactly what the next attempt expects.
+void SchedLaunch::commit(bool launched) {
+  if (slot && launched) ++((SchedSlot*)slot)->n;
 }
 
 SchedLaunch::~SchedLaunch() {
   if (slot) __atomic_store_n(&((SchedSlot*)slot)->lock, 0, __ATOMIC_RELEASE);
+}
+
+int sched_set_workspace(hipStream_t st, void* ptr, size_t bytes) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) { set_error("alpro_hip_set_sched_workspace: no current device"); return ALPRO_ERR_INVALID; }
+  TableGuard g;
+  SchedSlot* s = find_slot(dev, st);
+  if (s) {   // (the stream's launches so far are ordered before the clear make_slot() issues on it)
+    while (__atomic_exchange_n(&s->lock, 1, __ATOMIC_ACQUIRE)) {}
+    s->used = false;
+    __atomic_store_n(&s->lock, 0, __ATOMIC_RELEASE);
+  }
+  if (!ptr) return ALPRO_OK;
+  if (bytes < kPairBytes || ((uintptr_t)ptr % 16) != 0) { set_error("alpro_hip_set_sched_workspace: needs %zu bytes, 16-byte aligned (got %zu)", kPairBytes, bytes); return ALPRO_ERR_INVALID; }
+  if (!make_slot(dev, st, (uint32_t*)ptr)) { set_error("alpro_hip_set_sched_workspace: all %d (device, stream) slots are taken: release a stream first", kSchedSlots); return ALPRO_ERR_INVALID; }
+  return ALPRO_OK;
 }
 
 int check_launch(const char* what) {
@@ -610,6 +664,26 @@ extern "C" int alpro_hip_set_stream_option(void* stream, const char* name, int v
   }
   g_sopts[at].value = value;
   return ALPRO_OK;
+}
+
+extern "C" size_t alpro_hip_sched_workspace_bytes(void) { return (size_t)2 * alpro::SCHED_BLOCK_U32 * sizeof(uint32_t); }
+
+extern "C" int alpro_hip_set_sched_workspace(void* stream, void* ptr, size_t bytes) { return alpro::sched_set_workspace((hipStream_t)stream, ptr, bytes); }
+
+extern "C" int alpro_hip_release_stream(void* stream) {
+  using namespace alpro;
+  {   // every per-stream option override of that stream
+    SpinGuard g;
+    for (int i = 0; i < g_nsopts;) {
+      if (g_sopts[i].st == (hipStream_t)stream) {
+        g_sopts[i] = g_sopts[g_nsopts - 1];
+        __atomic_store_n(&g_nsopts, g_nsopts - 1, __ATOMIC_RELAXED);
+      } else {
+        ++i;
+      }
+    }
+  }
+  return sched_set_workspace((hipStream_t)stream, nullptr, 0);   // ... and its tile-scheduler slot (a caller-owned workspace is simply forgotten)
 }
 
 extern "C" int alpro_cast_from_f32(const float* src, void* dst, int dtype, int64_t n, void* stream) {

@@ -39,11 +39,26 @@ def rccl_cu_reserve():
     return max(0, min(64, int(os.environ.get("ALPRO_RCCL_CU_RESERVE", "16"))))
 
 
+def _single_node():
+    """True only when the launcher SAYS every rank is on this node: torchrun's LOCAL_WORLD_SIZE, Open MPI's OMPI_COMM_WORLD_LOCAL_SIZE or
+    Slurm's SLURM_NTASKS_PER_NODE / SLURM_NNODES equal to the world size.  Unknown (a launcher that sets none of them) counts as NOT single
+    node: the channel cap below is a single-node xGMI policy and would throttle an inter-node ring."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    for var in ("LOCAL_WORLD_SIZE", "OMPI_COMM_WORLD_LOCAL_SIZE", "MV2_COMM_WORLD_LOCAL_SIZE"):
+        if os.environ.get(var, "").isdigit():
+            return int(os.environ[var]) == world
+    if os.environ.get("SLURM_NNODES", "").isdigit():
+        return int(os.environ["SLURM_NNODES"]) == 1
+    if os.environ.get("SLURM_NTASKS_PER_NODE", "").isdigit():
+        return int(os.environ["SLURM_NTASKS_PER_NODE"]) == world
+    return False
+
+
 def init(backend=None):
     """Initialise from the torchrun-style environment; no-op when WORLD_SIZE is unset or 1 (unless ALPRO_FORCE_COLLECTIVES=1)."""
     if is_initialized() or (int(os.environ.get("WORLD_SIZE", "1")) <= 1 and not _FORCE[0]):
         return
-    single_node = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1"))) == int(os.environ.get("WORLD_SIZE", "1"))
+    single_node = _single_node()
     if rccl_cu_reserve() > 0 and os.environ.get("ALPRO_OVERLAP_BACKWARD", "1") != "0" and single_node and "NCCL_MAX_NCHANNELS" not in os.environ:
         # one channel = one resident workgroup = one CU.  Only for the measured configuration (one node, xGMI ring, the overlapped exchange);
         # multi-node jobs and users who set the variable themselves keep RCCL's own choice (ADVICE r4)

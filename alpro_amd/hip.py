@@ -23,7 +23,8 @@ _CODE = {v: k for k, v in _TORCH_DTYPE.items()}
 EXPORTS = ["alpro_hip_last_error", "alpro_hip_abi_version", "alpro_hip_set_option", "alpro_hip_set_stream_option", "alpro_gemm", "alpro_gemm_c2_tiled_rows", "alpro_layernorm_fwd",
            "alpro_attn_temporal_fwd", "alpro_attn_fwd", "alpro_patchify", "alpro_cls_mean_residual",
            "alpro_vit_final_pool", "alpro_bert_embed_fwd", "alpro_cast_from_f32", "alpro_attn_bwd", "alpro_attn_temporal_bwd",
-           "alpro_layernorm_bwd", "alpro_transpose", "alpro_transpose_batch", "alpro_gelu_bwd", "alpro_cls_mean_bwd", "alpro_scatter_add_rows", "alpro_gather_cast", "alpro_sumsq", "alpro_adamw_step", "alpro_gemm_tn_acc", "alpro_gemm_tn_acc_ws", "alpro_gemm_tn_workspace_bytes", "alpro_gemm_tn_ranges", "alpro_colsum_acc", "alpro_softmax_xent", "alpro_vtc_loss_fwd", "alpro_vtc_loss_bwd", "alpro_prepare_clips", "alpro_loss_scale_update", "alpro_add_layernorm_fwd", "alpro_layernorm_bwd_emit", "alpro_gemm_batch", "alpro_tproj_small", "alpro_attn_cls_fwd", "alpro_gemm_rows_f32", "alpro_gather_seq_fwd", "alpro_gather_seq_bwd", "alpro_scatter_add_rows_ordered"]
+           "alpro_layernorm_bwd", "alpro_transpose", "alpro_transpose_batch", "alpro_gelu_bwd", "alpro_cls_mean_bwd", "alpro_scatter_add_rows", "alpro_gather_cast", "alpro_sumsq", "alpro_adamw_step", "alpro_gemm_tn_acc", "alpro_gemm_tn_acc_ws", "alpro_gemm_tn_workspace_bytes", "alpro_gemm_tn_ranges", "alpro_colsum_acc", "alpro_softmax_xent", "alpro_vtc_loss_fwd", "alpro_vtc_loss_bwd", "alpro_prepare_clips", "alpro_loss_scale_update", "alpro_add_layernorm_fwd", "alpro_layernorm_bwd_emit", "alpro_gemm_batch", "alpro_tproj_small", "alpro_attn_cls_fwd", "alpro_gemm_rows_f32", "alpro_gather_seq_fwd", "alpro_gather_seq_bwd", "alpro_scatter_add_rows_ordered",
+           "alpro_hip_sched_workspace_bytes", "alpro_hip_set_sched_workspace", "alpro_hip_release_stream"]
 
 
 class GemmDesc(ctypes.Structure):
@@ -51,7 +52,7 @@ class TransposeJob(ctypes.Structure):
                 ("R", ctypes.c_int32), ("C", ctypes.c_int32), ("Rpad", ctypes.c_int32), ("tile0", ctypes.c_int32)]   # 48 bytes
 
 
-ABI_VERSION = 18
+ABI_VERSION = 19
 _lib = None
 
 
@@ -108,6 +109,9 @@ def load():
     lib.alpro_cast_from_f32.argtypes = [vp, vp, i32, i64, vp]
     lib.alpro_hip_set_option.argtypes = [ctypes.c_char_p, i32]
     lib.alpro_hip_set_stream_option.argtypes = [vp, ctypes.c_char_p, i32]
+    lib.alpro_hip_sched_workspace_bytes.restype = ctypes.c_size_t
+    lib.alpro_hip_set_sched_workspace.argtypes = [vp, vp, ctypes.c_size_t]
+    lib.alpro_hip_release_stream.argtypes = [vp]
     lib.alpro_scatter_add_rows_ordered.argtypes = [vp, vp, vp, i32, i32, i64, i64, vp, vp]
     lib.alpro_gather_seq_fwd.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]
     lib.alpro_gather_seq_bwd.argtypes = [vp, vp, i32, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]
@@ -142,6 +146,41 @@ def set_stream_option(name, value, stream=None):
     h = stream if stream is not None else (_stream() if torch.cuda.is_available() else ctypes.c_void_p(0))   # (CPU-only boxes: gloo tests of the exchange logic)
     _check(load().alpro_hip_set_stream_option(h, name.encode(), int(value)), "alpro_hip_set_stream_option")
     return h
+
+
+def _stream_handle(stream):
+    if stream is None:
+        return _stream()
+    return ctypes.c_void_p(stream.cuda_stream) if isinstance(stream, torch.cuda.Stream) else stream
+
+
+_sched_ws = {}   # (device index, raw stream handle) -> the tensor that backs the stream's tile-scheduler blocks (kept alive here)
+
+
+def set_sched_workspace(stream=None, tensor=None):
+    """alpro_hip_set_sched_workspace: give the persistent GEMM's tile scheduler on `stream` (a torch.cuda.Stream, a raw handle, default: the
+    current stream) its two counter blocks from CALLER memory -- with that the library allocates nothing, ever (otherwise the first persistent
+    launch on a device makes one 135 KB hipMalloc for all its streams; include/alpro_hip.h).  `tensor`: any CUDA tensor of at least
+    sched_workspace_bytes() bytes; default: a fresh one, kept alive here until release_stream().  The library clears it on the stream."""
+    lib = load()
+    h = _stream_handle(stream)
+    need = int(lib.alpro_hip_sched_workspace_bytes())
+    if tensor is None:
+        tensor = torch.empty(need, dtype=torch.uint8, device="cuda")
+    if not tensor.is_cuda or tensor.numel() * tensor.element_size() < need or not tensor.is_contiguous():
+        raise ValueError("set_sched_workspace: a contiguous CUDA tensor of >= %d bytes" % need)
+    _check(lib.alpro_hip_set_sched_workspace(h, ctypes.c_void_p(tensor.data_ptr()), tensor.numel() * tensor.element_size()), "alpro_hip_set_sched_workspace")
+    _sched_ws[(tensor.device.index, h.value)] = tensor
+    return tensor
+
+
+def release_stream(stream=None):
+    """alpro_hip_release_stream: forget everything the library keeps for `stream` on the current device -- its tile-scheduler slot (64 per
+    process) and its option overrides.  Call it for a stream that is idle and about to be destroyed: the runtime may hand the same handle
+    value to a later stream, which must not inherit the slot."""
+    h = _stream_handle(stream)
+    _check(load().alpro_hip_release_stream(h), "alpro_hip_release_stream")
+    _sched_ws.pop((torch.cuda.current_device() if torch.cuda.is_available() else 0, h.value), None)
 
 
 def get_option(name):
@@ -458,7 +497,7 @@ def scatter_add_rows(src, idx, dst, idx_mod=0, skip_idx=-1):
     _dev(src, torch.float32); _dev(dst, torch.float32)
     if idx is not None and _DETERMINISTIC[0]:
         idx = _dev(idx, torch.int64).view(-1)
-        if src.shape[0] <= 8192 and dst.shape[0] <= (1 << 19) and src.is_contiguous() and dst.is_contiguous():
+        if src.shape[0] <= 8192 and dst.shape[0] < (1 << 19) and src.is_contiguous() and dst.is_contiguous():
             # round 5: the library's own ordered scatter (keys sorted in LDS by one workgroup, one writer per destination row, ascending source order)
             ws = _SCATTER_KEYS.get(src.device)
             if ws is None:

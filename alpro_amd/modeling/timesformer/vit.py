@@ -858,6 +858,13 @@ class TimeSformer(nn.Module):
         self.drop_rate = model_cfg['drop_rate']
         self.use_pooling = model_cfg['use_maxpooling']
         self.use_grad_ckpt = model_cfg['gradient_checkpointing']
+        if self.use_grad_ckpt:
+            # config_release/timesformer_divst_8x32_224_k600_gc.json:9.  The reference re-runs each Block in backward to fit 16-40 GB devices
+            # (vit.py:366-370); this build keeps every activation a step needs (64 GB at B = 64 x 8 frames of the 288 GB) and never recomputes:
+            # the flag is accepted for config compatibility and has NO effect -- said once, not silently
+            import warnings
+            warnings.warn("alpro_amd: gradient_checkpointing=true is accepted and ignored -- activations are kept in HBM (288 GB per MI355X; "
+                          "B=64 x 8 frames peaks at 64 GB), no block is recomputed in backward", RuntimeWarning, stacklevel=2)
         self.attention_type = 'divided_space_time'
         self.num_classes = 400
         self.input_format = input_format

@@ -103,6 +103,16 @@ class FlatAdamW:
         self.flat = None  # built at the first step(), when we know which parameters actually receive gradients
         self.last_grad_norm = None
         self._pre_synced = None  # "sum" / "avg": synchronize() already ran for this step (hvd-style drivers call it themselves)
+        # ... and that only holds while nothing has written a gradient since: the reference's drivers call optimizer.synchronize() after
+        # EVERY micro-step of a gradient-accumulation window (run_pretrain_sparse.py:596-601 with gradient_accumulation_steps = 2 in
+        # config_release/msrvtt_qa.json, msvd_qa.json, pretrain_prompter.json), and each of those calls has to exchange what the backward
+        # before it added.  _writes counts "gradients may have been written" events (autograd's accumulation hooks, the
+        # hand-written backward passes' grads_final reports, backward(), amp.scale_loss); the stamp is (_writes, BACKWARD_EPOCH) at sync time.
+        self._writes = 0
+        self._sync_stamp = None
+        if hasattr(torch.Tensor, "register_post_accumulate_grad_hook"):
+            for p in self.params:   # from construction on (not from _build() on): the first step's micro-steps run before the flat buffers exist
+                p.register_post_accumulate_grad_hook(self._mark_dirty)
         # fp16 operands: dynamic loss scaling (alpro_amd/amp.py).  `scaler` is attached here when the compute dtype already is fp16 (so
         # that forward-time gradient producers -- the LM head -- see the scale), else by the first backward() / amp.scale_loss().
         self.scaler = None
@@ -144,10 +154,8 @@ class FlatAdamW:
         self._span = {id(p): (o, o + (p.numel() + 3) // 4 * 4) for p, o in zip(live, offs)}
         # "step() left the gradient buffer zeroed" (fused_zero_grad) holds until something writes a gradient: the hand-written backward passes
         # announce themselves (train.BACKWARD_EPOCH), torch's own accumulation (heads, temperature: a handful of tensors) through this hook --
-        # a driver that calls scaled_loss.backward() itself and then discards the step with zero_grad() must get a real clear
-        if hasattr(torch.Tensor, "register_post_accumulate_grad_hook"):
-            for p in live:
-                p.register_post_accumulate_grad_hook(self._mark_dirty)
+        # a driver that calls scaled_loss.backward() itself and then discards the step with zero_grad() must get a real clear;
+        # the hooks are registered by the constructor
         if self.allreduce and self.overlap_backward and dist.collectives_active():
             dist.register_grads_final_hook(self._on_grads_final)
         if self._pending_state is not None:
@@ -157,6 +165,18 @@ class FlatAdamW:
 
     def _mark_dirty(self, _p=None):
         self._g_clean = False
+        self._writes += 1
+
+    def _stamp(self):
+        return (self._writes, _backward_epoch())
+
+    def _note_synced(self, kind):
+        """kind: "sum" / "avg" (the gradients as they stand are exchanged) or None."""
+        self._pre_synced = kind
+        self._sync_stamp = self._stamp() if kind is not None else None
+
+    def _sync_is_current(self):
+        return self._pre_synced is not None and self._sync_stamp == self._stamp()
 
     def _layout(self):
         """[(index of the parameter in the constructor's list, flat offset, numel)]: what the m / v buffers mean."""
@@ -186,6 +206,7 @@ class FlatAdamW:
             h.wait()
         self._inflight, self._reduced = [], []
         self._reserve_cus(False)
+        self._note_synced(None)
         if self.flat is None:
             for p in self.params:
                 p.grad = None
@@ -242,6 +263,7 @@ class FlatAdamW:
         self._reduced.append((s, e))
 
     def _on_grads_final(self, params=None, all_but=None):
+        self._writes += 1
         self._g_clean = False   # gradients are being written (a driver's own scaled_loss.backward() does not pass through backward(): ADVICE r4)
         if self.flat is None or not self.allreduce or not dist.collectives_active():
             return
@@ -275,12 +297,12 @@ class FlatAdamW:
         average=True (the hvd.DistributedOptimizer.synchronize() contract: callers clip the AVERAGED gradients before
         step()) divides in place instead and makes the next step() skip both its own exchange and the scaling."""
         if not self.allreduce or not dist.collectives_active():
-            self._pre_synced = "avg" if average else None
+            self._note_synced("avg" if average else None)
             return 0
-        if self._pre_synced is not None:
-            # the exchange of this step already happened -- amp.unscale_ finished an overlapped exchange that was still in flight ("sum"), or
-            # the caller synchronised twice (a facade that lost track: ADVICE r4).  A second all-reduce would multiply the gradients by
-            # world once more; only the averaging may still be owed.
+        if self._sync_is_current() and not self._inflight:
+            # the exchange of the gradients AS THEY STAND already happened -- amp.unscale_ finished an overlapped exchange that was still in
+            # flight ("sum"), or the caller synchronised twice without a backward in between (a facade that lost track: ADVICE r4).  A second
+            # all-reduce would multiply the gradients by world once more; only the averaging may still be owed.
             if average and self._pre_synced == "sum":
                 if self.flat is not None:
                     self.flat["g"].div_(dist.size())
@@ -288,21 +310,32 @@ class FlatAdamW:
                     for p in self.params:
                         if real_grad(p) is not None:
                             p.grad.div_(dist.size())
-                self._pre_synced = "avg"
+                self._note_synced("avg")
             return 0
+        if self._pre_synced == "sum":
+            # a backward has accumulated LOCAL gradients on top of an exchanged SUM: sum1 + g2_local cannot be turned into sum1 + sum2 by
+            # any collective (an all-reduce gives world * sum1 + sum2).  On top of an exchanged AVERAGE it can (below) -- that is the
+            # reference's gradient-accumulation pattern, every micro-step followed by the facade's synchronize(average=True)
+            raise RuntimeError("FlatAdamW.synchronize: gradients were accumulated on top of an already exchanged SUM; with several backward "
+                               "passes per step call synchronize(average=True) after each of them (hvd.DistributedOptimizer.synchronize does) "
+                               "or only once before step()")
+        # _pre_synced == "avg" with newer gradients on top (micro-step k of an accumulation window: the buffer holds avg_1 + .. + avg_(k-1)
+        # + g_k local): every rank holds the same averaged part, so the all-reduce returns world * (avg_1 + ..) + sum_k = sum_1 + .. + sum_k,
+        # the plain SUM again -- and the average after the division, exactly what Horovod's repeated averaging all-reduce leaves behind
         if self.flat is None:  # first step: gradients are still separate tensors
             dist.allreduce_grads_(self.params, average=average)
-            self._pre_synced = "avg" if average else "sum"
+            self._note_synced("avg" if average else "sum")
             return 0
         g, n = self.flat["g"], self.flat["n"]
         self._finish_exchange()
         if average:
             g.div_(dist.size())
-        self._pre_synced = "avg" if average else "sum"
+        self._note_synced("avg" if average else "sum")
         return n * 4
 
     def backward(self, loss):
         self._g_clean = False
+        self._writes += 1
         return self._backward(loss)
 
     def _backward(self, loss):
@@ -318,7 +351,11 @@ class FlatAdamW:
             (loss * sc.scale.reshape(())).backward()
 
     def step(self, closure=None):
-        pre, self._pre_synced = self._pre_synced, None
+        if self._pre_synced is not None and not (self._sync_is_current() and not self._inflight) and self.allreduce and dist.collectives_active():
+            # gradients were written after the last synchronize() (an accumulation micro-step that was not followed by one): exchange them now
+            self.synchronize(average=self._pre_synced == "avg")
+        pre = self._pre_synced
+        self._note_synced(None)
         if self.flat is None and not self._build():
             # no parameter has a gradient yet: a no-op like torch.optim (the reference calls optimizer.step() once before the
             # first backward, run_pretrain_sparse.py:508-511)
@@ -329,7 +366,7 @@ class FlatAdamW:
             raise RuntimeError("%d parameters started receiving gradients after the flat buffers were built" % len(late))
         if pre is None:
             self.synchronize()
-            self._pre_synced = None
+            self._note_synced(None)
         world = dist.size() if (self.allreduce and pre != "avg") else 1
         if self.scaler is not None and getattr(self, "_scaler_steps_synced", None) is not self.scaler:
             # a loss scaler attached after some plain steps, or after load_state_dict(): the DEVICE step counter that drives Adam's bias

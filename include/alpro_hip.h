@@ -1,8 +1,12 @@
 /*
  * alpro_hip.h -- C ABI of libalpro_hip.so: the MI355X (gfx950) kernels behind ALPRO's
  * video-text hot path.  Plain pointers and sizes only; every pointer is a DEVICE pointer owned
- * by the caller (torch allocates), `stream` is a hipStream_t passed as void*, nothing is
- * allocated internally, every entry point is asynchronous on `stream` and re-entrant.
+ * by the caller (torch allocates), `stream` is a hipStream_t passed as void*, every entry point
+ * is asynchronous on `stream` (no device- or stream-wide synchronisation anywhere) and re-entrant.
+ * Workspaces are caller-provided.  State the library keeps: the option table, and per (device,
+ * stream) that launches the persistent GEMM a pair of tile-scheduler counter blocks -- from the
+ * caller (alpro_hip_set_sched_workspace) or, by default, from ONE lazily made hipMalloc of 135 KB
+ * per device (the only allocation this library makes; see alpro_hip_set_sched_workspace below).
  * Return value: 0 = ok, nonzero = error (text via alpro_hip_last_error()).
  *
  * The reference (salesforce/ALPRO) is pure Python: the "FFI" these entry points replace is the
@@ -25,7 +29,7 @@
 extern "C" {
 #endif
 
-#define ALPRO_HIP_ABI_VERSION 18
+#define ALPRO_HIP_ABI_VERSION 19
 
 enum { ALPRO_OK = 0, ALPRO_ERR_INVALID = 1, ALPRO_ERR_LAUNCH = 2 };
 enum { ALPRO_F32 = 0, ALPRO_BF16 = 1, ALPRO_F16 = 2 };
@@ -62,6 +66,21 @@ int alpro_hip_set_option(const char* name, int value);
  * on while the overlapped gradient exchange is in flight, run_pretrain_sparse.py:432,601); "gemm_sched" (1 = the persistent NT GEMM takes
  * its tiles from per-XCD ticket counters, 0 = the static round-robin walk) is a process-wide A/B knob.  No reference counterpart. */
 int alpro_hip_set_stream_option(void* stream, const char* name, int value);
+/* Round 6: who owns the tile scheduler's memory (no reference counterpart: ATen's allocator owns everything there).  The persistent 8-phase GEMM
+ * keeps two counter blocks per (device, stream) -- launch n draws its tile tickets from block n & 1 and clears the other.
+ *   alpro_hip_sched_workspace_bytes()            size of one such pair (2112 bytes).
+ *   alpro_hip_set_sched_workspace(stream, p, n)  use the caller's device memory p (n >= that size, 16-byte aligned, alive until the stream is
+ *                                                released) for launches on `stream` of the current device; cleared by a memset ON the stream.
+ *                                                p == NULL is alpro_hip_release_stream.  A process that registers a workspace for every stream
+ *                                                it launches GEMMs on makes the library allocation-free.
+ *   alpro_hip_release_stream(stream)             drop the stream's slot (64 per process; a further stream runs the static tile walk: same
+ *                                                results, no tolerance to CU theft) and its option overrides.  For a stream that is idle and
+ *                                                about to be destroyed: the runtime may give a later stream the same handle value.
+ * Without a registered workspace the first persistent launch on a device makes one hipMalloc of 64 pairs (135 KB) and clears the launching
+ * stream's pair with hipMemsetAsync on that stream -- no hipDeviceSynchronize (rounds 1-5 had one there). */
+size_t alpro_hip_sched_workspace_bytes(void);
+int alpro_hip_set_sched_workspace(void* stream, void* ptr, size_t bytes);
+int alpro_hip_release_stream(void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * C[map(m), n] = residual[map(m), n] + row_scale[m / row_scale_group] * act(alpha * sum_k A[m,k] W[n,k] + bias[n])
@@ -331,8 +350,9 @@ int alpro_cls_mean_bwd(const float* dx_out, int64_t ld_batch, float* dside, int 
  * With idx: fp32 atomics, the duplicates' order varies run to run (the reproducible caller sorts: alpro_amd/hip.py scatter_add_rows). */
 int alpro_scatter_add_rows(const float* src, const int64_t* idx, float* dst, int rows, int idx_mod, int D, int64_t skip_idx, void* stream);
 /* Round 5: the indexed form in a FIXED order without torch's sort-based index_put_: dst[idx[i], :] += src[i, :], duplicates added in ascending
- * i, one writer per destination row (idx values in [0, dst_rows), dst_rows <= 2^19; rows <= 8192: the keys are sorted by one workgroup in
- * LDS).  keys_ws: 8192 uint32 of scratch.  Rows with idx == skip_idx are dropped (-1 = none). */
+ * i, one writer per destination row (dst_rows < 2^19; rows <= 8192: the keys are sorted by one workgroup in LDS).  keys_ws: 8192 uint32 of
+ * scratch.  Rows with idx == skip_idx are dropped (-1 = none), and so are rows whose idx lies outside [0, dst_rows): nothing is ever
+ * written outside the table (torch's index_put_, which this replaces, device-asserts on such an index). */
 int alpro_scatter_add_rows_ordered(const float* src, const int64_t* idx, float* dst, int rows, int D, int64_t dst_rows, int64_t skip_idx, uint32_t* keys_ws,
                                    void* stream);
 

@@ -59,37 +59,41 @@ FULL_SIZE_BACKWARD_LIMITS = dict(grad_l2_rel_err_worst=1e-2, grad_l2_rel_err_med
                                  grad_cosine_worst=0.9999, grad_cosine_median=0.99998, global_grad_cosine=0.99999, global_grad_norm_rel_err=5e-4, loss_abs_err=1e-3)
 
 
-def full_size_backward_parity(bert_cfg, venc, make_cfg, device, dtype="fp16", cls_precise="auto", B=64, T=8, seed=4, loss_scale=65536.0):
+def full_size_backward_parity(bert_cfg, venc, make_cfg, device, dtype="fp16", cls_precise="auto", B=64, T=8, seed=4, loss_scale=65536.0, model="pretrain"):
     """Parity of the BACKWARD at the benchmarked size.  No golden vectors exist there; the exact fp32 HIP mode -- pinned to
     the reference's gradients at <= 2e-3 on the fixtures (tests/test_model_parity.py) -- is the oracle.  One training step's forward + backward
     of AlproForPretrain (VTC + VTM + MLM + MPM; B pairs x T frames x 224^2 + 40 tokens; train mode with drop-path and dropout at 0 so that both
     modes differentiate the same function; the hard negatives of the exact run are re-used) in the exact mode and in `dtype` (fp16: a loss-scaled
     backward at 2^16, like the timed steps; run_pretrain_sparse.py:557,595-601), then per parameter tensor:
         norm_rel = | |g| - |g_exact| | / |g_exact|,   cos = <g, g_exact> / (|g| |g_exact|),   l2_rel = |g - g_exact| / |g_exact|
-    -> dict with worst / median of each over all tensors that receive a gradient, the worst tensors' names and the four losses' errors."""
+    -> dict with worst / median of each over all tensors that receive a gradient, the worst tensors' names and the four losses' errors.
+    model="retrieval" (round 6): the FINETUNE step of BASELINE configs[4] instead -- AlproForVideoTextRetrieval, loss = itm_loss +
+    itc_loss (run_video_retrieval.py:432-434), at config_release/msrvtt_ret.json's geometry when called with B = 8, T = 8 (num_frm 8,
+    train_batch_size 8, max_txt_len 40)."""
     import bench
     from alpro_amd import amp, config as rt
-    from alpro_amd.modeling.alpro_models import AlproForPretrain
+    from alpro_amd.modeling.alpro_models import AlproBaseModel, AlproForPretrain, AlproForVideoTextRetrieval
     torch.manual_seed(seed)
     cfg = make_cfg(dict(bert_cfg, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0))
-    m = AlproForPretrain(cfg, dict(venc, num_frm=T, drop_path_rate=0.0)).to(device).train()
+    Model = AlproForPretrain if model == "pretrain" else AlproForVideoTextRetrieval
+    m = Model(cfg, dict(venc, num_frm=T, drop_path_rate=0.0)).to(device).train()
     with torch.no_grad():   # TimeSformer zero-initialises temporal_fc of blocks 1..11 (vit.py:306-315): the temporal halves would get exactly-zero gradients
         for blk in m.visual_encoder.model.blocks:
             torch.nn.init.normal_(blk.temporal_fc.weight, std=0.02)
-    batch = bench.synth_batch(B, T, device, seed=11, full=True)
+    batch = bench.synth_batch(B, T, device, seed=11, full=model == "pretrain")
     batch["text_input_mask"] = batch["text_input_mask"].clone()
     batch["text_input_mask"][::3, 31:] = 0
     negs = {}
-    orig_neg, orig_mn = AlproForPretrain._sample_negatives, torch.multinomial
+    orig_neg, orig_mn = AlproBaseModel.__dict__["_sample_negatives"], torch.multinomial   # (the staticmethod object of the shared base class)
 
     def record(sim_v2t, sim_t2v, bs):
         if "n" not in negs:
-            negs["n"] = orig_neg(sim_v2t, sim_t2v, bs)
+            negs["n"] = orig_neg.__func__(sim_v2t, sim_t2v, bs)
         return negs["n"]
-    AlproForPretrain._sample_negatives = staticmethod(record)
+    AlproBaseModel._sample_negatives = staticmethod(record)
     torch.multinomial = lambda w, n=1, *a, **k: w.argmax(dim=-1, keepdim=True)
     prev_armed = rt._armed[0]
-    keys = ("mlm_loss", "itm_loss", "itc_loss", "mpm_loss")
+    keys = ("mlm_loss", "itm_loss", "itc_loss", "mpm_loss") if model == "pretrain" else ("itm_loss", "itc_loss")
 
     used_cls = {}
 
@@ -103,7 +107,7 @@ def full_size_backward_parity(bert_cfg, venc, make_cfg, device, dtype="fp16", cl
                 sc, scale = amp.LossScaler(init_scale=loss_scale, dynamic=False, device=device), loss_scale
             rt.set_armed_loss_scaler(sc)
             out = m(batch)
-            loss = out["mlm_loss"] + out["itm_loss"] + out["itc_loss"] + out["mpm_loss"]
+            loss = sum(out[k] for k in keys)
             if sc is not None:
                 with rt.loss_scaling(sc):
                     (loss * sc.scale.reshape(())).backward()
@@ -115,7 +119,7 @@ def full_size_backward_parity(bert_cfg, venc, make_cfg, device, dtype="fp16", cl
         l32, g32 = run("fp32", "auto")
         l16, g16 = run(dtype, cls_precise)
     finally:
-        AlproForPretrain._sample_negatives = orig_neg
+        AlproBaseModel._sample_negatives = orig_neg
         torch.multinomial = orig_mn
         rt._armed[0] = prev_armed
     assert set(g16) == set(g32), sorted(set(g16) ^ set(g32))[:5]
@@ -145,3 +149,43 @@ def full_size_backward_parity(bert_cfg, venc, make_cfg, device, dtype="fp16", cl
     del m, g32, g16, gt
     torch.cuda.empty_cache()
     return rep
+
+
+def sampler_property_check(device, world, rank, draws, monkeypatch):
+    """The un-patched hard-negative sampler (alpro_amd/modeling/alpro_models.py::_sample_negatives) against the reference's semantics
+    (alpro_models.py:287-313): own-rank block, never the positive, frequencies ~ softmax of the similarities.  Used by the GPU test
+    (tests/test_model_parity.py) and, on the CPU, by tests/test_host_cpu.py."""
+    from alpro_amd import dist
+    from alpro_amd.modeling.alpro_models import AlproBaseModel
+    bs = 16
+    g = torch.Generator(device="cpu").manual_seed(5 + world)
+    sim_v2t = (torch.randn(bs, bs * world, generator=g) * 2.0).to(device)
+    sim_t2v = (torch.randn(bs, bs * world, generator=g) * 2.0).to(device)
+    monkeypatch.setattr(dist, "local_rank", lambda: rank)
+    torch.manual_seed(1234)
+    v0, t0 = sim_v2t.clone(), sim_t2v.clone()
+    cnt_v = torch.zeros(bs, bs, dtype=torch.long, device=device)
+    cnt_t = torch.zeros(bs, bs, dtype=torch.long, device=device)
+    rows = torch.arange(bs, device=device)
+    for _ in range(draws):
+        neg_video, neg_text = AlproBaseModel._sample_negatives(sim_v2t, sim_t2v, bs)
+        assert neg_video.shape == (bs,) and neg_text.shape == (bs,) and neg_video.dtype == torch.long
+        cnt_v[rows, neg_video] += 1       # a negative video for each text: drawn from sim_t2v's own-rank block
+        cnt_t[rows, neg_text] += 1
+    assert torch.equal(sim_v2t, v0) and torch.equal(sim_t2v, t0), "the sampler must not write into the similarity matrices (the loss still needs them)"
+    for cnt, sim, what in ((cnt_v, sim_t2v, "negative video per text"), (cnt_t, sim_v2t, "negative text per video")):
+        assert int(cnt.diagonal().sum()) == 0, "%s: the positive was drawn" % what
+        assert int(cnt.sum()) == bs * draws and int(cnt.min()) >= 0
+        w = sim[:, bs * rank:bs * (rank + 1)].double().clone()
+        w.fill_diagonal_(-float("inf"))
+        pr = torch.softmax(w, dim=1)
+        freq = cnt.double() / draws
+        sigma = (pr * (1 - pr) / draws).sqrt()
+        z = ((freq - pr).abs() / sigma.clamp_min(1e-9))
+        z[pr == 0] = 0.0
+        assert float(z.max()) < 4.0, "%s: a frequency is %.1f sigma from its softmax weight" % (what, float(z.max()))
+        # the other rank's block is never a candidate: with world 2 the weights of the wrong block would give a different table
+        if world == 2:
+            other = sim[:, bs * (1 - rank):bs * (2 - rank)].double().clone()
+            other.fill_diagonal_(-float("inf"))
+            assert float(((freq - torch.softmax(other, dim=1)).abs() / sigma.clamp_min(1e-9)).max()) > 8.0

@@ -108,7 +108,69 @@ def _worker(rank, world, port, out):
     dist.barrier()
     _hvd_facade_checks(rank, world)
     _amp_without_synchronize_checks(rank, world)
+    _gradient_accumulation_checks(rank, world)
     out.put((rank, "ok"))
+
+
+def _gradient_accumulation_checks(rank, world):
+    """ADVICE r5 (high): the unmodified drivers call optimizer.synchronize() after EVERY micro-step (run_pretrain_sparse.py:596-601;
+    gradient_accumulation_steps = 2 in config_release/msrvtt_qa.json, msvd_qa.json, pretrain_prompter.json).  Each call has to exchange what
+    the backward before it added: after two micro-steps every rank must hold avg(g1) + avg(g2), with nothing left in flight -- before the flat
+    buffers exist (first step: separate gradient tensors), after (_build), and with ranges launched from inside backward (overlap)."""
+    import alpro_amd.compat
+    if alpro_amd.compat.PATH not in sys.path:
+        sys.path.insert(0, alpro_amd.compat.PATH)
+    from horovod import torch as hvd
+    from alpro_amd import dist, hip
+    from alpro_amd.optim import FlatAdamW
+    hip.set_option = lambda *a, **k: None
+    hip.set_stream_option = lambda *a, **k: None
+    mean = lambda f: sum(f(r) for r in range(world)) / world     # noqa: E731
+
+    def micro(ps, k, final=None):
+        """one micro-step through autograd: d loss / d p = (rank + 1) * k for ps[0], 10 * that for ps[1]"""
+        loss = (ps[0].sum() + 10.0 * ps[1].sum()) * float((rank + 1) * k)
+        loss.backward()
+        if final is not None:
+            dist.grads_final(params=final)
+
+    for built, overlap in ((False, False), (True, False), (True, True)):
+        ps = [torch.nn.Parameter(torch.zeros(5, 7)), torch.nn.Parameter(torch.zeros(11))]
+        opt = FlatAdamW(ps, lr=0.0, overlap_backward=overlap)
+        fac = hvd.DistributedOptimizer(opt)
+        if built:
+            for p in ps:
+                p.grad = torch.zeros_like(p)
+            assert opt._build()
+        micro(ps, 1, final=[ps[0]] if overlap else None)
+        assert (len(opt._inflight) >= 1) == overlap
+        fac.synchronize()
+        want1 = mean(lambda r: float(r + 1))
+        assert torch.allclose(ps[0].grad, torch.full((5, 7), want1)) and torch.allclose(ps[1].grad, torch.full((11,), 10 * want1))
+        fac.synchronize()                                        # a repeated call without a backward in between changes nothing
+        assert torch.allclose(ps[0].grad, torch.full((5, 7), want1))
+        micro(ps, 2, final=[ps[0]] if overlap else None)         # second micro-step accumulates on top of the averaged first
+        fac.synchronize()
+        want2 = want1 + mean(lambda r: 2.0 * (r + 1))
+        assert torch.allclose(ps[0].grad, torch.full((5, 7), want2)), (built, overlap, ps[0].grad.flatten()[:2], want2)
+        assert torch.allclose(ps[1].grad, torch.full((11,), 10 * want2))
+        assert not opt._inflight and not opt._reduced and opt._pre_synced == "avg" and opt._sync_is_current()
+        micro(ps, 3)                                             # a micro-step NOT followed by synchronize(): step() must notice
+        assert not opt._sync_is_current()
+        opt.zero_grad()
+        assert opt._pre_synced is None
+    # local gradients on top of an exchanged SUM cannot be repaired by a collective: loud, not silent
+    ps = [torch.nn.Parameter(torch.zeros(3))]
+    opt = FlatAdamW(ps, lr=0.0, overlap_backward=False)
+    ps[0].sum().backward()
+    opt.synchronize(average=False)
+    ps[0].sum().backward()
+    try:
+        opt.synchronize(average=False)
+        raise AssertionError("expected a RuntimeError")
+    except RuntimeError as e:
+        assert "already exchanged SUM" in str(e)
+    dist.barrier()
 
 
 def _amp_without_synchronize_checks(rank, world):

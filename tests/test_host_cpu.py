@@ -948,11 +948,52 @@ def test_overlapped_exchange_reserves_cus_for_the_collective_library(monkeypatch
     monkeypatch.setenv("ALPRO_RCCL_CU_RESERVE", "24")
     monkeypatch.delenv("NCCL_MAX_NCHANNELS", raising=False)
     monkeypatch.setenv("WORLD_SIZE", "2")
+    for var in ("LOCAL_WORLD_SIZE", "OMPI_COMM_WORLD_LOCAL_SIZE", "MV2_COMM_WORLD_LOCAL_SIZE", "SLURM_NNODES", "SLURM_NTASKS_PER_NODE"):
+        monkeypatch.delenv(var, raising=False)
     seen = {}
     monkeypatch.setattr(dist.td, "init_process_group", lambda **k: seen.update(k, channels=os.environ.get("NCCL_MAX_NCHANNELS")))
     monkeypatch.setattr(dist, "is_initialized", lambda: False)
+    # a launcher that does not say where the ranks are (mpirun / srun-style environments without torchrun's LOCAL_WORLD_SIZE) is
+    # NOT taken for a single node -- the cap is an xGMI policy and would throttle an inter-node ring
+    dist.init(backend="gloo")
+    assert seen["channels"] is None and seen["world_size"] == 2
+    monkeypatch.setenv("LOCAL_WORLD_SIZE", "1")          # two nodes x one rank
+    dist.init(backend="gloo")
+    assert seen["channels"] is None
+    monkeypatch.delenv("LOCAL_WORLD_SIZE")
+    monkeypatch.setenv("OMPI_COMM_WORLD_LOCAL_SIZE", "2")   # mpirun, both ranks on this node
+    dist.init(backend="gloo")
+    assert seen["channels"] == "24"
+    monkeypatch.delenv("NCCL_MAX_NCHANNELS")
+    monkeypatch.delenv("OMPI_COMM_WORLD_LOCAL_SIZE")
+    monkeypatch.setenv("LOCAL_WORLD_SIZE", "2")          # torchrun --nproc-per-node 2
     dist.init(backend="gloo")
     assert seen["channels"] == "24" and seen["world_size"] == 2
+
+
+@pytest.mark.parametrize("world,rank", [(1, 0), (2, 1)])
+def test_hard_negative_sampler_semantics_on_the_cpu(monkeypatch, world, rank):
+    """The batched hard-negative sampler is plain torch: its semantics (own-rank block, never the positive, softmax frequencies;
+    reference alpro_models.py:287-313) are checked here without a GPU, un-patched; the GPU suite repeats it on the device."""
+    from tests.golden import parity_cases as pc
+    pc.sampler_property_check("cpu", world, rank, 2000, monkeypatch)
+
+
+def test_gradient_checkpointing_flag_is_accepted_and_says_that_it_is_ignored():
+    """config_release/timesformer_divst_8x32_224_k600_gc.json:9 sets gradient_checkpointing: true; the reference recomputes blocks in backward
+    (vit.py:366-370), this build keeps the activations and says so once per model instead of ignoring the flag silently."""
+    import warnings
+    from alpro_amd.modeling.timesformer.vit import TimeSformer
+    cfg = dict(VENC, num_frm=2, gradient_checkpointing=True)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        m = TimeSformer(model_cfg=cfg, input_format="RGB")
+    assert m.use_grad_ckpt is True
+    assert any("gradient_checkpointing" in str(x.message) and "ignored" in str(x.message) for x in w)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        TimeSformer(model_cfg=dict(VENC, num_frm=2), input_format="RGB")
+    assert not any("gradient_checkpointing" in str(x.message) for x in w)
 
 
 def test_flat_adamw_state_dict_carries_the_loss_scaler():

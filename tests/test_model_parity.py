@@ -657,6 +657,37 @@ def test_full_size_pretrain_backward_in_the_bench_dtype_vs_the_exact_mode(bert_c
     assert all(v <= lim["loss_abs_err"] for v in rep["loss_abs_err"].values()), rep["loss_abs_err"]
 
 
+def test_finetune_backward_at_the_msrvtt_geometry_in_the_bench_dtype_vs_the_exact_mode(bert_cfg):
+    """BASELINE configs[4]'s finetune step at config_release/msrvtt_ret.json's own geometry (num_frm 8, train_batch_size 8,
+    max_txt_len 40) -- the reference-generated gradient fixture for this model is T = 2, B = 3 (retrieval_grads_T2_B3.npz).  AlproForVideoTextRetrieval,
+    loss = itm_loss + itc_loss (run_video_retrieval.py:432-434), one forward + backward in the benchmark's mode (fp16 operands + precise CLS rows,
+    loss scale 2^16) against the exact fp32 HIP mode on the same weights, inputs and hard negatives, every parameter gradient.  Same bounds as
+    the B = 64 pretraining step (tests/golden/parity_cases.py::FULL_SIZE_BACKWARD_LIMITS)."""
+    from tests.golden import parity_cases as pc
+    rep = pc.full_size_backward_parity(bert_cfg, VENC, make_cfg, "cuda", B=8, T=8, model="retrieval")
+    print("\n[msrvtt_ret geometry backward, %s vs exact fp32] %d tensors | l2 rel err worst %.2e median %.2e | cosine worst %.6f | global norm %.2e cosine %.6f | losses %s | worst %s" % (
+        rep["mode"], rep["grad_tensors"], rep["grad_l2_rel_err_worst"], rep["grad_l2_rel_err_median"], rep["grad_cosine_worst"], rep["global_grad_norm_rel_err"],
+        rep["global_grad_cosine"], {k: float("%.2e" % v) for k, v in rep["loss_abs_err"].items()}, rep["worst_tensors"]))
+    assert not rep["nonfinite_tensors"], rep["nonfinite_tensors"]
+    assert rep["grad_tensors"] >= 400, rep["grad_tensors"]
+    lim = pc.FULL_SIZE_BACKWARD_LIMITS
+    assert rep["grad_l2_rel_err_worst"] <= lim["grad_l2_rel_err_worst"] and rep["grad_l2_rel_err_median"] <= lim["grad_l2_rel_err_median"], rep
+    assert rep["grad_cosine_worst"] >= lim["grad_cosine_worst"] and rep["global_grad_cosine"] >= lim["global_grad_cosine"], rep
+    assert rep["global_grad_norm_rel_err"] <= lim["global_grad_norm_rel_err"], rep
+    assert all(v <= lim["loss_abs_err"] for v in rep["loss_abs_err"].values()), rep["loss_abs_err"]
+
+
+@pytest.mark.parametrize("world,rank", [(1, 0), (2, 1)])
+def test_hard_negative_sampler_unpatched(monkeypatch, world, rank):
+    """every VTM parity test above replaces torch.multinomial by argmax.  This one runs the product's batched sampler
+    (alpro_models.py::_sample_negatives: ONE torch.multinomial per direction on the device) as it is and holds it to what the reference's per-row
+    loop does (alpro_models.py:287-313): the candidates are the rank's OWN block of the gathered similarity (columns [b*rank, b*(rank+1)) --
+    simulated world 2, rank 1), the positive (diagonal) is never drawn, and over 4000 draws the empirical frequency of every candidate is within
+    4 sigma of the softmax weight of its similarity (binomial standard error; 4 sigma over 2 x 16 x 15 cells: false-alarm rate < 2 %)."""
+    from tests.golden import parity_cases as pc
+    pc.sampler_property_check("cuda", world, rank, 4000, monkeypatch)
+
+
 def test_cls_chain_on_a_side_stream_is_result_neutral():
     """Round 5 (alpro_amd.config.cls_stream): the precise-CLS chain of the ViT blocks issued on a second HIP stream -- the same launches, ordered
     against the main path by events instead of by stream order -- gives bit-identical results on every path that carries it: the in-place
