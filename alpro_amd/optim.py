@@ -110,6 +110,13 @@ class FlatAdamW:
         # hand-written backward passes' grads_final reports, backward(), amp.scale_loss); the stamp is (_writes, BACKWARD_EPOCH) at sync time.
         self._writes = 0
         self._sync_stamp = None
+        # exchange diagnostics (round 6: the N > 1 bench line reads them, tests/test_bench_multirank.py asserts them): per finished exchange, how
+        # much went on the wire from inside backward, how much only at synchronize(), the CU budget in effect meanwhile, and how long the
+        # compute stream was held by the exchange after backward had returned (device events around the late launches and the handle waits)
+        self.record_exchange = False
+        self.exchange_log = []
+        self._early = [0, 0]           # ranges / elements launched by _on_grads_final since the last finished exchange
+        self._budget_seen = None
         if hasattr(torch.Tensor, "register_post_accumulate_grad_hook"):
             for p in self.params:   # from construction on (not from _build() on): the first step's micro-steps run before the flat buffers exist
                 p.register_post_accumulate_grad_hook(self._mark_dirty)
@@ -244,6 +251,7 @@ class FlatAdamW:
         if r > 0 and on != self._cus_reserved:
             if on:
                 ncu = torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count if torch.cuda.is_available() else 256
+                self._budget_seen = max(64, ncu - r)
                 self._cu_stream = hip.set_stream_option("cu_budget", max(64, ncu - r))
             else:
                 hip.set_stream_option("cu_budget", -1, stream=getattr(self, "_cu_stream", None))
@@ -276,21 +284,64 @@ class FlatAdamW:
                                    "construct the optimizer with overlap_backward=False for gradient accumulation")
             for c in range(s, e, self.bucket_elems):
                 self._launch(c, min(e, c + self.bucket_elems))
+                self._early[0] += 1
+                self._early[1] += min(e, c + self.bucket_elems) - c
 
     def _finish_exchange(self):
         """All-reduce whatever is not on the wire yet, then make the compute stream wait for every handle."""
         n = self.flat["n"]
+        rec = self.record_exchange
+        on_gpu = rec and self.flat["g"].is_cuda
+        if rec:
+            import time
+            t0 = time.perf_counter()
+            if on_gpu:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+        late = [0, 0]
         pos = 0
         for s, e in self._merge(self._reduced) + [(n, n)]:
             for c in range(pos, s, self.bucket_elems):
                 self._launch(c, min(s, c + self.bucket_elems))
+                late[0] += 1
+                late[1] += min(s, c + self.bucket_elems) - c
             pos = max(pos, e)
         for h, w, g in self._inflight:
             h.wait()
             if w is not None:
                 g.copy_(w)
         self._inflight, self._reduced = [], []
+        if rec:
+            if on_gpu:
+                e1.record()
+            wire = 4 if self.wire_dtype in (None, torch.float32) else torch.empty(0, dtype=self.wire_dtype).element_size()
+            self.exchange_log.append(dict(ranges_on_wire_early=self._early[0], bytes_on_wire_early=self._early[1] * wire, ranges_at_synchronize=late[0],
+                                          bytes_at_synchronize=late[1] * wire, cu_budget=self._budget_seen if self._cus_reserved else None,
+                                          events=(e0, e1) if on_gpu else None, host_ms=(time.perf_counter() - t0) * 1e3))
+        self._early = [0, 0]
         self._reserve_cus(False)
+
+    def exchange_stats(self, last=None):
+        """Mean over the logged exchanges (the last `last` of them): what the N > 1 bench line prints.  comm_exposed_ms = device time between the
+        moment backward had returned and synchronize() / step() asked for the sums, and the moment the compute stream got them (late launches +
+        waits for every handle): exchange time NOT hidden under backward.  With CPU tensors (gloo tests) the host time of the same span."""
+        log = self.exchange_log[-last:] if last else self.exchange_log
+        if not log:
+            return None
+        ms = []
+        for r in log:
+            if r["events"] is not None:
+                r["events"][1].synchronize()
+                ms.append(r["events"][0].elapsed_time(r["events"][1]))
+            else:
+                ms.append(r["host_ms"])
+        k = float(len(log))
+        budgets = sorted({r["cu_budget"] for r in log if r["cu_budget"] is not None})
+        return dict(exchanges=len(log), comm_exposed_ms=round(sum(ms) / k, 3), comm_exposed_ms_max=round(max(ms), 3),
+                    ranges_on_wire_early=round(sum(r["ranges_on_wire_early"] for r in log) / k, 2), bytes_on_wire_early=int(sum(r["bytes_on_wire_early"] for r in log) / k),
+                    ranges_at_synchronize=round(sum(r["ranges_at_synchronize"] for r in log) / k, 2), bytes_at_synchronize=int(sum(r["bytes_at_synchronize"] for r in log) / k),
+                    cu_budget_while_in_flight=budgets[0] if len(budgets) == 1 else (budgets or None), overlap_backward=bool(self.overlap_backward),
+                    timer="device events on the compute stream" if log[0]["events"] is not None else "host clock (CPU tensors)")
 
     def synchronize(self, average=False):
         """Sum gradients across ranks; step() folds the 1/world averaging into the AdamW kernel's grad_scale.

@@ -151,6 +151,36 @@ def full_size_backward_parity(bert_cfg, venc, make_cfg, device, dtype="fp16", cl
     return rep
 
 
+def full_size_forward_parity(bert_cfg, venc, make_cfg, device, dtype="fp16", cls_precise="auto", B=64, T=8, seed=4):
+    """VTC logits at the benchmarked size: AlproForPretrain, eval mode, B pairs x T frames x 224^2 + 40 tokens, random-init
+    weights; ALL B x B video-text logits (alpro_models.py:113-118: video_feat @ text_feat.T / temp) in `dtype` against the exact fp32 HIP mode --
+    the oracle at this size, pinned to the reference at <= 5e-6 on every fixture.  -> max / p99.9 / rms of the absolute error and whether the
+    north star's 1e-3 holds for the MAXIMUM."""
+    import bench
+    from alpro_amd import config as rt
+    from alpro_amd.modeling.alpro_models import AlproForPretrain
+    torch.manual_seed(seed)
+    m = AlproForPretrain(make_cfg(bert_cfg), dict(venc, num_frm=T)).eval().to(device)
+    batch = bench.synth_batch(B, T, device, seed=11, full=True)
+    batch["text_input_mask"] = batch["text_input_mask"].clone()
+    batch["text_input_mask"][::3, 31:] = 0
+
+    def logits(dt, cls):
+        with rt.use_compute_dtype(dt), rt.use_cls_precise(cls), torch.no_grad():
+            ve = m._forward_visual_embeds(batch["visual_inputs"])
+            _, tf = m._forward_text_feats(batch)
+            return (m._video_feat(ve) @ tf.t() / m.temp).double().cpu()
+    ref = logits("fp32", "auto")
+    e = (logits(dtype, cls_precise) - ref).abs().flatten()
+    rep = dict(batch=B, frames=T, logits=int(e.numel()), oracle="the exact fp32 HIP mode on the same weights and inputs",
+               vtc_logits_max_abs_err=float("%.3e" % float(e.max())), vtc_logits_p999_abs_err=float("%.3e" % float(e.kthvalue(max(1, int(0.999 * e.numel())))[0])),
+               vtc_logits_rms_err=float("%.3e" % float(e.pow(2).mean().sqrt())), north_star_bar=NORTH_STAR_BAR)
+    rep["max_meets_bar"] = bool(rep["vtc_logits_max_abs_err"] <= NORTH_STAR_BAR)
+    del m
+    torch.cuda.empty_cache()
+    return rep
+
+
 def sampler_property_check(device, world, rank, draws, monkeypatch):
     """The un-patched hard-negative sampler (alpro_amd/modeling/alpro_models.py::_sample_negatives) against the reference's semantics
     (alpro_models.py:287-313): own-rank block, never the positive, frequencies ~ softmax of the similarities.  Used by the GPU test

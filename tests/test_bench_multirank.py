@@ -37,3 +37,12 @@ def test_bench_two_ranks_gloo_shared_gpu(how):
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["value"] > 0 and d["config"]["per_gpu_batch"] == 2
     assert "cpu_baseline" not in d                          # reported at N=1 only
+    # the N > 1 line diagnoses its own gradient exchange -- one logged exchange per timed step on rank 0, the part that
+    # went on the wire from inside backward (the overlapped exchange is the default), what was left for synchronize(), the exposed time
+    x = d["exchange"]
+    assert x is not None and x["exchanges"] == d["steps"] == 1
+    assert x["overlap_backward"] is True and x["ranges_on_wire_early"] >= 1 and x["bytes_on_wire_early"] > 0
+    assert x["bytes_on_wire_early"] + x["bytes_at_synchronize"] >= 4 * 230e6      # the whole flat gradient buffer (234 M trained parameters, fp32 wire) went out
+    assert x["comm_exposed_ms"] >= 0.0 and x["comm_exposed_ms_max"] >= x["comm_exposed_ms"]
+    assert x["cu_budget_while_in_flight"] in (None, 240)   # 256 - ALPRO_RCCL_CU_RESERVE while all-reduces launched from backward are in flight
+    assert d["world_size"] == 2 and d["dist_backend"] == "gloo"

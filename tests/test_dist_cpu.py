@@ -137,6 +137,7 @@ def _gradient_accumulation_checks(rank, world):
     for built, overlap in ((False, False), (True, False), (True, True)):
         ps = [torch.nn.Parameter(torch.zeros(5, 7)), torch.nn.Parameter(torch.zeros(11))]
         opt = FlatAdamW(ps, lr=0.0, overlap_backward=overlap)
+        opt.record_exchange = True
         fac = hvd.DistributedOptimizer(opt)
         if built:
             for p in ps:
@@ -155,6 +156,11 @@ def _gradient_accumulation_checks(rank, world):
         assert torch.allclose(ps[0].grad, torch.full((5, 7), want2)), (built, overlap, ps[0].grad.flatten()[:2], want2)
         assert torch.allclose(ps[1].grad, torch.full((11,), 10 * want2))
         assert not opt._inflight and not opt._reduced and opt._pre_synced == "avg" and opt._sync_is_current()
+        if built:   # the exchange diagnostics the N > 1 bench line prints: one record per finished exchange
+            st = opt.exchange_stats()
+            assert st["exchanges"] == 2 and st["overlap_backward"] is overlap and st["comm_exposed_ms"] >= 0.0 and st["timer"].startswith("host clock")
+            assert st["ranges_on_wire_early"] == (1.0 if overlap else 0.0) and st["bytes_on_wire_early"] == (36 * 4 if overlap else 0)   # ps[0]: 35 -> 36 elements (16-byte views)
+            assert st["bytes_on_wire_early"] + st["bytes_at_synchronize"] == (36 + 12) * 4
         micro(ps, 3)                                             # a micro-step NOT followed by synchronize(): step() must notice
         assert not opt._sync_is_current()
         opt.zero_grad()

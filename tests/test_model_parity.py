@@ -629,7 +629,9 @@ def test_full_size_pretrain_forward_in_the_bench_dtype_vs_the_exact_mode(bert_cf
             print("[parity-report] full_size_proxy[%s] | VTC logits max / p99.9 / rms | err %.3e / %.3e / %.3e | limit 1.0e-03" % (name, rep[name]["max"], rep[name]["p999"], rep[name]["rms"]))
     if os.environ.get("ALPRO_PARITY_REPORT"):
         return
-    assert rep["fp16"]["p999"] <= 1e-3 and rep["fp16"]["max"] <= 1.5e-3, rep["fp16"]     # (tightened to what the first measurement shows)
+    # round 6: the north star's 1e-3 on the MAXIMUM of the 4096 logits, not only on p99.9 (measured: max 5.4e-4, p99.9 5.0e-4,
+    # profiles/r4_parity_pareto.txt; rounds 4-5 allowed 1.5e-3 on the maximum)
+    assert rep["fp16"]["max"] <= 1e-3 and rep["fp16"]["p999"] <= 1e-3, rep["fp16"]
     assert rep["fp16"]["rms"] < 0.6 * rep["fp16_plain"]["rms"], rep                        # the side path must carry its weight at full size too
     assert rep["fp16"]["itm"] <= 5e-3 and rep["fp16"]["mlm"] <= 2e-2 and rep["fp16"]["mpm"] <= 5e-3, rep["fp16"]
 
