@@ -261,13 +261,37 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qkv
 __device__ u32x4 g_attn_zero[4];
 constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
 
-template <typename T, int NKT, bool HAS_BIAS, bool CLS = false>
+// The precise CLS query (round 4: alpro_amd.config.cls_precise; stand-alone form: cls_precise.hip alpro_attn_cls_fwd) -- round 6 form.  The
+// CLS token's fp32 q row is carried THROUGH the 16-bit MFMA path as NS extra query columns whose values add up to it: x = p0 + p1 / C1
+// (+ p2 / (C1 C2)), every part exactly representable in T (fp16: 11 + 11 bits, the low part scaled by 2^11 into the normal range; bf16:
+// 8 + 8 + 8 bits).  A product of two 16-bit values is exact in the MFMA's fp32 accumulator, so the sum of the parts' score columns IS the
+// fp32 score of the unrounded q (to 2^-22), and the same split of the unnormalised probabilities carries P into P V without its 16-bit
+// rounding.  The columns are padded query slots of the last query tile (L = 197: 27 of them; an extra query tile when fewer than NS are
+// free), so the side path costs a few lane exchanges in ONE wave instead of rounds 4-5's VALU pass over all of K and V by all 256 threads
+// (+31 us on a 166 us launch at B = 64) -- and the 8-key-tile instantiation no longer needs a second register budget.
+template <typename T> struct ClsSplit;
+template <> struct ClsSplit<f16_t> { static constexpr int NS = 2; static constexpr float C1 = 2048.f, C2 = 1.f; };
+template <> struct ClsSplit<bf16_t> { static constexpr int NS = 3; static constexpr float C1 = 1.f, C2 = 1.f; };
+template <typename T> __device__ __forceinline__ void cls_split(float x, float& p0, float& p1, float& p2) {
+  p0 = quantize<T>(x);
+  const float r1 = (x - p0) * ClsSplit<T>::C1;   // exact: the residual of a rounding is representable, the scale is a power of two
+  p1 = quantize<T>(r1);
+  p2 = ClsSplit<T>::NS == 3 ? quantize<T>((r1 - p1) * ClsSplit<T>::C2) : 0.f;
+}
+template <typename T> __device__ __forceinline__ float cls_join(float v0, float v1, float v2) {
+  float r = fmaf(v1, 1.0f / ClsSplit<T>::C1, v0);
+  if (ClsSplit<T>::NS == 3) r = fmaf(v2, 1.0f / (ClsSplit<T>::C1 * ClsSplit<T>::C2), r);
+  return r;
+}
+
+template <typename T, int NKT, bool HAS_BIAS, bool CLS = false, bool DROP = false>
 __global__ __launch_bounds__(256, 2) void attn_fwd16_kernel(const T* __restrict__ qkv, T* __restrict__ out, int L, int H, float scale,
                                                             const float* __restrict__ key_bias, float* __restrict__ lse, float drop_p,
                                                             uint32_t drop_seed, int order, const float* __restrict__ cls_q, int cls_group,
                                                             float* __restrict__ cls_out) {
   static_assert(sizeof(T) == 2, "16-bit storage only");
   constexpr int LP = NKT * 32, RB = 128;
+  constexpr int NS = ClsSplit<T>::NS;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* Ks = smem;
   char* Vs = smem + LP * RB;
@@ -281,55 +305,115 @@ __global__ __launch_bounds__(256, 2) void attn_fwd16_kernel(const T* __restrict_
   for (int c = tid; c < LP; c += 256) Bs[c] = c < L ? (HAS_BIAS ? key_bias[(int64_t)b * L + c] * LOG2E : 0.f) : -INFINITY;
   const int64_t ldq = 3 * (int64_t)H * HD;  // elements per token row of qkv
   const T* base = qkv + (int64_t)b * L * ldq + h * HD;
-
-  // K (chunk ^ ((row >> 1) & 7)) and V (chunk ^ 4*bit1(row)) images: 1 KiB pieces of 8 rows; padded rows <- zero page
-  {
-    const uint32_t k_lds = lds_addr_of(Ks), v_lds = lds_addr_of(Vs);
-    const char* zero = (const char*)g_attn_zero;
-#pragma unroll
-    for (int i = 0; i < NKT; ++i) {
-      const int piece = wave + 4 * i;
-      const int row = piece * 8 + (lane >> 3), slot = lane & 7;
-      const T* src = base + (int64_t)row * ldq;
-      const char* ks = row < L ? (const char*)(src + H * HD + ((slot ^ ((row >> 1) & 7)) << 3)) : zero;
-      const char* vs = row < L ? (const char*)(src + 2 * H * HD + ((slot ^ (((row >> 1) & 1) << 2)) << 3)) : zero;
-      dma16(ks, __builtin_amdgcn_readfirstlane(k_lds + piece * 1024));
-      dma16(vs, __builtin_amdgcn_readfirstlane(v_lds + piece * 1024));
-    }
-  }
   const int nqt = (L + 31) >> 5;
   const int g = lane >> 5, ql = lane & 31;
-  auto load_q = [&](int qt, u32x4(&qf)[4]) {
+
+  // where the CLS query's NS parts ride: free query slots c0 .. c0 + NS - 1 of the last tile (inside one 16-lane row), else of an extra tile
+  int cls_tile = -1, c0 = 0, ntile = nqt;
+  if (CLS && cls_q) {   // (cls_q == nullptr with CLS compiled in: the dropout launches without a precise CLS query, see launch_attn16)
+    c0 = L - 32 * (nqt - 1);
+    if ((c0 & 15) + NS > 16) c0 = (c0 | 15) + 1;
+    cls_tile = nqt - 1;
+    if (c0 + NS > 32) { c0 = 0; cls_tile = nqt; ntile = nqt + 1; }
+  }
+
+  // K (chunk ^ ((row >> 1) & 7)) and V (chunk ^ 4*bit1(row)) images: 1 KiB pieces of 8 rows; padded rows <- zero page.  All of K first,
+  // then this wave's first Q fragments, then V: the first query tile's scores and softmax run while V is still on its way (round 6).
+  const uint32_t k_lds = lds_addr_of(Ks), v_lds = lds_addr_of(Vs);
+  const char* zero = (const char*)g_attn_zero;
+#pragma unroll
+  for (int i = 0; i < NKT; ++i) {
+    const int piece = wave + 4 * i;
+    const int row = piece * 8 + (lane >> 3), slot = lane & 7;
+    const T* src = base + (int64_t)row * ldq;
+    dma16(row < L ? (const char*)(src + H * HD + ((slot ^ ((row >> 1) & 7)) << 3)) : zero, __builtin_amdgcn_readfirstlane(k_lds + piece * 1024));
+  }
+  auto load_q = [&](int qt, u32x4(&qf)[4]) __attribute__((always_inline)) {
     const int qc = min(qt * 32 + ql, L - 1);
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const u32x4*)(base + (int64_t)qc * ldq + (2 * ks + g) * 8);
+    if constexpr (CLS) {
+      if (qt == cls_tile) {   // (wave-uniform) lanes c0 + j carry part j of the fp32 q row of this sequence's CLS token
+        const float* cq = cls_q + (int64_t)(b / cls_group) * ldq + h * HD;
+        const int j = ql - c0;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          const float4 a = *(const float4*)(cq + (2 * ks + g) * 8), c = *(const float4*)(cq + (2 * ks + g) * 8 + 4);
+          const float x[8] = {a.x, a.y, a.z, a.w, c.x, c.y, c.z, c.w};
+          float part[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            float p0, p1, p2;
+            cls_split<T>(x[e], p0, p1, p2);
+            part[e] = j == 0 ? p0 : (j == 1 ? p1 : p2);
+          }
+          const u32x4 pk = pack_chunk<T>(part);
+          if (j >= 0 && j < NS) qf[ks] = pk;
+        }
+      }
+    }
   };
+  // query tiles of this wave: t, t + 4, ... with t rotated by the workgroup index, so that the wave with one tile less (7 tiles on 4 waves)
+  // is not the same SIMD's in the two workgroups that share a CU
+  int qt = (wave + (int)(blockIdx.x >> 3)) & 3;
+  bool has = qt < ntile;
   u32x4 qf[4];
-  load_q(min(wave, nqt - 1), qf);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  load_q(has ? qt : 0, qf);
+#pragma unroll
+  for (int i = 0; i < NKT; ++i) {
+    const int piece = wave + 4 * i;
+    const int row = piece * 8 + (lane >> 3), slot = lane & 7;
+    const T* src = base + (int64_t)row * ldq;
+    dma16(row < L ? (const char*)(src + 2 * H * HD + ((slot ^ (((row >> 1) & 1) << 2)) << 3)) : zero, __builtin_amdgcn_readfirstlane(v_lds + piece * 1024));
+  }
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NKT) : "memory");   // K and Q have landed (in-order return); the NKT V pieces may still be in flight
   __syncthreads();
 
   const float sl = scale * LOG2E;
+  typedef float f32x2v_t __attribute__((ext_vector_type(2)));
   char* Ow = Os + wave * OW;
-  for (int qt = wave; qt < nqt; qt += 4) {
+  f32x16 s[NKT];
+  float inv = 0.f;
+  u32x4 qn[4];
+
+  // ---- S^T = K Q^T and the softmax (log2 domain) of query tile qt; leaves the unnormalised probabilities in s and 1 / sum in inv
+  auto scores = [&]() __attribute__((always_inline)) {
     const int q = qt * 32 + ql;
-    f32x16 s[NKT];
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) s[kt][r] = 0.f;
       const int krow = kt * 32 + ql;
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
         const u32x4 a = *(const u32x4*)(Ks + krow * RB + (((2 * ks + g) ^ ((krow >> 1) & 7)) << 4));
+        if (ks == 0) {
+          f32x16 z;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) z[r] = 0.f;
+          s[kt] = z;
+        }
         mma_chunk<T>(s[kt], a, qf[ks]);
       }
     }
-    u32x4 qn[4];
-    load_q(min(qt + 4, nqt - 1), qn);  // lands under the softmax
-
-    // ---- softmax (log2 domain); tiles with all 32 keys valid and no bias skip the bias FMA
+    load_q(min(qt + 4, ntile - 1), qn);  // lands under the softmax
+    const bool cls_here = CLS && qt == cls_tile;
+    if constexpr (CLS) {
+      if (cls_here) {   // lane c0: the fp32 score of the unrounded CLS query = the sum of its parts' columns
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float a = s[kt][r];
+            const float b1 = __shfl_down(a, 1, 64), b2 = NS == 3 ? __shfl_down(a, 2, 64) : 0.f;
+            s[kt][r] = ql == c0 ? cls_join<T>(a, b1, b2) : a;
+          }
+      }
+    }
+    // tiles with all 32 keys valid and no bias skip the bias FMA; quads of 4 keys that lie entirely beyond L are not evaluated at all
     float m = -INFINITY;
+    typedef __attribute__((address_space(3))) const char lds_cchar_t;
+    uint32_t bs_lane = 16u * (uint32_t)g;   // this lane's 4 of a quad's 8 keys; opaque per tile: hoisted over the tile loop, the 32 bias addresses of the
+    asm volatile("" : "+v"(bs_lane));       // 8-tile instantiations were kept in (spilled) registers instead of one base + immediate offsets
+    lds_cchar_t* bs_l = (lds_cchar_t*)(__attribute__((address_space(3))) char*)Bs + bs_lane;
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt) {
       if (!HAS_BIAS && (kt + 1) * 32 <= L) {
@@ -343,58 +427,112 @@ __global__ __launch_bounds__(256, 2) void attn_fwd16_kernel(const T* __restrict_
       if (HAS_BIAS || (kt + 1) * 32 > L) {
 #pragma unroll
         for (int rq = 0; rq < 4; ++rq) {
-          const float4 bq = *(const float4*)(Bs + kt * 32 + 8 * rq + 4 * g);
-          const float bb[4] = {bq.x, bq.y, bq.z, bq.w};
+          if (kt < NKT - 1 || kt * 32 + 8 * rq < L) {   // (wave-uniform; only the LAST key tile is looked at quad by quad: 16 more basic blocks per tile otherwise)
+            const f32x4 bq = *(const __attribute__((address_space(3))) f32x4*)(bs_l + (kt * 32 + 8 * rq) * 4);
+            const float bb[4] = {bq.x, bq.y, bq.z, bq.w};
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const float v = fmaf(s[kt][4 * rq + e], sl, bb[e]);
-            s[kt][4 * rq + e] = v;
-            m = fmaxf(m, v);
+            for (int e = 0; e < 4; ++e) {
+              const float v = fmaf(s[kt][4 * rq + e], sl, bb[e]);
+              s[kt][4 * rq + e] = v;
+              m = fmaxf(m, v);
+            }
           }
         }
       }
     }
     m = fmaxf(m, __shfl_xor(m, 32, 64));
-    float sum = 0.f;
+    const f32x2v_t sl2 = {sl, sl}, nm2 = {-m, -m};
+    f32x2v_t sum2 = {0.f, 0.f};
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt) {
       if (!HAS_BIAS && (kt + 1) * 32 <= L) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float pr = __builtin_amdgcn_exp2f(fmaf(s[kt][r], sl, -m));
-          s[kt][r] = pr;
-          sum += pr;
+        for (int r = 0; r < 16; r += 2) {
+          const f32x2v_t x = (f32x2v_t){s[kt][r], s[kt][r + 1]} * sl2 + nm2;   // v_pk_fma_f32
+          const f32x2v_t pr = {__builtin_amdgcn_exp2f(x.x), __builtin_amdgcn_exp2f(x.y)};
+          s[kt][r] = pr.x;
+          s[kt][r + 1] = pr.y;
+          sum2 += pr;
         }
       } else {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float pr = __builtin_amdgcn_exp2f(s[kt][r] - m);  // exp2(-inf) == 0 for masked keys
-          s[kt][r] = pr;
-          sum += pr;
+        for (int rq = 0; rq < 4; ++rq) {
+          if (kt < NKT - 1 || kt * 32 + 8 * rq < L) {
+#pragma unroll
+            for (int e = 0; e < 4; e += 2) {
+              const f32x2v_t x = (f32x2v_t){s[kt][4 * rq + e], s[kt][4 * rq + e + 1]} + nm2;
+              const f32x2v_t pr = {__builtin_amdgcn_exp2f(x.x), __builtin_amdgcn_exp2f(x.y)};  // exp2(-inf) == 0 for masked keys
+              s[kt][4 * rq + e] = pr.x;
+              s[kt][4 * rq + e + 1] = pr.y;
+              sum2 += pr;
+            }
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) s[kt][4 * rq + e] = 0.f;
+          }
         }
       }
     }
+    float sum = sum2.x + sum2.y;
     sum += __shfl_xor(sum, 32, 64);
-    const float inv = 1.0f / sum;
+    inv = 1.0f / sum;
     if (lse && g == 0 && q < L) lse[((int64_t)b * H + h) * L + q] = (m + __builtin_amdgcn_logf(sum)) * LN2;
-    if (drop_seed) {  // attention-probability dropout (xbert.py:331): mask is a pure function of (b, h, q, key)
+    if constexpr (DROP) {  // attention-probability dropout (xbert.py:331): mask is a pure function of (b, h, q, key); the CLS parts take query 0's.  (A template
+      // parameter since round 6: as a runtime branch its 112 hash indices were hoisted over the tile loop and spilled in every instantiation)
       const uint32_t th = drop_thresh24(drop_p);
       const float ks = 1.0f / (1.0f - drop_p);
-      const uint64_t base_i = (((uint64_t)b * H + h) * L + (uint64_t)min(q, L - 1)) * L;
+      int qd = (cls_here && ql >= c0 && ql < c0 + NS) ? 0 : min(q, L - 1);
+      asm volatile("" : "+v"(qd));
+      int lo = lane;
+      asm volatile("" : "+v"(lo));   // an opaque copy of the lane id, per tile: hoisted over the tile loop, the 112 per-register index terms were spilled
+      const uint64_t base_i = (((uint64_t)b * H + h) * L + (uint64_t)qd) * L + (uint64_t)(4 * (lo >> 5));
 #pragma unroll
       for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) s[kt][r] = drop_keep(drop_seed, base_i + kt * 32 + acc_row(r, lane), th) ? s[kt][r] * ks : 0.f;
+        for (int r = 0; r < 16; ++r) s[kt][r] = drop_keep(drop_seed, base_i + (uint64_t)(kt * 32 + acc_row(r, 0)), th) ? s[kt][r] * ks : 0.f;
     }
+    if constexpr (CLS) {
+      if (cls_here) {   // lane c0's probabilities, unrounded, as NS columns of 16-bit values that add up to them
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float pr = s[kt][r];
+            float h0, h1, h2;
+            cls_split<T>(pr, h0, h1, h2);
+            const float f1 = __shfl_up(h1, 1, 64), f2 = NS == 3 ? __shfl_up(h2, 2, 64) : 0.f;
+            s[kt][r] = ql == c0 ? h0 : (ql == c0 + 1 ? f1 : ((NS == 3 && ql == c0 + 2) ? f2 : pr));
+          }
+      }
+    }
+  };
 
+  // ---- O^T = V^T P^T of query tile qt, normalised, out through wave-private LDS as 16-byte row pieces
+  auto output = [&]() __attribute__((always_inline)) {
     f32x16 o[2];
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
     pv_tiles<T, NKT>(o, s, Vs, lane);
-
-    // ---- O^T (lane = query, 4 consecutive d per register quad) -> row-major rows through wave-private LDS
+    if constexpr (CLS) {
+      if (qt == cls_tile) {   // the CLS row in fp32: the parts' output columns added up in lane c0 (both d halves: lanes c0 and c0 + 32)
+        float* dst = cls_out + (int64_t)b * H * HD + h * HD;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+          for (int rq = 0; rq < 4; ++rq) {
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float a = o[dt][4 * rq + e];
+              const float b1 = __shfl_down(a, 1, 64), b2 = NS == 3 ? __shfl_down(a, 2, 64) : 0.f;
+              v[e] = cls_join<T>(a, b1, b2) * inv;
+            }
+            if (ql == c0) *(float4*)(dst + dt * 32 + 8 * rq + 4 * g) = make_float4(v[0], v[1], v[2], v[3]);
+          }
+      }
+    }
     if constexpr (!HALF) {
 #pragma unroll
       for (int dt = 0; dt < 2; ++dt)
@@ -433,103 +571,25 @@ __global__ __launch_bounds__(256, 2) void attn_fwd16_kernel(const T* __restrict_
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       }
     }
+  };
+
+  bool v_pending = true;   // (wave-uniform) the V image has not been waited for yet: every wave takes that barrier exactly once
+  while (has) {
+    scores();
+    if (v_pending) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // V (and the prefetched Q fragments)
+      __syncthreads();
+      v_pending = false;
+    }
+    output();
+    qt += 4;
+    has = qt < ntile;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) qf[ks] = qn[ks];
   }
-  // ---- precise CLS query (round 4, alpro_amd.config.cls_precise; stand-alone form: cls_precise.hip alpro_attn_cls_fwd).  Query 0 of the
-  // sequence once more, in fp32 on the VALU: q unrounded from cls_q (one fp32 row per `cls_group` sequences), K / V from the images already in
-  // LDS, scores / online softmax / P V in fp32 -- no P rounding, no output rounding.  Thread = (key slot tid >> 3 of 32, 8-element head chunk
-  // tid & 7); the 32 slots keep independent softmax states, merged over the wave by shuffles and over the four waves through the (now idle)
-  // output staging area.  ~NKT iterations of two ds_read_b128 + 40 VALU per thread on top of a 32 x NKT-tile workgroup.
-  // (CLS is a template parameter: the instantiations without the side path must keep the register allocation they had -- with the extra code
-  // compiled in, <8 key tiles, bias> went to 256 VGPRs + 112 bytes of scratch and produced wrong rows at B = 64, profiles/r4_fusion_diag.txt)
-  if constexpr (CLS) {
-    const int gs = tid >> 3, e = tid & 7;
-    float q[8];
-    {
-      const float* cq = cls_q + (int64_t)(b / cls_group) * ldq + h * HD + e * 8;
-      const float4 a = *(const float4*)cq, c = *(const float4*)(cq + 4);
-      q[0] = a.x * sl; q[1] = a.y * sl; q[2] = a.z * sl; q[3] = a.w * sl; q[4] = c.x * sl; q[5] = c.y * sl; q[6] = c.z * sl; q[7] = c.w * sl;
-    }
-    const uint32_t th = drop_thresh24(drop_p);
-    const float ks_ = drop_seed ? 1.0f / (1.0f - drop_p) : 1.0f;
-    const uint64_t base0 = (((uint64_t)b * H + h) * L) * (uint64_t)L;
-    float m = -INFINITY, l = 0.f, acc[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) acc[i] = 0.f;
-#pragma unroll
-    for (int it = 0; it < NKT; ++it) {
-      const int j = it * 32 + gs;
-      if (j < L) {   // (uniform over the 8 lanes of a key slot)
-        float kf[8], vf[8];
-        unpack_chunk<T>(*(const u32x4*)(Ks + j * RB + ((e ^ ((j >> 1) & 7)) << 4)), kf);
-        unpack_chunk<T>(*(const u32x4*)(Vs + j * RB + ((e ^ (((j >> 1) & 1) << 2)) << 4)), vf);
-        float d = 0.f;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) d = fmaf(q[i], kf[i], d);
-        d += __shfl_xor(d, 1, 64);
-        d += __shfl_xor(d, 2, 64);
-        d += __shfl_xor(d, 4, 64);
-        d += Bs[j];
-        const float mn = fmaxf(m, d);
-        const float alpha = __builtin_amdgcn_exp2f(m - mn);
-        const float p = __builtin_amdgcn_exp2f(d - mn);
-        l = fmaf(l, alpha, p);
-        float pd = p;
-        if (drop_seed) pd = drop_keep(drop_seed, base0 + (uint64_t)j, th) ? p * ks_ : 0.f;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) acc[i] = fmaf(acc[i], alpha, pd * vf[i]);
-        m = mn;
-      }
-    }
-    // merge the wave's 8 key slots (lanes with equal e) ...
-    float Mw = m;
-    Mw = fmaxf(Mw, __shfl_xor(Mw, 8, 64));
-    Mw = fmaxf(Mw, __shfl_xor(Mw, 16, 64));
-    Mw = fmaxf(Mw, __shfl_xor(Mw, 32, 64));
-    const float w0 = __builtin_amdgcn_exp2f(m - Mw);   // a slot without keys: exp2(-inf - M) = 0; a wave without keys: Mw = -inf -> NaN below is masked
-    float lw = (m == -INFINITY) ? 0.f : l * w0;
-    lw += __shfl_xor(lw, 8, 64);
-    lw += __shfl_xor(lw, 16, 64);
-    lw += __shfl_xor(lw, 32, 64);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      float a = (m == -INFINITY) ? 0.f : acc[i] * w0;
-      a += __shfl_xor(a, 8, 64);
-      a += __shfl_xor(a, 16, 64);
-      a += __shfl_xor(a, 32, 64);
-      acc[i] = a;
-    }
-    // ... and the four waves through LDS: [wave][0] = max, [1] = sum, [2 + e*8 + i] = accumulators
-    __syncthreads();   // every wave is past its last output tile: the staging area is free
-    float* sc = (float*)Os;
-    if (lane < 8) {
-      float* mine = sc + wave * 72;
-      if (lane == 0) { mine[0] = Mw; mine[1] = lw; }
-#pragma unroll
-      for (int i = 0; i < 8; ++i) mine[2 + lane * 8 + i] = acc[i];
-    }
+  if (v_pending) {   // a wave without a query tile (L <= 96)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (tid < 8) {
-      float M = -INFINITY;
-#pragma unroll
-      for (int w = 0; w < 4; ++w) M = fmaxf(M, sc[w * 72]);
-      float lt = 0.f, o[8];
-#pragma unroll
-      for (int i = 0; i < 8; ++i) o[i] = 0.f;
-#pragma unroll
-      for (int w = 0; w < 4; ++w) {   // fixed order
-        const float mw = sc[w * 72];
-        const float f = (mw == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(mw - M);
-        lt = fmaf(sc[w * 72 + 1], f, lt);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) o[i] = fmaf(sc[w * 72 + 2 + tid * 8 + i], f, o[i]);
-      }
-      const float inv = 1.0f / lt;
-      float* dst = cls_out + (int64_t)b * H * HD + h * HD + tid * 8;
-      *(float4*)dst = make_float4(o[0] * inv, o[1] * inv, o[2] * inv, o[3] * inv);
-      *(float4*)(dst + 4) = make_float4(o[4] * inv, o[5] * inv, o[6] * inv, o[7] * inv);
-    }
   }
 }
 
@@ -702,13 +762,20 @@ int launch_attn16(const void* qkv, void* out, int batch, int L, int H, float sca
   const size_t lds = 2 * (size_t)NKT * 32 * 128 + 4 * (NKT == 8 ? 2048 : 4096) + (size_t)NKT * 32 * sizeof(float);
   static DeviceOnce attr_once;
   attr_once.run([&] {
-    (void)hipFuncSetAttribute((const void*)attn_fwd16_kernel<T, NKT, HAS_BIAS, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipFuncSetAttribute((const void*)attn_fwd16_kernel<T, NKT, HAS_BIAS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)attn_fwd16_kernel<T, NKT, HAS_BIAS, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)attn_fwd16_kernel<T, NKT, HAS_BIAS, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)attn_fwd16_kernel<T, NKT, HAS_BIAS, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   });
-  if (cls_q)
-    hipLaunchKernelGGL((attn_fwd16_kernel<T, NKT, HAS_BIAS, true>), dim3(batch * H), dim3(256), lds, st, (const T*)qkv, (T*)out, L, H, scale, key_bias, lse, drop_p, drop_seed, get_option(OPT_ATTN_ORDER), cls_q, cls_group, cls_out);
-  else
-    hipLaunchKernelGGL((attn_fwd16_kernel<T, NKT, HAS_BIAS, false>), dim3(batch * H), dim3(256), lds, st, (const T*)qkv, (T*)out, L, H, scale, key_bias, lse, drop_p, drop_seed, get_option(OPT_ATTN_ORDER), cls_q, cls_group, cls_out);
+#define ALPRO_ATTN16_GO(CLS_, DROP_)                                                                                                                     \
+  hipLaunchKernelGGL((attn_fwd16_kernel<T, NKT, HAS_BIAS, CLS_, DROP_>), dim3(batch * H), dim3(256), lds, st, (const T*)qkv, (T*)out, L, H, scale, key_bias, lse, drop_p, \
+                     drop_seed, get_option(OPT_ATTN_ORDER), cls_q, cls_group, cls_out)
+  // Three instantiations per (NKT, bias): plain, with the CLS parts, with the CLS parts and dropout.  A dropout launch WITHOUT a precise CLS
+  // query runs the third one with cls_q == nullptr (the CLS code is skipped by a wave-uniform test): the <no CLS, dropout> form is the one
+  // instantiation the register allocator does not get through without spilling (224-420 bytes of scratch at 7 / 8 key tiles, ROCm 7.2).
+  if (drop_seed) ALPRO_ATTN16_GO(true, true);
+  else if (cls_q) ALPRO_ATTN16_GO(true, false);
+  else ALPRO_ATTN16_GO(false, false);
+#undef ALPRO_ATTN16_GO
   return check_launch("alpro_attn_fwd");
 }
 
