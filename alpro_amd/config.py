@@ -72,6 +72,19 @@ def set_cls_stream(v):
     _cls_stream[0] = v.lower() if isinstance(v, str) else ("1" if v else "0")
 
 
+# Round 6: the temporal half's qkv Linear and its T-frame attention as ONE launch in the inference forward (alpro_gemm_qkv_tattn: q | k | v are
+# consumed out of the GEMM's accumulators and never written; csrc/gemm_tattn.hip).  ALPRO_FUSE_TATTN = 1 (default) | 0 (the two launches).
+_fuse_tattn = [os.environ.get("ALPRO_FUSE_TATTN", "1") != "0"]
+
+
+def fuse_temporal_attention():
+    return _fuse_tattn[0]
+
+
+def set_fuse_temporal_attention(v):
+    _fuse_tattn[0] = bool(v)
+
+
 def set_cls_precise(v):
     _cls_precise[0] = v.lower() if isinstance(v, str) else ("1" if v else "0")
 

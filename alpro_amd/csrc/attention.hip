@@ -355,7 +355,11 @@ __global__ __launch_bounds__(256, 2) void attn_fwd16_kernel(const T* __restrict_
   };
   // query tiles of this wave: t, t + 4, ... with t rotated by the workgroup index, so that the wave with one tile less (7 tiles on 4 waves)
   // is not the same SIMD's in the two workgroups that share a CU
+#ifdef ATTN_NO_ROT
+  int qt = wave;
+#else
   int qt = (wave + (int)(blockIdx.x >> 3)) & 3;
+#endif
   bool has = qt < ntile;
   u32x4 qf[4];
   load_q(has ? qt : 0, qf);
@@ -366,7 +370,11 @@ __global__ __launch_bounds__(256, 2) void attn_fwd16_kernel(const T* __restrict_
     const T* src = base + (int64_t)row * ldq;
     dma16(row < L ? (const char*)(src + 2 * H * HD + ((slot ^ (((row >> 1) & 1) << 2)) << 3)) : zero, __builtin_amdgcn_readfirstlane(v_lds + piece * 1024));
   }
+#ifdef ATTN_NO_KV_SPLIT
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#else
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NKT) : "memory");   // K and Q have landed (in-order return); the NKT V pieces may still be in flight
+#endif
   __syncthreads();
 
   const float sl = scale * LOG2E;
@@ -447,6 +455,13 @@ __global__ __launch_bounds__(256, 2) void attn_fwd16_kernel(const T* __restrict_
     for (int kt = 0; kt < NKT; ++kt) {
       if (!HAS_BIAS && (kt + 1) * 32 <= L) {
 #pragma unroll
+#ifdef ATTN_NO_PK
+        for (int r = 0; r < 16; ++r) {
+          const float pr = __builtin_amdgcn_exp2f(fmaf(s[kt][r], sl, -m));
+          s[kt][r] = pr;
+          sum2.x += pr;
+        }
+#else
         for (int r = 0; r < 16; r += 2) {
           const f32x2v_t x = (f32x2v_t){s[kt][r], s[kt][r + 1]} * sl2 + nm2;   // v_pk_fma_f32
           const f32x2v_t pr = {__builtin_amdgcn_exp2f(x.x), __builtin_amdgcn_exp2f(x.y)};
@@ -454,6 +469,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd16_kernel(const T* __restrict_
           s[kt][r + 1] = pr.y;
           sum2 += pr;
         }
+#endif
       } else {
 #pragma unroll
         for (int rq = 0; rq < 4; ++rq) {
@@ -573,7 +589,11 @@ __global__ __launch_bounds__(256, 2) void attn_fwd16_kernel(const T* __restrict_
     }
   };
 
+#ifdef ATTN_NO_KV_SPLIT
+  bool v_pending = false;
+#else
   bool v_pending = true;   // (wave-uniform) the V image has not been waited for yet: every wave takes that barrier exactly once
+#endif
   while (has) {
     scores();
     if (v_pending) {

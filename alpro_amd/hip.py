@@ -24,7 +24,7 @@ EXPORTS = ["alpro_hip_last_error", "alpro_hip_abi_version", "alpro_hip_set_optio
            "alpro_attn_temporal_fwd", "alpro_attn_fwd", "alpro_patchify", "alpro_cls_mean_residual",
            "alpro_vit_final_pool", "alpro_bert_embed_fwd", "alpro_cast_from_f32", "alpro_attn_bwd", "alpro_attn_temporal_bwd",
            "alpro_layernorm_bwd", "alpro_transpose", "alpro_transpose_batch", "alpro_gelu_bwd", "alpro_cls_mean_bwd", "alpro_scatter_add_rows", "alpro_gather_cast", "alpro_sumsq", "alpro_adamw_step", "alpro_gemm_tn_acc", "alpro_gemm_tn_acc_ws", "alpro_gemm_tn_workspace_bytes", "alpro_gemm_tn_ranges", "alpro_colsum_acc", "alpro_softmax_xent", "alpro_vtc_loss_fwd", "alpro_vtc_loss_bwd", "alpro_prepare_clips", "alpro_loss_scale_update", "alpro_add_layernorm_fwd", "alpro_layernorm_bwd_emit", "alpro_gemm_batch", "alpro_tproj_small", "alpro_attn_cls_fwd", "alpro_gemm_rows_f32", "alpro_gather_seq_fwd", "alpro_gather_seq_bwd", "alpro_scatter_add_rows_ordered",
-           "alpro_hip_sched_workspace_bytes", "alpro_hip_set_sched_workspace", "alpro_hip_release_stream"]
+           "alpro_hip_sched_workspace_bytes", "alpro_hip_set_sched_workspace", "alpro_hip_release_stream", "alpro_gemm_qkv_tattn"]
 
 
 class GemmDesc(ctypes.Structure):
@@ -112,6 +112,7 @@ def load():
     lib.alpro_hip_sched_workspace_bytes.restype = ctypes.c_size_t
     lib.alpro_hip_set_sched_workspace.argtypes = [vp, vp, ctypes.c_size_t]
     lib.alpro_hip_release_stream.argtypes = [vp]
+    lib.alpro_gemm_qkv_tattn.argtypes = [vp, i64, vp, i64, vp, vp, i64, i32, i32, i32, i32, i32, f32, vp]
     lib.alpro_scatter_add_rows_ordered.argtypes = [vp, vp, vp, i32, i32, i64, i64, vp, vp]
     lib.alpro_gather_seq_fwd.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]
     lib.alpro_gather_seq_bwd.argtypes = [vp, vp, i32, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]
@@ -536,6 +537,28 @@ def attn(qkv, batch, L, H, scale, key_bias=None, want_lse=False, drop_p=0.0, dro
                               _ptr(cls_q), cls_group, _ptr(cls_out), _stream()), "alpro_attn_fwd")
     res = (out,) + ((lse,) if want_lse else ()) + ((cls_out,) if cls_q is not None else ())
     return res if len(res) > 1 else out
+
+
+def qkv_tattn_ok(a, T):
+    """Does alpro_gemm_qkv_tattn take these rows?  16-bit operands, whole 32-token wave blocks, a frame count that divides 16."""
+    return a.dtype in (torch.float16, torch.bfloat16) and a.shape[0] % 32 == 0 and T in (1, 2, 4, 8, 16) and a.shape[1] % 128 == 0 and a.stride(1) == 1 \
+        and (a.stride(0) * 2) % 128 == 0
+
+
+def gemm_qkv_tattn(a, w, bias, T, H, scale, out=None):
+    """The temporal half's qkv Linear + frame attention in one launch (alpro_gemm_qkv_tattn, forward only): a (M, K) 16-bit rows in x[:, 1:] order,
+    w (3*H*64, K) = Attention.qkv.weight in the operand dtype, bias (3*H*64) fp32 -> (M, H*64) attention output, heads merged."""
+    lib = load()
+    _dev(a); _dev(w)
+    M, K = a.shape
+    assert w.shape == (3 * H * 64, K) and w.dtype == a.dtype and w.stride(1) == 1 and a.stride(1) == 1
+    b = _dev(bias, torch.float32) if bias is not None else None
+    if out is None:
+        out = torch.empty((M, H * 64), dtype=a.dtype, device=a.device)
+    assert out.shape == (M, H * 64) and out.stride(1) == 1 and out.dtype == a.dtype
+    _check(lib.alpro_gemm_qkv_tattn(_ptr(a), a.stride(0), _ptr(w), w.stride(0), _ptr(b), _ptr(out), out.stride(0), _CODE[a.dtype], M, H, T, K, float(scale), _stream()),
+           "alpro_gemm_qkv_tattn")
+    return out
 
 
 def attn_cls(qkv, qkv_cls, batch, L, H, scale, group=1, key_bias=None, drop_p=0.0, drop_seed=0):

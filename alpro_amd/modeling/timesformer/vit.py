@@ -288,8 +288,13 @@ class Block(nn.Module):
         # ---- temporal (vit.py:146-162)
         h = hip.layernorm(x, self.temporal_norm1.weight, self.temporal_norm1.bias, VIT_EPS, dt, rows=B * N * T,
                           map_mode=hip.MAP_SKIP_CLS, map_p0=N * T)
-        qkv = hip.gemm(h, self._w("t_qkv", ta.qkv, dt), bias=ta.qkv.bias)
-        a = hip.attn_temporal(qkv, T, H, ta.scale)
+        if rt.fuse_temporal_attention() and hip.qkv_tattn_ok(h, T) and ta.qkv.bias is not None:
+            # round 6: qkv Linear + frame attention in one launch, q | k | v consumed out of the accumulators (alpro_gemm_qkv_tattn) -- the
+            # (B*N*T, 2304) tensor is never written.  Forward only: forward_train keeps the two launches, whose backward needs q, k, v
+            a = hip.gemm_qkv_tattn(h, self._w("t_qkv", ta.qkv, dt), ta.qkv.bias, T, H, ta.scale)
+        else:
+            qkv = hip.gemm(h, self._w("t_qkv", ta.qkv, dt), bias=ta.qkv.bias)
+            a = hip.attn_temporal(qkv, T, H, ta.scale)
         if self.fuse_residual_ln and self.merge_temporal_proj:
             # round 3: the two N = 768 projections write 16-bit deltas in plain row order; residual add + row maps + LayerNorm are one
             # streaming kernel each (alpro_add_layernorm_fwd) -- see the kernel's header comment in csrc/core.hip
@@ -418,8 +423,11 @@ class Block(nn.Module):
         ta, sa = self.temporal_attn, self.attn
         h = hip.layernorm(x, self.temporal_norm1.weight, self.temporal_norm1.bias, VIT_EPS, dt, rows=B * N * T,
                           map_mode=hip.MAP_SKIP_CLS, map_p0=N * T)
-        qkv = hip.gemm(h, self._w("t_qkv", ta.qkv, dt), bias=ta.qkv.bias)
-        a = hip.attn_temporal(qkv, T, H, ta.scale)
+        if rt.fuse_temporal_attention() and hip.qkv_tattn_ok(h, T) and ta.qkv.bias is not None:
+            a = hip.gemm_qkv_tattn(h, self._w("t_qkv", ta.qkv, dt), ta.qkv.bias, T, H, ta.scale)
+        else:
+            qkv = hip.gemm(h, self._w("t_qkv", ta.qkv, dt), bias=ta.qkv.bias)
+            a = hip.attn_temporal(qkv, T, H, ta.scale)
         if self.fuse_residual_ln and self.merge_temporal_proj:
             mg = self._merged_tproj(dt)
             d_t = hip.gemm(a, mg["w"], bias=mg["b1"])

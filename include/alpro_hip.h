@@ -82,6 +82,16 @@ size_t alpro_hip_sched_workspace_bytes(void);
 int alpro_hip_set_sched_workspace(void* stream, void* ptr, size_t bytes);
 int alpro_hip_release_stream(void* stream);
 
+/* Round 6: the temporal half's qkv Linear AND its attention in one launch (forward only; vit.py:84-98 Attention.forward on the
+ * 'b (h w t) m -> (b h w) t m' view of vit.py:152-156): out[m, h*64 + d] = sum_j softmax_j((q_m . k_j) * scale) v_j[d] over the T rows j of row m's
+ * frame group (rows g*T .. g*T + T - 1), with q | k | v = A W^T + bias computed per (256-row tile, head) and consumed out of the accumulators:
+ * the (M, 3*H*64) tensor is never written.  A (M, K) and W (3*H*64, K; rows [q | k | v], head-major like Attention.qkv.weight) K-contiguous
+ * 16-bit, bias (3*H*64) fp32 or NULL, out (M, H*64) 16-bit.  M % 32 == 0, T in {1, 2, 4, 8, 16}, K % 128 == 0.  Same roundings as
+ * alpro_gemm + alpro_attn_temporal_fwd (q, k, v, P and the output to 16 bits; everything else fp32); the two paths agree to the order of
+ * their fp32 sums. */
+int alpro_gemm_qkv_tattn(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, void* out, int64_t ldo, int dtype,
+                         int M, int H, int T, int K, float scale, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * C[map(m), n] = residual[map(m), n] + row_scale[m / row_scale_group] * act(alpha * sum_k A[m,k] W[n,k] + bias[n])
  * A (M,K) and W (N,K) are K-contiguous in `dtype`; accumulation is fp32 on MFMA

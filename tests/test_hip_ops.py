@@ -321,6 +321,33 @@ def test_attn_temporal(dt, T, groups):
     close(out, ref, *tol, "temporal attn")
 
 
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("M,H,T,K,with_bias", [(256 * 3, 12, 8, 768, True), (256 * 2 + 96, 12, 8, 768, True), (32, 2, 8, 128, False), (1568 * 2, 12, 8, 768, True),
+                                               (512, 3, 2, 256, True), (320, 12, 4, 768, True), (256, 1, 16, 384, True), (64, 12, 1, 768, True)])
+def test_gemm_qkv_temporal_attention_fused(dt, M, H, T, K, with_bias):
+    """alpro_gemm_qkv_tattn (round 6; vit.py:84-98 on the temporal view of vit.py:152-156): the qkv Linear and the T-frame attention in one launch,
+    q / k / v consumed out of the accumulators.  Against fp64 arithmetic on the operands as stored (q, k, v rounded to the storage dtype like the
+    two-launch path stores them), and against that two-launch path itself (alpro_gemm + alpro_attn_temporal_fwd) -- same roundings, so the two
+    agree to a few ulps of the output.  Ragged row panels (M % 256 != 0), every frame count the path allows, one and many heads, no bias."""
+    hip = _hip()
+    a = rnd(M, K, seed=700 + M).to(dt)
+    w = rnd(3 * H * 64, K, seed=701 + H, scale=2.0 / K ** 0.5).to(dt)
+    b = rnd(3 * H * 64, seed=702) if with_bias else None
+    scale = 0.125
+    out = hip.gemm_qkv_tattn(a.cuda(), w.cuda(), None if b is None else b.cuda(), T, H, scale)
+    qkv = a.double() @ w.double().T + (0 if b is None else b.double())
+    qkv = qkv.to(dt).double()                                   # the storage rounding of q, k, v
+    ref, _ = ref_attention(qkv, M // T, T, H, scale)
+    tol = {torch.bfloat16: (2e-2, 2e-2), torch.float16: (3e-3, 3e-3)}[dt]
+    close(out, ref, *tol, "fused qkv + temporal attention vs fp64")
+    two = hip.attn_temporal(hip.gemm(a.cuda(), w.cuda(), bias=None if b is None else b.cuda()), T, H, scale)
+    d = (out.float() - two.float()).abs().max().item()
+    ulp = {torch.bfloat16: 2.0 ** -8, torch.float16: 2.0 ** -11}[dt] * max(1.0, two.float().abs().max().item())
+    assert d <= 4 * ulp, "fused vs alpro_gemm + alpro_attn_temporal_fwd: %.3e (ulp %.1e)" % (d, ulp)
+    again = hip.gemm_qkv_tattn(a.cuda(), w.cuda(), None if b is None else b.cuda(), T, H, scale)
+    assert torch.equal(out, again)
+
+
 @pytest.mark.parametrize("M,N,K,case", [(64, 768, 3072, "res_scale"), (3, 2304, 768, "ln"), (512, 768, 768, "scale"), (64, 3072, 768, "ln_gelu"), (130, 256, 768, "plain"), (1, 768, 768, "ln")])
 def test_gemm_rows_f32(M, N, K, case):
     """alpro_gemm_rows_f32 (round 4: the fp32 Linears of the precise CLS-row chain, a few rows against a full fp32 weight, optional fused
