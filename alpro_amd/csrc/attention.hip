@@ -284,6 +284,15 @@ template <typename T> __device__ __forceinline__ float cls_join(float v0, float 
   return r;
 }
 
+// lane i <- lane i + N / lane i - N inside its row of 16 lanes: one VALU instruction (v_mov_b32_dpp row_shl / row_shr), where __shfl_down / __shfl_up
+// go through the LDS crossbar (ds_bpermute + a wait each: the 250 exchanges of a CLS tile cost that wave ~12 us that way, measured in round 6)
+template <int N> __device__ __forceinline__ float dpp_from_above(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x100 + N, 0xf, 0xf, true));
+}
+template <int N> __device__ __forceinline__ float dpp_from_below(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x110 + N, 0xf, 0xf, true));
+}
+
 template <typename T, int NKT, bool HAS_BIAS, bool CLS = false, bool DROP = false>
 __global__ __launch_bounds__(256, 2) void attn_fwd16_kernel(const T* __restrict__ qkv, T* __restrict__ out, int L, int H, float scale,
                                                             const float* __restrict__ key_bias, float* __restrict__ lse, float drop_p,
@@ -411,7 +420,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd16_kernel(const T* __restrict_
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const float a = s[kt][r];
-            const float b1 = __shfl_down(a, 1, 64), b2 = NS == 3 ? __shfl_down(a, 2, 64) : 0.f;
+            const float b1 = dpp_from_above<1>(a), b2 = NS == 3 ? dpp_from_above<2>(a) : 0.f;
             s[kt][r] = ql == c0 ? cls_join<T>(a, b1, b2) : a;
           }
       }
@@ -516,7 +525,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd16_kernel(const T* __restrict_
             const float pr = s[kt][r];
             float h0, h1, h2;
             cls_split<T>(pr, h0, h1, h2);
-            const float f1 = __shfl_up(h1, 1, 64), f2 = NS == 3 ? __shfl_up(h2, 2, 64) : 0.f;
+            const float f1 = dpp_from_below<1>(h1), f2 = NS == 3 ? dpp_from_below<2>(h2) : 0.f;
             s[kt][r] = ql == c0 ? h0 : (ql == c0 + 1 ? f1 : ((NS == 3 && ql == c0 + 2) ? f2 : pr));
           }
       }
@@ -542,7 +551,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd16_kernel(const T* __restrict_
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
               const float a = o[dt][4 * rq + e];
-              const float b1 = __shfl_down(a, 1, 64), b2 = NS == 3 ? __shfl_down(a, 2, 64) : 0.f;
+              const float b1 = dpp_from_above<1>(a), b2 = NS == 3 ? dpp_from_above<2>(a) : 0.f;
               v[e] = cls_join<T>(a, b1, b2) * inv;
             }
             if (ql == c0) *(float4*)(dst + dt * 32 + 8 * rq + 4 * g) = make_float4(v[0], v[1], v[2], v[3]);

@@ -67,7 +67,9 @@ struct TattnArgs {
   const void* W;        // (3 * H * 64, K) 16-bit, row stride ldw: Attention.qkv.weight
   const float* bias;    // (3 * H * 64) fp32 or nullptr
   void* out;            // (M, H * 64) 16-bit, row stride ldo: the attention output, heads merged (vit.py:96)
-  int64_t lda, ldw, ldo;
+  void* qkv_out;        // training: (M, 3 * H * 64) 16-bit, row stride ldq -- q | k | v as the qkv Linear stores them (the backward reads them) -- or nullptr
+  float* lse;           // training: log-sum-exp of every (32-row chunk, head, token), alpro_attn_temporal_fwd's layout ((chunk * H + h) * 32 + token), or nullptr
+  int64_t lda, ldw, ldo, ldq;
   int M, H, K, Tn;
   float scale;
 };
@@ -258,65 +260,50 @@ __global__ __launch_bounds__(NTH, 2) void gemm_qkv_tattn_kernel(const TattnArgs 
           bv[nf] = c;
         }
         char* ost = smem + 2 * PAR_BYTES + wave * 4096;
+        // the staged 32 x 64 block (token rows of 128 bytes, 16-byte chunks XORed with the row) -> 16-byte row pieces at `dst` (row stride ld elements)
+        auto drain = [&](T* dst, int64_t ld) __attribute__((always_inline)) {
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // DS operations of one wave complete in order; the staging area is wave-private
 #pragma unroll
-        for (int mf = 0; mf < 2; ++mf) {
-          // q^T, k^T fragment pairs -> K = 32 operands (lane = token, 8 features: registers of fragments 2 f and 2 f + 1)
-          u32x4 qo[2], ko[2];
+          for (int pz = 0; pz < 4; ++pz) {
+            const int row = pz * 8 + (le >> 3), slot = le & 7;
+            const u32x4 v = *(const u32x4*)(ost + row * 128 + ((slot ^ (row & 7)) << 4));
+            store16_sc1(dst + (int64_t)row * ld + slot * 8, v);
+          }
+          asm volatile("" ::: "memory");
+        };
+        if (g.qkv_out) {   // training: q | k | v of this (32 tokens, head) to HBM as well, in the qkv Linear's layout
+          T* qb = (T*)g.qkv_out + (int64_t)row0 * g.ldq + h * 64;
 #pragma unroll
-          for (int f = 0; f < 2; ++f) {
-            float qv[8], kv[8];
+          for (int part = 0; part < 2; ++part) {   // q, k: lane = token, registers = 4 consecutive features -> 8-byte pieces
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-              const int nf = 2 * f + (e >> 2), r = e & 3;
-              qv[e] = acc[mf][nf][r] + bq[nf][r];
-              kv[e] = acc[mf][4 + nf][r] + bk[nf][r];
+            for (int mf = 0; mf < 2; ++mf)
+#pragma unroll
+              for (int nf = 0; nf < 4; ++nf) {
+                const f32x4 a = acc[mf][part * 4 + nf];
+                const float* bb = part == 0 ? bq[nf] : bk[nf];
+                const int row = mf * 16 + el15;
+                *(u32x2*)(ost + row * 128 + (((2 * nf + (ekg >> 1)) ^ (row & 7)) << 4) + (ekg & 1) * 8) =
+                    mk2(pack2(a[0] + bb[0], a[1] + bb[1], (T*)0), pack2(a[2] + bb[2], a[3] + bb[3], (T*)0));
+              }
+            drain(qb + (int64_t)part * g.H * 64, g.ldq);
+          }
+#pragma unroll
+          for (int mf = 0; mf < 2; ++mf)   // v: lane = feature, registers = 4 consecutive tokens -> 2-byte pieces
+#pragma unroll
+            for (int nf = 0; nf < 4; ++nf) {
+              const f32x4 a = acc[mf][8 + nf];
+              const uint32_t p01 = pack2(a[0] + bv[nf], a[1] + bv[nf], (T*)0), p23 = pack2(a[2] + bv[nf], a[3] + bv[nf], (T*)0);
+              const int col = nf * 16 + el15;
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                const int row = mf * 16 + 4 * ekg + r;
+                const uint32_t w2 = r < 2 ? p01 : p23;
+                *(uint16_t*)(ost + row * 128 + (((col >> 3) ^ (row & 7)) << 4) + (col & 7) * 2) = (uint16_t)((r & 1) ? (w2 >> 16) : (w2 & 0xffffu));
+              }
             }
-            qo[f] = pack_chunk<T>(qv);
-            ko[f] = pack_chunk<T>(kv);
-          }
-          f32x4 st = {0.f, 0.f, 0.f, 0.f};
-          st = Mfma<T>::k32(ko[0], qo[0], st);
-          st = Mfma<T>::k32(ko[1], qo[1], st);    // S^T[j = 4 kg + r][i = l15]
-          // softmax over the T keys of the query's own group, log2 domain
-          float x[4], m = -INFINITY;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const bool ok = ((4 * ekg + r) >> tsh) == (el15 >> tsh);
-            x[r] = ok ? st[r] * sl : -INFINITY;
-            m = fmaxf(m, x[r]);
-          }
-          m = fmaxf(m, __shfl_xor(m, 16, 64));
-          m = fmaxf(m, __shfl_xor(m, 32, 64));
-          float pr[4], sum = 0.f;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            pr[r] = __builtin_amdgcn_exp2f(x[r] - m);   // exp2(-inf) == 0 on the other groups' keys
-            sum += pr[r];
-          }
-          sum += __shfl_xor(sum, 16, 64);
-          sum += __shfl_xor(sum, 32, 64);
-          const float inv = 1.0f / sum;
-          const u32x2 pt = mk2(pack2(pr[0], pr[1], (T*)0), pack2(pr[2], pr[3], (T*)0));   // P^T: B operand (lane = query, 4 keys)
-#pragma unroll
-          for (int f = 0; f < 4; ++f) {
-            const u32x2 vo = mk2(pack2(acc[mf][8 + f][0] + bv[f], acc[mf][8 + f][1] + bv[f], (T*)0),
-                                 pack2(acc[mf][8 + f][2] + bv[f], acc[mf][8 + f][3] + bv[f], (T*)0));   // v: A operand (lane = feature, 4 tokens)
-            f32x4 o = {0.f, 0.f, 0.f, 0.f};
-            o = Mfma<T>::k16(vo, pt, o);          // O^T[d = 16 f + 4 kg + r][i = l15]
-            const u32x2 ow = mk2(pack2(o[0] * inv, o[1] * inv, (T*)0), pack2(o[2] * inv, o[3] * inv, (T*)0));
-            const int row = mf * 16 + el15;       // 16-byte chunk 2 f + (kg >> 1) of the token's 128-byte row, XORed with the row
-            *(u32x2*)(ost + row * 128 + (((2 * f + (ekg >> 1)) ^ (row & 7)) << 4) + (ekg & 1) * 8) = ow;
-          }
+          drain(qb + (int64_t)2 * g.H * 64, g.ldq);
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // DS operations of one wave complete in order; the staging area is wave-private
-        T* ob = (T*)g.out + (int64_t)row0 * g.ldo + h * 64;
-#pragma unroll
-        for (int pz = 0; pz < 4; ++pz) {
-          const int row = pz * 8 + (le >> 3), slot = le & 7;
-          const u32x4 v = *(const u32x4*)(ost + row * 128 + ((slot ^ (row & 7)) << 4));
-          store16_sc1(ob + (int64_t)row * g.ldo + slot * 8, v);
-        }
-        asm volatile("" ::: "memory");
+        drain((T*)g.out + (int64_t)row0 * g.ldo + h * 64, g.ldo);
       }
     }
     if (nxt_t < 0) break;
@@ -334,7 +321,7 @@ __global__ __launch_bounds__(NTH, 2) void gemm_qkv_tattn_kernel(const TattnArgs 
 using namespace alpro;
 
 extern "C" int alpro_gemm_qkv_tattn(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, void* out, int64_t ldo, int dtype,
-                                    int M, int H, int T, int K, float scale, void* stream) {
+                                    int M, int H, int T, int K, float scale, void* qkv_out, int64_t ldq, float* lse, void* stream) {
   ALPRO_CHECK(A && W && out && M > 0 && H > 0 && T > 0, "alpro_gemm_qkv_tattn: bad args");
   ALPRO_CHECK(dtype == ALPRO_BF16 || dtype == ALPRO_F16, "alpro_gemm_qkv_tattn: 16-bit operand dtypes only (the exact fp32 mode keeps the separate launches)");
   ALPRO_CHECK(16 % T == 0, "alpro_gemm_qkv_tattn: num_frm=%d must divide 16 (a frame group lives inside one 16-token accumulator fragment)", T);
@@ -344,8 +331,9 @@ extern "C" int alpro_gemm_qkv_tattn(const void* A, int64_t lda, const void* W, i
   ALPRO_CHECK(((uintptr_t)A % 16) == 0 && ((uintptr_t)W % 16) == 0 && ((uintptr_t)out % 16) == 0 && (!bias || ((uintptr_t)bias % 16) == 0), "alpro_gemm_qkv_tattn: pointers must be 16-byte aligned");
   ALPRO_CHECK((int64_t)M * lda * 2 < (int64_t)0x7FFF0000 && (int64_t)3 * H * 64 * ldw * 2 < (int64_t)0x7FFF0000, "alpro_gemm_qkv_tattn: operands beyond 2 GiB need 64-bit copy offsets");
   TattnArgs g;
-  g.A = A; g.W = W; g.bias = bias; g.out = out;
-  g.lda = lda; g.ldw = ldw; g.ldo = ldo;
+  ALPRO_CHECK(!qkv_out || ((ldq % 8) == 0 && ((uintptr_t)qkv_out % 16) == 0), "alpro_gemm_qkv_tattn: qkv_out rows must be 16-byte aligned");
+  g.A = A; g.W = W; g.bias = bias; g.out = out; g.qkv_out = qkv_out; g.lse = lse;
+  g.lda = lda; g.ldw = ldw; g.ldo = ldo; g.ldq = ldq;
   g.M = M; g.H = H; g.K = K; g.Tn = T;
   g.scale = scale;
   hipStream_t st = (hipStream_t)stream;

@@ -112,7 +112,7 @@ def load():
     lib.alpro_hip_sched_workspace_bytes.restype = ctypes.c_size_t
     lib.alpro_hip_set_sched_workspace.argtypes = [vp, vp, ctypes.c_size_t]
     lib.alpro_hip_release_stream.argtypes = [vp]
-    lib.alpro_gemm_qkv_tattn.argtypes = [vp, i64, vp, i64, vp, vp, i64, i32, i32, i32, i32, i32, f32, vp]
+    lib.alpro_gemm_qkv_tattn.argtypes = [vp, i64, vp, i64, vp, vp, i64, i32, i32, i32, i32, i32, f32, vp, i64, vp, vp]
     lib.alpro_scatter_add_rows_ordered.argtypes = [vp, vp, vp, i32, i32, i64, i64, vp, vp]
     lib.alpro_gather_seq_fwd.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]
     lib.alpro_gather_seq_bwd.argtypes = [vp, vp, i32, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]
@@ -545,9 +545,11 @@ def qkv_tattn_ok(a, T):
         and (a.stride(0) * 2) % 128 == 0
 
 
-def gemm_qkv_tattn(a, w, bias, T, H, scale, out=None):
-    """The temporal half's qkv Linear + frame attention in one launch (alpro_gemm_qkv_tattn, forward only): a (M, K) 16-bit rows in x[:, 1:] order,
-    w (3*H*64, K) = Attention.qkv.weight in the operand dtype, bias (3*H*64) fp32 -> (M, H*64) attention output, heads merged."""
+def gemm_qkv_tattn(a, w, bias, T, H, scale, out=None, want_qkv=False):
+    """The temporal half's qkv Linear + frame attention in one launch (alpro_gemm_qkv_tattn): a (M, K) 16-bit rows in x[:, 1:] order, w (3*H*64, K)
+    = Attention.qkv.weight in the operand dtype, bias (3*H*64) fp32 -> (M, H*64) attention output, heads merged.  want_qkv (training): also
+    returns q | k | v (M, 3*H*64) as alpro_gemm would have stored them and the log-sum-exp rows alpro_attn_temporal_bwd needs:
+    -> (out, qkv, lse)."""
     lib = load()
     _dev(a); _dev(w)
     M, K = a.shape
@@ -556,9 +558,11 @@ def gemm_qkv_tattn(a, w, bias, T, H, scale, out=None):
     if out is None:
         out = torch.empty((M, H * 64), dtype=a.dtype, device=a.device)
     assert out.shape == (M, H * 64) and out.stride(1) == 1 and out.dtype == a.dtype
-    _check(lib.alpro_gemm_qkv_tattn(_ptr(a), a.stride(0), _ptr(w), w.stride(0), _ptr(b), _ptr(out), out.stride(0), _CODE[a.dtype], M, H, T, K, float(scale), _stream()),
-           "alpro_gemm_qkv_tattn")
-    return out
+    qkv = torch.empty((M, 3 * H * 64), dtype=a.dtype, device=a.device) if want_qkv else None
+    lse = torch.empty(((M + 31) // 32, H, 32), dtype=torch.float32, device=a.device) if want_qkv else None
+    _check(lib.alpro_gemm_qkv_tattn(_ptr(a), a.stride(0), _ptr(w), w.stride(0), _ptr(b), _ptr(out), out.stride(0), _CODE[a.dtype], M, H, T, K, float(scale),
+                                    _ptr(qkv), 3 * H * 64, _ptr(lse), _stream()), "alpro_gemm_qkv_tattn")
+    return (out, qkv, lse) if want_qkv else out
 
 
 def attn_cls(qkv, qkv_cls, batch, L, H, scale, group=1, key_bias=None, drop_p=0.0, drop_seed=0):

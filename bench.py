@@ -103,6 +103,10 @@ class KernelTimer:
             return "M=%d N=%d K=%d act=%s res=%d out=%s map=%s" % (a.shape[0], w.shape[0], a.shape[1], k.get("act", 0), k.get("residual") is not None,
                                                               str(od).replace("torch.", "") if od is not None else "-", k.get("map_mode", 0))
         wrap("gemm", lambda a, w, *r, **k: 2.0 * a.shape[0] * a.shape[1] * w.shape[0], gemm_key)
+        # round 6: the temporal half's qkv Linear + frame attention in one launch: priced on the GEMM's flops plus the attention's (the same two
+        # figures the separate launches are priced on); its time joins the GEMM family of the roofline object, where the qkv GEMM's was
+        wrap("gemm_qkv_tattn", lambda a, w, bias, T, H, *r, **k: 2.0 * a.shape[0] * a.shape[1] * w.shape[0] + 4.0 * a.shape[0] * T * H * 64,
+             lambda a, w, bias, T, H, *r, **k: "M=%d N=%d K=%d T=%d fused qkv + temporal attention" % (a.shape[0], w.shape[0], a.shape[1], T))
         wrap("attn", lambda qkv, batch, L, H, *r, **k: 4.0 * batch * H * L * L * 64)
         wrap("attn_temporal", lambda qkv, T, H, *r, **k: 4.0 * qkv.shape[0] * T * H * 64)
         wrap("layernorm", lambda *a, **k: 0.0)
@@ -506,9 +510,10 @@ def main():
         ms = elapsed / args.steps * 1e3
         value = world * B * args.steps / elapsed
         gemm = dict(ks["gemm"])
-        if "gemm_tn_acc" in ks:  # the wgrad GEMMs belong to the same MFMA-bound family
-            for k_ in ("launches", "flops", "ms"):
-                gemm[k_] += ks["gemm_tn_acc"][k_]
+        for fam in ("gemm_tn_acc", "gemm_qkv_tattn"):  # the wgrad GEMMs and the fused qkv + temporal-attention tiles belong to the same MFMA-bound family
+            if fam in ks:
+                for k_ in ("launches", "flops", "ms"):
+                    gemm[k_] += ks[fam][k_]
         ach = gemm["flops"] / (gemm["ms"] * 1e-3) / 1e12
         traffic, traffic_src, pm = None, None, {}
         import glob

@@ -88,9 +88,11 @@ int alpro_hip_release_stream(void* stream);
  * the (M, 3*H*64) tensor is never written.  A (M, K) and W (3*H*64, K; rows [q | k | v], head-major like Attention.qkv.weight) K-contiguous
  * 16-bit, bias (3*H*64) fp32 or NULL, out (M, H*64) 16-bit.  M % 32 == 0, T in {1, 2, 4, 8, 16}, K % 128 == 0.  Same roundings as
  * alpro_gemm + alpro_attn_temporal_fwd (q, k, v, P and the output to 16 bits; everything else fp32); the two paths agree to the order of
- * their fp32 sums. */
+ * their fp32 sums.  Training: qkv_out (M, 3*H*64; row stride ldq) != NULL also receives q | k | v exactly as alpro_gemm would have stored them,
+ * and lse != NULL the per-row log-sum-exp in alpro_attn_temporal_fwd's layout ((32-row chunk * H + h) * 32 + row in chunk) -- what
+ * alpro_attn_temporal_bwd reads; the saving is then the attention launch and its re-read of q | k | v, not the write. */
 int alpro_gemm_qkv_tattn(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, void* out, int64_t ldo, int dtype,
-                         int M, int H, int T, int K, float scale, void* stream);
+                         int M, int H, int T, int K, float scale, void* qkv_out, int64_t ldq, float* lse, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * C[map(m), n] = residual[map(m), n] + row_scale[m / row_scale_group] * act(alpha * sum_k A[m,k] W[n,k] + bias[n])

@@ -346,6 +346,15 @@ def test_gemm_qkv_temporal_attention_fused(dt, M, H, T, K, with_bias):
     assert d <= 4 * ulp, "fused vs alpro_gemm + alpro_attn_temporal_fwd: %.3e (ulp %.1e)" % (d, ulp)
     again = hip.gemm_qkv_tattn(a.cuda(), w.cuda(), None if b is None else b.cuda(), T, H, scale)
     assert torch.equal(out, again)
+    # the training form: the same output, plus q | k | v as the qkv Linear stores them and the log-sum-exp rows the temporal backward reads
+    out3, qkv3, lse3 = hip.gemm_qkv_tattn(a.cuda(), w.cuda(), None if b is None else b.cuda(), T, H, scale, want_qkv=True)
+    assert torch.equal(out3, out)
+    g2 = hip.gemm(a.cuda(), w.cuda(), bias=None if b is None else b.cuda())
+    dq = (qkv3.float() - g2.float()).abs().max().item()
+    assert dq <= {torch.bfloat16: 2.0 ** -7, torch.float16: 2.0 ** -10}[dt] * max(1.0, g2.float().abs().max().item()), "q | k | v vs alpro_gemm: %.3e" % dq
+    _, lse2 = hip.attn_temporal(qkv3, T, H, scale, want_lse=True)
+    assert lse3.shape == lse2.shape
+    close(lse3, lse2.double().cpu(), 2e-5, 2e-5, "log-sum-exp rows vs alpro_attn_temporal_fwd on the same q | k | v")
 
 
 @pytest.mark.parametrize("M,N,K,case", [(64, 768, 3072, "res_scale"), (3, 2304, 768, "ln"), (512, 768, 768, "scale"), (64, 3072, 768, "ln_gelu"), (130, 256, 768, "plain"), (1, 768, 768, "ln")])

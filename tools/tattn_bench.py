@@ -32,6 +32,9 @@ for B in (32, 64):
     qkv = hip.gemm(a, w, bias=b)
     t_a = timeit(lambda: hip.attn_temporal(qkv, T, H, 0.125))
     t_f = timeit(lambda: hip.gemm_qkv_tattn(a, w, b, T, H, 0.125))
+    t_t = timeit(lambda: hip.gemm_qkv_tattn(a, w, b, T, H, 0.125, want_qkv=True))
+    t_a2 = timeit(lambda: hip.attn_temporal(qkv, T, H, 0.125, want_lse=True))
+    print("B=%d training form: fused + q|k|v + lse written %.1f us against %.1f us (gemm + attention with lse)" % (B, t_t * 1e3, (t_g + t_a2) * 1e3))
     d = (hip.gemm_qkv_tattn(a, w, b, T, H, 0.125).float() - hip.attn_temporal(qkv, T, H, 0.125).float()).abs().max().item()
     print("B=%d M=%d: qkv gemm %.1f us (%.0f TF/s) + temporal attention %.1f us = %.1f us | fused %.1f us (%.0f TF/s on the GEMM's flops) | max |fused - two launches| %.2e" % (
         B, M, t_g * 1e3, fl / t_g / 1e9, t_a * 1e3, (t_g + t_a) * 1e3, t_f * 1e3, fl / t_f / 1e9, d))
