@@ -62,6 +62,13 @@ template <> struct Mfma<bf16_t> {
   }
 };
 
+// Keep a value alive up to this point (no instruction).  Used behind the epilogue's small MFMAs: their A / B operands die with the instruction,
+// and the register allocator then likes to give the result the SAME registers at a shifted offset (seen in the built object:
+// `v_mfma_f32_16x16x16_f16 v[58:61], v[60:61], v[70:71], 0`), which gfx950 does not execute correctly -- rows 17/19/21/23 of every 32-token
+// block came out wrong in two of the four result registers, deterministically, in one build and not in the previous one (round 6; LLVM only
+// forbids the overlap for results wider than four registers).  With the operands live across the instruction there is nothing to overlap with.
+template <typename X> __device__ __forceinline__ void keep_alive(const X& x) { asm volatile("" ::"v"(x)); }
+
 struct TattnArgs {
   const void* A;        // (M, K) 16-bit, row stride lda elements: the normalised token rows (x[:, 1:] order: T consecutive rows = one patch)
   const void* W;        // (3 * H * 64, K) 16-bit, row stride ldw: Attention.qkv.weight
@@ -287,21 +294,88 @@ __global__ __launch_bounds__(NTH, 2) void gemm_qkv_tattn_kernel(const TattnArgs 
               }
             drain(qb + (int64_t)part * g.H * 64, g.ldq);
           }
+          // v: lane = feature, registers = 4 consecutive tokens.  Staged as 8-byte units (4 tokens x 1 feature) at [token group mf * 4 + kg][feature]; a
+          // lane then reads the 8 units of (token group le >> 3, features 8 (le & 7) .. + 7) and permutes them into four 16-byte row pieces (the
+          // packed epilogue of gemm_nt256q_kernel does the same)
 #pragma unroll
-          for (int mf = 0; mf < 2; ++mf)   // v: lane = feature, registers = 4 consecutive tokens -> 2-byte pieces
+          for (int mf = 0; mf < 2; ++mf)
 #pragma unroll
             for (int nf = 0; nf < 4; ++nf) {
               const f32x4 a = acc[mf][8 + nf];
-              const uint32_t p01 = pack2(a[0] + bv[nf], a[1] + bv[nf], (T*)0), p23 = pack2(a[2] + bv[nf], a[3] + bv[nf], (T*)0);
-              const int col = nf * 16 + el15;
-#pragma unroll
-              for (int r = 0; r < 4; ++r) {
-                const int row = mf * 16 + 4 * ekg + r;
-                const uint32_t w2 = r < 2 ? p01 : p23;
-                *(uint16_t*)(ost + row * 128 + (((col >> 3) ^ (row & 7)) << 4) + (col & 7) * 2) = (uint16_t)((r & 1) ? (w2 >> 16) : (w2 & 0xffffu));
-              }
+              *(u32x2*)(ost + ((mf * 4 + ekg) * 64 + nf * 16 + el15) * 8) = mk2(pack2(a[0] + bv[nf], a[1] + bv[nf], (T*)0), pack2(a[2] + bv[nf], a[3] + bv[nf], (T*)0));
             }
-          drain(qb + (int64_t)2 * g.H * 64, g.ldq);
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          {
+            const int rg = le >> 3, cb = le & 7;
+            u32x4 qv[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) qv[j] = *(const u32x4*)(ost + (rg * 64 + cb * 8 + 2 * j) * 8);
+            T* vb = qb + (int64_t)2 * g.H * 64 + (int64_t)(4 * rg) * g.ldq + cb * 8;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              u32x4 o;
+#pragma unroll
+              for (int j = 0; j < 4; ++j) {
+                const uint32_t lo2 = (r & 2) ? qv[j].y : qv[j].x, hi2 = (r & 2) ? qv[j].w : qv[j].z;   // features 2 j / 2 j + 1, tokens (r & 2), (r & 2) + 1
+                o[j] = __builtin_amdgcn_perm(hi2, lo2, (r & 1) ? 0x07060302u : 0x05040100u);
+              }
+              store16_sc1(vb + (int64_t)r * g.ldq, o);
+            }
+            asm volatile("" ::: "memory");
+          }
+        }
+#pragma unroll
+        for (int mf = 0; mf < 2; ++mf) {
+          // q^T, k^T fragment pairs -> K = 32 operands (lane = token, 8 features: registers of fragments 2 f and 2 f + 1)
+          u32x4 qo[2], ko[2];
+#pragma unroll
+          for (int f = 0; f < 2; ++f) {
+            float qv[8], kv[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              const int nf = 2 * f + (e >> 2), r = e & 3;
+              qv[e] = acc[mf][nf][r] + bq[nf][r];
+              kv[e] = acc[mf][4 + nf][r] + bk[nf][r];
+            }
+            qo[f] = pack_chunk<T>(qv);
+            ko[f] = pack_chunk<T>(kv);
+          }
+          f32x4 st = {0.f, 0.f, 0.f, 0.f};
+          st = Mfma<T>::k32(ko[0], qo[0], st);
+          st = Mfma<T>::k32(ko[1], qo[1], st);    // S^T[j = 4 kg + r][i = l15]
+          keep_alive(ko[0]); keep_alive(qo[0]); keep_alive(ko[1]); keep_alive(qo[1]);
+          // softmax over the T keys of the query's own group, log2 domain
+          float x[4], m = -INFINITY;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const bool ok = ((4 * ekg + r) >> tsh) == (el15 >> tsh);
+            x[r] = ok ? st[r] * sl : -INFINITY;
+            m = fmaxf(m, x[r]);
+          }
+          m = fmaxf(m, __shfl_xor(m, 16, 64));
+          m = fmaxf(m, __shfl_xor(m, 32, 64));
+          float pr[4], sum = 0.f;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            pr[r] = __builtin_amdgcn_exp2f(x[r] - m);   // exp2(-inf) == 0 on the other groups' keys
+            sum += pr[r];
+          }
+          sum += __shfl_xor(sum, 16, 64);
+          sum += __shfl_xor(sum, 32, 64);
+          const float inv = 1.0f / sum;
+          if (g.lse && ekg == 0) g.lse[((int64_t)(row0 >> 5) * g.H + h) * 32 + mf * 16 + el15] = (m + __builtin_amdgcn_logf(sum)) * 0.6931471805599453f;
+          const u32x2 pt = mk2(pack2(pr[0], pr[1], (T*)0), pack2(pr[2], pr[3], (T*)0));   // P^T: B operand (lane = query, 4 keys)
+#pragma unroll
+          for (int f = 0; f < 4; ++f) {
+            const u32x2 vo = mk2(pack2(acc[mf][8 + f][0] + bv[f], acc[mf][8 + f][1] + bv[f], (T*)0),
+                                 pack2(acc[mf][8 + f][2] + bv[f], acc[mf][8 + f][3] + bv[f], (T*)0));   // v: A operand (lane = feature, 4 tokens)
+            f32x4 o = {0.f, 0.f, 0.f, 0.f};
+            o = Mfma<T>::k16(vo, pt, o);          // O^T[d = 16 f + 4 kg + r][i = l15]
+            keep_alive(vo); keep_alive(pt);
+            const u32x2 ow = mk2(pack2(o[0] * inv, o[1] * inv, (T*)0), pack2(o[2] * inv, o[3] * inv, (T*)0));
+            const int row = mf * 16 + el15;       // 16-byte chunk 2 f + (kg >> 1) of the token's 128-byte row, XORed with the row
+            *(u32x2*)(ost + row * 128 + (((2 * f + (ekg >> 1)) ^ (row & 7)) << 4) + (ekg & 1) * 8) = ow;
+          }
         }
         drain((T*)g.out + (int64_t)row0 * g.ldo + h * 64, g.ldo);
       }

@@ -996,6 +996,65 @@ def test_gradient_checkpointing_flag_is_accepted_and_says_that_it_is_ignored():
     assert not any("gradient_checkpointing" in str(x.message) for x in w)
 
 
+def test_fused_qkv_temporal_attention_isa(tmp_path):
+    """gemm_qkv_tattn_kernel (round 6, csrc/gemm_tattn.hip) counts its own LDS-DMA copies like the 8-phase GEMM: one `s_waitcnt vmcnt(3)` per K-tile
+    stands for "everything issued before this phase has landed".  On the built object, per instantiation: the K loop (first to last big MFMA of
+    the two unrolled K-tiles) holds 96 v_mfma_f32_16x16x32, 14 copies, two counted waits, 10 barriers and no other vector-memory operation or
+    spill; and NO small MFMA of the attention epilogue writes its result over its own A / B operand registers at a shifted offset
+    (`v_mfma_f32_16x16x16_f16 v[58:61], v[60:61], ...`): gfx950 computed two of four result registers wrong for a quarter of the rows with that
+    allocation -- the operands are kept alive across the instruction in the source (keep_alive) so that the allocator has nothing to overlap."""
+    import re
+    import shutil
+    import subprocess
+    llvm = "/opt/rocm/lib/llvm/bin"
+    obj = os.path.join(ROOT, "alpro_amd", "lib", "obj", "gemm_tattn.o")
+    if not (os.path.exists(obj) and os.path.exists(os.path.join(llvm, "llvm-objdump"))):
+        pytest.skip("needs the built gemm_tattn.o (python -m alpro_amd.build) and llvm-objdump")
+    work = tmp_path / "gemm_tattn.o"
+    shutil.copy(obj, work)
+    subprocess.run([os.path.join(llvm, "llvm-objdump"), "--offloading", str(work)], check=True, capture_output=True, cwd=tmp_path)
+    dev = [f for f in os.listdir(tmp_path) if "gfx950" in f]
+    assert len(dev) == 1, os.listdir(tmp_path)
+    dis = subprocess.run([os.path.join(llvm, "llvm-objdump"), "-d", str(tmp_path / dev[0])], check=True, capture_output=True, text=True).stdout
+    funcs = re.split(r"\n(?=[0-9a-f]{16} <)", dis)
+    seen = 0
+
+    def regs(tok):   # "v[58:61]," -> {58..61}; "v7," -> {7}; "0" -> {}
+        m = re.match(r"v\[(\d+):(\d+)\]", tok)
+        if m:
+            return set(range(int(m.group(1)), int(m.group(2)) + 1))
+        m = re.match(r"v(\d+)\b", tok)
+        return {int(m.group(1))} if m else set()
+    for fn in funcs:
+        head = fn.split("\n", 1)[0]
+        if "gemm_qkv_tattn_kernel" not in head:
+            continue
+        seen += 1
+        code = [l.split("//")[0].strip() for l in fn.split("\n")[1:]]
+        # the tied-accumulator MFMAs of the K loop: source C is a register range (the epilogue's start from the constant 0)
+        big = [i for i, l in enumerate(code) if re.match(r"v_mfma_f32_16x16x32_\w+ v\[\d+:\d+\], v\[\d+:\d+\], v\[\d+:\d+\], v\[", l)]
+        loop = [i for i in big if not any(re.match(r"v_mfma_f32_16x16x16", code[j]) for j in range(i, min(i + 40, len(code))))]
+        assert len(big) >= 96, (head, len(big))
+        k0 = big[0]
+        k1 = max(i for i in big if i - k0 < 4000 and sum(1 for j in big if k0 <= j <= i) <= 96)
+        span = code[k0:k1 + 1]
+        count = lambda pat: sum(1 for l in span if re.search(pat, l))   # noqa: E731
+        assert count(r"^v_mfma_f32_16x16x32") == 96, (head, count(r"^v_mfma_f32_16x16x32"))
+        assert count(r"\bglobal_load_lds_dwordx4\b") == 13, (head, count(r"global_load_lds"))    # 14 per two K-tiles minus the first phase's one (before the first MFMA)
+        assert count(r"s_waitcnt vmcnt\(3\)") == 2 and count(r"s_waitcnt.*vmcnt") == 2, (head, [l for l in span if "vmcnt" in l])
+        assert count(r"\bs_barrier\b") == 10, (head, count(r"\bs_barrier\b"))    # 12 per two K-tiles minus the one before the first and the one behind the last MFMA
+        for bad in (r"\bscratch_", r"\bbuffer_", r"\bflat_", r"\bglobal_(load|store)_(?!lds)", r"\bglobal_atomic", r"\bv_readlane", r"\bv_writelane"):
+            assert count(bad) == 0, (head, bad, [l for l in span if re.search(bad, l)][:3])
+        assert not any(l.startswith("flat_") for l in code), head
+        small = [l for l in code if re.match(r"v_mfma_f32_16x16x(16|32)_\w+ v\[\d+:\d+\], \S+ \S+ 0$", l)]
+        assert len(small) >= 6, (head, len(small))
+        for l in small:
+            t = l.split()
+            dst, a, b = regs(t[1]), regs(t[2]), regs(t[3])
+            assert not (dst & a) and not (dst & b), (head, l)
+    assert seen == 2, seen
+
+
 def test_flat_adamw_state_dict_carries_the_loss_scaler():
     """under loss scaling Adam's bias correction runs on the scaler's device counter of APPLIED steps; the host step counter
     also counts overflow-skipped steps.  The optimizer's state_dict therefore carries the scaler, and loading it must NOT re-seed the applied
