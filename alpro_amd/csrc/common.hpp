@@ -244,8 +244,11 @@ __device__ __forceinline__ void dma16(const void* src, uint32_t lds_addr) {
 // 16-byte write-through store (sc1): the line leaves the XCD's L2 and lands memory-side.  Used for the attention outputs (read next by
 // the projection GEMM / the weight gradient): same speed as a non-temporal store for the attention kernel, ~0.3 % of the step for its
 // consumers (profiles/r2_gemm_epilogue_experiments.txt, experiment 10d); on the GEMM's own 16-bit outputs it LOSES 1.8 ms.
+// (the trailing s_nop 1: a store of more than 8 bytes reads its data registers a moment after it issues, and the compiler -- which sees an
+// opaque string, not a store -- may let the very next VALU instruction overwrite them; round 6: the q | k | v rows of the fused temporal kernel
+// came out wrong in some builds and bitwise right in others until the wait states were inside the string)
 __device__ __forceinline__ void store16_sc1(void* p, const u32x4& v) {
-  asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
 }
 // A SCALAR load of read-only data at a wave-uniform index (s_load_dword: counted on lgkmcnt, not on vmcnt -- it cannot put a vmcnt(0) join
 // between an epilogue's output stores).  The constant address space is what makes the compiler pick the scalar path.

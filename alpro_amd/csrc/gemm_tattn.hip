@@ -9,9 +9,9 @@
 //  * Orientation per fragment column: q and k are accumulated TRANSPOSED (v_mfma_f32_16x16x32 with the W fragment as the A operand: lane =
 //    token, registers = 4 consecutive features), v normally (lane = feature, registers = 4 consecutive tokens).  A transposed q / k fragment
 //    pair, packed to 16 bits, IS a K = 32 MFMA operand (lane = token row, 8 features per lane; the feature order is a permutation of d that
-//    q and k share, and a dot product does not care), a normal v fragment IS the A operand of the K = 16 MFMA that contracts over tokens:
+//    q and k share, and a dot product does not care), a normal v fragment IS (the lower half of) the A operand of the MFMA that contracts over tokens:
 //        S^T[j][i] = sum_d k[j][d] q[i][d]     2 x v_mfma_f32_16x16x32     (lane = query i, registers = keys j = 4 (lane >> 4) + r)
-//        O^T[d][i] = sum_j v[j][d] P^T[j][i]   4 x v_mfma_f32_16x16x16     (lane = token i, registers = 4 consecutive d)
+//        O^T[d][i] = sum_j v[j][d] P^T[j][i]   4 x v_mfma_f32_16x16x32 (upper k half zero)   (lane = token i, registers = 4 consecutive d)
 //    per 16-token fragment row (16 / T groups, block-diagonal mask), with the softmax on 4 registers per lane in between.  The attention of a
 //    256 x 64 head tile costs 48 small MFMAs and ~350 VALU instructions per wave -- under 3 % of the tile's K loop.
 //  * K loop: the 8-phase idea of gemm_nt256q_kernel (gemm.hip) on a 3-phase K-tile: phase p = the 64 W rows of part p (q, k, v) = 4 fragment
@@ -44,29 +44,20 @@ constexpr int LDS_BYTES = 2 * PAR_BYTES + OST_BYTES;
 
 template <typename T> struct Mfma;
 template <> struct Mfma<f16_t> {
-  typedef _Float16 h4 __attribute__((ext_vector_type(4)));
   static __device__ __forceinline__ f32x4 k32(const u32x4& a, const u32x4& b, const f32x4& c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
   }
-  static __device__ __forceinline__ f32x4 k16(const u32x2& a, const u32x2& b, const f32x4& c) {
-    return __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(h4, a), __builtin_bit_cast(h4, b), c, 0, 0, 0);
-  }
 };
 template <> struct Mfma<bf16_t> {
-  typedef short s4 __attribute__((ext_vector_type(4)));
   static __device__ __forceinline__ f32x4 k32(const u32x4& a, const u32x4& b, const f32x4& c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
-  }
-  static __device__ __forceinline__ f32x4 k16(const u32x2& a, const u32x2& b, const f32x4& c) {
-    return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s4, a), __builtin_bit_cast(s4, b), c, 0, 0, 0);
   }
 };
 
 // Keep a value alive up to this point (no instruction).  Used behind the epilogue's small MFMAs: their A / B operands die with the instruction,
 // and the register allocator then likes to give the result the SAME registers at a shifted offset (seen in the built object:
-// `v_mfma_f32_16x16x16_f16 v[58:61], v[60:61], v[70:71], 0`), which gfx950 does not execute correctly -- rows 17/19/21/23 of every 32-token
-// block came out wrong in two of the four result registers, deterministically, in one build and not in the previous one (round 6; LLVM only
-// forbids the overlap for results wider than four registers).  With the operands live across the instruction there is nothing to overlap with.
+// `v_mfma ... v[58:61], v[60:61], v[70:71], 0`; LLVM only forbids the overlap for results wider than four registers).  With the operands
+// live across the instruction there is nothing to overlap with -- a precaution, checked on the built object by tests/test_host_cpu.py.
 template <typename X> __device__ __forceinline__ void keep_alive(const X& x) { asm volatile("" ::"v"(x)); }
 
 struct TattnArgs {
@@ -370,8 +361,14 @@ __global__ __launch_bounds__(NTH, 2) void gemm_qkv_tattn_kernel(const TattnArgs 
             const u32x2 vo = mk2(pack2(acc[mf][8 + f][0] + bv[f], acc[mf][8 + f][1] + bv[f], (T*)0),
                                  pack2(acc[mf][8 + f][2] + bv[f], acc[mf][8 + f][3] + bv[f], (T*)0));   // v: A operand (lane = feature, 4 tokens)
             f32x4 o = {0.f, 0.f, 0.f, 0.f};
-            o = Mfma<T>::k16(vo, pt, o);          // O^T[d = 16 f + 4 kg + r][i = l15]
-            keep_alive(vo); keep_alive(pt);
+            // O^T[d = 16 f + 4 kg + r][i = l15].  The contraction over the fragment's 16 tokens runs on the K = 32 instruction with the upper four
+            // k-elements of both operands zero: the K = 16 form (v_mfma_f32_16x16x16_f16 / _bf16) gave wrong values in two of four result
+            // registers for rows 17 / 19 / 21 / 23 of every 32-token block on gfx950 -- in one build and not in the previous one, with or without
+            // wait states behind it, with or without result / operand register overlap (round 6, tools/r6 variants: k32 0 wrong of 589824,
+            // every k16 variant ~8900); the K = 32 form is the one this chip's GEMMs run on
+            const u32x4 va = mk4(vo.x, vo.y, 0u, 0u), pb = mk4(pt.x, pt.y, 0u, 0u);
+            o = Mfma<T>::k32(va, pb, o);
+            keep_alive(va); keep_alive(pb);
             const u32x2 ow = mk2(pack2(o[0] * inv, o[1] * inv, (T*)0), pack2(o[2] * inv, o[3] * inv, (T*)0));
             const int row = mf * 16 + el15;       // 16-byte chunk 2 f + (kg >> 1) of the token's 128-byte row, XORed with the row
             *(u32x2*)(ost + row * 128 + (((2 * f + (ekg >> 1)) ^ (row & 7)) << 4) + (ekg & 1) * 8) = ow;

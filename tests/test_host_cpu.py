@@ -1000,9 +1000,9 @@ def test_fused_qkv_temporal_attention_isa(tmp_path):
     """gemm_qkv_tattn_kernel (round 6, csrc/gemm_tattn.hip) counts its own LDS-DMA copies like the 8-phase GEMM: one `s_waitcnt vmcnt(3)` per K-tile
     stands for "everything issued before this phase has landed".  On the built object, per instantiation: the K loop (first to last big MFMA of
     the two unrolled K-tiles) holds 96 v_mfma_f32_16x16x32, 14 copies, two counted waits, 10 barriers and no other vector-memory operation or
-    spill; and NO small MFMA of the attention epilogue writes its result over its own A / B operand registers at a shifted offset
-    (`v_mfma_f32_16x16x16_f16 v[58:61], v[60:61], ...`): gfx950 computed two of four result registers wrong for a quarter of the rows with that
-    allocation -- the operands are kept alive across the instruction in the source (keep_alive) so that the allocator has nothing to overlap."""
+    spill; NO small MFMA of the attention epilogue writes its result over its own A / B operand registers at a shifted offset
+    (`v_mfma ... v[58:61], v[60:61], ...`; the operands are kept alive across the instruction in the source, keep_alive), and none of them is
+    the K = 16 form, which computed a quarter of the rows wrong on gfx950 (csrc/gemm_tattn.hip, the P V product)."""
     import re
     import shutil
     import subprocess
@@ -1052,6 +1052,7 @@ def test_fused_qkv_temporal_attention_isa(tmp_path):
             t = l.split()
             dst, a, b = regs(t[1]), regs(t[2]), regs(t[3])
             assert not (dst & a) and not (dst & b), (head, l)
+        assert not any("16x16x16" in l for l in code), head
     assert seen == 2, seen
 
 
