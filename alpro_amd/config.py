@@ -72,17 +72,24 @@ def set_cls_stream(v):
     _cls_stream[0] = v.lower() if isinstance(v, str) else ("1" if v else "0")
 
 
-# Round 6: the temporal half's qkv Linear and its T-frame attention as ONE launch in the inference forward (alpro_gemm_qkv_tattn: q | k | v are
-# consumed out of the GEMM's accumulators and never written; csrc/gemm_tattn.hip).  ALPRO_FUSE_TATTN = 1 (default) | 0 (the two launches).
-_fuse_tattn = [os.environ.get("ALPRO_FUSE_TATTN", "1") != "0"]
+# Round 6: the temporal half's qkv Linear and its T-frame attention as ONE launch (alpro_gemm_qkv_tattn: q | k | v are consumed out of the GEMM's
+# accumulators; csrc/gemm_tattn.hip).  ALPRO_FUSE_TATTN = infer (default: every no-grad forward -- the retrieval / inference models and, inside a
+# training step, the frozen prompter's visual pass) | 1 (the training forward too: the kernel then also writes q | k | v and the log-sum-exp rows
+# for the backward) | 0 (the two launches everywhere).  Measured (MI355X, B = 64, fp16, one box): inference form 365 us against 308 + 115 us for
+# the two launches inside a step; training form 441 us against the same 423 us -- its 256 x 192 tiles run the K loop at ~975 TF/s where the
+# 8-phase qkv GEMM reaches ~1150, so with q | k | v still to be written the fusion does not pay in training and stays off there.
+_fuse_tattn = [os.environ.get("ALPRO_FUSE_TATTN", "infer").lower()]
 
 
-def fuse_temporal_attention():
-    return _fuse_tattn[0]
+def fuse_temporal_attention(training=False):
+    v = _fuse_tattn[0]
+    if v in ("1", "true", "on"):
+        return True
+    return v == "infer" and not training
 
 
 def set_fuse_temporal_attention(v):
-    _fuse_tattn[0] = bool(v)
+    _fuse_tattn[0] = v.lower() if isinstance(v, str) else ("1" if v else "0")
 
 
 def set_cls_precise(v):

@@ -345,8 +345,8 @@ class Block(nn.Module):
             x_cls_in, cls_q, o_c_buf = self._cls_side_begin(cside, x, B, T, snapshot=False)
         h = hip.layernorm(x, self.temporal_norm1.weight, self.temporal_norm1.bias, VIT_EPS, dt, rows=B * N * T,
                           map_mode=hip.MAP_SKIP_CLS, map_p0=N * T)
-        if rt.fuse_temporal_attention() and hip.qkv_tattn_ok(h, T) and ta.qkv.bias is not None:
-            # round 6: one launch; q | k | v are still written (the backward reads them), what goes away is the attention launch and its re-read
+        if rt.fuse_temporal_attention(training=True) and hip.qkv_tattn_ok(h, T) and ta.qkv.bias is not None:
+            # round 6 (ALPRO_FUSE_TATTN=1; off by default: alpro_amd/config.py): one launch; q | k | v are still written (the backward reads them), what goes away is the attention launch and its re-read
             a_t, qkv_t, lse_t = hip.gemm_qkv_tattn(h, self._w("t_qkv", ta.qkv, dt), ta.qkv.bias, T, H, ta.scale, want_qkv=True)
         else:
             qkv_t = hip.gemm(h, self._w("t_qkv", ta.qkv, dt), bias=ta.qkv.bias)

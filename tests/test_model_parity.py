@@ -732,3 +732,55 @@ def test_cls_chain_on_a_side_stream_is_result_neutral():
     finally:
         rt.set_cls_stream(prev)
     assert bool(torch.isfinite(res["ref"][3]).all()) and float(res["ref"][3].abs().sum()) > 0
+
+
+@pytest.mark.parametrize("mode", ["fp16", "bf16"])
+def test_fused_temporal_half_against_the_two_launches(mode):
+    """Round 6 (alpro_amd.config.fuse_temporal_attention; csrc/gemm_tattn.hip): the temporal half's qkv Linear + frame attention as one launch, on
+    every path that carries it -- the in-place inference forward, forward_cls (the prompter's entry) and, opt-in, the training forward with its
+    hand-written backward (the kernel then also writes q | k | v and the log-sum-exp rows) -- against the two launches on the same weights and
+    clips.  Same roundings on both sides (q, k, v, P and the attention output to 16 bits), different fp32 summation orders inside the softmax:
+    the encoder outputs agree to a few units of the operand dtype's resolution, the parameter gradients to 1e-3 of their norm."""
+    from alpro_amd import config as rt
+    from alpro_amd.modeling.timesformer.vit import TimeSformer
+    torch.manual_seed(31)
+    T, B = 4, 4                                  # B * 196 * T = 3136 rows: 12 full 256-row panels + a ragged one of 64 rows
+    enc = TimeSformer(dict(VENC, num_frm=T, drop_path_rate=0.0), input_format="RGB").cuda()
+    with torch.no_grad():                        # TimeSformer zero-initialises temporal_fc of blocks 1..11: the temporal halves would not reach the output
+        for blk in enc.model.blocks:
+            torch.nn.init.normal_(blk.temporal_fc.weight, std=0.02)
+    x = torch.randn(B, 3, T, 224, 224, device="cuda")
+    dout = torch.randn(B, 197, 768, device="cuda") * 1e-2
+    prev = rt._fuse_tattn[0]
+    res = {}
+    try:
+        for fuse in ("0", "1"):
+            rt.set_fuse_temporal_attention(fuse)
+            with rt.use_compute_dtype(mode), rt.use_cls_precise("0"):
+                enc.eval()
+                with torch.no_grad():
+                    y = enc.forward_features(x).float().clone()
+                    c = enc.forward_cls(x).float().clone()
+                enc.train()
+                for p in enc.parameters():
+                    p.grad = None
+                sc = arm_scale(mode)
+                with torch.enable_grad():
+                    yt = enc.forward_features(x)
+                    gs = backward((yt * dout).sum(), mode)
+                g = torch.cat([p.grad.reshape(-1) for p in enc.parameters() if p.grad is not None]).double() / gs
+                del sc
+            torch.cuda.synchronize()
+            res[fuse] = (y, c, yt.detach().float().clone(), g)
+    finally:
+        rt.set_fuse_temporal_attention(prev)
+        rt.set_armed_loss_scaler(None)
+    eps = {"fp16": 2.0 ** -10, "bf16": 2.0 ** -7}[mode]
+    for i, what in enumerate(("forward_features", "forward_cls", "training forward")):
+        a, b = res["1"][i], res["0"][i]
+        err = float((a - b).abs().max())
+        assert err <= 8 * eps * max(1.0, float(b.abs().max())), "%s: fused vs two launches %.3e" % (what, err)
+    ga, gb = res["1"][3], res["0"][3]
+    rel = float((ga - gb).norm() / gb.norm())
+    print("\n[fused temporal half %s] outputs within 8 eps; gradient l2 rel diff %.2e" % (mode, rel))
+    assert bool(torch.isfinite(ga).all()) and rel <= {"fp16": 1e-3, "bf16": 8e-3}[mode], rel
