@@ -1558,12 +1558,31 @@ int launch_gemm_inst(const alpro_gemm_desc_t& g, hipStream_t st) {
     if (take_q) {
       alpro_gemm_desc_t gq = g;
       if (!ragged_in_kernel) gq.M = m_full;
-      const int tiles = (g.N / BN2) * ((gq.M + BM2 - 1) / BM2);
-      (void)tiles;
       // one workgroup per CU the launch may count on, whatever the tile count: the per-XCD lists are chunks of 32 tiles, and a workgroup
       // whose list (and, dynamic walk, every other list) is empty returns at once
       int grid = cu_budget(st);
       if (const int cap = get_option(OPT_GEMM_GRID)) grid = cap < grid ? (cap + 7) / 8 * 8 : grid;
+      // Tail hand-over (round 6, option gemm_tail; VERDICT r3-r5 "the last partial round of the N = 768 projections").  With tiles = Q * grid + R
+      // and a small R the last round keeps R workgroups busy for a whole tile time while the others idle -- at B = 32: the N = 768 projections
+      // 588 / 591 tiles = 2.3 rounds, fc1 2352 = 9.19, fc2 588 (K = 3072).  A two-group 8-phase tile cannot be cut (a half tile takes as long as
+      // a whole one: DESIGN.md), and split-K pays 256 KiB of fp32 partials per tile at K = 768.  What does work: the row panels that make up
+      // the partial round go to the 128 x 128 kernel as a SECOND launch -- 4 R small tiles, two workgroups per CU, one short round behind the
+      // Q full ones -- when R <= 0.4 grid (beyond that the small kernel's lower rate eats the saving).  Same arithmetic per element, different
+      // summation order inside the MFMAs: not bitwise equal to the unsplit launch (tests pin both against fp64), bit-reproducible run to run.
+      const int ntn_q = g.N / BN2, ntm_q = (gq.M + BM2 - 1) / BM2;
+      const int tiles = ntn_q * ntm_q;
+      int tail_panels = 0;
+      if (get_option(OPT_GEMM_TAIL) == 1 && !g.c2_tiled && tiles > grid) {
+        const int R = tiles % grid;
+        if (R > 0 && 5 * R <= 2 * grid) tail_panels = (R + ntn_q - 1) / ntn_q;
+      }
+      int64_t m_tail0 = -1;   // first row of what the second launch computes (-1: nothing)
+      if (tail_panels > 0 && tail_panels < ntm_q) {
+        m_tail0 = (int64_t)(ntm_q - tail_panels) * BM2;
+        gq.M = (int)m_tail0;
+      } else if (m_rem && !ragged_in_kernel) {
+        m_tail0 = m_full;
+      }
       TileSched sc;
       sc.blk = sc.prev = nullptr;
       sc.magic_ntn = magic_u32((uint32_t)(g.N / BN2));
@@ -1575,14 +1594,14 @@ int launch_gemm_inst(const alpro_gemm_desc_t& g, hipStream_t st) {
         hipLaunchKernelGGL((gemm_nt256q_kernel<T, ACT, MAP>), dim3(grid), dim3(NT2), 2 * STAGE2_BYTES + EPI_BYTES, st, gq, sc);
         blocks.commit(hipPeekAtLastError() == hipSuccess);
       }
-      if (m_rem && !ragged_in_kernel) {
+      if (m_tail0 >= 0) {
         alpro_gemm_desc_t gr = g;
-        gr.M = m_rem;
-        gr.A = (const char*)g.A + (int64_t)m_full * g.lda * 2;
-        gr.C = (char*)g.C + (int64_t)m_full * g.ldc * (g.c_dtype == ALPRO_F32 ? 4 : 2);
-        gr.m_off = g.m_off + m_full;
-        if (g.C2) gr.C2 = (char*)g.C2 + (int64_t)m_full * g.ldc2 * 2;
-        if (g.residual) gr.residual = g.residual + (int64_t)m_full * g.ldr;
+        gr.M = (int)(g.M - m_tail0);
+        gr.A = (const char*)g.A + m_tail0 * g.lda * 2;
+        gr.C = (char*)g.C + m_tail0 * g.ldc * (g.c_dtype == ALPRO_F32 ? 4 : 2);
+        gr.m_off = g.m_off + m_tail0;
+        if (g.C2) gr.C2 = (char*)g.C2 + m_tail0 * g.ldc2 * 2;
+        if (g.residual) gr.residual = g.residual + m_tail0 * g.ldr;
         const int ntn = (gr.N + BN - 1) / BN, ntm = (gr.M + BM - 1) / BM;
         hipLaunchKernelGGL((gemm_nt_kernel<T, ACT, MAP>), dim3(ntn * ntm), dim3(NT), 4 * TILE_BYTES, st, gr);
       }

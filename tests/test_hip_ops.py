@@ -140,7 +140,7 @@ def test_gemm_tail_split_is_bitwise_neutral(dt):
         bias = rnd(N, seed=62, scale=0.3).cuda()
         outs = []
         for tail in (0, 1):
-            with hip.option("gemm_tail", tail):
+            with hip.option("gemm_tail", tail), hip.option("gemm_kind", 0):   # (the round-3 kernel: on the 8-phase kernel gemm_tail is the round-6 hand-over below)
                 if kind == "c16":
                     outs.append((hip.gemm(a, w, bias=bias),))
                 elif kind == "res":
@@ -155,6 +155,50 @@ def test_gemm_tail_split_is_bitwise_neutral(dt):
         ref = a[-300:].double().cpu() @ w.double().cpu().T + bias.double().cpu()
         if kind == "c16":
             close(outs[1][0][-300:], ref, *OUT_TOL[dt], "tail rows vs fp64")
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+def test_gemm_tail_handover_to_the_small_tile_kernel(dt):
+    """Round 6 (option gemm_tail on the 8-phase kernel): when the last round of 256 x 256 tiles would keep at most 40 % of the workgroups busy, the
+    row panels that make it up are computed by the 128 x 128 kernel in a second launch.  Same arithmetic per element, another summation order:
+    with and without the hand-over the results agree to the output dtype's resolution (fp32 outputs: to 1e-5 of the row), the handed-over rows
+    match fp64, two runs are bitwise equal, and every epilogue the model sends down this path survives the cut -- 16-bit output, fp32 residual +
+    row scale (groups cut by the split point), inference GELU, drop-path row scale, a ragged last panel.  Shapes: the B = 32 projections (588 /
+    591 tiles), fc2 (K = 3072), fc1 (2352 tiles), and one whose remainder is too large to be handed over (must not change at all)."""
+    hip = _hip()
+    cases = [(50176, 768, 768, "c16", True), (50432, 768, 768, "scale", True), (50208, 768, 3072, "res", True), (50176, 3072, 768, "gelu", True), (100352, 768, 768, "c16", False)]
+    for (M, N, K, kind, expect_split) in cases:
+        tiles = ((M + 255) // 256) * (N // 256)
+        R = tiles % 256
+        assert (0 < R and 5 * R <= 2 * 256) == expect_split, (M, N, tiles, R)
+        a = rnd(M, K, seed=70, scale=0.5).to(dt).cuda()
+        w = rnd(N, K, seed=71, scale=0.05).to(dt).cuda()
+        bias = rnd(N, seed=72, scale=0.3).cuda()
+        kw = dict(bias=bias)
+        if kind == "res":
+            kw.update(out_dtype=torch.float32, residual=rnd(M, N, seed=73).cuda(), row_scale=(torch.rand(M // 1569 + 1, generator=torch.Generator().manual_seed(5)) + 0.5).cuda(),
+                      row_scale_group=1569)
+        elif kind == "scale":
+            kw.update(row_scale=(torch.rand(M // 197 + 1, generator=torch.Generator().manual_seed(6)) + 0.5).cuda(), row_scale_group=197)
+        elif kind == "gelu":
+            kw.update(act=hip.ACT_GELU)
+        outs = []
+        for tail in (0, 1, 1):
+            with hip.option("gemm_tail", tail):
+                outs.append(hip.gemm(a, w, **kw))
+        assert torch.equal(outs[1], outs[2]), (M, N, K, kind)
+        if not expect_split:
+            assert torch.equal(outs[0], outs[1]), (M, N, K, kind)
+            continue
+        d = (outs[0].float() - outs[1].float()).abs().max().item()
+        lim = 1e-5 * max(1.0, outs[0].float().abs().max().item()) * (K / 768) if kind == "res" else {torch.bfloat16: 2.0 ** -7, torch.float16: 2.0 ** -10}[dt] * max(1.0, outs[0].float().abs().max().item())
+        assert d <= lim, (M, N, K, kind, d, lim)
+        first_tail = (((M + 255) // 256) - (R + N // 256 - 1) // (N // 256)) * 256
+        assert not torch.equal(outs[0][first_tail:], outs[1][first_tail:]) or d == 0.0        # (the hand-over did happen: the tail rows come from another kernel)
+        assert torch.equal(outs[0][:first_tail], outs[1][:first_tail]), (M, N, K, kind)          # ... and nothing in front of it moved
+        ref = a[-300:].double().cpu() @ w.double().cpu().T + bias.double().cpu()
+        if kind == "c16":
+            close(outs[1][-300:], ref, *OUT_TOL[dt], "handed-over rows vs fp64")
 
 
 def test_gemm_rejects_bad_k():
