@@ -1567,12 +1567,16 @@ int launch_gemm_inst(const alpro_gemm_desc_t& g, hipStream_t st) {
       // 588 / 591 tiles = 2.3 rounds, fc1 2352 = 9.19, fc2 588 (K = 3072).  A two-group 8-phase tile cannot be cut (a half tile takes as long as
       // a whole one: DESIGN.md), and split-K pays 256 KiB of fp32 partials per tile at K = 768.  What does work: the row panels that make up
       // the partial round go to the 128 x 128 kernel as a SECOND launch -- 4 R small tiles, two workgroups per CU, one short round behind the
-      // Q full ones -- when R <= 0.4 grid (beyond that the small kernel's lower rate eats the saving).  Same arithmetic per element, different
-      // summation order inside the MFMAs: not bitwise equal to the unsplit launch (tests pin both against fp64), bit-reproducible run to run.
+      // Q full ones -- when R <= 0.4 grid (beyond that the small kernel's lower rate eats the saving) AND K >= 2048.  Measured (MI355X, fp16, B = 32,
+      // tools/gemm_tail_ab.py, profiles/r6_gemm_tail_handover.txt): fc2 (K = 3072, 591 tiles) 274 -> 261 us (-4.7 %); the K = 768 projections
+      // 74.4 -> 75.3 / 70.2 -> 71.2 us and fc1 (2364 tiles) 242 -> 239: the small kernel runs 304 tiles of 128 x 128 x 768 at ~300 TF/s, i.e. as
+      // long as the round it replaces -- at K = 768 a tile is mostly epilogue and fill, and there the hand-over is NOT taken.  Same arithmetic per
+      // element, different summation order inside the MFMAs: not bitwise equal to the unsplit launch (tests pin both against fp64),
+      // bit-reproducible run to run.
       const int ntn_q = g.N / BN2, ntm_q = (gq.M + BM2 - 1) / BM2;
       const int tiles = ntn_q * ntm_q;
       int tail_panels = 0;
-      if (get_option(OPT_GEMM_TAIL) == 1 && !g.c2_tiled && tiles > grid) {
+      if (get_option(OPT_GEMM_TAIL) == 1 && !g.c2_tiled && tiles > grid && g.K >= 2048) {
         const int R = tiles % grid;
         if (R > 0 && 5 * R <= 2 * grid) tail_panels = (R + ntn_q - 1) / ntn_q;
       }

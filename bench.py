@@ -111,6 +111,7 @@ class KernelTimer:
         wrap("attn_temporal", lambda qkv, T, H, *r, **k: 4.0 * qkv.shape[0] * T * H * 64)
         wrap("layernorm", lambda *a, **k: 0.0)
         wrap("add_layernorm", lambda *a, **k: 0.0)
+        wrap("gemm_rows", lambda *a, **k: 0.0)
         wrap("attn_bwd", lambda qkv, out, dout, lse, batch, L, H, *r, **k: 10.0 * batch * H * L * L * 64)
         wrap("attn_temporal_bwd", lambda qkv, out, dout, lse, T, H, *r, **k: 10.0 * qkv.shape[0] * T * H * 64)
         wrap("layernorm_bwd", lambda *a, **k: 0.0)
@@ -279,6 +280,62 @@ def measure_divst(dev, T, model=None, B=32, iters=5):
         finally:
             vit.Block.forward, hip.cls_mean_residual, hip.add_layernorm = orig_fwd, orig_cls, orig_add
             rt.set_cls_stream(prev_cs)
+    # Per-block table: one more forward with every library call of the region under its own pair of HIP events; the rows are
+    # means over the 12 blocks, `unattributed` is what the region's own events measured beyond the sum (launch gaps, torch's small copies).
+    table = None
+    try:
+        spans = []
+        with torch.no_grad(), KernelTimer(hip) as kt2:
+            rec = kt2.rec
+            wrapped_add = hip.add_layernorm
+
+            def fwd2(self, *a, **k):
+                spans.append([len(rec), None])
+                return orig_fwd(self, *a, **k)
+
+            def add2(*a, **k):
+                out = wrapped_add(*a, **k)
+                if k.get("mode") == hip.ADD_PRE_MLP:
+                    spans[-1][1] = len(rec)
+                return out
+            vit.Block.forward, hip.add_layernorm = fwd2, add2
+            rt.set_cls_stream("0")
+            try:
+                model.forward_features(x)
+            finally:
+                vit.Block.forward, hip.add_layernorm = orig_fwd, wrapped_add
+                rt.set_cls_stream(prev_cs)
+        torch.cuda.synchronize()
+        rows = {}
+        for lo, hi in spans:
+            if hi is None:
+                continue
+            seq = rec[lo:hi]
+            n_gemm = 0
+            for i, (name, fl, e0, e1, key) in enumerate(seq):
+                us = e0.elapsed_time(e1) * 1e3
+                if name == "gemm":
+                    n_gemm += 1
+                    fused = any(r[0] == "gemm_qkv_tattn" for r in seq)
+                    order = ["temporal projection (merged proj + temporal_fc) GEMM", "spatial qkv GEMM", "spatial projection GEMM"] if fused else \
+                            ["temporal qkv GEMM", "temporal projection (merged proj + temporal_fc) GEMM", "spatial qkv GEMM", "spatial projection GEMM"]
+                    label = order[n_gemm - 1] if n_gemm <= len(order) else "other GEMM"
+                elif name == "add_layernorm":
+                    last = i == len(seq) - 1
+                    label = "residual add + norm2 (5/6 counted)" if last else "residual add + norm1"
+                    if last:
+                        us *= 5.0 / 6.0
+                else:
+                    label = {"layernorm": "temporal_norm1", "gemm_qkv_tattn": "temporal qkv GEMM + frame attention (fused)", "attn_temporal": "temporal attention",
+                             "attn": "spatial attention (+ precise CLS query)", "gemm_rows": "precise CLS rows (fp32 q | k | v of the CLS token)"}.get(name, name)
+                d_ = rows.setdefault(label, [0, 0.0])
+                d_[0] += 1
+                d_[1] += us
+        nb = max(1, len([1 for lo, hi in spans if hi is not None]))
+        table = {k_: round(v_[1] / nb, 1) for k_, v_ in rows.items()}
+        table["sum_us_per_block"] = round(sum(table.values()), 1)
+    except Exception as e:   # the table is a diagnostic: never let it take the measurement down
+        table = {"error": repr(e)}
     # The PRE_MLP kernel is the spatial half's residual add (reads x and the 16-bit delta, writes x': 7.5 of its 9 KB per row) AND the MLP
     # half's norm2 (the 16-bit normalised row: 1.5 KB).  Its time is attributed 5/6 to the attention sub-blocks, 1/6 to the MLP.
     tail_ms = sum(a.elapsed_time(b) for a, b in tails) / iters
@@ -289,6 +346,7 @@ def measure_divst(dev, T, model=None, B=32, iters=5):
             "encoder_forward_ms": round(t0.elapsed_time(t1) / iters, 3), "gflop_per_clip": DIVST_GFLOP_PER_CLIP_8F * (T / 8.0),
             "achieved": round(tf, 1), "peak": MFMA_PEAK_TFLOPS["bf16"], "unit": "TFLOP/s", "frac": round(tf / MFMA_PEAK_TFLOPS["bf16"], 4), "target_frac": 0.40,
             # the conservative figure: the whole fused add + norm2 kernel counted here (no 1/6 attribution to the MLP half)
+            "per_block_us": table, "measured_us_per_block": round(ms * 1e3 / 12.0, 1),
             "ms_end_to_end": round(ms + tail_ms / 6.0, 3), "frac_end_to_end": round(B * DIVST_GFLOP_PER_CLIP_8F * (T / 8.0) / (ms + tail_ms / 6.0) / MFMA_PEAK_TFLOPS["bf16"], 4)}
 
 
