@@ -86,7 +86,7 @@ template <typename T, int ACT> __device__ __forceinline__ float apply_act(float 
 }
 
 // Output / residual accesses are non-temporal: they are streamed once (150-600 MB per launch against 32 MB of L2), and
-// keeping them out of the L2 allocation path is worth 7-8 % on the bf16-output GEMMs (tools/gemm_bench.py).
+// keeping them out of the L2 allocation path is worth 7-8 % on the bf16-output GEMMs (round-2 measurement).
 // Epilogue of 16 staged rows x 64 columns of one wave: lane l handles columns 4*(l&15)..+3 of rows p*4 + (l>>4),
 // p = 0..3, so every global access is a 16-byte (fp32) / 8-byte (16-bit) piece of a 256-/128-byte row segment.
 // FAST (wave-uniform): the whole 16x64 block is in range and every stride is vector-aligned -> no per-element
@@ -508,7 +508,7 @@ constexpr int EPI_BYTES = 8 * 16 * 64 * 4;  // 32 KiB: 8 waves x (16 rows x 64 c
 //   0  copy c after MFMA 4c+1 (waves 0-3) / 4c+3 (waves 4-7): spread over the whole step -- the last piece is issued ~100 cycles
 //      before the step ends, so its full L2 / MALL latency is exposed at the next step's vmcnt(0)
 //   1  copy c after MFMA 2c+1 / 2c+2: all pieces out in the first half of the step (default: +3-5 % on every shape,
-//      tools/gemm_tune_bench.py, gpurun_out/r2b_tune.txt)
+//      round-2 A/B of the variants on the model shapes)
 //   2  copy c after MFMA 3c+1 / 3c+2: first three quarters
 //   3, 4  ablations of the 16-bit-output epilogue (no global stores / no epilogue at all; wrong results by construction) -- the
 //      measurements and the three epilogue rewrites they led to are in profiles/r2_gemm_epilogue_experiments.txt

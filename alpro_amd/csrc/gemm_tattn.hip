@@ -364,7 +364,7 @@ __global__ __launch_bounds__(NTH, 2) void gemm_qkv_tattn_kernel(const TattnArgs 
             // O^T[d = 16 f + 4 kg + r][i = l15].  The contraction over the fragment's 16 tokens runs on the K = 32 instruction with the upper four
             // k-elements of both operands zero: the K = 16 form (v_mfma_f32_16x16x16_f16 / _bf16) gave wrong values in two of four result
             // registers for rows 17 / 19 / 21 / 23 of every 32-token block on gfx950 -- in one build and not in the previous one, with or without
-            // wait states behind it, with or without result / operand register overlap (round 6, tools/r6 variants: k32 0 wrong of 589824,
+            // wait states behind it, with or without result / operand register overlap (round 6, profiles/r6_tattn_mfma_k16_finding.txt: K = 32 form 0 wrong of 589824,
             // every k16 variant ~8900); the K = 32 form is the one this chip's GEMMs run on
             const u32x4 va = mk4(vo.x, vo.y, 0u, 0u), pb = mk4(pt.x, pt.y, 0u, 0u);
             o = Mfma<T>::k32(va, pb, o);

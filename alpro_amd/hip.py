@@ -773,7 +773,7 @@ def gemm_tn_acc(a, b, c, colsum=None, atomic=None):
     used in stream order) and are added in a fixed order: bit-reproducible.  atomic=True: alpro_gemm_tn_acc, partials combined by
     fp32 atomics (no workspace; run-to-run differences in the last bits, tests/test_hip_bwd_ops.py pins 2e-6 of scale).
     atomic=None: the workspace (deterministic) plan, unless set_deterministic_wgrad(False) opted into the measured faster one per shape
-    (tools/gemm_tn_shapes.py) -- the workspace up to 65536 tokens or <= 9 tiles (the workgroups finish together there and the atomics
+    (round-2 measurement) -- the workspace up to 65536 tokens or <= 9 tiles (the workgroups finish together there and the atomics
     queue up: -10..-25 %), atomics above (the ranges finish spread out and the atomics hide under the stragglers' MFMAs; the extra
     reduce launch costs +3..7 % of the kernel)."""
     lib = load()
