@@ -194,9 +194,15 @@ class Block(nn.Module):
     # tokens as the 16-bit GEMM produced them) -> proj -> frame mean + residual (:184-187) -> norm2 -> Mlp -> residual (:198-212).
     # B*T + 3*B fp32 rows per block against B*(1 + N*T) 16-bit rows; drop-path scales are the main path's.
     def _cls_qkv(self, x_cls_in, out=None):
-        """(B, D) fp32 CLS rows of the block input -> their unrounded q | k | v (norm1 fused into the operand load)."""
+        """(B, D) fp32 CLS rows of the block input -> their unrounded q in a (B, 3 D) buffer laid out like q | k | v (norm1 fused into the operand
+        load).  Only the q third is computed (round 6): alpro_attn_fwd's CLS query reads q from this buffer and every K / V row -- the CLS
+        token's included -- from the 16-bit images in LDS, so the k and v thirds were 2/3 of a 25 us launch per block for nothing."""
         sa = self.attn
-        return hip.gemm_rows(x_cls_in, self._w("s_qkv", sa.qkv, torch.float32), bias=sa.qkv.bias, ln=(self.norm1.weight, self.norm1.bias, VIT_EPS), out=out)
+        D = x_cls_in.shape[-1]
+        if out is None:
+            out = torch.empty((x_cls_in.shape[0], 3 * D), dtype=torch.float32, device=x_cls_in.device)
+        hip.gemm_rows(x_cls_in, self._w("s_qkv", sa.qkv, torch.float32)[:D], bias=sa.qkv.bias[:D], ln=(self.norm1.weight, self.norm1.bias, VIT_EPS), out=out[:, :D])
+        return out
 
     def _cls_side_begin(self, side, x, B, T, snapshot):
         """Side stream, at block entry: (snapshot of) the block input's CLS rows and their q | k | v.  -> (x_cls_in, cls_q, o_c buffer)."""

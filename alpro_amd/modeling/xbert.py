@@ -123,7 +123,11 @@ class BertLayer(nn.Module):
         wqkv = tr.fused_param_view([sa.query.weight, sa.key.weight, sa.value.weight])   # a view when FlatAdamW laid them out back to back
         if wqkv is None:
             wqkv = self._ops.get("qkv_w32", (sa.query.weight, sa.key.weight, sa.value.weight), torch.float32)
-        return hip.gemm_rows(hc, wqkv, bias=self._ops.get("qkv_b", (sa.query.bias, sa.key.bias, sa.value.bias), torch.float32))
+        # only the q third (round 6): alpro_attn_fwd's CLS query reads q from the buffer and every K / V row from the 16-bit images in LDS
+        D = hc.shape[-1]
+        out = torch.empty((hc.shape[0], 3 * D), dtype=torch.float32, device=hc.device)
+        hip.gemm_rows(hc, wqkv[:D], bias=self._ops.get("qkv_b", (sa.query.bias, sa.key.bias, sa.value.bias), torch.float32)[:D], out=out[:, :D])
+        return out
 
     def _cls_chain(self, hc, ctx_c, d1, d2, B, L, hp):
         """ctx_c: (B, D) fp32 attention output of the [CLS] query (alpro_attn_fwd's cls_out)."""
