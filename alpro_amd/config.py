@@ -92,6 +92,46 @@ def set_fuse_temporal_attention(v):
     _fuse_tattn[0] = v.lower() if isinstance(v, str) else ("1" if v else "0")
 
 
+# Round 6: the no-grad encoder forward as two half batches on two HIP streams (modeling/timesformer/vit.py::run_blocks).  Every big launch of a
+# block is a persistent kernel whose last round of tiles leaves most CUs idle (the N = 768 projections at B = 32: 591 tiles = 2.3 rounds on 256
+# CUs) and the next launch of the same stream depends on it; the other half's launches do not, and the dynamic tile scheduler lets their
+# workgroups start on the CUs the first kernel's workgroups have left.  ALPRO_SPLIT_STREAMS = 0 | 1 | auto (default; on for even B >= 16).
+_split_streams = [os.environ.get("ALPRO_SPLIT_STREAMS", "auto").lower()]
+
+
+def split_streams(B):
+    v = _split_streams[0]
+    if v in ("0", "false", "off") or B % 2 != 0:
+        return False
+    if v in ("1", "true", "on"):
+        return B >= 2
+    return B >= 16
+
+
+def split_lockstep():
+    """ALPRO_SPLIT_LOCKSTEP=1: the two streams meet at every block boundary (measurement aid: a block's launches are then bracketed on the launch
+    stream); default: they meet once, behind the last block."""
+    return os.environ.get("ALPRO_SPLIT_LOCKSTEP", "0") == "1"
+
+
+def set_split_streams(v):
+    _split_streams[0] = v.lower() if isinstance(v, str) else ("1" if v else "0")
+
+
+# Round 6: the no-grad Block.forward keeps the block input until both attention halves are done -- the add + norm1 kernel reads it and writes only the
+# normalised rows, the add + norm2 kernel adds the temporal AND the spatial branch (alpro_add_layernorm_pre_mlp2; bit for bit the same sums).
+# ALPRO_DEFER_TEMPORAL_ADD=0: the round-3 form (x + temporal branch written by the first kernel), for A/B.
+_defer_tadd = [os.environ.get("ALPRO_DEFER_TEMPORAL_ADD", "1") != "0"]
+
+
+def defer_temporal_add():
+    return _defer_tadd[0]
+
+
+def set_defer_temporal_add(v):
+    _defer_tadd[0] = bool(v)
+
+
 def set_cls_precise(v):
     _cls_precise[0] = v.lower() if isinstance(v, str) else ("1" if v else "0")
 

@@ -432,6 +432,10 @@ __global__ __launch_bounds__(256) void gather_seq_bwd_kernel(const float* __rest
 //                           k = 0: v = x_in[r] + mean_t delta[(b*T+t)*(N+1)]  (vit.py:184-196)                             -> x_out[r], y[r]
 //   ALPRO_ADD_PRE_TEMPORAL  row r = b*S + k: v = x_in[r] + delta[r] -> x_out[r];  k > 0: y[r - b - 1] = LN(v)  (MLP branch of the
 //                           previous block folded into the next block's temporal LayerNorm, vit.py:212 -> :154)
+// Deferred temporal add (round 6, alpro_add_layernorm_pre_mlp2): PRE_MLP with a second delta -- the temporal branch in x[:, 1:] order, added
+// FIRST (then its bias, then the spatial delta: the order of fp32 additions of the PRE_SPATIAL + PRE_MLP pair, so x' is bit for bit the same).
+// The inference forward then runs PRE_SPATIAL with x_out = NULL: the intermediate x + temporal branch is never written (-3 KB of 9 per row there,
+// +1.5 KB here).
 template <typename T>
 __device__ __forceinline__ void add_delta_row(const T* drow, int lane, float (&v)[12], float w) {
 #pragma unroll
@@ -453,7 +457,8 @@ __device__ __forceinline__ void add_delta_row(const T* drow, int lane, float (&v
 template <typename T, int MODE>
 __global__ __launch_bounds__(256) void add_layernorm_fwd_kernel(const float* __restrict__ x_in, const T* __restrict__ delta, const float* __restrict__ dbias,
                                                                 float* __restrict__ x_out, const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                                float eps, T* __restrict__ y, float* __restrict__ y32, int64_t rows, int p0, int p1) {
+                                                                float eps, T* __restrict__ y, float* __restrict__ y32, int64_t rows, int p0, int p1,
+                                                                const T* __restrict__ delta2 = nullptr, const float* __restrict__ dbias2 = nullptr) {
   const int lane = threadIdx.x & 63;
   const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int64_t nwaves = (int64_t)gridDim.x * 4;
@@ -497,6 +502,18 @@ __global__ __launch_bounds__(256) void add_layernorm_fwd_kernel(const float* __r
     }
     float v[12];
     ln_load_nt(x_in + r * LN_D, lane, v);
+    if constexpr (MODE == ALPRO_ADD_PRE_MLP) {
+      if (delta2 && !cls_mean) {  // the deferred temporal branch of this patch row (x[:, 1:] order), its bias behind it
+        add_delta_row<T>(delta2 + (r - b - 1) * LN_D, lane, v, 1.0f);
+        if (dbias2) {
+#pragma unroll
+          for (int i = 0; i < LN_V; ++i) {
+            const float4 f = *(const float4*)(dbias2 + i * 256 + lane * 4);
+            v[4 * i] += f.x; v[4 * i + 1] += f.y; v[4 * i + 2] += f.z; v[4 * i + 3] += f.w;
+          }
+        }
+      }
+    }
     if (d0) {
       add_delta_row<T>(d0, lane, v, 1.0f);
       if (dbias) {
@@ -846,6 +863,19 @@ extern "C" int alpro_add_layernorm_fwd(const float* x_in, const void* delta, int
   ALPRO_CHECK(((uintptr_t)x_in % 16) == 0 && ((uintptr_t)delta % 16) == 0 && ((uintptr_t)y % 16) == 0, "alpro_add_layernorm_fwd: pointers must be 16-byte aligned");
   ALPRO_DISPATCH_DTYPE(dtype, T, return launch_add_ln<T>(add_mode, x_in, delta, delta_bias, x_out, gamma, beta, eps, y, y32, rows, p0, p1, (hipStream_t)stream));
   return ALPRO_OK;
+}
+
+extern "C" int alpro_add_layernorm_pre_mlp2(const float* x_in, const void* delta_t, const float* delta_t_bias, const void* delta_s, int dtype, float* x_out,
+                                            const float* gamma, const float* beta, float eps, void* y, int64_t rows, int D, int T, int N, void* stream) {
+  ALPRO_CHECK(x_in && delta_t && delta_s && gamma && beta && y && rows > 0, "alpro_add_layernorm_pre_mlp2: bad args");
+  ALPRO_CHECK(D == LN_D, "alpro_add_layernorm_pre_mlp2: D=%d unsupported (hidden size is 768 on this path)", D);
+  ALPRO_CHECK(T > 0 && N > 0 && rows % (1 + (int64_t)T * N) == 0, "alpro_add_layernorm_pre_mlp2: rows=%lld is not a whole number of clips of 1 + %d x %d tokens", (long long)rows, N, T);
+  ALPRO_CHECK(((uintptr_t)x_in % 16) == 0 && ((uintptr_t)delta_t % 16) == 0 && ((uintptr_t)delta_s % 16) == 0 && ((uintptr_t)y % 16) == 0,
+              "alpro_add_layernorm_pre_mlp2: pointers must be 16-byte aligned");
+  const dim3 grid(grid_for(rows, 4, 256 * 32)), blk(256);
+  ALPRO_DISPATCH_DTYPE(dtype, T_, hipLaunchKernelGGL((add_layernorm_fwd_kernel<T_, ALPRO_ADD_PRE_MLP>), grid, blk, 0, (hipStream_t)stream, x_in, (const T_*)delta_s,
+                                                     (const float*)nullptr, x_out, gamma, beta, eps, (T_*)y, (float*)nullptr, rows, T, N, (const T_*)delta_t, delta_t_bias));
+  return check_launch("alpro_add_layernorm_pre_mlp2");
 }
 
 extern "C" int alpro_vit_final_pool(const float* x, const float* gamma, const float* beta, float eps, float* out32, void* out_t,

@@ -24,7 +24,7 @@ EXPORTS = ["alpro_hip_last_error", "alpro_hip_abi_version", "alpro_hip_set_optio
            "alpro_attn_temporal_fwd", "alpro_attn_fwd", "alpro_patchify", "alpro_cls_mean_residual",
            "alpro_vit_final_pool", "alpro_bert_embed_fwd", "alpro_cast_from_f32", "alpro_attn_bwd", "alpro_attn_temporal_bwd",
            "alpro_layernorm_bwd", "alpro_transpose", "alpro_transpose_batch", "alpro_gelu_bwd", "alpro_cls_mean_bwd", "alpro_scatter_add_rows", "alpro_gather_cast", "alpro_sumsq", "alpro_adamw_step", "alpro_gemm_tn_acc", "alpro_gemm_tn_acc_ws", "alpro_gemm_tn_workspace_bytes", "alpro_gemm_tn_ranges", "alpro_colsum_acc", "alpro_softmax_xent", "alpro_vtc_loss_fwd", "alpro_vtc_loss_bwd", "alpro_prepare_clips", "alpro_loss_scale_update", "alpro_add_layernorm_fwd", "alpro_layernorm_bwd_emit", "alpro_gemm_batch", "alpro_tproj_small", "alpro_attn_cls_fwd", "alpro_gemm_rows_f32", "alpro_gather_seq_fwd", "alpro_gather_seq_bwd", "alpro_scatter_add_rows_ordered",
-           "alpro_hip_sched_workspace_bytes", "alpro_hip_set_sched_workspace", "alpro_hip_release_stream", "alpro_gemm_qkv_tattn"]
+           "alpro_hip_sched_workspace_bytes", "alpro_hip_set_sched_workspace", "alpro_hip_release_stream", "alpro_gemm_qkv_tattn", "alpro_add_layernorm_pre_mlp2"]
 
 
 class GemmDesc(ctypes.Structure):
@@ -52,7 +52,7 @@ class TransposeJob(ctypes.Structure):
                 ("R", ctypes.c_int32), ("C", ctypes.c_int32), ("Rpad", ctypes.c_int32), ("tile0", ctypes.c_int32)]   # 48 bytes
 
 
-ABI_VERSION = 19
+ABI_VERSION = 20
 _lib = None
 
 
@@ -105,6 +105,7 @@ def load():
     lib.alpro_patchify.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp]
     lib.alpro_cls_mean_residual.argtypes = [vp, i64, vp, vp, i64, i32, i32, i32, vp]
     lib.alpro_vit_final_pool.argtypes = [vp, vp, vp, f32, vp, vp, i32, i32, i32, i32, i32, vp]
+    lib.alpro_add_layernorm_pre_mlp2.argtypes = [vp, vp, vp, vp, i32, vp, vp, vp, f32, vp, i64, i32, i32, i32, vp]
     lib.alpro_bert_embed_fwd.argtypes = [vp, vp, vp, vp, vp, vp, f32, vp, vp, i32, vp, vp, i32, i32, i32, f32, u32, vp]
     lib.alpro_cast_from_f32.argtypes = [vp, vp, i32, i64, vp]
     lib.alpro_hip_set_option.argtypes = [ctypes.c_char_p, i32]
@@ -379,6 +380,26 @@ def add_layernorm(x_in, delta, gamma, beta, eps, mode=ADD_IDENTITY, x_out=None, 
     if out32:
         return y, (y32 if y32 is not None else y), x_out
     return y, x_out
+
+
+def add_layernorm_pre_mlp2(x_in, delta_t, delta_t_bias, delta_s, gamma, beta, eps, T, N, x_out=None):
+    """ADD_PRE_MLP with the temporal branch's deferred add in front (alpro_add_layernorm_pre_mlp2): x' = x_in + delta_t (x[:, 1:] order) + delta_t_bias +
+    delta_s (frame order; CLS rows: the frame mean of delta_s only) -> x_out (default: x_in itself), returns LayerNorm(x') in the deltas' dtype."""
+    lib = load()
+    _dev(x_in, torch.float32); _dev(delta_t); _dev(delta_s)
+    D = x_in.shape[-1]
+    tokens = x_in.numel() // D
+    if T <= 0 or N <= 0 or tokens % (1 + N * T) != 0:
+        raise RuntimeError("add_layernorm_pre_mlp2: %d token rows are not a whole number of clips of 1 + %d x %d tokens" % (tokens, N, T))
+    B = tokens // (1 + N * T)
+    if tuple(delta_t.shape) != (B * N * T, D) or tuple(delta_s.shape) != (B * T * (N + 1), D) or delta_t.dtype != delta_s.dtype:
+        raise RuntimeError("add_layernorm_pre_mlp2: deltas %s / %s do not fit %d clips" % (tuple(delta_t.shape), tuple(delta_s.shape), B))
+    x_out = x_in if x_out is None else _dev(x_out, torch.float32)
+    y = torch.empty((tokens, D), dtype=delta_s.dtype, device=x_in.device)
+    _check(lib.alpro_add_layernorm_pre_mlp2(_ptr(x_in), _ptr(delta_t), _ptr(_dev(delta_t_bias, torch.float32)) if delta_t_bias is not None else None, _ptr(delta_s),
+                                            _CODE[delta_s.dtype], _ptr(x_out), _ptr(_dev(gamma, torch.float32)), _ptr(_dev(beta, torch.float32)), eps, _ptr(y),
+                                            tokens, D, T, N, _stream()), "alpro_add_layernorm_pre_mlp2")
+    return y
 
 
 def attn_temporal(qkv, T, H, scale, want_lse=False):

@@ -104,8 +104,13 @@ class _ClsSide:
         self.done = None
 
     @classmethod
+    def _key(cls, device):
+        # one chain (side stream + buffers) per LAUNCH stream: the two-stream block runner (run_blocks) drives two of them at once
+        return (device.type, device.index if device.index is not None else torch.cuda.current_device(), torch.cuda.current_stream(device).cuda_stream)
+
+    @classmethod
     def get(cls, device):
-        key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+        key = cls._key(device)
         obj = cls._by_device.get(key)
         if obj is None:
             obj = cls._by_device[key] = cls(device)
@@ -125,9 +130,65 @@ class _ClsSide:
 
     @classmethod
     def join(cls, device):
-        obj = cls._by_device.get((device.type, device.index if device.index is not None else torch.cuda.current_device())) if device.type == "cuda" else None
+        """The current stream waits for the chain that was driven from it."""
+        obj = cls._by_device.get(cls._key(device)) if device.type == "cuda" else None
         if obj is not None:
             obj.wait_done()
+
+
+_AUX_STREAMS = {}
+
+
+def _aux_stream(device):
+    key = (device.index if device.index is not None else torch.cuda.current_device(), torch.cuda.current_stream(device).cuda_stream)
+    s = _AUX_STREAMS.get(key)
+    if s is None:
+        s = _AUX_STREAMS[key] = torch.cuda.Stream(device)
+    return s
+
+
+def run_blocks(blocks, tok, B, T, W):
+    """The no-grad forward through `blocks` (tok updated in place and returned), CLS chains joined.
+
+    Round 6: with alpro_amd.config.split_streams(B) the two halves of the batch go through every block on two HIP streams (clips are
+    independent: vit.py:146-212 never mixes them).  Each half's launches are ordered on its own stream (and its precise-CLS chain on that
+    stream's own side stream); the second stream is forked behind the embedding -- and again behind any block whose operand copies the launch
+    stream had to (re)build -- and the launch stream waits for it once, behind the last block (ALPRO_SPLIT_LOCKSTEP=1: at every block boundary,
+    a measurement aid that costs more than the split returns).  What it buys: a persistent GEMM's last, partly filled round of tiles and every
+    kernel's ramp-up / drain no longer idle the chip -- workgroups of the other half's next launch take the CUs as they are vacated
+    (B = 32 x 8 frames: -1.3 ... -3.2 % per forward, profiles/r6_split_streams_ab.txt).  Outputs are those of the one-stream forward bit for
+    bit as long as the half batch sends every Linear to the same GEMM kernel as the whole batch."""
+    dev = tok.device
+    if not (tok.is_cuda and not torch.is_grad_enabled() and rt.split_streams(B)):
+        for blk in blocks:
+            tok = blk(tok, B, T, W)
+        _ClsSide.join(dev)
+        return tok
+    from alpro_amd.modeling import weights
+    main, aux = torch.cuda.current_stream(dev), _aux_stream(dev)
+    h = B // 2
+    lo, hi = tok[:h], tok[h:]
+    lockstep = rt.split_lockstep()
+    ev = main.record_event()        # the embedding is written
+    for i, blk in enumerate(blocks):
+        r0 = weights.operand_rebuilds()
+        blk(lo, h, T, W)
+        if weights.operand_rebuilds() != r0:   # the launch stream (re)built operand copies of this block: the second stream may only read them afterwards
+            ev = main.record_event()
+        with torch.cuda.stream(aux):
+            if ev is not None:
+                aux.wait_event(ev)
+                ev = None
+            blk(hi, h, T, W)
+            if lockstep or i == len(blocks) - 1:
+                _ClsSide.join(dev)
+                ev_hi = aux.record_event()
+        if lockstep or i == len(blocks) - 1:
+            _ClsSide.join(dev)
+            main.wait_event(ev_hi)
+            if lockstep:
+                ev = main.record_event()
+    return tok
 
 
 class Block(nn.Module):
@@ -186,6 +247,8 @@ class Block(nn.Module):
             b1 = torch.mv(wf.detach(), bp.detach()).contiguous()
             m = dict(w=we if dt == torch.float32 else hip.cast(we, dt), wT=hip.transpose(we, out_dtype=dt, pad_to=64), b1=b1)
         self._ops._store["t_merged"] = (ver, m)
+        from alpro_amd.modeling import weights
+        weights.note_operand_rebuild()
         return m
 
     # ---- precise CLS rows (alpro_amd.config.cls_precise; csrc/cls_precise.hip) -------------------------------------------------
@@ -308,8 +371,11 @@ class Block(nn.Module):
             d_t = hip.gemm(a, mg["w"], bias=mg["b1"], row_scale=drop_t, row_scale_group=T)
             if side is not None:
                 side.wait_done()   # the previous block's chain has written this block's input CLS rows (first read: the kernel below)
-            hs, _ = hip.add_layernorm(x, d_t, self.norm1.weight, self.norm1.bias, VIT_EPS, mode=hip.ADD_PRE_SPATIAL, x_out=x,
-                                      delta_bias=self.temporal_fc.bias, T=T, N=N)
+            # round 6 (alpro_amd.config.defer_temporal_add): x + temporal branch (vit.py:162) is not written here -- the add + norm2 kernel below
+            # adds both branches to the block input in the same order of fp32 additions (bit for bit the same x')
+            defer = rt.defer_temporal_add()
+            hs, _ = hip.add_layernorm(x, d_t, self.norm1.weight, self.norm1.bias, VIT_EPS, mode=hip.ADD_PRE_SPATIAL, x_out=None if defer else x,
+                                      want_x=not defer, delta_bias=self.temporal_fc.bias, T=T, N=N)
             qkv = hip.gemm(hs, self._w("s_qkv", sa.qkv, dt), bias=sa.qkv.bias)
             if side is not None:
                 torch.cuda.current_stream().wait_event(side.ev_q)
@@ -320,7 +386,10 @@ class Block(nn.Module):
             else:
                 a = hip.attn(qkv, B * T, N + 1, H, sa.scale)
             d_s = hip.gemm(a, self._w("s_proj", sa.proj, dt), bias=sa.proj.bias, row_scale=drop_s, row_scale_group=N + 1)
-            h2, _ = hip.add_layernorm(x, d_s, self.norm2.weight, self.norm2.bias, VIT_EPS, mode=hip.ADD_PRE_MLP, x_out=x, T=T, N=N)
+            if defer:
+                h2 = hip.add_layernorm_pre_mlp2(x, d_t, self.temporal_fc.bias, d_s, self.norm2.weight, self.norm2.bias, VIT_EPS, T, N, x_out=x)
+            else:
+                h2, _ = hip.add_layernorm(x, d_s, self.norm2.weight, self.norm2.bias, VIT_EPS, mode=hip.ADD_PRE_MLP, x_out=x, T=T, N=N)
         else:
             self._forward_halves_unfused(x, xf, a, B, T, N, H, D, dt, drop_t, drop_s)
             h2 = hip.layernorm(x, self.norm2.weight, self.norm2.bias, VIT_EPS, dt)
@@ -663,6 +732,8 @@ class _MergedTProjBank:
             hip.tproj_small(*st["t_b1"], D, 0)
         st["key"] = key
         self.state = st
+        from alpro_amd.modeling import weights
+        weights.note_operand_rebuild()
         return st
 
     # ---- backward ------------------------------------------------------------------------------------------------
@@ -849,9 +920,7 @@ class VisionTransformer(nn.Module):
     def forward_features(self, x, return_all_tokens=False):
         B = x.shape[0]
         tok, T, W, N = self._embed(x)
-        for blk in self.blocks:
-            tok = blk(tok, B, T, W)
-        _ClsSide.join(tok.device)
+        tok = run_blocks(self.blocks, tok, B, T, W)
         y = hip.layernorm(tok, self.norm.weight, self.norm.bias, VIT_EPS, torch.float32).view(B, -1, self.embed_dim)
         return y if return_all_tokens else y[:, 0]
 
@@ -908,9 +977,7 @@ class TimeSformer(nn.Module):
         m = self.model
         B = x.shape[0]
         tok, T, W, N = m._embed(x)
-        for blk in m.blocks:
-            tok = blk(tok, B, T, W)
-        _ClsSide.join(tok.device)
+        tok = run_blocks(m.blocks, tok, B, T, W)
         out32, _ = hip.vit_final_pool(tok, m.norm.weight, m.norm.bias, VIT_EPS, B, T, N, torch.float32)
         return out32
 
@@ -922,9 +989,7 @@ class TimeSformer(nn.Module):
         m = self.model
         B = x.shape[0]
         tok, T, W, N = m._embed(x)
-        for blk in m.blocks[:-1]:
-            tok = blk(tok, B, T, W)
-        _ClsSide.join(tok.device)
+        tok = run_blocks(m.blocks[:-1], tok, B, T, W)
         cls = m.blocks[-1].forward_cls(tok, B, T, W)
         return hip.layernorm(cls, m.norm.weight, m.norm.bias, VIT_EPS, torch.float32)
 

@@ -98,6 +98,19 @@ def _flat_lp_view(plist, dtype):
     return f["lp"][off:off + total].view(-1, cols)
 
 
+# Counts operand copies (re)built since import: the two-stream block runner (modeling/timesformer/vit.py::run_blocks) orders its second stream
+# behind the launch stream whenever a block built one (the copy kernels run on the stream that missed).
+_REBUILDS = [0]
+
+
+def operand_rebuilds():
+    return _REBUILDS[0]
+
+
+def note_operand_rebuild():
+    _REBUILDS[0] += 1
+
+
 class OperandCache:
     def __init__(self):
         self._store = {}
@@ -122,6 +135,7 @@ class OperandCache:
             src = src.contiguous().float()
             out = hip.cast(src, dtype) if dtype != torch.float32 else src
         self._store[key] = (ver, out)
+        note_operand_rebuild()
         return out
 
     def clear(self):

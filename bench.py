@@ -111,6 +111,7 @@ class KernelTimer:
         wrap("attn_temporal", lambda qkv, T, H, *r, **k: 4.0 * qkv.shape[0] * T * H * 64)
         wrap("layernorm", lambda *a, **k: 0.0)
         wrap("add_layernorm", lambda *a, **k: 0.0)
+        wrap("add_layernorm_pre_mlp2", lambda *a, **k: 0.0)
         wrap("gemm_rows", lambda *a, **k: 0.0)
         wrap("attn_bwd", lambda qkv, out, dout, lse, batch, L, H, *r, **k: 10.0 * batch * H * L * L * 64)
         wrap("attn_temporal_bwd", lambda qkv, out, dout, lse, T, H, *r, **k: 10.0 * qkv.shape[0] * T * H * 64)
@@ -232,7 +233,9 @@ def measure_divst(dev, T, model=None, B=32, iters=5):
         model = vit.TimeSformer(dict(VENC, num_frm=T), input_format="RGB").eval().to(dev)
     x = torch.randn(B, 3, T, 224, 224, device=dev)
     marks, tails = [], []
-    orig_fwd, orig_cls, orig_add = vit.Block.forward, hip.cls_mean_residual, hip.add_layernorm
+    deferred = rt.defer_temporal_add()   # round 6: the add + norm2 kernel also carries the temporal branch's add (10.5 KB per row, 1.5 of them the MLP half's norm2 rows)
+    mlp_share = 1.0 / 7.0 if deferred else 1.0 / 6.0
+    orig_fwd, orig_cls, orig_add, orig_add2 = vit.Block.forward, hip.cls_mean_residual, hip.add_layernorm, hip.add_layernorm_pre_mlp2
 
     def fwd(self, *a, **k):
         e0 = torch.cuda.Event(enable_timing=True)
@@ -248,26 +251,35 @@ def measure_divst(dev, T, model=None, B=32, iters=5):
             marks[-1][1] = e1
         return out
 
-    def add_ln(*a, **k):   # round-3 form: they end inside the PRE_MLP add-LayerNorm kernel (see the accounting note below)
-        if k.get("mode") != hip.ADD_PRE_MLP:
-            return orig_add(*a, **k)
+    def end_mark(fn, a, k):
         ea = torch.cuda.Event(enable_timing=True)
         ea.record()
-        out = orig_add(*a, **k)
+        out = fn(*a, **k)
         e1 = torch.cuda.Event(enable_timing=True)
         e1.record()
         marks[-1][1] = e1
         tails.append((ea, e1))
         return out
+
+    def add_ln(*a, **k):   # round-3 form: they end inside the PRE_MLP add-LayerNorm kernel (see the accounting note below)
+        if k.get("mode") != hip.ADD_PRE_MLP:
+            return orig_add(*a, **k)
+        return end_mark(orig_add, a, k)
+
+    def add_ln2(*a, **k):  # round 6: the same kernel with the temporal branch's deferred add (alpro_add_layernorm_pre_mlp2)
+        return end_mark(orig_add2, a, k)
     # The region is timed with HIP events on the MAIN stream, so it is measured with the precise-CLS chain on that stream too (ALPRO_CLS_STREAM=0 for
     # this pass): every launch the sub-blocks need is then inside the region.  On its side stream (the inference default) part of the chain runs
     # beside the MLP half and the region would both lose that work and gain the main stream's waits (profiles/r5_cls_stream_ab.txt).
-    prev_cs = rt._cls_stream[0]
+    # ... and, for the same reason, with the whole batch on the launch stream (ALPRO_SPLIT_STREAMS off for this pass: the product default runs the
+    # two halves of the batch on two free-running streams, profiles/r6_split_streams_ab.txt, where a block's region has no single start and end)
+    prev_cs, prev_split = rt._cls_stream[0], rt._split_streams[0]
     rt.set_cls_stream("0")
+    rt.set_split_streams("0")
     with torch.no_grad():
         for _ in range(2):
             model.forward_features(x)
-        vit.Block.forward, hip.cls_mean_residual, hip.add_layernorm = fwd, cls, add_ln
+        vit.Block.forward, hip.cls_mean_residual, hip.add_layernorm, hip.add_layernorm_pre_mlp2 = fwd, cls, add_ln, add_ln2
         try:
             torch.cuda.synchronize()
             t0 = torch.cuda.Event(enable_timing=True)
@@ -278,8 +290,9 @@ def measure_divst(dev, T, model=None, B=32, iters=5):
             t1.record()
             torch.cuda.synchronize()
         finally:
-            vit.Block.forward, hip.cls_mean_residual, hip.add_layernorm = orig_fwd, orig_cls, orig_add
+            vit.Block.forward, hip.cls_mean_residual, hip.add_layernorm, hip.add_layernorm_pre_mlp2 = orig_fwd, orig_cls, orig_add, orig_add2
             rt.set_cls_stream(prev_cs)
+            rt.set_split_streams(prev_split)
     # Per-block table: one more forward with every library call of the region under its own pair of HIP events; the rows are
     # means over the 12 blocks, `unattributed` is what the region's own events measured beyond the sum (launch gaps, torch's small copies).
     table = None
@@ -293,18 +306,27 @@ def measure_divst(dev, T, model=None, B=32, iters=5):
                 spans.append([len(rec), None])
                 return orig_fwd(self, *a, **k)
 
+            wrapped_add_p2 = hip.add_layernorm_pre_mlp2
+
             def add2(*a, **k):
                 out = wrapped_add(*a, **k)
                 if k.get("mode") == hip.ADD_PRE_MLP:
                     spans[-1][1] = len(rec)
                 return out
-            vit.Block.forward, hip.add_layernorm = fwd2, add2
+
+            def add2_p2(*a, **k):
+                out = wrapped_add_p2(*a, **k)
+                spans[-1][1] = len(rec)
+                return out
+            vit.Block.forward, hip.add_layernorm, hip.add_layernorm_pre_mlp2 = fwd2, add2, add2_p2
             rt.set_cls_stream("0")
+            rt.set_split_streams("0")
             try:
                 model.forward_features(x)
             finally:
-                vit.Block.forward, hip.add_layernorm = orig_fwd, wrapped_add
+                vit.Block.forward, hip.add_layernorm, hip.add_layernorm_pre_mlp2 = orig_fwd, wrapped_add, wrapped_add_p2
                 rt.set_cls_stream(prev_cs)
+                rt.set_split_streams(prev_split)
         torch.cuda.synchronize()
         rows = {}
         for lo, hi in spans:
@@ -320,9 +342,12 @@ def measure_divst(dev, T, model=None, B=32, iters=5):
                     order = ["temporal projection (merged proj + temporal_fc) GEMM", "spatial qkv GEMM", "spatial projection GEMM"] if fused else \
                             ["temporal qkv GEMM", "temporal projection (merged proj + temporal_fc) GEMM", "spatial qkv GEMM", "spatial projection GEMM"]
                     label = order[n_gemm - 1] if n_gemm <= len(order) else "other GEMM"
+                elif name == "add_layernorm_pre_mlp2":
+                    label = "residual adds (temporal + spatial) + norm2 (6/7 counted)"
+                    us *= 6.0 / 7.0
                 elif name == "add_layernorm":
                     last = i == len(seq) - 1
-                    label = "residual add + norm2 (5/6 counted)" if last else "residual add + norm1"
+                    label = "residual add + norm2 (5/6 counted)" if last else ("residual add + norm1" if not deferred else "norm1 of block input + temporal branch (nothing but the normalised rows written)")
                     if last:
                         us *= 5.0 / 6.0
                 else:
@@ -339,15 +364,16 @@ def measure_divst(dev, T, model=None, B=32, iters=5):
     # The PRE_MLP kernel is the spatial half's residual add (reads x and the 16-bit delta, writes x': 7.5 of its 9 KB per row) AND the MLP
     # half's norm2 (the 16-bit normalised row: 1.5 KB).  Its time is attributed 5/6 to the attention sub-blocks, 1/6 to the MLP.
     tail_ms = sum(a.elapsed_time(b) for a, b in tails) / iters
-    ms = sum(a.elapsed_time(b) for a, b in marks) / iters - tail_ms / 6.0
+    ms = sum(a.elapsed_time(b) for a, b in marks) / iters - tail_ms * mlp_share
     tf = B * DIVST_GFLOP_PER_CLIP_8F * (T / 8.0) / ms          # GFLOP / ms == TFLOP/s
     return {"workload": "divided space-time attention sub-blocks of the TimeSformer forward, B=%d x %df x 224^2 (BASELINE configs[1]), %s operands" % (B, T, str(rt.compute_dtype()).replace("torch.", "")),
-            "ms": round(ms, 3), "accounting": "Block entry .. end of the spatial residual add; the fused add+norm2 kernel (%.3f ms over 12 blocks) counts 5/6 here (its x read, delta read, x' write) and 1/6 as the MLP half's norm2" % tail_ms if tails else "Block entry .. alpro_cls_mean_residual",
+            "ms": round(ms, 3), "accounting": ("Block entry .. end of the spatial residual add; the fused add+norm2 kernel (%.3f ms over 12 blocks) counts %s here (its x read, delta read%s, x' write) and %s as the MLP half's norm2"
+                           % (tail_ms, "6/7" if deferred else "5/6", "s" if deferred else "", "1/7" if deferred else "1/6")) if tails else "Block entry .. alpro_cls_mean_residual",
             "encoder_forward_ms": round(t0.elapsed_time(t1) / iters, 3), "gflop_per_clip": DIVST_GFLOP_PER_CLIP_8F * (T / 8.0),
             "achieved": round(tf, 1), "peak": MFMA_PEAK_TFLOPS["bf16"], "unit": "TFLOP/s", "frac": round(tf / MFMA_PEAK_TFLOPS["bf16"], 4), "target_frac": 0.40,
             # the conservative figure: the whole fused add + norm2 kernel counted here (no 1/6 attribution to the MLP half)
             "per_block_us": table, "measured_us_per_block": round(ms * 1e3 / 12.0, 1),
-            "ms_end_to_end": round(ms + tail_ms / 6.0, 3), "frac_end_to_end": round(B * DIVST_GFLOP_PER_CLIP_8F * (T / 8.0) / (ms + tail_ms / 6.0) / MFMA_PEAK_TFLOPS["bf16"], 4)}
+            "ms_end_to_end": round(ms + tail_ms * mlp_share, 3), "frac_end_to_end": round(B * DIVST_GFLOP_PER_CLIP_8F * (T / 8.0) / (ms + tail_ms * mlp_share) / MFMA_PEAK_TFLOPS["bf16"], 4)}
 
 
 def mode_name(dtype):
@@ -559,9 +585,17 @@ def main():
 
     # per-kernel-family device time: one extra, untimed step under HIP events.  EVERY rank runs it (the training step holds
     # collectives: a rank-0-only pass would wait forever for its peers); only rank 0 reports.
-    with (torch.enable_grad() if train else torch.no_grad()), KernelTimer(hip) as kt:
-        step()
-    ks = kt.summary()
+    # Launches are timed one at a time on the launch stream: the two-stream forward (alpro_amd.config.split_streams) is off for this pass, so that a
+    # kernel's time is its own and not its share of the chip beside the other half's launches.
+    from alpro_amd import config as _rt
+    _prev_split = _rt._split_streams[0]
+    _rt.set_split_streams("0")
+    try:
+        with (torch.enable_grad() if train else torch.no_grad()), KernelTimer(hip) as kt:
+            step()
+        ks = kt.summary()
+    finally:
+        _rt.set_split_streams(_prev_split)
     dist.barrier()
     result = None
     if rank == 0:

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define ALPRO_HIP_ABI_VERSION 19
+#define ALPRO_HIP_ABI_VERSION 20
 
 enum { ALPRO_OK = 0, ALPRO_ERR_INVALID = 1, ALPRO_ERR_LAUNCH = 2 };
 enum { ALPRO_F32 = 0, ALPRO_BF16 = 1, ALPRO_F16 = 2 };
@@ -192,6 +192,12 @@ enum { ALPRO_ADD_IDENTITY = 0, ALPRO_ADD_PRE_SPATIAL = 1, ALPRO_ADD_PRE_MLP = 2,
 int alpro_add_layernorm_fwd(const float* x_in, const void* delta, int dtype, const float* delta_bias, int add_mode, float* x_out,
                             const float* gamma, const float* beta, float eps, void* y, float* y32, int64_t rows, int D, int p0, int p1,
                             void* stream);
+/* ALPRO_ADD_PRE_MLP with the temporal branch's add deferred into it (round 6; the no-grad forward): v = x_in[r] + delta_t[r - b - 1] +
+ * delta_t_bias + delta_s[(b*T+t)*(N+1)+1+n] for patch rows (in this order: bit for bit what ALPRO_ADD_PRE_SPATIAL followed by ALPRO_ADD_PRE_MLP
+ * store), the CLS row as in ALPRO_ADD_PRE_MLP.  The caller runs ALPRO_ADD_PRE_SPATIAL with x_out = NULL before it, so the intermediate
+ * x + temporal branch (vit.py:162) is never written.  rows = B*(1+N*T); x_out may alias x_in. */
+int alpro_add_layernorm_pre_mlp2(const float* x_in, const void* delta_t, const float* delta_t_bias, const void* delta_s, int dtype, float* x_out,
+                                 const float* gamma, const float* beta, float eps, void* y, int64_t rows, int D, int T, int N, void* stream);
 
 /* Divided space-time attention, temporal half (vit.py:146-157 -> Attention.forward :81-96):
  * rows = B*N*T tokens in (b, n, t) order, each group of T consecutive rows attends within itself.

@@ -784,3 +784,58 @@ def test_fused_temporal_half_against_the_two_launches(mode):
     rel = float((ga - gb).norm() / gb.norm())
     print("\n[fused temporal half %s] outputs within 8 eps; gradient l2 rel diff %.2e" % (mode, rel))
     assert bool(torch.isfinite(ga).all()) and rel <= {"fp16": 1e-3, "bf16": 8e-3}[mode], rel
+
+
+@pytest.mark.parametrize("mode", ["fp16", "bf16"])
+def test_inference_forward_schedules_are_bitwise_neutral(mode):
+    """Round 6, two schedule changes of the no-grad encoder forward that must not move a bit:
+    (i) alpro_amd.config.defer_temporal_add -- add + norm1 does not write x + temporal branch, add + norm2 adds both branches to the block input
+        in the same order of fp32 additions (alpro_add_layernorm_pre_mlp2);
+    (ii) alpro_amd.config.split_streams -- the two halves of the batch through every block on two HIP streams (vit.run_blocks), with and without
+        the precise CLS chain on its side streams, meeting once behind the last block or at every block boundary.
+    forward_features and forward_cls of the same clips, every combination against the one-stream round-3 form.  (B = 16 x 4 frames: the whole batch
+    and its halves send every Linear to the same GEMM kernel -- N = 768: 147 / 72 tiles, the 128 x 128 kernel; N = 2304 / 3072: >= 216 tiles, the 8-phase
+    kernel -- so every output element is the same sequence of fp32 operations; across the 160-tile switch the two kernels sum in different orders.)"""
+    import os
+    from alpro_amd import config as rt
+    from alpro_amd.modeling.timesformer.vit import TimeSformer
+    torch.manual_seed(37)
+    T, B = 4, 16
+    enc = TimeSformer(dict(VENC, num_frm=T, drop_path_rate=0.0), input_format="RGB").cuda().eval()
+    with torch.no_grad():
+        for blk in enc.model.blocks:
+            torch.nn.init.normal_(blk.temporal_fc.weight, std=0.02)
+            torch.nn.init.normal_(blk.temporal_fc.bias, std=0.02)
+    x = torch.randn(B, 3, T, 224, 224, device="cuda")
+    prev = (rt._defer_tadd[0], rt._split_streams[0], rt._cls_stream[0], os.environ.get("ALPRO_SPLIT_LOCKSTEP"))
+    outs = {}
+    try:
+        for cp in ("0", "1"):
+            for defer in (False, True):
+                for split, lock, cs in (("0", "0", "0"), ("1", "0", "0"), ("1", "0", "infer"), ("1", "1", "infer")):
+                    rt.set_defer_temporal_add(defer)
+                    rt.set_split_streams(split)
+                    rt.set_cls_stream(cs)
+                    os.environ["ALPRO_SPLIT_LOCKSTEP"] = lock
+                    with rt.use_compute_dtype(mode), rt.use_cls_precise(cp), torch.no_grad():
+                        for rep in range(2):   # twice: the second pass runs with warm operand copies (no fork-after-rebuild event)
+                            y = enc.forward_features(x).float().clone()
+                            c = enc.forward_cls(x).float().clone()
+                    torch.cuda.synchronize()
+                    outs[(cp, defer, split, lock, cs)] = (y, c)
+    finally:
+        rt.set_defer_temporal_add(prev[0])
+        rt.set_split_streams(prev[1])
+        rt.set_cls_stream(prev[2])
+        if prev[3] is None:
+            os.environ.pop("ALPRO_SPLIT_LOCKSTEP", None)
+        else:
+            os.environ["ALPRO_SPLIT_LOCKSTEP"] = prev[3]
+    for cp in ("0", "1"):
+        ref = outs[(cp, False, "0", "0", "0")]
+        assert bool(torch.isfinite(ref[0]).all()) and float(ref[0].abs().sum()) > 0
+        for key, (y, c) in outs.items():
+            if key[0] != cp:
+                continue
+            assert torch.equal(y, ref[0]), "forward_features differs for (cls_precise, defer, split, lockstep, cls_stream) = %s" % (key,)
+            assert torch.equal(c, ref[1]), "forward_cls differs for %s" % (key,)
