@@ -365,11 +365,21 @@ __global__ __launch_bounds__(256, 2) void attn_fwd16_kernel(const T* __restrict_
   // query tiles of this wave: t, t + 4, ... with t rotated by the workgroup index, so that the wave with one tile less (7 tiles on 4 waves)
   // is not the same SIMD's in the two workgroups that share a CU
 #ifdef ATTN_NO_ROT
-  int qt = wave;
+  int seq = wave;
 #else
-  int qt = (wave + (int)(blockIdx.x >> 3)) & 3;
+  int seq = (wave + (int)(blockIdx.x >> 3)) & 3;
 #endif
-  bool has = qt < ntile;
+  // The tile that carries the CLS parts costs its wave ~2000 more VALU instructions (part splits, DPP joins over all NKT * 16 score registers,
+  // twice).  With 7 tiles on 4 waves the walk above gives it -- the last tile -- to a wave that has two tiles, i.e. puts the extras on the
+  // workgroup's critical path; swapped with the one tile of the wave that has a round less (positions 3 <-> 6 at L = 197) they ride for free.
+  int swap_a = -1, swap_b = -1;
+  if (CLS && cls_tile >= 0 && cls_tile == ntile - 1 && (ntile & 3) != 0 && (cls_tile & 3) != 3 && ntile > 4) {
+    swap_a = cls_tile;
+    swap_b = ((ntile - 1) & ~3) - 1;   // the last position of the walk that starts at 3: the wave with one tile less
+  }
+  auto tile_at = [&](int pos) __attribute__((always_inline)) { return pos == swap_a ? swap_b : (pos == swap_b ? swap_a : pos); };
+  int qt = tile_at(seq);
+  bool has = seq < ntile;
   u32x4 qf[4];
   load_q(has ? qt : 0, qf);
 #pragma unroll
@@ -411,7 +421,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd16_kernel(const T* __restrict_
         mma_chunk<T>(s[kt], a, qf[ks]);
       }
     }
-    load_q(min(qt + 4, ntile - 1), qn);  // lands under the softmax
+    load_q(tile_at(min(seq + 4, ntile - 1)), qn);  // lands under the softmax
     const bool cls_here = CLS && qt == cls_tile;
     if constexpr (CLS) {
       if (cls_here) {   // lane c0: the fp32 score of the unrounded CLS query = the sum of its parts' columns
@@ -611,8 +621,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd16_kernel(const T* __restrict_
       v_pending = false;
     }
     output();
-    qt += 4;
-    has = qt < ntile;
+    seq += 4;
+    has = seq < ntile;
+    qt = tile_at(min(seq, ntile - 1));
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) qf[ks] = qn[ks];
   }

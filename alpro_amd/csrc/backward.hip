@@ -253,6 +253,15 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
       continue;
     }
     const SrcRow src = ln_src_row(mode, p0, p1, m);
+    // round 6: the row of dx that the result is added to is fetched WITH the row's x / dy (it used to be read behind the four dependent wave
+    // reductions: a second exposed memory latency per row)
+    f32x4 cin[3];
+    const bool acc_here = accumulate && !src.shared;
+    if (acc_here) {
+      const float* o = dx + src.row * ld_dx;
+#pragma unroll
+      for (int i = 0; i < 3; ++i) cin[i] = __builtin_nontemporal_load((const f32x4*)(o + i * 256 + lane * 4));
+    }
     float fin[12];  // the finished gradient row
     row_grad(m, src.row, fin);
     if (src.shared) {
@@ -274,9 +283,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
       float* p = o + i * 256 + lane * 4;
-      if (accumulate) {
-        const float4 c = *(const float4*)p;
-        fin[4 * i] += c.x; fin[4 * i + 1] += c.y; fin[4 * i + 2] += c.z; fin[4 * i + 3] += c.w;
+      if (acc_here) {
+        fin[4 * i] += cin[i].x; fin[4 * i + 1] += cin[i].y; fin[4 * i + 2] += cin[i].z; fin[4 * i + 3] += cin[i].w;
       }
       __builtin_nontemporal_store(f32x4{fin[4 * i], fin[4 * i + 1], fin[4 * i + 2], fin[4 * i + 3]}, (f32x4*)p);
     }

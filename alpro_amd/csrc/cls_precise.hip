@@ -134,7 +134,33 @@ __global__ __launch_bounds__(NW * 64) void gemm_rows_f32_kernel(const float* __r
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n0 = blockIdx.x * 16, m0 = blockIdx.y * 64;
   const int r15 = lane & 15, kg = lane >> 4;
-  if (LN) {   // statistics of the 64 rows: four lanes per row (a quarter of the row each, float4 loads), two passes (mean, then centred squares)
+  if (LN && NW == 8 && K == 768) {
+    // round 6: the hidden size on 8 waves -- eight lanes per row, the lane's 24 float4 loaded ONCE (all in flight together: one memory latency
+    // instead of 2 x 48 loads per lane in dependent batches, which was ~half of the launch's 25 us) and both passes taken from registers
+    const int r = tid >> 3, q = tid & 7;
+    const float* a = A + (int64_t)min(m0 + r, M - 1) * lda + q * 4;
+    float4 t[24];
+#pragma unroll
+    for (int i = 0; i < 24; ++i) t[i] = *(const float4*)(a + i * 32);
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 24; ++i) sum += (t[i].x + t[i].y) + (t[i].z + t[i].w);
+    sum += __shfl_xor(sum, 1, 64);
+    sum += __shfl_xor(sum, 2, 64);
+    sum += __shfl_xor(sum, 4, 64);
+    const float mean = sum / 768.0f;
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < 24; ++i) {
+      const float d0 = t[i].x - mean, d1 = t[i].y - mean, d2 = t[i].z - mean, d3 = t[i].w - mean;
+      sq += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+    }
+    sq += __shfl_xor(sq, 1, 64);
+    sq += __shfl_xor(sq, 2, 64);
+    sq += __shfl_xor(sq, 4, 64);
+    if (q == 0) { stat[r][0] = mean; stat[r][1] = rsqrtf(sq / 768.0f + eps); }
+    __syncthreads();
+  } else if (LN) {   // statistics of the 64 rows: four lanes per row (a quarter of the row each, float4 loads), two passes (mean, then centred squares)
     if (wave < 4) {
       const int r = wave * 16 + (lane >> 2), q = lane & 3;
       const float* a = A + (int64_t)min(m0 + r, M - 1) * lda + q * (K >> 2);
