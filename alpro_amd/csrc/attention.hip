@@ -278,6 +278,15 @@ template <typename T> __device__ __forceinline__ void cls_split(float x, float& 
   p1 = quantize<T>(r1);
   p2 = ClsSplit<T>::NS == 3 ? quantize<T>((r1 - p1) * ClsSplit<T>::C2) : 0.f;
 }
+// The same decomposition by TRUNCATION (round 6): the leading part keeps the operand dtype's explicit mantissa bits of x (one AND; exactly
+// representable in the dtype for normal values), the residual of a truncation is exact like that of a rounding, and the LAST part is rounded by
+// the 16-bit pack that follows anyway: 10 + 11 (fp16) / 7 + 7 + 8 (bf16) mantissa bits, i.e. x to 2^-21 / 2^-22 -- for 3 instead of 8-10 VALU
+// instructions per value (the cvt pairs of quantize() were two thirds of the ~1900 instructions the CLS parts cost their wave).
+template <typename T> struct ClsTrunc;
+template <> struct ClsTrunc<f16_t> { static constexpr uint32_t MASK = 0xFFFFE000u; };
+template <> struct ClsTrunc<bf16_t> { static constexpr uint32_t MASK = 0xFFFF0000u; };
+__device__ __forceinline__ float and_bits(float x, uint32_t m) { return __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, x) & m); }
+
 template <typename T> __device__ __forceinline__ float cls_join(float v0, float v1, float v2) {
   float r = fmaf(v1, 1.0f / ClsSplit<T>::C1, v0);
   if (ClsSplit<T>::NS == 3) r = fmaf(v2, 1.0f / (ClsSplit<T>::C1 * ClsSplit<T>::C2), r);
@@ -351,9 +360,11 @@ __global__ __launch_bounds__(256, 2) void attn_fwd16_kernel(const T* __restrict_
           const float x[8] = {a.x, a.y, a.z, a.w, c.x, c.y, c.z, c.w};
           float part[8];
 #pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            float p0, p1, p2;
-            cls_split<T>(x[e], p0, p1, p2);
+          for (int e = 0; e < 8; ++e) {   // truncation split (ClsTrunc); the pack below rounds the last part
+            const float p0 = and_bits(x[e], ClsTrunc<T>::MASK);
+            const float r1 = (x[e] - p0) * ClsSplit<T>::C1;
+            float p1 = r1, p2 = 0.f;
+            if (NS == 3) { p1 = and_bits(r1, ClsTrunc<T>::MASK); p2 = (r1 - p1) * ClsSplit<T>::C2; }
             part[e] = j == 0 ? p0 : (j == 1 ? p1 : p2);
           }
           const u32x4 pk = pack_chunk<T>(part);
@@ -373,7 +384,11 @@ __global__ __launch_bounds__(256, 2) void attn_fwd16_kernel(const T* __restrict_
   // twice).  With 7 tiles on 4 waves the walk above gives it -- the last tile -- to a wave that has two tiles, i.e. puts the extras on the
   // workgroup's critical path; swapped with the one tile of the wave that has a round less (positions 3 <-> 6 at L = 197) they ride for free.
   int swap_a = -1, swap_b = -1;
+#ifdef ATTN_NO_CLS_SWAP   // (measurement builds, tools/build_attn_variants.sh)
+  if (false) {
+#else
   if (CLS && cls_tile >= 0 && cls_tile == ntile - 1 && (ntile & 3) != 0 && (cls_tile & 3) != 3 && ntile > 4) {
+#endif
     swap_a = cls_tile;
     swap_b = ((ntile - 1) & ~3) - 1;   // the last position of the walk that starts at 3: the wave with one tile less
   }
@@ -424,14 +439,17 @@ __global__ __launch_bounds__(256, 2) void attn_fwd16_kernel(const T* __restrict_
     load_q(tile_at(min(seq + 4, ntile - 1)), qn);  // lands under the softmax
     const bool cls_here = CLS && qt == cls_tile;
     if constexpr (CLS) {
-      if (cls_here) {   // lane c0: the fp32 score of the unrounded CLS query = the sum of its parts' columns
+      if (cls_here) {   // lane c0: the fp32 score of the unrounded CLS query = the sum of its parts' columns.  The weights are per-lane constants
+        // (zero outside lane c0: raw scores are finite, so 0 * neighbour adds nothing): one DPP + one FMA per part and register, no select
+        const float w1 = ql == c0 ? 1.0f / ClsSplit<T>::C1 : 0.f, w2 = ql == c0 ? 1.0f / (ClsSplit<T>::C1 * ClsSplit<T>::C2) : 0.f;
 #pragma unroll
         for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const float a = s[kt][r];
-            const float b1 = dpp_from_above<1>(a), b2 = NS == 3 ? dpp_from_above<2>(a) : 0.f;
-            s[kt][r] = ql == c0 ? cls_join<T>(a, b1, b2) : a;
+            float v = fmaf(dpp_from_above<1>(a), w1, a);
+            if (NS == 3) v = fmaf(dpp_from_above<2>(a), w2, v);
+            s[kt][r] = v;
           }
       }
     }
@@ -527,16 +545,33 @@ __global__ __launch_bounds__(256, 2) void attn_fwd16_kernel(const T* __restrict_
         for (int r = 0; r < 16; ++r) s[kt][r] = drop_keep(drop_seed, base_i + (uint64_t)(kt * 32 + acc_row(r, 0)), th) ? s[kt][r] * ks : 0.f;
     }
     if constexpr (CLS) {
-      if (cls_here) {   // lane c0's probabilities, unrounded, as NS columns of 16-bit values that add up to them
+      if (cls_here) {   // lane c0's probabilities, unrounded, as NS columns of 16-bit values that add up to them (truncation split, ClsTrunc: the
+        // mask is all ones outside lane c0, so the other lanes keep their value and their residual is an exact zero; the pack in pv_tiles
+        // rounds the last part)
+        // (the lane selects are bit selects on per-lane masks -- v_bfi_b32: written as ?: the compiler turned each of the 112 into an
+        // exec-masked branch, ~8 scalar instructions and two jumps per register)
+        const uint32_t tm = ql == c0 ? ClsTrunc<T>::MASK : 0xFFFFFFFFu;
+        const uint32_t sel1 = ql == c0 + 1 ? 0xFFFFFFFFu : 0u, sel2 = (NS == 3 && ql == c0 + 2) ? 0xFFFFFFFFu : 0u;
 #pragma unroll
         for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const float pr = s[kt][r];
-            float h0, h1, h2;
-            cls_split<T>(pr, h0, h1, h2);
-            const float f1 = dpp_from_below<1>(h1), f2 = NS == 3 ? dpp_from_below<2>(h2) : 0.f;
-            s[kt][r] = ql == c0 ? h0 : (ql == c0 + 1 ? f1 : ((NS == 3 && ql == c0 + 2) ? f2 : pr));
+            const uint32_t hb = __builtin_bit_cast(uint32_t, pr) & tm;
+            const float h0 = __builtin_bit_cast(float, hb);
+            const float r1 = (pr - h0) * ClsSplit<T>::C1;
+            uint32_t o;
+            if (NS == 2) {
+              const uint32_t d1 = __builtin_bit_cast(uint32_t, dpp_from_below<1>(r1));
+              o = (d1 & sel1) | (hb & ~sel1);
+            } else {
+              const float h1 = and_bits(r1, ClsTrunc<T>::MASK);
+              const float r2 = (r1 - h1) * ClsSplit<T>::C2;
+              const uint32_t d1 = __builtin_bit_cast(uint32_t, dpp_from_below<1>(h1)), d2 = __builtin_bit_cast(uint32_t, dpp_from_below<2>(r2));
+              o = (d1 & sel1) | (hb & ~sel1);
+              o = (d2 & sel2) | (o & ~sel2);
+            }
+            s[kt][r] = __builtin_bit_cast(float, o);
           }
       }
     }
@@ -813,7 +848,11 @@ int launch_attn16(const void* qkv, void* out, int batch, int L, int H, float sca
   // query runs the third one with cls_q == nullptr (the CLS code is skipped by a wave-uniform test): the <no CLS, dropout> form is the one
   // instantiation the register allocator does not get through without spilling (224-420 bytes of scratch at 7 / 8 key tiles, ROCm 7.2).
   if (drop_seed) ALPRO_ATTN16_GO(true, true);
+#ifdef ATTN_CLS_FORCE_TPL  // (measurement builds: the instantiation with the CLS code on launches without a CLS query -- what does the code cost the regular rows?)
+  else if (true) ALPRO_ATTN16_GO(true, false);
+#else
   else if (cls_q) ALPRO_ATTN16_GO(true, false);
+#endif
   else ALPRO_ATTN16_GO(false, false);
 #undef ALPRO_ATTN16_GO
   return check_launch("alpro_attn_fwd");

@@ -1,6 +1,10 @@
 #!/bin/bash
-# CPU: measurement builds of the library that differ in attention.hip only (variant macros ATTN_NO_ROT / ATTN_NO_KV_SPLIT / ATTN_NO_PK, and the
-# round-5 kernel) -> alpro_amd/lib/variants/libalpro_hip_<v>.so; they travel with the snapshot, tools/r6_call3.sh times them on one box.
+# CPU: measurement builds of the library that differ in attention.hip only (variant macros) -> alpro_amd/lib/variants/libalpro_hip_<v>.so; they travel
+# with the snapshot and are timed on one box (round 6, second session: what do the precise CLS parts still cost the spatial attention forward?)
+#   new        the product
+#   noswap     -DATTN_NO_CLS_SWAP      the tile with the CLS parts stays with the wave that has two tiles
+#   forcetpl   -DATTN_CLS_FORCE_TPL    launches WITHOUT a CLS query run the instantiation that carries the CLS code
+#   norot      -DATTN_NO_ROT           no rotation of the tile -> wave walk by workgroup index
 set -e
 cd "$(dirname "$0")/.."
 L=alpro_amd/lib; V=$L/variants; mkdir -p $V
@@ -12,13 +16,9 @@ build() {  # name, source, flags
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $V/libalpro_hip_$1.so $OBJS $V/attention_$1.o
   rm $V/attention_$1.o
 }
-git show 0f6f40f:alpro_amd/csrc/attention.hip > /tmp/attention_r5.hip
 build new alpro_amd/csrc/attention.hip "" &
+build noswap alpro_amd/csrc/attention.hip "-DATTN_NO_CLS_SWAP" &
+build forcetpl alpro_amd/csrc/attention.hip "-DATTN_CLS_FORCE_TPL" &
 build norot alpro_amd/csrc/attention.hip "-DATTN_NO_ROT" &
-build nokv alpro_amd/csrc/attention.hip "-DATTN_NO_KV_SPLIT" &
-build nopk alpro_amd/csrc/attention.hip "-DATTN_NO_PK" &
-wait
-build nokvrot alpro_amd/csrc/attention.hip "-DATTN_NO_KV_SPLIT -DATTN_NO_ROT" &
-build r5 /tmp/attention_r5.hip "-Wno-error=inline-asm" &
 wait
 ls -la $V
