@@ -24,7 +24,7 @@ EXPORTS = ["alpro_hip_last_error", "alpro_hip_abi_version", "alpro_hip_set_optio
            "alpro_attn_temporal_fwd", "alpro_attn_fwd", "alpro_patchify", "alpro_cls_mean_residual",
            "alpro_vit_final_pool", "alpro_bert_embed_fwd", "alpro_cast_from_f32", "alpro_attn_bwd", "alpro_attn_temporal_bwd",
            "alpro_layernorm_bwd", "alpro_transpose", "alpro_transpose_batch", "alpro_gelu_bwd", "alpro_cls_mean_bwd", "alpro_scatter_add_rows", "alpro_gather_cast", "alpro_sumsq", "alpro_adamw_step", "alpro_gemm_tn_acc", "alpro_gemm_tn_acc_ws", "alpro_gemm_tn_workspace_bytes", "alpro_gemm_tn_ranges", "alpro_colsum_acc", "alpro_softmax_xent", "alpro_vtc_loss_fwd", "alpro_vtc_loss_bwd", "alpro_prepare_clips", "alpro_loss_scale_update", "alpro_add_layernorm_fwd", "alpro_layernorm_bwd_emit", "alpro_gemm_batch", "alpro_tproj_small", "alpro_attn_cls_fwd", "alpro_gemm_rows_f32", "alpro_gather_seq_fwd", "alpro_gather_seq_bwd", "alpro_scatter_add_rows_ordered",
-           "alpro_hip_sched_workspace_bytes", "alpro_hip_set_sched_workspace", "alpro_hip_release_stream", "alpro_gemm_qkv_tattn", "alpro_add_layernorm_pre_mlp2"]
+           "alpro_hip_sched_workspace_bytes", "alpro_hip_set_sched_workspace", "alpro_hip_release_stream", "alpro_gemm_qkv_tattn", "alpro_add_layernorm_pre_mlp2", "alpro_adamw_step_lp"]
 
 
 class GemmDesc(ctypes.Structure):
@@ -93,6 +93,7 @@ def load():
     lib.alpro_colsum_acc.argtypes = [vp, i64, vp, i32, i32, i32, vp]
     lib.alpro_transpose_batch.argtypes = [vp, i32, i32, i32, vp]
     lib.alpro_adamw_step.argtypes = [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, f32, vp, f32, f32, vp, i32, i32, i32, vp]
+    lib.alpro_adamw_step_lp.argtypes = [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, f32, vp, f32, f32, vp, i32, i32, i32, vp, i32, vp]
     lib.alpro_loss_scale_update.argtypes = [vp, vp, f32, f32, i32, f32, f32, vp]
     lib.alpro_gather_cast.argtypes = [vp, i64, vp, i32, i32, i32, i32, i32, i32, vp, i32, f32, f32, u32, vp, vp, vp, ctypes.c_size_t, vp]
     lib.alpro_cls_mean_bwd.argtypes = [vp, i64, vp, i32, i32, i32, vp]
@@ -721,16 +722,22 @@ def sumsq(x, out):
 
 
 def adamw_step(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step_size, gnorm_sq=None, max_norm=0.0, grad_scale=1.0, dyn_state=None,
-               grads_scaled=True, correct_bias=True, zero_grad=False):
-    """dyn_state: (4,) fp32 device tensor {loss scale, growth tracker, applied steps, skipped steps} -- see alpro_adamw_step."""
+               grads_scaled=True, correct_bias=True, zero_grad=False, lp=None):
+    """dyn_state: (4,) fp32 device tensor {loss scale, growth tracker, applied steps, skipped steps} -- see alpro_adamw_step.
+    lp: optional 16-bit mirror of p (same numel), refreshed by the same pass (alpro_adamw_step_lp)."""
     lib = load()
     for t in (p, g, m, v):
         _dev(t, torch.float32)
     if dyn_state is not None:
         _dev(dyn_state, torch.float32)
         assert dyn_state.numel() >= 4 and gnorm_sq is not None
-    _check(lib.alpro_adamw_step(_ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), lr, beta1, beta2, eps, weight_decay, step_size,
-                                _ptr(gnorm_sq), max_norm, grad_scale, _ptr(dyn_state), int(bool(grads_scaled)), int(bool(correct_bias)), int(bool(zero_grad)), _stream()),
+    if lp is not None:
+        _dev(lp)
+        if lp.dtype not in (torch.float16, torch.bfloat16) or lp.numel() != p.numel() or not lp.is_contiguous():
+            raise RuntimeError("adamw_step: lp must be a contiguous 16-bit tensor with p's number of elements")
+    _check(lib.alpro_adamw_step_lp(_ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), lr, beta1, beta2, eps, weight_decay, step_size,
+                                   _ptr(gnorm_sq), max_norm, grad_scale, _ptr(dyn_state), int(bool(grads_scaled)), int(bool(correct_bias)), int(bool(zero_grad)),
+                                   _ptr(lp), _CODE[lp.dtype] if lp is not None else 0, _stream()),
            "alpro_adamw_step")
 
 

@@ -438,9 +438,18 @@ class FlatAdamW:
             norm.zero_()
             hip.sumsq(f["g"], norm)
             self.last_grad_norm = norm  # squared norm of the SUMMED (and, after a scaled backward, loss-scaled) gradient, device tensor (no host sync)
+        # the 16-bit mirror of the parameters (the GEMM operands are views of it, weights.py) is refreshed BY the optimizer pass (round 6: it was a
+        # separate cast launch over the same 0.94 GB); allocated -- and filled once, so that an overflow-skipped first step leaves a valid mirror -- here
+        dt = rt.compute_dtype()
+        lp = None
+        if dt != torch.float32:
+            if f.get("lp") is None or f["lp"].dtype != dt:
+                f["lp"] = torch.empty(f["n"], dtype=dt, device=f["p"].device)
+                hip.cast(f["p"], dt, out=f["lp"])
+            lp = f["lp"]
         hip.adamw_step(f["p"], f["g"], f["m"], f["v"], lr, b1, b2, grp["eps"], grp["weight_decay"], step_size, norm,
                        float(self.max_grad_norm or 0.0), 1.0 / world, dyn_state=sc.state if sc is not None else None,
-                       grads_scaled=self._grads_scaled, correct_bias=grp["correct_bias"], zero_grad=self.fused_zero_grad)
+                       grads_scaled=self._grads_scaled, correct_bias=grp["correct_bias"], zero_grad=self.fused_zero_grad, lp=lp)
         self._g_clean = self.fused_zero_grad
         self._clean_epoch = _backward_epoch()
         if sc is not None:  # overflow -> the kernel skipped the update; the schedule halves / grows the scale on the device
@@ -448,12 +457,8 @@ class FlatAdamW:
             hip.loss_scale_update(sc.state, norm, sc.growth if dyn else 1.0, sc.backoff if dyn else 1.0, sc.window, sc.min_scale, sc.max_scale)
         self._grads_scaled = False
         bump_param_epoch()
-        dt = rt.compute_dtype()
-        if dt != torch.float32:  # refresh the 16-bit GEMM operands of every parameter with one launch (weights.py)
-            if f.get("lp") is None or f["lp"].dtype != dt:
-                f["lp"] = torch.empty(f["n"], dtype=dt, device=f["p"].device)
-            hip.cast(f["p"], dt, out=f["lp"])
-            register_flat_lp(f["p"], f["lp"], f["live"])
+        if lp is not None:  # the 16-bit GEMM operands of every parameter are current again (weights.py)
+            register_flat_lp(f["p"], lp, f["live"])
         from alpro_amd.modeling.train import refresh_transposed_operands
         refresh_transposed_operands()  # the dgrad operands W^T of every Linear, one launch (modeling/train.py)
 

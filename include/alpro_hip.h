@@ -440,6 +440,12 @@ int alpro_adamw_step(float* p, float* g, float* m, float* v, int64_t n, float lr
                      float eps, float weight_decay, float step_size, const float* gnorm_sq, float max_norm,
                      float grad_scale, const float* dyn_state, int grads_scaled, int correct_bias,
                      int zero_grad /* round 4: also clear g (optimizer.zero_grad(), run_pretrain_sparse.py:648, folded in) */, void* stream);
+/* ... and the same pass ALSO refreshing the 16-bit mirror of the parameters (round 6; lp: n values of lp_dtype = ALPRO_BF16 / ALPRO_F16, the flat
+ * copy the GEMM operands are views of; rounded exactly as alpro_cast_from_f32 rounds; NULL = alpro_adamw_step).  A skipped step (overflow)
+ * leaves the mirror alone, like the parameters.  Replaces the separate cast launch behind the step: 6 B / parameter less traffic. */
+int alpro_adamw_step_lp(float* p, float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps, float weight_decay,
+                        float step_size, const float* gnorm_sq, float max_norm, float grad_scale, const float* dyn_state, int grads_scaled,
+                        int correct_bias, int zero_grad, void* lp, int lp_dtype, void* stream);
 
 /* After alpro_adamw_step on the same stream: *gnorm_sq not finite -> S = max(S * backoff, min_scale), tracker = 0, skipped += 1;
  * else applied += 1, tracker += 1 and after `window` clean steps S = min(S * growth, max_scale).  apex defaults: growth 2, backoff 0.5,

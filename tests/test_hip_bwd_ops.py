@@ -185,6 +185,44 @@ def test_flat_adamw_matches_reference_update():
         assert all(float(p.grad.abs().sum()) == 0 for p in params)
 
 
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+def test_adamw_step_refreshes_the_16_bit_mirror(dt):
+    """Round 6 (alpro_adamw_step_lp): the optimizer pass also writes the 16-bit mirror of the parameters the GEMM operands are views of -- bit for
+    bit what alpro_cast_from_f32 of the updated parameters gives (it replaced that launch), parameters / moments bit for bit those of the pass
+    without a mirror, on a ragged size (two float4 per thread and iteration, the tail element by element), and a skipped step (non-finite
+    squared norm under dynamic loss scaling) leaves parameters, moments AND mirror alone while still clearing the gradients."""
+    hip = _hip()
+    n = 256 * 4 * 37 + 4 * 5 + 3
+    g = torch.Generator().manual_seed(5)
+    p0, g0 = torch.randn(n, generator=g), torch.randn(n, generator=g) * 3
+    m0, v0 = torch.randn(n, generator=g) * 0.1, torch.rand(n, generator=g) * 0.1
+    norm = (g0.double() ** 2).sum().float().reshape(1).cuda()
+    res = {}
+    for with_lp in (False, True):
+        p, gg, m, v = p0.clone().cuda(), g0.clone().cuda(), m0.clone().cuda(), v0.clone().cuda()
+        lp = torch.full((n,), 7.0, dtype=dt).cuda() if with_lp else None
+        hip.adamw_step(p, gg, m, v, 1e-2, 0.9, 0.98, 1e-6, 0.01, 1e-2, norm, 2.0, 1.0, zero_grad=True, lp=lp)
+        res[with_lp] = (p, m, v, gg, lp)
+    for a, b, what in zip(res[True][:4], res[False][:4], ("p", "m", "v", "g")):
+        assert torch.equal(a, b), what
+    assert float(res[True][3].abs().sum()) == 0
+    assert torch.equal(res[True][4], hip.cast(res[True][0], dt)), "mirror != cast of the updated parameters"
+    ref_p = p0.double()
+    coef = min(2.0 / (math.sqrt(float((g0.double() ** 2).sum())) + 1e-6), 1.0)
+    gr = g0.double() * coef
+    rm, rv = m0.double() * 0.9 + 0.1 * gr, v0.double() * 0.98 + 0.02 * gr * gr
+    ref_p = ref_p - 1e-2 * rm / (rv.sqrt() + 1e-6)
+    ref_p = ref_p - 1e-2 * 0.01 * ref_p
+    close(res[True][0], ref_p, 1e-5, 1e-6, "adamw with mirror")
+    # overflow-skipped step
+    p, gg, m, v = p0.clone().cuda(), g0.clone().cuda(), m0.clone().cuda(), v0.clone().cuda()
+    lp = hip.cast(p, dt)
+    lp_before = lp.clone()
+    dyn = torch.tensor([65536.0, 0.0, 3.0, 0.0]).cuda()
+    hip.adamw_step(p, gg, m, v, 1e-2, 0.9, 0.98, 1e-6, 0.01, 1e-2, torch.tensor([float("inf")]).cuda(), 2.0, 1.0, dyn_state=dyn, zero_grad=True, lp=lp)
+    assert torch.equal(p.cpu(), p0) and torch.equal(m.cpu(), m0) and torch.equal(v.cpu(), v0) and torch.equal(lp, lp_before) and float(gg.abs().sum()) == 0
+
+
 @pytest.mark.parametrize("tn_kind", [0, 2])
 @pytest.mark.parametrize("atomic", [False, True])
 @pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])

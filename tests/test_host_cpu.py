@@ -895,8 +895,8 @@ def test_reference_driver_optimizer_lines_run_unchanged_on_the_fused_optimizer(m
     assert get_lr_sched.__code__.co_filename.startswith(ref) and setup_e2e_optimizer.__code__.co_filename.startswith(ref) and zero_none_grad is optim.zero_none_grad
     assert shim.__file__.startswith(ROOT) and setup_e2e_optimizer.__globals__["AdamW"] is shim.AdamW
 
-    def fake_adamw(p, g, m, v, lr, b1, b2, eps, wd, step_size, gnorm_sq=None, max_norm=0.0, grad_scale=1.0, dyn_state=None, grads_scaled=True, correct_bias=True, zero_grad=False):
-        assert gnorm_sq is None and max_norm == 0.0 and grad_scale == 1.0   # the driver clipped; the facade averaged
+    def fake_adamw(p, g, m, v, lr, b1, b2, eps, wd, step_size, gnorm_sq=None, max_norm=0.0, grad_scale=1.0, dyn_state=None, grads_scaled=True, correct_bias=True, zero_grad=False, lp=None):
+        assert lp is None and gnorm_sq is None and max_norm == 0.0 and grad_scale == 1.0   # the driver clipped; the facade averaged
         ao.clip_and_adamw_step([p], [g], [m], [v], fake_adamw.t, lr, (b1, b2), eps, wd, None, correct_bias)   # (fake_adamw.t: step counter kept by the test)
         if zero_grad:
             g.zero_()
@@ -1307,7 +1307,8 @@ def test_reference_training_loop_runs_unchanged_through_the_facade(monkeypatch):
 
     t_ = [0]
 
-    def fake_adamw(p, g, m, v, lr, b1, b2, eps, wd, step_size, gnorm_sq=None, max_norm=0.0, grad_scale=1.0, dyn_state=None, grads_scaled=True, correct_bias=True, zero_grad=False):
+    def fake_adamw(p, g, m, v, lr, b1, b2, eps, wd, step_size, gnorm_sq=None, max_norm=0.0, grad_scale=1.0, dyn_state=None, grads_scaled=True, correct_bias=True, zero_grad=False, lp=None):
+        assert lp is None   # (fp32 operands on the CPU: no 16-bit mirror)
         t_[0] += 1
         ao.clip_and_adamw_step([p], [g], [m], [v], t_[0], lr, (b1, b2), eps, wd, None, correct_bias)
         if zero_grad:

@@ -5,7 +5,7 @@ import torch
 from alpro_amd import hip
 hip.load()
 dt = torch.bfloat16
-for M in (2560, 15168, 30336):
+for M in (2560, 5120, 15168):
     for (N, K, res) in ((2304, 768, False), (768, 768, False), (768, 768, True), (3072, 768, False), (768, 3072, False), (768, 3072, True), (768, 2304, False)):
         a = torch.randn(M, K, device="cuda").to(dt); w = (torch.randn(N, K, device="cuda") * 0.05).to(dt)
         r = torch.randn(M, N, device="cuda") if res else None
