@@ -662,6 +662,9 @@ def main():
             "vs_baseline": None, "dtype": args.dtype, "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2**30, 2), "data": "synthetic (randn clips, random token ids; random-init weights)",
             "config": {"workload": wl, "per_gpu_batch": B, "frames": T, "parallelism": ("dp%d (RCCL: feature all-gather + flat gradient all-reduce)" % world) if train else ("dp%d (independent clips, no data-path collective)" % world)},
             "mode": mode_name(args.dtype), "deterministic_reductions": bool(hip.deterministic()),
+            # how the no-grad encoder forwards of the timed steps were scheduled (the visual_fwd workload itself; inside a training step the frozen
+            # prompter's pass): 2 = two half batches on two HIP streams (alpro_amd.config.split_streams); the divST region is always measured on one
+            "no_grad_forward_streams": 2 if _rt.split_streams(B) else 1,
             "world_size": world, "dist_backend": (torch.distributed.get_backend() if torch.distributed.is_initialized() else "none (single process)"),
             "rccl_version": ".".join(str(v) for v in torch.cuda.nccl.version()) if hasattr(torch.cuda, "nccl") else None,
             "nccl_channels": {k_: os.environ.get(k_) for k_ in ("NCCL_MAX_NCHANNELS", "NCCL_MIN_NCHANNELS", "ALPRO_OVERLAP_BACKWARD") if os.environ.get(k_) is not None},
