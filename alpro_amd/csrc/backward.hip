@@ -628,12 +628,24 @@ __global__ __launch_bounds__(256) void tproj_small_kernel(const alpro_tproj_job_
     __shared__ float red[4][64];
     const int m = blockIdx.x * 64 + lane;
     const float bpm = jb.bp[m];
+    // eight rows per trip, all 24 loads issued before the first store (round 6: one row per trip was 192 dependent memory round trips per wave,
+    // 150 us for a launch that moves 20 MB); the sum over n keeps a fixed order (rows w, w + 4, ... in ascending order)
     float acc = 0.f;
-    for (int n = w; n < D; n += 4) {
-      const float d = jb.db1[n];
-      const int64_t i = (int64_t)n * D + m;
-      jb.g_fc[i] += d * bpm;
-      acc = fmaf(jb.wfc[i], d, acc);
+    for (int n0 = w; n0 < D; n0 += 32) {   // D = 768: 24 trips of 8 rows (n0 + 4 k < D for every k)
+      float d[8], gf[8], wf[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int n = n0 + 4 * k;
+        const int64_t i = (int64_t)n * D + m;
+        d[k] = jb.db1[n];
+        gf[k] = jb.g_fc[i];
+        wf[k] = jb.wfc[i];
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        jb.g_fc[(int64_t)(n0 + 4 * k) * D + m] = gf[k] + d[k] * bpm;
+        acc = fmaf(wf[k], d[k], acc);
+      }
     }
     red[w][lane] = acc;
     __syncthreads();
