@@ -65,60 +65,6 @@ __global__ __launch_bounds__(256) void xent_kernel(const float* __restrict__ log
   }
 }
 
-// The same arithmetic with the row held in registers (round 6): 256 threads x 60 float2 = 30720 >= BERT's 30522-word vocabulary, so the logits
-// are read ONCE instead of three times (the second and third sweep came out of L2, but each was 60 dependent-latency trips per thread: 283 us for
-// 2560 rows).  Same per-thread order of the partial sums, same expf arguments: bit for bit the results of xent_kernel.
-constexpr int XENT_IT = 60;
-template <typename T>
-__global__ __launch_bounds__(256) void xent_row_kernel(const float* __restrict__ logits, int64_t ld, const int64_t* __restrict__ labels, int ignore_index,
-                                                       float* __restrict__ loss_rows, T* __restrict__ dlogits, int64_t ldd,
-                                                       const float* __restrict__ grad_scale, int V, int Vpad) {
-  __shared__ float sh[4];
-  const int m = blockIdx.x;
-  const float* x = logits + (int64_t)m * ld;
-  const int64_t label = labels[m];
-  const bool valid = label != ignore_index;
-  float2 v[XENT_IT];
-#pragma unroll
-  for (int it = 0; it < XENT_IT; ++it) {
-    const int i = threadIdx.x * 2 + it * 512;
-    if (i + 1 < V) v[it] = *(const float2*)(x + i);   // rows are 8-byte aligned (ld even)
-    else v[it] = make_float2(i < V ? x[i] : -INFINITY, -INFINITY);
-  }
-  float mx = -INFINITY;
-#pragma unroll
-  for (int it = 0; it < XENT_IT; ++it) mx = fmaxf(mx, fmaxf(v[it].x, v[it].y));
-  mx = block_reduce(mx, sh, true);
-  float s = 0.f;
-#pragma unroll
-  for (int it = 0; it < XENT_IT; ++it) {
-    const int i = threadIdx.x * 2 + it * 512;
-    if (i + 1 < V) s += expf(v[it].x - mx) + expf(v[it].y - mx);
-    else if (i < V) s += expf(v[it].x - mx);
-  }
-  s = block_reduce(s, sh, false);
-  const float lse = mx + logf(s);
-  if (threadIdx.x == 0) loss_rows[m] = valid ? lse - x[label] : 0.f;
-  if (dlogits) {
-    const float gs = valid ? *grad_scale : 0.f;
-    T* d = dlogits + (int64_t)m * ldd;
-#pragma unroll
-    for (int it = 0; it < XENT_IT; ++it) {
-      const int i = threadIdx.x * 2 + it * 512;
-      if (i >= Vpad) continue;
-      float g0 = 0.f, g1 = 0.f;
-      if (i < V) g0 = (expf(v[it].x - lse) - (i == label ? 1.f : 0.f)) * gs;
-      if (i + 1 < V) g1 = (expf(v[it].y - lse) - (i + 1 == label ? 1.f : 0.f)) * gs;
-      if constexpr (sizeof(T) == 4) {
-        d[i] = g0;
-        if (i + 1 < Vpad) d[i + 1] = g1;
-      } else {
-        *(uint32_t*)(d + i) = pack2(g0, g1, (T*)0);  // Vpad and ldd are even
-      }
-    }
-  }
-}
-
 // ---- video-text contrastive loss (alpro_models.py:103-128 / 570-587 / 750-779) ----------------------------------------------------
 // sim_v2t = v gt^T / temp, sim_t2v = t gv^T / temp over the GATHERED features (G = world * B rows), soft-target cross entropy with
 // the positives at columns col0 + i, both directions averaged: loss = (mean_i ce_v[i] + mean_i ce_t[i]) / 2.  B x G x 256 is tiny
@@ -265,10 +211,6 @@ extern "C" int alpro_softmax_xent(const float* logits, int64_t ld, const int64_t
   ALPRO_CHECK(logits && labels && loss_rows && M > 0 && V > 0, "alpro_softmax_xent: bad args");
   ALPRO_CHECK(ld % 2 == 0 && ((uintptr_t)logits % 8) == 0, "alpro_softmax_xent: logits rows must be 8-byte aligned");
   ALPRO_CHECK(!dlogits || (grad_scale && Vpad >= V && Vpad % 2 == 0 && ldd >= Vpad && ldd % 2 == 0), "alpro_softmax_xent: bad gradient buffer");
-  if ((dlogits ? Vpad : V) <= 512 * XENT_IT) {   // the row fits the registers of one workgroup: one sweep
-    ALPRO_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL(xent_row_kernel<T>, dim3(M), dim3(256), 0, (hipStream_t)stream, logits, ld, labels, ignore_index, loss_rows, (T*)dlogits, ldd, grad_scale, V, Vpad));
-  } else {
-    ALPRO_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL(xent_kernel<T>, dim3(M), dim3(256), 0, (hipStream_t)stream, logits, ld, labels, ignore_index, loss_rows, (T*)dlogits, ldd, grad_scale, V, Vpad));
-  }
+  ALPRO_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL(xent_kernel<T>, dim3(M), dim3(256), 0, (hipStream_t)stream, logits, ld, labels, ignore_index, loss_rows, (T*)dlogits, ldd, grad_scale, V, Vpad));
   return check_launch("alpro_softmax_xent");
 }
