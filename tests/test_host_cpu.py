@@ -1369,3 +1369,42 @@ def test_reference_training_loop_runs_unchanged_through_the_facade(monkeypatch):
     for (n_, a), (_, b) in zip(model.named_parameters(), twin.named_parameters()):
         assert torch.allclose(a.detach(), b.detach(), rtol=2e-5, atol=1e-7), n_
     assert inner.param_groups[0]["lr"] == pytest.approx(lr, rel=1e-12)
+
+
+def test_round6_forward_schedule_switches(monkeypatch):
+    """alpro_amd.config: where the two-stream half-batch forward and the deferred temporal residual add are taken (host logic only; the schedules
+    themselves are pinned bit for bit on the GPU, tests/test_model_parity.py::test_inference_forward_schedules_are_bitwise_neutral), and that the
+    block runner stays on the plain path whenever the split cannot apply."""
+    from alpro_amd import config as rt
+    from alpro_amd.modeling.timesformer import vit
+    prev = (rt._split_streams[0], rt._defer_tadd[0])
+    try:
+        rt.set_split_streams("auto")
+        assert [rt.split_streams(b) for b in (1, 2, 8, 15, 16, 17, 32, 64)] == [False, False, False, False, True, False, True, True]
+        rt.set_split_streams("1")
+        assert rt.split_streams(2) and rt.split_streams(6) and not rt.split_streams(3) and not rt.split_streams(1)
+        rt.set_split_streams("0")
+        assert not rt.split_streams(64)
+        rt.set_split_streams(True)
+        assert rt.split_streams(4)
+        rt.set_defer_temporal_add(False)
+        assert rt.defer_temporal_add() is False
+        rt.set_defer_temporal_add(True)
+        assert rt.defer_temporal_add() is True
+        # a CPU token tensor (or autograd enabled) never forks a stream: run_blocks walks the blocks in line
+        calls = []
+
+        class Blk:
+            def __call__(self, tok, B, T, W):
+                calls.append((tok.shape[0], B))
+                return tok
+        rt.set_split_streams("1")
+        tok = torch.zeros(4, 3, 8)
+        with torch.no_grad():
+            out = vit.run_blocks([Blk(), Blk()], tok, 4, 2, 14)
+        assert out is tok and calls == [(4, 4), (4, 4)]
+    finally:
+        rt.set_split_streams(prev[0])
+        rt.set_defer_temporal_add(prev[1])
+    from alpro_amd import hip
+    assert "alpro_add_layernorm_pre_mlp2" in hip.EXPORTS and "alpro_adamw_step_lp" in hip.EXPORTS
