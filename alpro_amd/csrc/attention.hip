@@ -159,6 +159,43 @@ __device__ __forceinline__ void pv_tiles(f32x16 (&o)[2], const f32x16 (&p)[NKT],
   }
 }
 
+// The same product with the V^T operand chunks fetched PDV steps ahead of the MFMA that consumes them (round 6).  pv_tiles() fences the
+// scheduler per key tile (its reads would pile up in VGPRs otherwise), so every key tile began with an exposed LDS round trip, and inside a
+// tile the reads were issued one step ahead: ~35 % of a query tile's cycles went to `s_waitcnt lgkmcnt` in front of an MFMA.  Step i =
+// (key tile i / (2 CPT), P chunk (i / 2) % CPT, d half i & 1); the ring holds PDV chunks; a scheduling fence per step keeps the order.
+#ifndef ATTN_PDV
+#define ATTN_PDV 3   // ring depths of the 7-tile (ViT) form; measurement builds override them
+#endif
+#ifndef ATTN_PDK
+#define ATTN_PDK 4
+#endif
+template <typename T, int NKT, int PDV = 3>
+__device__ __forceinline__ void pv_tiles_pipelined(f32x16 (&o)[2], const f32x16 (&p)[NKT], const char* vt, int lane) {
+  typedef AttnCfg<T> C;
+  constexpr int NSTEP = NKT * C::CPT * 2;
+  u32x4 ring[PDV];
+  auto vchunk = [&](int i) __attribute__((always_inline)) {
+    const int kt = i / (2 * C::CPT), cc = (i >> 1) % C::CPT, dt = i & 1;
+    return load_vt_chunk<T>(vt + kt * 32 * C::RB, cc, lane, dt);
+  };
+#pragma unroll
+  for (int i = 0; i < PDV && i < NSTEP; ++i) ring[i] = vchunk(i);
+  u32x4 b = mk4(0u, 0u, 0u, 0u);
+#pragma unroll
+  for (int i = 0; i < NSTEP; ++i) {
+    const int kt = i / (2 * C::CPT), cc = (i >> 1) % C::CPT, dt = i & 1;
+    if (dt == 0) {
+      float pv[C::CN];
+#pragma unroll
+      for (int e = 0; e < C::CN; ++e) pv[e] = p[kt][cc * C::CN + e];
+      b = pack_chunk<T>(pv);
+    }
+    mma_chunk<T>(o[dt], ring[i % PDV], b);
+    if (i + PDV < NSTEP) ring[i % PDV] = vchunk(i + PDV);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
 template <typename T>
 __device__ __forceinline__ void store_o(T* out_row, const f32x16 (&o)[2], int lane) {
   const int g = lane >> 5;
@@ -421,19 +458,46 @@ __global__ __launch_bounds__(256, 2) void attn_fwd16_kernel(const T* __restrict_
   // ---- S^T = K Q^T and the softmax (log2 domain) of query tile qt; leaves the unnormalised probabilities in s and 1 / sum in inv
   auto scores = [&]() __attribute__((always_inline)) {
     const int q = qt * 32 + ql;
+    // K fragments PDK steps ahead of their MFMA (round 6; step i = (k-step i / NKT, key tile i % NKT): consecutive MFMAs hit different
+    // accumulators).  The compiler's own order kept two reads in flight and waited for one in front of every MFMA.  ViT shape -3 % on one box
+    // (profiles/r6_attn_fwd_rings.txt); with 8 key tiles the 128 score registers leave no room for the ring (spills, +2..4 %): compiler order.
+    if constexpr (NKT <= 7) {
+      constexpr int NF = NKT * 4, PDK = ATTN_PDK;
+      auto kfrag = [&](int i) __attribute__((always_inline)) {
+        const int ks = i / NKT, krow = (i % NKT) * 32 + ql;
+        return *(const u32x4*)(Ks + krow * RB + (((2 * ks + g) ^ ((krow >> 1) & 7)) << 4));
+      };
+      u32x4 ka[PDK];
 #pragma unroll
-    for (int kt = 0; kt < NKT; ++kt) {
-      const int krow = kt * 32 + ql;
+      for (int i = 0; i < PDK; ++i) ka[i] = kfrag(i);
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        const u32x4 a = *(const u32x4*)(Ks + krow * RB + (((2 * ks + g) ^ ((krow >> 1) & 7)) << 4));
+      for (int i = 0; i < NF; ++i) {
+        const int ks = i / NKT, kt = i % NKT;
         if (ks == 0) {
           f32x16 z;
 #pragma unroll
           for (int r = 0; r < 16; ++r) z[r] = 0.f;
           s[kt] = z;
         }
-        mma_chunk<T>(s[kt], a, qf[ks]);
+        mma_chunk<T>(s[kt], ka[i % PDK], qf[ks]);
+        if (i + PDK < NF) ka[i % PDK] = kfrag(i + PDK);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else {
+#pragma unroll
+      for (int kt = 0; kt < NKT; ++kt) {
+        const int krow = kt * 32 + ql;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          const u32x4 a = *(const u32x4*)(Ks + krow * RB + (((2 * ks + g) ^ ((krow >> 1) & 7)) << 4));
+          if (ks == 0) {
+            f32x16 z;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) z[r] = 0.f;
+            s[kt] = z;
+          }
+          mma_chunk<T>(s[kt], a, qf[ks]);
+        }
       }
     }
     load_q(tile_at(min(seq + 4, ntile - 1)), qn);  // lands under the softmax
@@ -584,7 +648,12 @@ __global__ __launch_bounds__(256, 2) void attn_fwd16_kernel(const T* __restrict_
     for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
+#ifdef ATTN_NO_PIPE_V   // (measurement builds, tools/build_attn_variants.sh)
     pv_tiles<T, NKT>(o, s, Vs, lane);
+#else
+    if constexpr (NKT <= 7) pv_tiles_pipelined<T, NKT, ATTN_PDV>(o, s, Vs, lane);
+    else pv_tiles<T, NKT>(o, s, Vs, lane);
+#endif
     if constexpr (CLS) {
       if (qt == cls_tile) {   // the CLS row in fp32: the parts' output columns added up in lane c0 (both d halves: lanes c0 and c0 + 32)
         float* dst = cls_out + (int64_t)b * H * HD + h * HD;
