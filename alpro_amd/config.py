@@ -118,6 +118,56 @@ def set_split_streams(v):
     _split_streams[0] = v.lower() if isinstance(v, str) else ("1" if v else "0")
 
 
+# Round 6 (third session): weight gradients on a side stream.  Inside an anchored backward (alpro_amd.modeling.train.Anchor) every 16-bit weight-gradient
+# GEMM (alpro_gemm_tn_acc_ws: dW += dY^T X, a leaf of the backward graph -- nothing downstream reads it before the optimizer / the gradient exchange)
+# is launched on a second HIP stream behind an event of the launch stream; the launch stream goes on with the data gradient and waits for the side
+# stream once, where the backward returns (and before a gradient range is reported final to the exchange).  What it buys is what the two-stream
+# forward buys: the weight-gradient kernel's workgroups take the CUs a persistent GEMM's last, partly filled round of tiles leaves idle, and vice
+# versa.  Sums are unchanged bit for bit (each kernel's own order; accumulations into one .grad stay ordered on the side stream).
+# Measured (profiles/r6_wgrad_side_stream_ab.txt): B = 64 pretrain step -0.3 ... -1.0 % on one box, +0.08 GB peak memory.  ALPRO_WGRAD_STREAM = 0 | 1 (default 1).
+_wgrad_stream = [os.environ.get("ALPRO_WGRAD_STREAM", "1") != "0"]
+_wgrad_active = [0]      # > 0 while an anchored backward runs
+_WGRAD_SIDE = {}         # (device index, launch stream handle) -> [side stream, work pending]
+
+
+def set_wgrad_stream(v):
+    _wgrad_stream[0] = bool(v)
+
+
+def wgrad_stream_enabled():
+    return _wgrad_stream[0]
+
+
+def wgrad_scope(enter):
+    _wgrad_active[0] += 1 if enter else -1
+
+
+def wgrad_side_stream(device):
+    """The side stream of the current launch stream, or None when weight gradients stay on the launch stream."""
+    if not (_wgrad_stream[0] and _wgrad_active[0] > 0 and device.type == "cuda"):
+        return None
+    import torch
+    key = (device.index if device.index is not None else torch.cuda.current_device(), torch.cuda.current_stream(device).cuda_stream)
+    ent = _WGRAD_SIDE.get(key)
+    if ent is None:
+        ent = _WGRAD_SIDE[key] = [torch.cuda.Stream(device), False]
+    ent[1] = True
+    return ent[0]
+
+
+def join_wgrad():
+    """The current stream of every device waits for the weight gradients that were launched from it."""
+    if not _WGRAD_SIDE:
+        return
+    import torch
+    for (idx, handle), ent in _WGRAD_SIDE.items():
+        if ent[1]:
+            cur = torch.cuda.current_stream(idx)
+            if cur.cuda_stream == handle:
+                cur.wait_stream(ent[0])
+                ent[1] = False
+
+
 # Round 6: the no-grad Block.forward keeps the block input until both attention halves are done -- the add + norm1 kernel reads it and writes only the
 # normalised rows, the add + norm2 kernel adds the temporal AND the spatial branch (alpro_add_layernorm_pre_mlp2; bit for bit the same sums).
 # ALPRO_DEFER_TEMPORAL_ADD=0: the round-3 form (x + temporal branch written by the first kernel), for A/B.

@@ -161,6 +161,8 @@ def grads_final(params=None, all_but=None):
     """Called from backward code: the gradients of `params` (or of every parameter EXCEPT `all_but`) are complete for this step."""
     if not collectives_active() or not _GRAD_FINAL_HOOKS:
         return
+    from alpro_amd import config as rt
+    rt.join_wgrad()   # "final" includes the weight gradients still queued on the side stream (alpro_amd.config, ALPRO_WGRAD_STREAM)
     live = []
     for ref in _GRAD_FINAL_HOOKS:
         fn = ref()

@@ -747,13 +747,16 @@ def loss_scale_update(dyn_state, gnorm_sq, growth=2.0, backoff=0.5, window=2000,
            "alpro_loss_scale_update")
 
 
-_TN_WORKSPACE = {}  # device index -> grow-only byte buffer for the partial tiles of the weight-gradient GEMM
+_TN_WORKSPACE = {}  # (device index, raw stream handle) -> grow-only byte buffer for the partial tiles of the weight-gradient GEMM
 
 
 def _tn_workspace(device, nbytes):
-    ws = _TN_WORKSPACE.get(device.index)
+    """The workspace of the CURRENT stream: its users run in stream order, so one buffer per (device, stream) is enough -- and a second
+    stream (the weight-gradient side stream of alpro_amd.modeling.train.wgrad) must not share the launch stream's."""
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    ws = _TN_WORKSPACE.get(key)
     if ws is None or ws.numel() < nbytes:
-        ws = _TN_WORKSPACE[device.index] = torch.empty(max(nbytes, 64 << 20), dtype=torch.uint8, device=device)
+        ws = _TN_WORKSPACE[key] = torch.empty(max(nbytes, 64 << 20), dtype=torch.uint8, device=device)
     return ws
 
 

@@ -147,7 +147,17 @@ def wgrad(dy_t, x_t, weight, bias, bias_done=False):
     gw, existed = grad_buffer(weight, zero=True)
     gw2 = gw.view(gw.shape[0], -1)
     if dy_t.dtype != torch.float32:
-        hip.gemm_tn_acc(dy_t, x_t, gw2, colsum=gb if bias is not None else None)  # bias gradient from the same pass over dy
+        from alpro_amd import config as rt
+        side = rt.wgrad_side_stream(dy_t.device)
+        if side is None:
+            hip.gemm_tn_acc(dy_t, x_t, gw2, colsum=gb if bias is not None else None)  # bias gradient from the same pass over dy
+            return
+        # side stream (alpro_amd.config, ALPRO_WGRAD_STREAM): behind everything the launch stream has queued so far (dy, x, the zeroed buffers)
+        side.wait_stream(torch.cuda.current_stream(dy_t.device))
+        with torch.cuda.stream(side):
+            hip.gemm_tn_acc(dy_t, x_t, gw2, colsum=gb if bias is not None else None)
+        dy_t.record_stream(side)   # the launch stream's allocator may not hand these blocks out again before the side stream is done with them
+        x_t.record_stream(side)
         return
     dyT = hip.transpose(dy_t, colsum=gb if bias is not None else None)
     hip.gemm(dyT, hip.transpose(x_t), out=gw2, out_dtype=torch.float32, residual=gw2)
@@ -224,10 +234,13 @@ class Anchor(torch.autograd.Function):
         BACKWARD_EPOCH[0] += 1
         from alpro_amd import config as rt
         rt.check_backward_precision(getattr(ctx.run, "dt", None) or ctx.dt)
+        rt.wgrad_scope(True)
         try:
             with torch.no_grad():
                 g = ctx.run.backward(*[None if x is None else x.contiguous() for x in grads])
         finally:
+            rt.wgrad_scope(False)
+            rt.join_wgrad()   # weight gradients launched on the side stream: the launch stream has them from here on
             _LIVE_ANCHORS.discard(ctx)
         g = (g,) if (torch.is_tensor(g) or g is None) else tuple(g)
         g = g + (None,) * (ctx.n_act - len(g))

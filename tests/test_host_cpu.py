@@ -1406,5 +1406,17 @@ def test_round6_forward_schedule_switches(monkeypatch):
     finally:
         rt.set_split_streams(prev[0])
         rt.set_defer_temporal_add(prev[1])
+    # weight gradients on a side stream: only inside an anchored backward, only on a GPU tensor's device, only when switched on
+    prev_w = rt.wgrad_stream_enabled()
+    try:
+        rt.set_wgrad_stream(True)
+        assert rt.wgrad_side_stream(torch.device("cpu")) is None
+        rt.wgrad_scope(True)
+        assert rt.wgrad_side_stream(torch.device("cpu")) is None      # CPU tensors never fork a stream
+        rt.wgrad_scope(False)
+        assert rt._wgrad_active[0] == 0
+        rt.join_wgrad()                                                # nothing pending: a no-op without a GPU
+    finally:
+        rt.set_wgrad_stream(prev_w)
     from alpro_amd import hip
     assert "alpro_add_layernorm_pre_mlp2" in hip.EXPORTS and "alpro_adamw_step_lp" in hip.EXPORTS

@@ -787,6 +787,50 @@ def test_fused_temporal_half_against_the_two_launches(mode):
 
 
 @pytest.mark.parametrize("mode", ["fp16", "bf16"])
+def test_weight_gradients_on_the_side_stream_are_bitwise_neutral(mode):
+    """Round 6 (alpro_amd.config.wgrad_side_stream; alpro_amd.modeling.train.wgrad): inside an anchored backward the 16-bit weight-gradient GEMMs
+    are launched on a second HIP stream behind an event of the launch stream, which waits for them where the backward returns.  Same kernels, same
+    operands, same summation order: every parameter gradient of the encoder's training forward + hand-written backward must be bit for bit what
+    the one-stream backward leaves (three backward passes each, the later ones into warm allocator blocks that the side stream has used)."""
+    from alpro_amd import config as rt
+    from alpro_amd.modeling.timesformer.vit import TimeSformer
+    torch.manual_seed(41)
+    T, B = 4, 8
+    enc = TimeSformer(dict(VENC, num_frm=T, drop_path_rate=0.0), input_format="RGB").cuda().train()
+    with torch.no_grad():
+        for blk in enc.model.blocks:
+            torch.nn.init.normal_(blk.temporal_fc.weight, std=0.02)
+    x = torch.randn(B, 3, T, 224, 224, device="cuda")
+    dout = torch.randn(B, 197, 768, device="cuda") * 1e-2
+    prev = rt.wgrad_stream_enabled()
+    res = {}
+    try:
+        for side in (False, True, False, True):
+            rt.set_wgrad_stream(side)
+            with rt.use_compute_dtype(mode), rt.use_cls_precise("0"):
+                for rep in range(3):
+                    for p in enc.parameters():
+                        p.grad = None
+                    sc = arm_scale(mode)
+                    with torch.enable_grad():
+                        yt = enc.forward_features(x)
+                        backward((yt * dout).sum(), mode)
+                    del sc
+                    g = torch.cat([p.grad.reshape(-1) for p in enc.parameters() if p.grad is not None]).clone()
+                    torch.cuda.synchronize()
+                    if "ref" not in res:
+                        res["ref"] = g
+                    assert torch.equal(g, res["ref"]), "parameter gradients differ (side stream %s, pass %d): max %.3e" % (side, rep, float((g - res["ref"]).abs().max()))
+            if side:
+                ent = [e for e in rt._WGRAD_SIDE.values()]
+                assert ent and all(not e[1] for e in ent), "the side stream was not used, or not joined where the backward returned"
+    finally:
+        rt.set_wgrad_stream(prev)
+        rt.set_armed_loss_scaler(None)
+    assert bool(torch.isfinite(res["ref"]).all()) and float(res["ref"].abs().sum()) > 0
+
+
+@pytest.mark.parametrize("mode", ["fp16", "bf16"])
 def test_inference_forward_schedules_are_bitwise_neutral(mode):
     """Round 6, two schedule changes of the no-grad encoder forward that must not move a bit:
     (i) alpro_amd.config.defer_temporal_add -- add + norm1 does not write x + temporal branch, add + norm2 adds both branches to the block input

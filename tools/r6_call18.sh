@@ -1,0 +1,21 @@
+#!/bin/bash
+# round 6, call 18: weight gradients on a side stream (ALPRO_WGRAD_STREAM=1) against the launch-stream form, same box, A/B/A/B; then the
+# bitwise check (two steps from the same state, with and without the side stream, must give the same parameters)
+export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+O=$R/gpurun_out/r6c18
+mkdir -p $O
+cd $R
+timeout 900 python tools/wgrad_stream_check.py > $O/bitwise.txt 2>&1
+tail -5 $O/bitwise.txt
+for i in 1 2; do
+for v in 0 1; do
+ALPRO_WGRAD_STREAM=$v python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-parity --no-divst > $O/step_${v}_$i.json 2>> $O/err.log
+python - $v $i <<'PY'
+import json, sys
+d = json.loads([x for x in open("gpurun_out/r6c18/step_%s_%s.json" % (sys.argv[1], sys.argv[2])) if x.startswith("{")][0])
+print("wgrad_stream", sys.argv[1], "step ms", d["ms_per_step"], d["value"], "peak GB", d["peak_mem_gb"], d.get("wgrad_side_stream"))
+PY
+done
+done
+tail -3 $O/err.log
