@@ -168,6 +168,50 @@ def join_wgrad():
                 ent[1] = False
 
 
+# Round 6 (third session): the pretraining forward's 2B-caption text-encoder pass (M = 2B x 40 rows: 60 ... 240 tiles per Linear, a quarter to all of the
+# CUs for a few microseconds each) on a side stream beside the visual encoder's forward, and -- autograd runs a node's backward on the stream of its
+# forward -- its backward beside the visual encoder's backward.  The launch stream waits for the side stream where the text rows are first needed
+# (the VTC features); the side stream's parameter gradients are handed to the caller's stream by an end-of-backward callback, and any gradient range
+# reported final to the exchange (N > 1) waits for the side stream first.  Measured (profiles/r6_text_side_stream_ab.txt): B = 64 pretrain step
+# 151.7 -> 149.4 ms (-1.5 %, A/B/A/B on one box), outputs and gradients bit for bit, +0.14 GB.  ALPRO_TEXT_STREAM = 0 | 1 (default 1).
+_text_stream = [os.environ.get("ALPRO_TEXT_STREAM", "1") != "0"]
+_TEXT_SIDE = {}          # (device index, launch stream handle) -> side stream
+
+
+def set_text_stream(v):
+    _text_stream[0] = bool(v)
+
+
+def text_stream_enabled():
+    return _text_stream[0]
+
+
+def text_side_stream(device):
+    if not (_text_stream[0] and device.type == "cuda"):
+        return None
+    import torch
+    key = (device.index if device.index is not None else torch.cuda.current_device(), torch.cuda.current_stream(device).cuda_stream)
+    s = _TEXT_SIDE.get(key)
+    if s is None:
+        s = _TEXT_SIDE[key] = torch.cuda.Stream(device)
+    return s
+
+
+def is_text_side_stream(stream):
+    return any(s.cuda_stream == stream.cuda_stream for s in _TEXT_SIDE.values())
+
+
+def join_text_streams():
+    """The current stream waits for every text side stream that was forked from it (gradient ranges about to go on the wire)."""
+    if not _TEXT_SIDE:
+        return
+    import torch
+    for (idx, handle), s in _TEXT_SIDE.items():
+        cur = torch.cuda.current_stream(idx)
+        if cur.cuda_stream == handle:
+            cur.wait_stream(s)
+
+
 # Round 6: the no-grad Block.forward keeps the block input until both attention halves are done -- the add + norm1 kernel reads it and writes only the
 # normalised rows, the add + norm2 kernel adds the temporal AND the spatial branch (alpro_add_layernorm_pre_mlp2; bit for bit the same sums).
 # ALPRO_DEFER_TEMPORAL_ADD=0: the round-3 form (x + temporal branch written by the first kernel), for A/B.

@@ -163,6 +163,7 @@ def grads_final(params=None, all_but=None):
         return
     from alpro_amd import config as rt
     rt.join_wgrad()   # "final" includes the weight gradients still queued on the side stream (alpro_amd.config, ALPRO_WGRAD_STREAM)
+    rt.join_text_streams()   # ... and the text encoder's, when its backward runs on its own stream (ALPRO_TEXT_STREAM)
     live = []
     for ref in _GRAD_FINAL_HOOKS:
         fn = ref()

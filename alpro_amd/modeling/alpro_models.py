@@ -231,21 +231,38 @@ class AlproForPretrain(AlproBaseModel):
         use_mpm = 'mpm_mask' in batch
         device = visual_inputs.device
         b = visual_inputs.shape[0]
+        batched = 'mlm_labels' in batch and self.batch_encoder_passes
+        from alpro_amd import config as rt
+        text_side = rt.text_side_stream(device) if batched else None
+        if text_side is not None:
+            ev_inputs = torch.cuda.current_stream(device).record_event()   # everything the text pass reads (ids, masks, this step's operand mirrors) is older
         if use_mpm and np.random.uniform() < self.use_mask_prob:
             total = self._forward_visual_embeds(torch.cat([visual_inputs, batch['context_visual_inputs']], dim=0))
             video_embeds = total[:b]
         else:
             video_embeds = self._forward_visual_embeds(visual_inputs)
+        text_atts = batch['text_input_mask']
+        both = None
+        if text_side is not None:
+            # the 2B-caption text pass on its side stream (alpro_amd.config, ALPRO_TEXT_STREAM): queued BEHIND the visual encoder's launches on the host
+            # (the visual anchor is the older autograd node, so the text backward still runs first and BERT's gradients can go on the wire early) but
+            # ordered only behind `ev_inputs` on the device -- it runs beside the visual forward
+            text_side.wait_event(ev_inputs)
+            with torch.cuda.stream(text_side):
+                both = self._text_embeds(torch.cat([batch['text_input_ids'], batch['mlm_text_input_ids']], dim=0), torch.cat([text_atts, text_atts], dim=0))
         video_feat = self._video_feat(video_embeds)
         video_atts = torch.ones(video_embeds.size()[:-1], dtype=torch.long, device=device)
-        text_atts = batch['text_input_mask']
         pos_patch_rows = None
-        if 'mlm_labels' in batch and self.batch_encoder_passes:
+        if batched:
             # Same sequences through the same weights as the reference's three fusion calls (positive pairs :278, 2B negatives
             # :325, MLM pairs :360) and two text-encoder calls (:99, :354), but as ONE 4B-sequence fusion batch and ONE
             # 2B-caption text batch: every row of a BERT layer is independent of the batch it sits in, and M = 4B*237 fills
             # the 256x256 GEMM tiles far better than 3 launches at B / 2B / B.
-            both = self._text_embeds(torch.cat([batch['text_input_ids'], batch['mlm_text_input_ids']], dim=0), torch.cat([text_atts, text_atts], dim=0))
+            if both is None:
+                both = self._text_embeds(torch.cat([batch['text_input_ids'], batch['mlm_text_input_ids']], dim=0), torch.cat([text_atts, text_atts], dim=0))
+            else:
+                torch.cuda.current_stream(device).wait_stream(text_side)
+                both.record_stream(torch.cuda.current_stream(device))   # allocated on the side stream, read (and possibly outlived) on this one
             text_embeds, mlm_text_embeds = both[:b], both[b:]
             text_feat = self._text_feat(text_embeds)
             vtc_loss, sim_v2t, sim_t2v, _ = self._vtc(video_feat, text_feat)

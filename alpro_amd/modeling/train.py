@@ -242,6 +242,13 @@ class Anchor(torch.autograd.Function):
             rt.wgrad_scope(False)
             rt.join_wgrad()   # weight gradients launched on the side stream: the launch stream has them from here on
             _LIVE_ANCHORS.discard(ctx)
+        if grads and any(x is not None and x.is_cuda for x in grads):
+            cur = torch.cuda.current_stream()
+            if rt.is_text_side_stream(cur):
+                # this backward ran on the text side stream (autograd: the stream of the node's forward) and wrote parameter gradients behind autograd's
+                # back: the caller's stream takes them over when the whole backward pass is done (final callbacks run on the caller's streams)
+                ev = cur.record_event()
+                torch.autograd.Variable._execution_engine.queue_callback(lambda: torch.cuda.current_stream().wait_event(ev))
         g = (g,) if (torch.is_tensor(g) or g is None) else tuple(g)
         g = g + (None,) * (ctx.n_act - len(g))
         ctx.run = None

@@ -588,9 +588,10 @@ def main():
     # Launches are timed one at a time on the launch stream: the two-stream forward (alpro_amd.config.split_streams) is off for this pass, so that a
     # kernel's time is its own and not its share of the chip beside the other half's launches.
     from alpro_amd import config as _rt
-    _prev_split, _prev_wgs = _rt._split_streams[0], _rt.wgrad_stream_enabled()
+    _prev_split, _prev_wgs, _prev_txt = _rt._split_streams[0], _rt.wgrad_stream_enabled(), _rt.text_stream_enabled()
     _rt.set_split_streams("0")
-    _rt.set_wgrad_stream(False)   # ... and the weight gradients stay on the launch stream for the same reason
+    _rt.set_wgrad_stream(False)   # ... and the weight gradients / the text pass stay on the launch stream for the same reason
+    _rt.set_text_stream(False)
     try:
         with (torch.enable_grad() if train else torch.no_grad()), KernelTimer(hip) as kt:
             step()
@@ -598,6 +599,7 @@ def main():
     finally:
         _rt.set_split_streams(_prev_split)
         _rt.set_wgrad_stream(_prev_wgs)
+        _rt.set_text_stream(_prev_txt)
     dist.barrier()
     result = None
     if rank == 0:
@@ -669,6 +671,7 @@ def main():
             "no_grad_forward_streams": 2 if _rt.split_streams(B) else 1,
             # weight-gradient GEMMs of the timed steps on a side stream beside the data-gradient chain (alpro_amd.config, ALPRO_WGRAD_STREAM)
             "wgrad_side_stream": bool(train and _rt.wgrad_stream_enabled()),
+            "text_side_stream": bool(args.workload != "visual_fwd" and _rt.text_stream_enabled()),
             "world_size": world, "dist_backend": (torch.distributed.get_backend() if torch.distributed.is_initialized() else "none (single process)"),
             "rccl_version": ".".join(str(v) for v in torch.cuda.nccl.version()) if hasattr(torch.cuda, "nccl") else None,
             "nccl_channels": {k_: os.environ.get(k_) for k_ in ("NCCL_MAX_NCHANNELS", "NCCL_MIN_NCHANNELS", "ALPRO_OVERLAP_BACKWARD") if os.environ.get(k_) is not None},

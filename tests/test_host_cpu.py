@@ -1416,6 +1416,11 @@ def test_round6_forward_schedule_switches(monkeypatch):
         rt.wgrad_scope(False)
         assert rt._wgrad_active[0] == 0
         rt.join_wgrad()                                                # nothing pending: a no-op without a GPU
+        prev_t = rt.text_stream_enabled()
+        rt.set_text_stream(True)
+        assert rt.text_side_stream(torch.device("cpu")) is None       # the text pass of a CPU batch stays in line
+        rt.join_text_streams()
+        rt.set_text_stream(prev_t)
     finally:
         rt.set_wgrad_stream(prev_w)
     from alpro_amd import hip

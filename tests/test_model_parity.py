@@ -786,6 +786,45 @@ def test_fused_temporal_half_against_the_two_launches(mode):
     assert bool(torch.isfinite(ga).all()) and rel <= {"fp16": 1e-3, "bf16": 8e-3}[mode], rel
 
 
+@pytest.mark.parametrize("mode", ["fp16", "fp32"])
+def test_text_pass_on_its_side_stream_is_bitwise_neutral(fixture_models, monkeypatch, mode):
+    """Round 6 (alpro_amd.config.text_side_stream; AlproForPretrain.forward): the 2B-caption text-encoder pass runs on a side stream beside the visual
+    encoder's forward, its backward (autograd: on the stream of the forward) beside the visual encoder's backward; the launch stream waits where the
+    text rows are first needed and takes the side stream's parameter gradients over in an end-of-backward callback.  Every output of the pretraining
+    forward and every parameter gradient must be bit for bit what the one-stream step gives -- twice each, alternating, on the 8-frame fixture model."""
+    from alpro_amd import config as rt
+    m, batch, _ = fixture_models("pretrain_T8")
+    monkeypatch.setattr(torch, "multinomial", argmax_multinomial)
+    monkeypatch.setattr(np.random, "uniform", lambda *a, **k: 1.0)      # use_mask_prob branch not taken, on every pass
+    prev, was_training = rt.text_stream_enabled(), m.training
+    ref = None
+    try:
+        for side in (False, True, False, True):
+            rt.set_text_stream(side)
+            fresh_grads(m)
+            with rt.use_compute_dtype(mode), torch.enable_grad():
+                sc = arm_scale(mode)
+                out = m(batch)
+                loss = out["mlm_loss"] + out["itm_loss"] + out["itc_loss"] + out["mpm_loss"]
+                backward(loss, mode)
+                del sc
+            cur = [out[k].detach().float().clone() for k in ("itc_loss", "itm_loss", "mlm_loss", "mpm_loss", "itm_scores", "mpm_logits")]
+            cur.append(torch.cat([p.grad.reshape(-1).float() for p in m.parameters() if p.grad is not None]).clone())
+            torch.cuda.synchronize()
+            if side:
+                assert rt._TEXT_SIDE, "the side stream was never created"
+            if ref is None:
+                ref = cur
+                assert bool(torch.isfinite(ref[-1]).all()) and float(ref[-1].abs().sum()) > 0
+            for a, b, what in zip(cur, ref, ("itc_loss", "itm_loss", "mlm_loss", "mpm_loss", "itm_scores", "mpm_logits", "parameter gradients")):
+                assert torch.equal(a, b), "%s differs with the text pass on its side stream = %s (max %.3e)" % (what, side, float((a - b).abs().max()))
+    finally:
+        rt.set_text_stream(prev)
+        rt.set_armed_loss_scaler(None)
+        fresh_grads(m)
+        m.train(was_training)
+
+
 @pytest.mark.parametrize("mode", ["fp16", "bf16"])
 def test_weight_gradients_on_the_side_stream_are_bitwise_neutral(mode):
     """Round 6 (alpro_amd.config.wgrad_side_stream; alpro_amd.modeling.train.wgrad): inside an anchored backward the 16-bit weight-gradient GEMMs

@@ -1,6 +1,7 @@
 """GPU: the fp16 pretrain step with the weight gradients on a side stream (ALPRO_WGRAD_STREAM=1) against the launch-stream form.  Two processes run
 the same two training steps (bench.py's model, batch and optimizer at B pairs) from the same seed; the losses and every parameter gradient of both steps
-must agree bit for bit (the side stream changes when a weight-gradient kernel runs, not what it adds up).  python tools/wgrad_stream_check.py [B ...]"""
+must agree bit for bit (the side stream changes when a weight-gradient kernel runs, not what it adds up).  Likewise the 2B-caption text-encoder pass on its
+own side stream (ALPRO_TEXT_STREAM=1), alone and together with the weight-gradient stream.  python tools/wgrad_stream_check.py [B ...]"""
 import os, subprocess, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -43,8 +44,8 @@ def worker(out, B):
     torch.save(rec, out)
 
 
-def run(B, side, out):
-    env = dict(os.environ, ALPRO_WGRAD_STREAM="1" if side else "0")
+def run(B, side, out, text=False):
+    env = dict(os.environ, ALPRO_WGRAD_STREAM="1" if side else "0", ALPRO_TEXT_STREAM="1" if text else "0")
     p = subprocess.run([sys.executable, os.path.abspath(__file__), "--worker", out, str(B)], cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=1200)
     assert p.returncode == 0, p.stdout[-3000:]
     return torch.load(out)
@@ -58,11 +59,13 @@ if __name__ == "__main__":
     for B in [int(x) for x in sys.argv[1:]] or [4, 32]:
         with tempfile.TemporaryDirectory() as d:
             a, b, c = run(B, False, os.path.join(d, "a.pt")), run(B, True, os.path.join(d, "b.pt")), run(B, False, os.path.join(d, "c.pt"))
+            t, tb = run(B, False, os.path.join(d, "t.pt"), text=True), run(B, True, os.path.join(d, "tb.pt"), text=True)
         assert not a["side"] and b["side"]
-        for name, x in (("side stream vs launch stream", b), ("launch stream again (the control)", c)):
+        for name, x in (("side stream vs launch stream", b), ("launch stream again (the control)", c), ("text pass on its side stream (ALPRO_TEXT_STREAM=1)", t),
+                        ("text pass and weight gradients on side streams", tb)):
             diff = [(it, n) for it in range(2) for i, n in enumerate(a["names"]) if not torch.equal(a["sums"][it][i], x["sums"][it][i])]
             same = a["loss"] == x["loss"] and not diff
             print("B = %d, %s: losses %s / %s, %d gradients x 2 steps, %d differ %s -> %s (peak %.1f / %.1f GB)"
                   % (B, name, a["loss"], x["loss"], len(a["names"]), len(diff), diff[:4], "BITWISE EQUAL" if same else "DIFFERENT", a["peak_gb"], x["peak_gb"]))
-            bad += (not same) and x is b
+            bad += (not same) and x is not c
     sys.exit(1 if bad else 0)
