@@ -212,6 +212,34 @@ def join_text_streams():
             cur.wait_stream(s)
 
 
+# Third session: the frozen prompter's pass (get_pseudo_labels: a no-grad B-clip encoder forward, itself two half batches on two streams)
+# forked BEHIND the trained visual encoder's forward, so that it runs beside the VTC / negative sampling / fusion / head launches of the launch stream
+# instead of after them.  Forked at the START of the forward it ran beside the visual encoder's forward and cost +0.2 ... +0.7 % (profiles/r6_split_streams_ab.txt:
+# big beside big); forked behind it: 150.47 -> 150.09 ms (-0.25 %, A/B/A/B on one box, run-to-run spread 0.03 ms; profiles/r6_prompter_side_stream_ab.txt),
+# labels bit for bit.  ALPRO_PROMPTER_STREAM = 0 | 1 (default 1).
+_prompter_stream = [os.environ.get("ALPRO_PROMPTER_STREAM", "1") != "0"]
+_PROMPTER_SIDE = {}
+
+
+def set_prompter_stream(v):
+    _prompter_stream[0] = bool(v)
+
+
+def prompter_stream_enabled():
+    return _prompter_stream[0]
+
+
+def prompter_side_stream(device):
+    if not (_prompter_stream[0] and device.type == "cuda"):
+        return None
+    import torch
+    key = (device.index if device.index is not None else torch.cuda.current_device(), torch.cuda.current_stream(device).cuda_stream)
+    s = _PROMPTER_SIDE.get(key)
+    if s is None:
+        s = _PROMPTER_SIDE[key] = torch.cuda.Stream(device)
+    return s
+
+
 # Round 6: the no-grad Block.forward keeps the block input until both attention halves are done -- the add + norm1 kernel reads it and writes only the
 # normalised rows, the add + norm2 kernel adds the temporal AND the spatial branch (alpro_add_layernorm_pre_mlp2; bit for bit the same sums).
 # ALPRO_DEFER_TEMPORAL_ADD=0: the round-3 form (x + temporal branch written by the first kernel), for A/B.

@@ -250,6 +250,13 @@ class AlproForPretrain(AlproBaseModel):
             text_side.wait_event(ev_inputs)
             with torch.cuda.stream(text_side):
                 both = self._text_embeds(torch.cat([batch['text_input_ids'], batch['mlm_text_input_ids']], dim=0), torch.cat([text_atts, text_atts], dim=0))
+        pseudo = p_side = None
+        if use_mpm:
+            p_side = rt.prompter_side_stream(device)
+            if p_side is not None:   # (alpro_amd.config, ALPRO_PROMPTER_STREAM) behind the visual forward, beside what the launch stream does from here on
+                p_side.wait_stream(torch.cuda.current_stream(device))
+                with torch.cuda.stream(p_side):
+                    pseudo = self.get_pseudo_labels(batch)
         video_feat = self._video_feat(video_embeds)
         video_atts = torch.ones(video_embeds.size()[:-1], dtype=torch.long, device=device)
         pos_patch_rows = None
@@ -303,7 +310,13 @@ class AlproForPretrain(AlproBaseModel):
             else:
                 mlm_logits = mlm_loss = mlm_labels = None
         if use_mpm:
-            mpm_labels, ignore_masks = self.get_pseudo_labels(batch)
+            if pseudo is None:
+                mpm_labels, ignore_masks = self.get_pseudo_labels(batch)
+            else:
+                torch.cuda.current_stream(device).wait_stream(p_side)
+                mpm_labels, ignore_masks = pseudo
+                for t_ in pseudo:
+                    t_.record_stream(torch.cuda.current_stream(device))
             mpm_loss, mpm_logits = self.compute_mpm_with_encoder_out(encoder_outputs_pos, text_atts, mpm_labels, ignore_masks, batch['mpm_mask'], visual_output=pos_patch_rows)
         else:
             mpm_loss = mpm_logits = mpm_labels = None

@@ -592,6 +592,8 @@ def main():
     _rt.set_split_streams("0")
     _rt.set_wgrad_stream(False)   # ... and the weight gradients / the text pass stay on the launch stream for the same reason
     _rt.set_text_stream(False)
+    _prev_ps = _rt.prompter_stream_enabled()
+    _rt.set_prompter_stream(False)
     try:
         with (torch.enable_grad() if train else torch.no_grad()), KernelTimer(hip) as kt:
             step()
@@ -600,6 +602,7 @@ def main():
         _rt.set_split_streams(_prev_split)
         _rt.set_wgrad_stream(_prev_wgs)
         _rt.set_text_stream(_prev_txt)
+        _rt.set_prompter_stream(_prev_ps)
     dist.barrier()
     result = None
     if rank == 0:
@@ -672,6 +675,7 @@ def main():
             # weight-gradient GEMMs of the timed steps on a side stream beside the data-gradient chain (alpro_amd.config, ALPRO_WGRAD_STREAM)
             "wgrad_side_stream": bool(train and _rt.wgrad_stream_enabled()),
             "text_side_stream": bool(args.workload != "visual_fwd" and _rt.text_stream_enabled()),
+            "prompter_side_stream": bool(args.workload != "visual_fwd" and _rt.prompter_stream_enabled()),
             "world_size": world, "dist_backend": (torch.distributed.get_backend() if torch.distributed.is_initialized() else "none (single process)"),
             "rccl_version": ".".join(str(v) for v in torch.cuda.nccl.version()) if hasattr(torch.cuda, "nccl") else None,
             "nccl_channels": {k_: os.environ.get(k_) for k_ in ("NCCL_MAX_NCHANNELS", "NCCL_MIN_NCHANNELS", "ALPRO_OVERLAP_BACKWARD") if os.environ.get(k_) is not None},

@@ -44,8 +44,8 @@ def worker(out, B):
     torch.save(rec, out)
 
 
-def run(B, side, out, text=False):
-    env = dict(os.environ, ALPRO_WGRAD_STREAM="1" if side else "0", ALPRO_TEXT_STREAM="1" if text else "0")
+def run(B, side, out, text=False, prompter=False):
+    env = dict(os.environ, ALPRO_WGRAD_STREAM="1" if side else "0", ALPRO_TEXT_STREAM="1" if text else "0", ALPRO_PROMPTER_STREAM="1" if prompter else "0")
     p = subprocess.run([sys.executable, os.path.abspath(__file__), "--worker", out, str(B)], cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=1200)
     assert p.returncode == 0, p.stdout[-3000:]
     return torch.load(out)
@@ -60,9 +60,10 @@ if __name__ == "__main__":
         with tempfile.TemporaryDirectory() as d:
             a, b, c = run(B, False, os.path.join(d, "a.pt")), run(B, True, os.path.join(d, "b.pt")), run(B, False, os.path.join(d, "c.pt"))
             t, tb = run(B, False, os.path.join(d, "t.pt"), text=True), run(B, True, os.path.join(d, "tb.pt"), text=True)
+            pr = run(B, True, os.path.join(d, "pr.pt"), text=True, prompter=True)
         assert not a["side"] and b["side"]
         for name, x in (("side stream vs launch stream", b), ("launch stream again (the control)", c), ("text pass on its side stream (ALPRO_TEXT_STREAM=1)", t),
-                        ("text pass and weight gradients on side streams", tb)):
+                        ("text pass and weight gradients on side streams", tb), ("... and the prompter's pass on its side stream (ALPRO_PROMPTER_STREAM=1)", pr)):
             diff = [(it, n) for it in range(2) for i, n in enumerate(a["names"]) if not torch.equal(a["sums"][it][i], x["sums"][it][i])]
             same = a["loss"] == x["loss"] and not diff
             print("B = %d, %s: losses %s / %s, %d gradients x 2 steps, %d differ %s -> %s (peak %.1f / %.1f GB)"
