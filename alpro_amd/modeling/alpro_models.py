@@ -203,7 +203,7 @@ class AlproBaseModel(nn.Module):
         pos, neg = both[:bs], both[bs:]
         vl_embeddings = torch.cat([pos[:, 0, :], neg[:, 0, :]], dim=0)
         vtm_logits = _linear32(vl_embeddings, self.itm_head)
-        vtm_labels = torch.cat([torch.ones(bs, dtype=torch.long), torch.zeros(2 * bs, dtype=torch.long)], dim=0).to(device)
+        vtm_labels = torch.cat([torch.ones(bs, dtype=torch.long, device=device), torch.zeros(2 * bs, dtype=torch.long, device=device)], dim=0)   # built on the device: a pageable .to(device) makes the host wait for the launch stream
         vtm_loss = F.cross_entropy(vtm_logits, vtm_labels)
         return vtm_loss, vtm_logits, vtm_labels, pos
 
@@ -296,7 +296,9 @@ class AlproForPretrain(AlproBaseModel):
                 encoder_outputs_pos, neg, mlm_out = fused[:b], fused[b:3 * b], fused[3 * b:]
                 cls_rows, mlm_rows, pos_patch_rows = torch.cat([encoder_outputs_pos[:, 0, :], neg[:, 0, :]], dim=0), mlm_out[:, :txt_len], None
             vtm_logits = _linear32(cls_rows, self.itm_head)
-            vtm_labels = torch.cat([torch.ones(b, dtype=torch.long), torch.zeros(2 * b, dtype=torch.long)], dim=0).to(device)
+            # built on the device: `.to(device)` of a pageable host tensor makes the host wait for everything queued on the launch stream (both encoders'
+            # forwards), after which the device idles until the next launches arrive (tools/sync_probe.py found this one; the reference has the same line, :327)
+            vtm_labels = torch.cat([torch.ones(b, dtype=torch.long, device=device), torch.zeros(2 * b, dtype=torch.long, device=device)], dim=0)
             vtm_loss = F.cross_entropy(vtm_logits, vtm_labels)
             mlm_labels = batch['mlm_labels']
             mlm_logits, mlm_loss = self.text_encoder.cls.predictions.forward_with_loss(mlm_rows, mlm_labels)
