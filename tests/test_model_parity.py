@@ -786,6 +786,36 @@ def test_fused_temporal_half_against_the_two_launches(mode):
     assert bool(torch.isfinite(ga).all()) and rel <= {"fp16": 1e-3, "bf16": 8e-3}[mode], rel
 
 
+def test_pretrain_step_never_makes_the_host_wait_for_the_device(fixture_models):
+    """Round 6 (profiles/r6_host_sync_probe.txt): a warmed AlproForPretrain forward + backward queues its launches without a single synchronising
+    call -- torch.cuda.set_sync_debug_mode("error") raises on any (the reference's `vtm_labels ... .to(device)`, alpro_models.py:327, was one: a
+    pageable upload waits for everything queued on the launch stream).  With the host a whole step ahead, the side streams' launches are queued
+    when a CU frees up, and the only syncs of a training loop are the ones the driver asks for."""
+    from alpro_amd import amp, config as rt
+    m, batch, _ = fixture_models("pretrain_T8")
+    was_training = m.training
+    sc = amp.LossScaler(init_scale=4096.0, dynamic=False, device="cuda")   # (built before the check: its state is uploaded from a host list)
+    try:
+        fresh_grads(m)
+        for rep in range(3):   # gradients accumulate into the buffers of the first pass, as under FlatAdamW's flat views: job tables keyed on them are built once
+            if rep == 2:
+                torch.cuda.synchronize()
+                torch.cuda.set_sync_debug_mode("error")
+            with rt.use_compute_dtype("fp16"), torch.enable_grad():
+                rt.set_armed_loss_scaler(sc)
+                out = m(batch)
+                loss = out["mlm_loss"] + out["itm_loss"] + out["itc_loss"] + out["mpm_loss"]
+                with rt.loss_scaling(sc):
+                    (loss * sc.scale.reshape(())).backward()
+    finally:
+        torch.cuda.set_sync_debug_mode("default")
+        rt.set_armed_loss_scaler(None)
+        torch.cuda.synchronize()
+        fresh_grads(m)
+        m.train(was_training)
+    assert bool(torch.isfinite(loss.detach()).all())
+
+
 @pytest.mark.parametrize("mode", ["fp16", "fp32"])
 def test_text_pass_on_its_side_stream_is_bitwise_neutral(fixture_models, monkeypatch, mode):
     """Round 6 (alpro_amd.config.text_side_stream; AlproForPretrain.forward): the 2B-caption text-encoder pass runs on a side stream beside the visual
