@@ -155,6 +155,20 @@ def wgrad_side_stream(device):
     return ent[0]
 
 
+def side_streams_of_current(device):
+    """Raw handles of the side streams that carry weight-gradient GEMMs for the current launch stream (created if the switch is on): per-stream
+    launch options of the launch stream (FlatAdamW's cu_budget while all-reduces are in flight) have to be mirrored onto them -- the weight-gradient
+    kernel plans one workgroup per available CU, and it runs on the side stream now."""
+    if not (_wgrad_stream[0] and device.type == "cuda"):
+        return []
+    import torch
+    key = (device.index if device.index is not None else torch.cuda.current_device(), torch.cuda.current_stream(device).cuda_stream)
+    ent = _WGRAD_SIDE.get(key)
+    if ent is None:
+        ent = _WGRAD_SIDE[key] = [torch.cuda.Stream(device), False]
+    return [ent[0].cuda_stream]
+
+
 def join_wgrad():
     """The current stream of every device waits for the weight gradients that were launched from it."""
     if not _WGRAD_SIDE:

@@ -253,8 +253,19 @@ class FlatAdamW:
                 ncu = torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count if torch.cuda.is_available() else 256
                 self._budget_seen = max(64, ncu - r)
                 self._cu_stream = hip.set_stream_option("cu_budget", max(64, ncu - r))
+                # ... and the side stream this launch stream sends its weight-gradient GEMMs to (alpro_amd.config, ALPRO_WGRAD_STREAM): the kernel that
+                # needs the budget most -- one workgroup per CU, a displaced one waits a whole round -- runs there
+                import ctypes
+                from alpro_amd import config as rt
+                on_gpu = torch.cuda.is_available() and self.flat is not None and self.flat["g"].is_cuda
+                self._cu_side = [ctypes.c_void_p(h) for h in rt.side_streams_of_current(self.flat["g"].device)] if on_gpu else []
+                for h in self._cu_side:
+                    hip.set_stream_option("cu_budget", max(64, ncu - r), stream=h)
             else:
                 hip.set_stream_option("cu_budget", -1, stream=getattr(self, "_cu_stream", None))
+                for h in getattr(self, "_cu_side", []):
+                    hip.set_stream_option("cu_budget", -1, stream=h)
+                self._cu_side = []
             self._cus_reserved = on
 
     def _launch(self, s, e):
