@@ -147,7 +147,13 @@ def wgrad_side_stream(device):
     if not (_wgrad_stream[0] and _wgrad_active[0] > 0 and device.type == "cuda"):
         return None
     import torch
-    key = (device.index if device.index is not None else torch.cuda.current_device(), torch.cuda.current_stream(device).cuda_stream)
+    cur = torch.cuda.current_stream(device)
+    if os.environ.get("ALPRO_WGRAD_STREAM_NESTED", "0") != "1" and any(s.cuda_stream == cur.cuda_stream for s in _TEXT_SIDE.values()):
+        # a backward that already runs on the text side stream keeps its weight gradients there: at most four streams are active at a time (launch, text,
+        # weight gradients in backward; launch, text, 2 x prompter in forward) -- the number of hardware queues that do not share a dispatch pipe
+        # (profiles/r6_hw_queues.txt; nested form 148.75 ms, this one 148.5)
+        return None
+    key = (device.index if device.index is not None else torch.cuda.current_device(), cur.cuda_stream)
     ent = _WGRAD_SIDE.get(key)
     if ent is None:
         ent = _WGRAD_SIDE[key] = [torch.cuda.Stream(device), False]

@@ -61,6 +61,12 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    hq = os.environ.get("GPU_MAX_HW_QUEUES")
+    if hq and hq.isdigit() and int(hq) > 4 and any(os.environ.get(k, "1") != "0" for k in ("ALPRO_WGRAD_STREAM", "ALPRO_TEXT_STREAM", "ALPRO_PROMPTER_STREAM")):
+        import warnings
+        warnings.warn("alpro_amd: GPU_MAX_HW_QUEUES=%s -- with more than 4 hardware queues the training step's side streams (ALPRO_WGRAD_STREAM / "
+                      "ALPRO_TEXT_STREAM / ALPRO_PROMPTER_STREAM) measured 11 %% SLOWER than with the runtime's default of 4 (profiles/r6_hw_queues.txt): "
+                      "a fifth queue shares a dispatch pipe with the launch stream's" % hq)
     if not os.path.exists(LIB_PATH):
         raise RuntimeError("libalpro_hip.so not found at %s -- run `python -m alpro_amd.build` "
                            "(there is no CPU fallback for the ALPRO hot path)" % LIB_PATH)
