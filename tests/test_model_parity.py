@@ -787,16 +787,18 @@ def test_fused_temporal_half_against_the_two_launches(mode):
 
 
 def test_side_stream_backward_is_handed_to_the_callers_stream():
-    """The mechanism behind ALPRO_TEXT_STREAM, isolated: an anchored run whose forward was queued on the text side stream gets its backward on that
-    stream (autograd's rule), where it writes a buffer behind autograd's back -- as the hand-written backwards write parameter gradients -- after a
-    long spin (torch.cuda._sleep: ~0.3 s of device time, so an unordered read on the caller's stream WOULD see the old value).  When
-    loss.backward() returns, the caller's stream must be ordered behind that write (alpro_amd.modeling.train.Anchor.backward queues an engine
-    callback that makes the caller's stream wait for an event of the side stream); the same for weight gradients sent to the weight-gradient
-    side stream from inside the backward (joined where the backward returns).
-    Negative controls run once by hand on torch 2.10 (not part of the suite): without `join_wgrad` the second assertion fails, as it must; without
-    the callback the first one still holds -- this torch's engine orders the caller's stream behind every stream a backward node ran on by itself
-    (a plain autograd.Function on a side stream shows the same) -- so the callback is the documented guarantee for engines that do not, and this
-    test pins the property either way.  The streams are picked among eight candidates that demonstrably run beside the launch stream."""
+    """The mechanisms behind ALPRO_TEXT_STREAM and ALPRO_WGRAD_STREAM, isolated.
+    (a) An anchored run whose forward was queued on the text side stream gets its backward on that stream (autograd's rule), where it writes a buffer
+        behind autograd's back -- as the hand-written backwards write parameter gradients -- after a long spin (torch.cuda._sleep: ~0.3 s of device
+        time, so an unordered read on the caller's stream WOULD see the old value).  When loss.backward() returns, the caller's stream must be ordered
+        behind that write (alpro_amd.modeling.train.Anchor.backward queues an engine callback that makes the caller's stream wait for an event of the
+        side stream).  A backward on the text side stream keeps its weight gradients there (no side stream of a side stream: profiles/r6_hw_queues.txt).
+    (b) An anchored run on the launch stream sends a "weight gradient" to the weight-gradient side stream from inside its backward (what
+        alpro_amd.modeling.train.wgrad does); the launch stream must be ordered behind it where the backward returns.
+    Negative controls run once by hand on torch 2.10 (not part of the suite): without `join_wgrad` (b) fails, as it must; without the callback (a)
+    still holds -- this torch's engine orders the caller's stream behind every stream a backward node ran on by itself (a plain autograd.Function on
+    a side stream shows the same) -- so the callback is the documented guarantee for engines that do not, and this test pins the property either way.
+    The streams are picked among eight candidates that demonstrably run beside the launch stream."""
     from alpro_amd import config as rt
     from alpro_amd.modeling import train as tr
     dev = torch.device("cuda", torch.cuda.current_device())
@@ -806,21 +808,26 @@ def test_side_stream_backward_is_handed_to_the_callers_stream():
     seen = {}
 
     class Run:
+        def __init__(self, tag):
+            self.tag = tag
+
         def forward(self, x):
             return x * 2.0
 
         def backward(self, g):
-            seen["stream"] = torch.cuda.current_stream().cuda_stream
-            torch.cuda._sleep(600_000_000)
-            self.buf.fill_(7.0)
-            w = rt.wgrad_side_stream(g.device)          # what tr.wgrad does with a weight-gradient GEMM: behind the launch stream, on its side stream
-            seen["wgrad_side"] = w is not None
-            if w is not None:
+            seen[self.tag + "_stream"] = torch.cuda.current_stream().cuda_stream
+            w = rt.wgrad_side_stream(g.device)          # what tr.wgrad asks for a weight-gradient GEMM
+            seen[self.tag + "_wgrad_side"] = w
+            if w is None:                                # (a): everything on the stream of the backward
+                torch.cuda._sleep(600_000_000)
+                self.buf.fill_(7.0)
+            else:                                        # (b): behind the launch stream, on its side stream
                 w.wait_stream(torch.cuda.current_stream())
                 with torch.cuda.stream(w):
-                    torch.cuda._sleep(300_000_000)
-                    self.buf2.fill_(9.0)
+                    torch.cuda._sleep(600_000_000)
+                    self.buf.fill_(9.0)
             return g * 2.0
+
     def runs_beside(main, cand):
         """Does `cand` execute independently of `main`?  (HIP maps streams onto a few hardware queues; two streams that share one run in submission
         order, which would order the caller's stream behind the side stream by accident and make this test prove nothing.)"""
@@ -833,37 +840,47 @@ def test_side_stream_backward_is_handed_to_the_callers_stream():
         early = flag.clone()          # on main, unordered: sees 0 if the candidate's spin has not held it up
         torch.cuda.synchronize()
         return float(early.item()) == 0.0
-    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
+    main = torch.cuda.current_stream(dev)
+    key = (dev.index, main.cuda_stream)
     prev_side, prev_wside = rt._TEXT_SIDE.get(key), rt._WGRAD_SIDE.copy()
     try:
-        main = torch.cuda.current_stream(dev)
         cands = [torch.cuda.Stream(dev) for _ in range(8)]
         free = [c for c in cands if runs_beside(main, c)]
         assert len(free) >= 2, "no stream of eight runs beside the launch stream on this box"
-        rt._TEXT_SIDE[key] = free[0]                                             # the text side stream of this launch stream ...
-        rt._WGRAD_SIDE[(dev.index, free[0].cuda_stream)] = [free[1], False]      # ... and the weight-gradient side stream of THAT stream
+        rt._TEXT_SIDE[key] = free[0]                 # the text side stream of this launch stream ...
+        rt._WGRAD_SIDE[key] = [free[1], False]       # ... and its weight-gradient side stream
         side = rt.text_side_stream(dev)
         assert side is free[0] and side.cuda_stream != main.cuda_stream
-        run = Run()
-        run.buf, run.buf2 = torch.zeros(4, device=dev), torch.zeros(4, device=dev)
-        # no gradient flows OUT of the run to a tensor of the caller's stream (as with the text encoder: token ids in, parameters only) -- otherwise the
-        # engine's own producer -> consumer ordering for that gradient would order the caller's stream behind the side stream and hide a missing hand-over
+        # no gradient flows OUT of the runs to a tensor of the caller's stream (as with the text encoder: token ids in, parameters only) -- otherwise the
+        # engine's own producer -> consumer ordering for that gradient would hide a missing hand-over
         x = torch.ones(8, device=dev)
         p = torch.nn.Parameter(torch.zeros(1, device=dev))
+        # (a)
+        a = Run("a")
+        a.buf = torch.zeros(4, device=dev)
         torch.cuda.synchronize()
         side.wait_stream(main)
         with torch.cuda.stream(side):
-            y = tr.run_anchored(run, [x], [p])
+            y = tr.run_anchored(a, [x], [p])
         main.wait_stream(side)
         y.record_stream(main)
         assert y.requires_grad
         y.sum().backward()
-        got, got2 = run.buf.clone(), run.buf2.clone()     # queued on the caller's stream right behind backward(): no device-wide sync in between
+        got_a = a.buf.clone()     # queued on the caller's stream right behind backward(): no device-wide sync in between
         torch.cuda.synchronize()
-        assert seen["stream"] == side.cuda_stream, "autograd did not run the anchored backward on the stream of its forward"
-        assert seen["wgrad_side"], "no weight-gradient side stream inside an anchored backward"
-        assert got.tolist() == [7.0] * 4, "the caller's stream read the side stream's write too early: %s" % got.tolist()
-        assert got2.tolist() == [9.0] * 4, "the weight-gradient side stream was not joined where the backward returned: %s" % got2.tolist()
+        assert seen["a_stream"] == side.cuda_stream, "autograd did not run the anchored backward on the stream of its forward"
+        assert seen["a_wgrad_side"] is None, "a backward on the text side stream was given a side stream of its own"
+        assert got_a.tolist() == [7.0] * 4, "the caller's stream read the side stream's write too early: %s" % got_a.tolist()
+        # (b)
+        b = Run("b")
+        b.buf = torch.zeros(4, device=dev)
+        torch.cuda.synchronize()
+        y = tr.run_anchored(b, [x], [p])
+        y.sum().backward()
+        got_b = b.buf.clone()
+        torch.cuda.synchronize()
+        assert seen["b_stream"] == main.cuda_stream and seen["b_wgrad_side"] is free[1], "no weight-gradient side stream inside an anchored backward on the launch stream"
+        assert got_b.tolist() == [9.0] * 4, "the weight-gradient side stream was not joined where the backward returned: %s" % got_b.tolist()
     finally:
         torch.cuda.synchronize()
         rt.set_text_stream(prev_t)
