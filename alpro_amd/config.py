@@ -130,6 +130,16 @@ _wgrad_active = [0]      # > 0 while an anchored backward runs
 _WGRAD_SIDE = {}         # (device index, launch stream handle) -> [side stream, work pending]
 
 
+def _new_side_stream(device):
+    """A side stream; ALPRO_SIDE_PRIORITY = default | high | low picks its HIP priority (measurement switch: high costs 14 %, there is no class below normal -- profiles/r6_hw_queues.txt, section 4)."""
+    import torch
+    pr = os.environ.get("ALPRO_SIDE_PRIORITY", "default")
+    if pr == "default":
+        return torch.cuda.Stream(device)
+    lo, hi = torch.cuda.Stream.priority_range()   # (lowest, highest): numerically lower = higher priority
+    return torch.cuda.Stream(device, priority=hi if pr == "high" else lo)
+
+
 def set_wgrad_stream(v):
     _wgrad_stream[0] = bool(v)
 
@@ -156,7 +166,7 @@ def wgrad_side_stream(device):
     key = (device.index if device.index is not None else torch.cuda.current_device(), cur.cuda_stream)
     ent = _WGRAD_SIDE.get(key)
     if ent is None:
-        ent = _WGRAD_SIDE[key] = [torch.cuda.Stream(device), False]
+        ent = _WGRAD_SIDE[key] = [_new_side_stream(device), False]
     ent[1] = True
     return ent[0]
 
@@ -171,7 +181,7 @@ def side_streams_of_current(device):
     key = (device.index if device.index is not None else torch.cuda.current_device(), torch.cuda.current_stream(device).cuda_stream)
     ent = _WGRAD_SIDE.get(key)
     if ent is None:
-        ent = _WGRAD_SIDE[key] = [torch.cuda.Stream(device), False]
+        ent = _WGRAD_SIDE[key] = [_new_side_stream(device), False]
     return [ent[0].cuda_stream]
 
 
@@ -213,7 +223,7 @@ def text_side_stream(device):
     key = (device.index if device.index is not None else torch.cuda.current_device(), torch.cuda.current_stream(device).cuda_stream)
     s = _TEXT_SIDE.get(key)
     if s is None:
-        s = _TEXT_SIDE[key] = torch.cuda.Stream(device)
+        s = _TEXT_SIDE[key] = _new_side_stream(device)
     return s
 
 
@@ -256,7 +266,7 @@ def prompter_side_stream(device):
     key = (device.index if device.index is not None else torch.cuda.current_device(), torch.cuda.current_stream(device).cuda_stream)
     s = _PROMPTER_SIDE.get(key)
     if s is None:
-        s = _PROMPTER_SIDE[key] = torch.cuda.Stream(device)
+        s = _PROMPTER_SIDE[key] = _new_side_stream(device)
     return s
 
 
