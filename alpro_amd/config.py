@@ -130,6 +130,19 @@ _wgrad_active = [0]      # > 0 while an anchored backward runs
 _WGRAD_SIDE = {}         # (device index, launch stream handle) -> [side stream, work pending]
 
 
+def _several_ranks():
+    """True in a job with more than one rank.  The weight-gradient and prompter side streams are single-GPU schedules unless forced
+    (ALPRO_WGRAD_STREAM=force / ALPRO_PROMPTER_STREAM=force): with the collective library's stream the job would have more than four streams in play,
+    i.e. streams sharing a hardware queue -- and a weight-gradient kernel queued in front of an all-reduce (or behind one) on a shared queue is exactly
+    the coupling the overlapped exchange must not have.  Nothing of this could be measured on more than one GPU; with the text
+    side stream alone a rank has launch + collective + text + the prompter's second half-batch stream = four, each on a queue of its own."""
+    try:
+        import torch.distributed as td
+        return td.is_available() and td.is_initialized() and td.get_world_size() > 1
+    except Exception:  # noqa: BLE001
+        return False
+
+
 def _new_side_stream(device):
     """A side stream; ALPRO_SIDE_PRIORITY = default | high | low picks its HIP priority (measurement switch: high costs 14 %, there is no class below normal -- profiles/r6_hw_queues.txt, section 4)."""
     import torch
@@ -154,7 +167,7 @@ def wgrad_scope(enter):
 
 def wgrad_side_stream(device):
     """The side stream of the current launch stream, or None when weight gradients stay on the launch stream."""
-    if not (_wgrad_stream[0] and _wgrad_active[0] > 0 and device.type == "cuda"):
+    if not (_wgrad_stream[0] and _wgrad_active[0] > 0 and device.type == "cuda") or (_several_ranks() and os.environ.get("ALPRO_WGRAD_STREAM") != "force"):
         return None
     import torch
     cur = torch.cuda.current_stream(device)
@@ -175,7 +188,7 @@ def side_streams_of_current(device):
     """Raw handles of the side streams that carry weight-gradient GEMMs for the current launch stream (created if the switch is on): per-stream
     launch options of the launch stream (FlatAdamW's cu_budget while all-reduces are in flight) have to be mirrored onto them -- the weight-gradient
     kernel plans one workgroup per available CU, and it runs on the side stream now."""
-    if not (_wgrad_stream[0] and device.type == "cuda"):
+    if not (_wgrad_stream[0] and device.type == "cuda") or (_several_ranks() and os.environ.get("ALPRO_WGRAD_STREAM") != "force"):
         return []
     import torch
     key = (device.index if device.index is not None else torch.cuda.current_device(), torch.cuda.current_stream(device).cuda_stream)
@@ -260,7 +273,7 @@ def prompter_stream_enabled():
 
 
 def prompter_side_stream(device):
-    if not (_prompter_stream[0] and device.type == "cuda"):
+    if not (_prompter_stream[0] and device.type == "cuda") or (_several_ranks() and os.environ.get("ALPRO_PROMPTER_STREAM") != "force"):
         return None
     import torch
     key = (device.index if device.index is not None else torch.cuda.current_device(), torch.cuda.current_stream(device).cuda_stream)

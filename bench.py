@@ -673,9 +673,9 @@ def main():
             # prompter's pass): 2 = two half batches on two HIP streams (alpro_amd.config.split_streams); the divST region is always measured on one
             "no_grad_forward_streams": 2 if _rt.split_streams(B) else 1,
             # weight-gradient GEMMs of the timed steps on a side stream beside the data-gradient chain (alpro_amd.config, ALPRO_WGRAD_STREAM)
-            "wgrad_side_stream": bool(train and _rt.wgrad_stream_enabled()),
+            "wgrad_side_stream": bool(train and _rt.wgrad_stream_enabled() and (world == 1 or os.environ.get("ALPRO_WGRAD_STREAM") == "force")),   # single-GPU schedule unless forced
             "text_side_stream": bool(args.workload != "visual_fwd" and _rt.text_stream_enabled()),
-            "prompter_side_stream": bool(args.workload != "visual_fwd" and _rt.prompter_stream_enabled()),
+            "prompter_side_stream": bool(args.workload != "visual_fwd" and _rt.prompter_stream_enabled() and (world == 1 or os.environ.get("ALPRO_PROMPTER_STREAM") == "force")),
             "world_size": world, "dist_backend": (torch.distributed.get_backend() if torch.distributed.is_initialized() else "none (single process)"),
             "rccl_version": ".".join(str(v) for v in torch.cuda.nccl.version()) if hasattr(torch.cuda, "nccl") else None,
             "nccl_channels": {k_: os.environ.get(k_) for k_ in ("NCCL_MAX_NCHANNELS", "NCCL_MIN_NCHANNELS", "ALPRO_OVERLAP_BACKWARD") if os.environ.get(k_) is not None},

@@ -1416,6 +1416,21 @@ def test_round6_forward_schedule_switches(monkeypatch):
         rt.wgrad_scope(False)
         assert rt._wgrad_active[0] == 0
         rt.join_wgrad()                                                # nothing pending: a no-op without a GPU
+        # a job with several ranks keeps the weight-gradient and prompter side streams off (launch + collective + text + the prompter's second half = the
+        # four hardware queues): asked for a CUDA device, both decline BEFORE touching the runtime
+        monkeypatch.setattr(rt, "_several_ranks", lambda: True)
+        monkeypatch.delenv("ALPRO_WGRAD_STREAM", raising=False)
+        monkeypatch.delenv("ALPRO_PROMPTER_STREAM", raising=False)
+        rt.wgrad_scope(True)
+        try:
+            assert rt.wgrad_side_stream(torch.device("cuda", 0)) is None and rt.side_streams_of_current(torch.device("cuda", 0)) == []
+        finally:
+            rt.wgrad_scope(False)
+        prev_p = rt.prompter_stream_enabled()
+        rt.set_prompter_stream(True)
+        assert rt.prompter_side_stream(torch.device("cuda", 0)) is None
+        rt.set_prompter_stream(prev_p)
+        monkeypatch.setattr(rt, "_several_ranks", lambda: False)
         prev_t = rt.text_stream_enabled()
         rt.set_text_stream(True)
         assert rt.text_side_stream(torch.device("cpu")) is None       # the text pass of a CPU batch stays in line
