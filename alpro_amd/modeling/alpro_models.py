@@ -215,11 +215,30 @@ class AlproForPretrain(AlproBaseModel):
         self.use_mask_prob = 0
         self.batch_encoder_passes = True  # one 4B fusion pass / one 2B text pass instead of the reference's 3 / 2 calls
         self.gather_fusion_input = os.environ.get("ALPRO_GATHER_FUSION", "1") != "0"   # the 4B fusion batch as a row gather (alpro_gather_seq_*), 0 = torch.cat + autograd (A/B)
+        # Round 6 (third session): the LAST fusion layer's row-wise tail (attention-output dense, LayerNorms, FFN) only on the rows the heads read -- the 3B
+        # [CLS] rows, the MLM pairs' text rows, the positives' patch rows: 239 of every 948 rows of the 4B x 237 batch; nothing else of that layer's output
+        # reaches a loss (alpro_models.py:283,331-338,366-371,215-218), forward or backward.  ALPRO_FUSION_TAIL_ROWS=0: every row, as before (A/B).
+        self.fusion_tail_rows = os.environ.get("ALPRO_FUSION_TAIL_ROWS", "1") != "0"
+        self._out_rows_cache = {}
         self.mpm_head = nn.Sequential(nn.Linear(config.hidden_size, config.hidden_size * 2), nn.ReLU(True),
                                       nn.Linear(config.hidden_size * 2, self.prompter.entity_num))
 
     def build_text_prompts(self, prompts):
         self.prompter.build_text_prompts(prompts)
+
+    def _fusion_out_rows(self, b, txt_len, seq_len, device):
+        """Flat row indices (into the 4B x seq_len rows of the fusion batch: positives | negative videos | negative texts | MLM pairs) of what the heads
+        read: row 0 of the first 3B sequences (ITM), rows 0..txt_len-1 of the MLM pairs (LM head), rows txt_len+1.. of the positives (MPM: the patch
+        tokens behind the video [CLS]).  Built once per geometry, on the device."""
+        key = (b, txt_len, seq_len, str(device))
+        idx = self._out_rows_cache.get(key)
+        if idx is None:
+            ar = lambda n: torch.arange(n, device=device, dtype=torch.long)
+            cls_ = ar(3 * b) * seq_len
+            mlm = ((3 * b + ar(b))[:, None] * seq_len + ar(txt_len)[None, :]).reshape(-1)
+            vis = (ar(b)[:, None] * seq_len + (txt_len + 1 + ar(seq_len - txt_len - 1))[None, :]).reshape(-1)
+            idx = self._out_rows_cache[key] = torch.cat([cls_, mlm, vis]).contiguous()
+        return idx
 
     def get_pseudo_labels(self, batch):
         return self.prompter.get_pseudo_labels(batch)
@@ -282,14 +301,23 @@ class AlproForPretrain(AlproBaseModel):
                 ar = torch.arange(b, device=device)
                 ti = torch.cat([ar, ar, neg_text, ar + b])
                 vi = torch.cat([ar, neg_video, ar, ar])
+                txt_len_, seq_len_ = text_atts.shape[1], text_atts.shape[1] + video_embeds.shape[1]
+                tail = use_mpm and self.fusion_tail_rows and getattr(self.text_encoder.bert.encoder.layer[-1], 'fuse_residual_ln', False)
+                rows = self._fusion_out_rows(b, txt_len_, seq_len_, device) if tail else None
                 fused = self.text_encoder.bert(encoder_embeds_parts=(both, video_embeds, ti, vi), attention_mask=torch.cat([ta_all, va_all], dim=1), return_dict=True,
-                                               mode='fusion').last_hidden_state
+                                               mode='fusion', out_rows=rows).last_hidden_state
             else:
                 t_all = torch.cat([text_embeds, text_embeds, text_embeds[neg_text], mlm_text_embeds], dim=0)
                 v_all = torch.cat([video_embeds, video_embeds[neg_video], video_embeds, video_embeds], dim=0)
                 fused = self._fusion(torch.cat([t_all, v_all], dim=1), torch.cat([ta_all, va_all], dim=1))
             txt_len = text_atts.shape[1]
-            if self.gather_fusion_input and use_mpm:
+            if self.gather_fusion_input and use_mpm and rows is not None:
+                # `fused` holds only the rows the heads read, in this order (see _fusion_out_rows): 3B [CLS] rows | B x txt_len MLM text rows | B x N patch rows
+                n_cls, n_mlm = 3 * b, b * txt_len
+                cls_rows, mlm_rows = fused[:n_cls], fused[n_cls:n_cls + n_mlm].view(b, txt_len, -1)
+                pos_patch_rows = fused[n_cls + n_mlm:].view(b, -1, fused.shape[-1])
+                encoder_outputs_pos = None
+            elif self.gather_fusion_input and use_mpm:
                 cls_rows, mlm_rows, pos_patch_rows = _FusionOutputs.apply(fused, b, txt_len)
                 encoder_outputs_pos = None
             else:

@@ -148,13 +148,17 @@ class BertLayer(nn.Module):
         o32_c = hip.layernorm(s2_c, self.output.LayerNorm.weight, self.output.LayerNorm.bias, eps, f32)
         return s1_c, a32_c, s2_c, o32_c
 
-    def forward(self, h32, h_t, key_bias, B, L):
-        """h32 (B*L, H) fp32 residual stream, h_t the same in the operand dtype; returns the next pair."""
-        o32, o_t, _ = self.forward_train(h32, h_t, key_bias, B, L, save=False)
+    def forward(self, h32, h_t, key_bias, B, L, rows=None):
+        """h32 (B*L, H) fp32 residual stream, h_t the same in the operand dtype; returns the next pair (of the `rows` only, if given)."""
+        o32, o_t, _ = self.forward_train(h32, h_t, key_bias, B, L, save=False, rows=rows)
         return o32, o_t
 
     # ---- training path ---------------------------------------------------------------------------------
-    def forward_train(self, h32, h_t, key_bias, B, L, save=True):
+    def forward_train(self, h32, h_t, key_bias, B, L, save=True, rows=None):
+        """rows (optional, LongTensor of flat row indices): the only rows of this layer's OUTPUT anybody reads (the last fusion layer: [CLS] rows, the
+        MLM pairs' text rows, the positives' patch rows -- a quarter of the 4B x 237).  Attention still runs over every row (all keys / values are
+        needed, and the kernel's unit is a whole sequence); everything behind it -- attention-output dense, both LayerNorms, the FFN -- is row-wise
+        and runs on the gathered rows only; the outputs are then (len(rows), D)."""
         hp, seed1, seed2, ap, seed_a = self._drop()
         dt = rt.compute_dtype()
         sa, so = self.attention.self, self.attention.output
@@ -170,7 +174,13 @@ class BertLayer(nn.Module):
             ctx, lse, ctx_c = hip.attn(qkv, B, L, H, scale, key_bias, want_lse=True, drop_p=ap, drop_seed=seed_a, cls_q=self._cls_qkv(hc), cls_group=1)
         else:
             ctx, lse = hip.attn(qkv, B, L, H, scale, key_bias, want_lse=True, drop_p=ap, drop_seed=seed_a)
-        u, u_tiled = tr.gelu_save_buffer(h_t.shape[0], self.intermediate.dense.out_features, h_t.shape[1], dt, h_t.device) if save else (None, False)
+        ctx_full, M_full = ctx, h_t.shape[0]
+        if rows is not None and (cp or not self.fuse_residual_ln):
+            raise RuntimeError("BertLayer: an output row subset is supported on the fused residual + LayerNorm path of the fusion layers only")
+        if rows is not None:
+            ctx = ctx.index_select(0, rows)
+            h32 = h32.index_select(0, rows)
+        u, u_tiled = tr.gelu_save_buffer(ctx.shape[0], self.intermediate.dense.out_features, h_t.shape[1], dt, h_t.device) if save else (None, False)
         if self.fuse_residual_ln:
             # the two dense Linears write their (dropped-out) 16-bit output only; residual add + post-LayerNorm are one streaming kernel
             # (alpro_add_layernorm_fwd), which also leaves the pre-LayerNorm sums s1 / s2 the backward needs (training only)
@@ -197,7 +207,7 @@ class BertLayer(nn.Module):
                           drop_p=hp, drop_seed=seed2)
             o_t, o32 = hip.layernorm(s2, self.output.LayerNorm.weight, self.output.LayerNorm.bias, eps, dt, out32=True)
         sv = dict(h_t=h_t, qkv=qkv, ctx=ctx, lse=lse, s1=s1, a_t=a_t, u=u, u_grad=tr.SAVE_GELU_GRAD, u_tiled=u_tiled, it=it, s2=s2, kb=key_bias, dims=(B, L, H, scale), dt=dt,
-                  drop=(hp, seed1, seed2, ap, seed_a)) if save else None
+                  drop=(hp, seed1, seed2, ap, seed_a), rows=rows, ctx_full=ctx_full, M_full=M_full) if save else None
         return o32, o_t, sv
 
     def backward(self, sv, do32, do_t):
@@ -232,7 +242,15 @@ class BertLayer(nn.Module):
         ds1, ds1_t = ln_bwd(so.LayerNorm, sv["s1"], da_t, ds2, seed1)       # ds1 is also d(h32): identity residual; ds1_t: through the attention-output dropout
         tr.wgrad(ds1_t, sv["ctx"], so.dense.weight, so.dense.bias)
         dctx = tr.dgrad(ds1_t, tr.transposed_operand(self._ops, "ao_w^T", so.dense.weight, dt))
-        dqkv = hip.attn_bwd(sv["qkv"], sv["ctx"], dctx, sv["lse"], B, L, H, scale, sv["kb"], drop_p=ap, drop_seed=seed_a)
+        rows = sv.get("rows")
+        if rows is not None:   # the row-wise tail ran on the gathered output rows only: their gradients go back to their places, every other row's is zero
+            full = torch.zeros((sv["M_full"], D), dtype=dctx.dtype, device=dev)
+            full.index_copy_(0, rows, dctx)
+            dctx = full
+            full32 = torch.zeros((sv["M_full"], D), dtype=torch.float32, device=dev)
+            full32.index_copy_(0, rows, ds1)
+            ds1 = full32
+        dqkv = hip.attn_bwd(sv["qkv"], sv["ctx_full"], dctx, sv["lse"], B, L, H, scale, sv["kb"], drop_p=ap, drop_seed=seed_a)
         # fused q/k/v projection: the three weight gradients come from the three column blocks of dqkv
         Hd = sa.all_head_size
         lins = (sa.query, sa.key, sa.value)
@@ -382,11 +400,13 @@ class BertModel(BertPreTrainedModel):
         """(B, L) {0,1} -> additive fp32 bias (1 - m) * -10000 (xbert.py:936-937)."""
         return ((1.0 - attention_mask.to(torch.float32)) * -10000.0).contiguous()
 
-    def forward(self, input_ids=None, attention_mask=None, encoder_embeds=None, return_dict=True, mode='multi_modal', encoder_embeds_parts=None, **unused):
+    def forward(self, input_ids=None, attention_mask=None, encoder_embeds=None, return_dict=True, mode='multi_modal', encoder_embeds_parts=None, out_rows=None, **unused):
         """encoder_embeds_parts (this repo's extension; the reference passes encoder_embeds): (text_pool (Pt, Lt, D), video_pool (Pv, Lv, D), ti (S,),
         vi (S,)) -- the fusion batch as a gather, sequence s = [text_pool[ti[s]] ; video_pool[vi[s]]], i.e. what the reference's
         torch.cat([text_embeds, video_embeds], dim=1) over concatenated / index-selected batches holds (alpro_models.py:278-281,325-330,360-363),
-        built by one kernel and differentiated by one (alpro_gather_seq_fwd / _bwd) instead of materialised by torch.cat and autograd."""
+        built by one kernel and differentiated by one (alpro_gather_seq_fwd / _bwd) instead of materialised by torch.cat and autograd.
+        out_rows (this repo's extension): flat indices into the (B * L) output rows -- last_hidden_state is then (len(out_rows), D), those rows only, and
+        the last layer's row-wise tail runs on them alone (BertLayer.forward_train)."""
         parts = encoder_embeds_parts
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
             lo, hi = self.encoder.layer_range(mode)
@@ -394,6 +414,7 @@ class BertModel(BertPreTrainedModel):
             if encoder_embeds is None and parts is None:
                 params += list(self.embeddings.parameters())
             run = _BertRun(self, input_ids, attention_mask, mode)
+            run.out_rows = out_rows
             if parts is not None:
                 run.parts = (parts[2].contiguous(), parts[3].contiguous())
                 out = tr.run_anchored(run, [parts[0], parts[1]], params)
@@ -426,8 +447,8 @@ class BertModel(BertPreTrainedModel):
         kb = self.key_bias(attention_mask)
         lo, hi = self.encoder.layer_range(mode)
         for i in range(lo, hi):
-            h32, h_t = self.encoder.layer[i](h32, h_t, kb, B, L)
-        out = h32.view(B, L, -1)
+            h32, h_t = self.encoder.layer[i](h32, h_t, kb, B, L, rows=out_rows if i == hi - 1 else None)
+        out = h32.view(B, L, -1) if out_rows is None else h32
         if not return_dict:
             return (out,)
         return SimpleNamespace(last_hidden_state=out, pooler_output=None, hidden_states=None, attentions=None,
@@ -440,6 +461,7 @@ class _BertRun:
     def __init__(self, model, input_ids, attention_mask, mode):
         self.m, self.ids, self.mask, self.mode = model, input_ids, attention_mask, mode
         self.parts = None   # (ti, vi): the input is a gather of (text pool, video pool) sequences, the two activations of forward()
+        self.out_rows = None   # flat indices of the only output rows the caller reads (BertModel.forward out_rows)
 
     def forward(self, encoder_embeds=None, video_pool=None):
         m, cfg = self.m, self.m.config
@@ -475,15 +497,15 @@ class _BertRun:
         lo, hi = m.encoder.layer_range(self.mode)
         self.range = (lo, hi)
         for i in range(lo, hi):
-            h32, h_t, sv = m.encoder.layer[i].forward_train(h32, h_t, kb, B, L)
+            h32, h_t, sv = m.encoder.layer[i].forward_train(h32, h_t, kb, B, L, rows=self.out_rows if i == hi - 1 else None)
             self.saved.append(sv)
-        return h32.view(B, L, -1)
+        return h32.view(B, L, -1) if self.out_rows is None else h32
 
     def backward(self, dout):
         m, cfg = self.m, self.m.config
         B, L = self.dims
         lo, hi = self.range
-        d32, d_t = dout.reshape(B * L, -1).contiguous(), None
+        d32, d_t = (dout.reshape(B * L, -1) if self.out_rows is None else dout.reshape(self.out_rows.numel(), -1)).contiguous(), None
         for i in range(hi - 1, lo - 1, -1):
             d32, d_t = m.encoder.layer[i].backward(self.saved.pop(), d32, d_t)
         if self.parts is not None:   # per pool row, the sum over the sequences that used it (and of the 16-bit + fp32 parts of the gradient)

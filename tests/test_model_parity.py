@@ -786,6 +786,46 @@ def test_fused_temporal_half_against_the_two_launches(mode):
     assert bool(torch.isfinite(ga).all()) and rel <= {"fp16": 1e-3, "bf16": 8e-3}[mode], rel
 
 
+@pytest.mark.parametrize("mode,tol", [("fp32", 2e-5), ("fp16", 4e-3)])
+def test_last_fusion_layer_tail_on_the_read_rows_only(fixture_models, monkeypatch, mode, tol):
+    """Round 6 (AlproForPretrain.fusion_tail_rows; BertLayer.forward_train rows=...): the last fusion layer's attention-output dense, LayerNorms and FFN
+    run on the 239 of every 948 rows the heads read ([CLS] rows, MLM text rows, the positives' patch rows) -- dead-row elimination, forward and
+    backward.  Every output of the pretraining forward and every parameter gradient against the every-row form on the 8-frame fixture model: the same
+    values up to the summation order of GEMMs over fewer rows (fp32: 2e-5 of the tensor's scale; fp16 operands: a few units of their resolution)."""
+    from alpro_amd import config as rt
+    m, batch, _ = fixture_models("pretrain_T8")
+    monkeypatch.setattr(torch, "multinomial", argmax_multinomial)
+    monkeypatch.setattr(np.random, "uniform", lambda *a, **k: 1.0)
+    prev, was_training = m.fusion_tail_rows, m.training
+    res = {}
+    try:
+        for tail in (False, True):
+            m.fusion_tail_rows = tail
+            fresh_grads(m)
+            with rt.use_compute_dtype(mode), torch.enable_grad():
+                sc = arm_scale(mode)
+                out = m(batch)
+                loss = out["mlm_loss"] + out["itm_loss"] + out["itc_loss"] + out["mpm_loss"]
+                gs = backward(loss, mode)
+                del sc
+            res[tail] = ({k: out[k].detach().float().clone() for k in ("itc_loss", "itm_loss", "mlm_loss", "mpm_loss", "itm_scores", "mpm_logits", "mlm_scores")},
+                         {n: (p.grad.detach().double() / gs).clone() for n, p in m.named_parameters() if p.grad is not None})
+            torch.cuda.synchronize()
+    finally:
+        m.fusion_tail_rows = prev
+        rt.set_armed_loss_scaler(None)
+        fresh_grads(m)
+        m.train(was_training)
+    (oa, ga), (ob, gb) = res[False], res[True]
+    for k in oa:
+        err = float((oa[k] - ob[k]).abs().max())
+        assert err <= tol * max(1.0, float(oa[k].abs().max())), "%s: %.3e" % (k, err)
+    assert set(ga) == set(gb)
+    worst = max(((float((ga[n] - gb[n]).norm() / ga[n].norm().clamp_min(1e-12)), n) for n in ga if float(ga[n].norm()) > 0), default=(0.0, ""))
+    print("\n[fusion tail rows %s] worst relative gradient difference %.2e (%s)" % (mode, worst[0], worst[1]))
+    assert worst[0] <= (1e-4 if mode == "fp32" else 2e-2), worst
+
+
 def test_side_stream_backward_is_handed_to_the_callers_stream():
     """The mechanisms behind ALPRO_TEXT_STREAM and ALPRO_WGRAD_STREAM, isolated.
     (a) An anchored run whose forward was queued on the text side stream gets its backward on that stream (autograd's rule), where it writes a buffer
