@@ -2,7 +2,7 @@
 # round 6, final validation: smoke(), the whole GPU suite, then the round's profile pass (tools/profile_round.sh r6) on the final binary
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/r6final6
+O=$R/gpurun_out/r6final7
 mkdir -p $O
 cd $R
 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1
