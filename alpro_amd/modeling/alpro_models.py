@@ -188,8 +188,10 @@ class AlproBaseModel(nn.Module):
             neg_text = torch.multinomial(weights_v2t, 1).view(-1)   # a negative text for each video
         return neg_video, neg_text
 
-    def _vtm(self, text_embeds, text_atts, video_embeds, video_atts, sim_v2t, sim_t2v):
-        """Video-text matching with in-batch hard negatives (alpro_models.py:269-344 / 800-872)."""
+    def _vtm(self, text_embeds, text_atts, video_embeds, video_atts, sim_v2t, sim_t2v, cls_only=False):
+        """Video-text matching with in-batch hard negatives (alpro_models.py:269-344 / 800-872).
+        cls_only: the caller reads nothing but the ITM logits (the retrieval model, alpro_models.py:800-872) -- the last fusion layer's row-wise tail then
+        runs on the 3B [CLS] rows alone (BertLayer.forward_train rows=...; ALPRO_FUSION_TAIL_ROWS=0: every row) and `pos` is not returned."""
         device = text_embeds.device
         bs = text_embeds.shape[0]
         neg_video, neg_text = self._sample_negatives(sim_v2t, sim_t2v, bs)
@@ -199,9 +201,18 @@ class AlproBaseModel(nn.Module):
         text_atts_all = torch.cat([text_atts, text_atts, text_atts[neg_text]], dim=0)
         video_embeds_all = torch.cat([video_embeds, video_embeds[neg_video], video_embeds], dim=0)
         video_atts_all = torch.cat([video_atts, video_atts, video_atts], dim=0)
-        both = self._fusion(torch.cat([text_embeds_all, video_embeds_all], dim=1), torch.cat([text_atts_all, video_atts_all], dim=1))
-        pos, neg = both[:bs], both[bs:]
-        vl_embeddings = torch.cat([pos[:, 0, :], neg[:, 0, :]], dim=0)
+        bert = self.text_encoder.bert if hasattr(self.text_encoder, "bert") else self.text_encoder
+        if (cls_only and os.environ.get("ALPRO_FUSION_TAIL_ROWS", "1") != "0" and text_embeds.is_cuda
+                and getattr(bert.encoder.layer[-1], "fuse_residual_ln", False)):
+            seq_len = text_embeds_all.shape[1] + video_embeds_all.shape[1]
+            rows = torch.arange(3 * bs, device=device, dtype=torch.long) * seq_len
+            vl_embeddings = bert(encoder_embeds=torch.cat([text_embeds_all, video_embeds_all], dim=1), attention_mask=torch.cat([text_atts_all, video_atts_all], dim=1),
+                                 return_dict=True, mode='fusion', out_rows=rows).last_hidden_state
+            pos = None
+        else:
+            both = self._fusion(torch.cat([text_embeds_all, video_embeds_all], dim=1), torch.cat([text_atts_all, video_atts_all], dim=1))
+            pos, neg = both[:bs], both[bs:]
+            vl_embeddings = torch.cat([pos[:, 0, :], neg[:, 0, :]], dim=0)
         vtm_logits = _linear32(vl_embeddings, self.itm_head)
         vtm_labels = torch.cat([torch.ones(bs, dtype=torch.long, device=device), torch.zeros(2 * bs, dtype=torch.long, device=device)], dim=0)   # built on the device: a pageable .to(device) makes the host wait for the launch stream
         vtm_loss = F.cross_entropy(vtm_logits, vtm_labels)
@@ -479,7 +490,7 @@ class AlproForVideoTextRetrieval(AlproBaseModel):
         text_embeds = self._text_embeds(batch['text_input_ids'], text_atts)
         text_feat = self._text_feat(text_embeds)
         vtc_loss, sim_v2t, sim_t2v, _ = self._vtc(video_feat, text_feat)
-        vtm_loss, vtm_logits, vtm_labels, _ = self._vtm(text_embeds, text_atts, video_embeds, video_atts, sim_v2t, sim_t2v)
+        vtm_loss, vtm_logits, vtm_labels, _ = self._vtm(text_embeds, text_atts, video_embeds, video_atts, sim_v2t, sim_t2v, cls_only=True)
         return dict(itm_scores=vtm_logits, itm_loss=vtm_loss, itm_labels=vtm_labels, itc_loss=vtc_loss)
 
     def compute_vtm(self, text_embeds, text_atts, image_embeds, image_atts, sim_i2t, sim_t2i):
