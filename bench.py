@@ -675,6 +675,10 @@ def main():
             # weight-gradient GEMMs of the timed steps on a side stream beside the data-gradient chain (alpro_amd.config, ALPRO_WGRAD_STREAM)
             "wgrad_side_stream": bool(train and _rt.wgrad_stream_enabled() and (world == 1 or os.environ.get("ALPRO_WGRAD_STREAM") == "force")),   # single-GPU schedule unless forced
             "text_side_stream": bool(args.workload != "visual_fwd" and _rt.text_stream_enabled()),
+            # work the reference computes and nobody reads, left out (same outputs, same gradients: tests/test_model_parity.py::test_last_fusion_layer_tail_on_the_read_rows_only;
+            # ALPRO_FUSION_TAIL_ROWS=0 computes it).  model_tflops_per_gpu stays priced on the reference's FLOP count
+            "dead_rows_skipped": (None if args.workload == "visual_fwd" or not getattr(model, "fusion_tail_rows", False) else
+                                  "last fusion layer: attention-output dense / LayerNorms / FFN on the 239 of every 948 rows the heads read"),
             "prompter_side_stream": bool(args.workload != "visual_fwd" and _rt.prompter_stream_enabled() and (world == 1 or os.environ.get("ALPRO_PROMPTER_STREAM") == "force")),
             "world_size": world, "dist_backend": (torch.distributed.get_backend() if torch.distributed.is_initialized() else "none (single process)"),
             "rccl_version": ".".join(str(v) for v in torch.cuda.nccl.version()) if hasattr(torch.cuda, "nccl") else None,
